@@ -1,0 +1,208 @@
+/*
+ * pairnet_hip.h -- C ABI of libpairnet_hip.so: hand-written gfx950 (MI355X) kernels
+ * for the Pair-Net inference hot path.
+ *
+ * Conventions (SURVEY.md 8b "operator-level boundary"):
+ *   - every entry point is extern "C", returns a hipError_t value as int (0 = ok;
+ *     -1 = argument contract violated, nothing launched);
+ *   - plain device pointers + sizes, no torch types; `stream` is a hipStream_t;
+ *   - no allocation, no global state, caller-owned buffers, re-entrant per stream,
+ *     asynchronous (the caller synchronises), graph-capturable;
+ *   - all floating-point data is fp32 (the reference runs fp32, no AMP:
+ *     configs/mask2former/pairnet.py has no fp16 key); indices are int64, as torch
+ *     produces them; token / pixel tensors are channel-last ("token-major").
+ *
+ * The reference has exactly one native operator boundary on this path, the
+ * third-party mmcv extension `ms_deform_attn_forward` (reached from
+ * configs/mask2former/pairnet.py:43-54 via pairnet_head.py:94,262); every other
+ * native kernel it runs is an ATen/cuDNN/cuBLAS kernel behind a torch call.  Each
+ * entry below names the reference call site(s) (file:line under /root/reference)
+ * whose arithmetic it replaces.  INTEGRATION.md shows the reference-side binding.
+ */
+#ifndef PAIRNET_HIP_H_
+#define PAIRNET_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN_ABI_VERSION 1
+int pn_abi_version(void);
+
+/* ------------------------------------------------------------------------- *
+ * Dense contraction (f32 MFMA 32x32x2, exact fp32 accumulate)
+ *   C[z][m][n] = act( sum_k (A[z][m][k] + Aadd[m % aadd_rows][k]) * W[z][n][k]
+ *                     + bias[n] ) + Res[z][m][n]
+ * Replaces every nn.Linear / 1x1 Conv2d / einsum / matmul on the path:
+ *   pairnet_head.py:240-243 (cls_embed, mask_embed, einsum "bqc,bchw->bqhw"),
+ *   :323-327 (sub/obj MLPs, importance matmul), :378 (rel_cls_embed), the packed
+ *   in_proj / out_proj of nn.MultiheadAttention and the FFNs behind :302-312 and
+ *   :367-376, and the pixel decoder's value_proj / sampling_offsets /
+ *   attention_weights / output_proj / FFN / 1x1 convs behind :262.
+ * `Aadd` fuses the positional add the reference does before a projection
+ * (query + query_pos, key + key_pos: facebook_detr.py:329-332).
+ * ------------------------------------------------------------------------- */
+#define PN_GEMM_RELU       1   /* act = ReLU (else identity)                        */
+#define PN_GEMM_A_COLMAJOR 2   /* A is stored [K][lda] (an NCHW feature map)        */
+#define PN_GEMM_FORCE_TILE 4   /* testing: force the 128x128 LDS-tiled kernel       */
+#define PN_GEMM_FORCE_SKINNY 8 /* testing: force the 32x32 split-K-in-block kernel  */
+
+typedef struct pn_gemm_desc {
+  const float* A;     int64_t lda;    int64_t strideA;    /* [M][K] (or [K][M])    */
+  const float* Aadd;  int64_t ldaadd; int32_t aadd_rows;  /* optional, may be NULL */
+  const float* W;     int64_t ldw;    int64_t strideW;    /* [N][K]                */
+  const float* bias;                                      /* [N] or NULL           */
+  const float* Res;   int64_t ldres;  int64_t strideRes;  /* optional residual     */
+  float*       C;     int64_t ldc;    int64_t strideC;    /* [M][N]                */
+  int32_t M, N, K, batch, flags;
+} pn_gemm_desc;
+
+int pn_gemm_f32(const pn_gemm_desc* d, void* stream);
+
+/* Implicit-GEMM KHxKW convolution, stride 1, zero padding, channel-last:
+ *   out[b][y][x][co] = act(sum_{ky,kx,ci} in[b][y+ky-pad][x+kx-pad][ci]
+ *                          * Wp[co][(ky*KW+kx)*Cin+ci] + bias[co])
+ * Replaces the pixel decoder's 3x3 output conv (behind pairnet_head.py:262) and
+ * the 64->64 7x7 layer of the Matrix Learner (cnn_factory.py:31-41).
+ * Cin % 32 == 0. */
+int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float* bias,
+                       float* out, int B, int H, int W, int Cin, int Cout,
+                       int KH, int KW, int pad, int relu, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Normalisation
+ * ------------------------------------------------------------------------- */
+/* y[r][:] = LayerNorm(x[r][:]) * gamma + beta, C == 256, eps 1e-5.
+ * (norms of BaseTransformerLayer, facebook_detr.py:406-408; post_norm,
+ * pairnet_head.py:236.) */
+int pn_layernorm_f32(const float* x, const float* gamma, const float* beta,
+                     float* y, int64_t rows, int C, float eps, void* stream);
+
+/* GroupNorm over channel-last x[b][HW][C] with G groups (+ optional ReLU); image b
+ * starts at x + b*x_bstride / y + b*y_bstride (floats).  `partials` is caller
+ * scratch of B * nblk * G * 2 doubles, nblk = pn_groupnorm_nblk(HW).  (ConvModule norm of the pixel decoder, behind
+ * pairnet_head.py:262.) */
+int pn_groupnorm_nblk(int64_t HW);
+int pn_groupnorm_nhwc_f32(const float* x, const float* gamma, const float* beta,
+                          float* y, double* partials, int B, int64_t HW, int C,
+                          int G, float eps, int relu, int64_t x_bstride,
+                          int64_t y_bstride, void* stream);
+
+/* y[r][:] = x[r][:] / max(||x[r]||_2, eps)   (F.normalize, pairnet_head.py:325-326) */
+int pn_l2normalize_f32(const float* x, float* y, int64_t rows, int C, float eps,
+                       void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Multi-scale deformable attention sampling.  THE reference's native boundary:
+ * replaces mmcv `ext_module.ms_deform_attn_forward(value, spatial_shapes,
+ * level_start_index, sampling_locations, attention_weights, im2col_step)` and
+ * fuses what precedes it in MultiScaleDeformableAttention.forward: softmax over
+ * the L*P logits and reference_point + offset / (W_l, H_l).
+ *   value   [B][N][H*D]      projected value tokens, levels concatenated
+ *   offaw   [B][N][H*L*P*3]  raw Linear outputs: H*L*P*2 offsets (x,y) followed
+ *                            by H*L*P attention logits
+ *   out     [B][N][H*D]
+ * Queries are the N tokens themselves (encoder self-attention); the reference
+ * point of token n is its own pixel centre ((x+.5)/w, (y+.5)/h).
+ * H == 8, D == 32, P == 4, L <= 4. */
+int pn_msda_f32(const float* value, const float* offaw, float* out, int B,
+                int L, const int32_t* level_h /* host */,
+                const int32_t* level_w /* host */, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Positional encoding / resampling
+ * ------------------------------------------------------------------------- */
+/* out[(y*w+x)][c] = SinePositionalEncoding(num_feats=C/2, normalize=True,
+ * temperature, scale=2pi, eps=1e-6)(y,x)[c] + add[c]  (add may be NULL).
+ * (pairnet_head.py:278; level_encoding add in the pixel decoder.) */
+int pn_sine_pe_f32(float* out, const float* add, int h, int w, int C,
+                   float temperature, void* stream);
+
+/* Bilinear resize, align_corners=False (F.interpolate semantics).
+ * nhwc:   in [b][hi][wi][C] -> out [b][ho][wo][C], out = (accumulate? out:0)+v;
+ *         image b at in + b*in_bstride / out + b*out_bstride (floats)
+ * planar: in [P][hi][wi]    -> out [P][ho][wo]
+ * (FPN top-down add behind pairnet_head.py:262; attention-mask resize :244-246;
+ * mask upsampling in _get_bboxes_single :826-843.) */
+int pn_bilinear_nhwc_f32(const float* in, float* out, int B, int hi, int wi,
+                         int ho, int wo, int C, int accumulate, int64_t in_bstride,
+                         int64_t out_bstride, void* stream);
+int pn_bilinear_planar_f32(const float* in, float* out, int64_t P, int hi,
+                           int wi, int ho, int wo, void* stream);
+/* planar resize + (sigmoid(v) > 0.5  <=>  v > 0) -> uint8 {0,1}  (:834,:842) */
+int pn_bilinear_planar_gt0_u8(const float* in, uint8_t* out, int64_t P, int hi,
+                              int wi, int ho, int wo, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Attention
+ * ------------------------------------------------------------------------- */
+/* Bit-pack the boolean attention mask and apply the reference's all-masked fix:
+ *   bits[r][w] bit j = (logits[r][32w+j] < 0)   (== sigmoid < 0.5, :256)
+ *   rowall[r] = 1 if every one of the Nk keys of row r is masked (:300)
+ * logits [R][Nk]; bits [R][nwords], nwords = (Nk+31)/32. */
+int pn_mask_pack(const float* logits, uint32_t* bits, int32_t* rowall,
+                 int64_t R, int Nk, void* stream);
+
+/* softmax(q k^T * scale + mask) v per head, flash-style over key chunks
+ * (f32 MFMA for both contractions), then a combine pass.
+ *   q [B][Q][ldq], k [B][Nk][ldk], v [B][Nk][ldv]: projected, head h at columns
+ *   [32h, 32h+32); out [B][Q][ldo]; 8 heads x 32.
+ *   maskbits/rowall from pn_mask_pack (NULL = no mask), shared by the 8 heads.
+ *   scratch: pn_attn_scratch_floats(B, Q, Nk) floats.
+ * (nn.MultiheadAttention core behind pairnet_head.py:302-312, :367-376.) */
+int64_t pn_attn_scratch_floats(int B, int Q, int Nk);
+int pn_attention_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
+                     const float* v, int64_t ldv, const uint32_t* maskbits,
+                     const int32_t* rowall, float* out, int64_t ldo,
+                     float* scratch, int B, int Q, int Nk, float scale,
+                     void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Pair Proposal Network
+ * ------------------------------------------------------------------------- */
+/* Matrix Learner edge layers (cnn_factory.py:22-29, 42-48):
+ *   first: in [B][S][S]     -> out [B][S][S][C] = relu(conv7x7(1->C) + b)
+ *          w1 [C][49]
+ *   last:  in [B][S][S][C]  -> out [B][S][S]    = conv7x7(C->1) + b
+ *          w3 [49][C]
+ * The C->C middle layer is pn_conv2d_nhwc_f32. */
+int pn_mlearner_first_f32(const float* in, const float* w1, const float* b1,
+                          float* out, int B, int S, int C, void* stream);
+int pn_mlearner_last_f32(const float* in, const float* w3, const float* b3,
+                         float* out, int B, int S, int C, void* stream);
+
+/* Top-k pair selection (pairnet_head.py:334-340): for each image the k largest of
+ * the n = Q*Q scores, sorted descending; ties broken by the smaller flat index
+ * (torch leaves tie order unspecified).  idx/sub/obj [B][k] int64:
+ * sub = idx / Q (trunc), obj = idx % Q.  n <= 65536, k <= 256. */
+int pn_topk_pairs(const float* scores, int64_t* idx, int64_t* sub, int64_t* obj,
+                  int B, int Q, int k, void* stream);
+
+/* out[b][r][:] = in[b][index[b][r]][:], rows of `len` floats
+ * (torch.gather at pairnet_head.py:342-351, 380-403). */
+int pn_gather_rows_f32(const float* in, const int64_t* index, float* out, int B,
+                       int rows_in, int rows_out, int64_t len, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Post-processing (pairnet_head.py:788-924)
+ * ------------------------------------------------------------------------- */
+/* softmax over C logits, drop the last (background) column, max/argmax
+ * (:811-815, :823-825).  label = argmax (0-based), score = max prob. */
+int pn_cls_argmax_f32(const float* logits, int64_t* label, float* score,
+                      int64_t rows, int C, void* stream);
+/* r_dists[r][0] = 0, r_dists[r][1:] = softmax(logits[r][:])  (:817-820) */
+int pn_rel_dists_f32(const float* logits, float* out, int64_t rows, int C,
+                     void* stream);
+/* Panoptic id map (:866-871): masks [n][HW] fp32 logits ->
+ * m_id[p] = argmax_i softmax_i(masks[:, p]); remap[i] merges stuff duplicates
+ * (:873-878); seg[p] = id*1000 + labels[id]; area[i] = #pixels with id i. */
+int pn_panoptic_f32(const float* masks, const int64_t* labels,
+                    const int32_t* remap, int64_t* seg, int32_t* area, int n,
+                    int64_t HW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAIRNET_HIP_H_ */

@@ -1,0 +1,130 @@
+"""Import the reference's own CrossHead2 / ConvTiny from /root/reference.
+
+TEST INFRASTRUCTURE, usable in the build container only (/root/reference does not
+exist on the GPU box; nothing here is imported by `-m gpu` tests, smoke() or
+bench.py).  Nothing is copied: the reference files are executed from where they
+lie, with bytecode writing disabled so that no __pycache__ appears in the
+read-only tree.
+
+`mmcv` / `mmdet` are absent from the image, so name-only stub modules are put in
+sys.modules.  Their builders return the restated layers of oracle/layers.py, so a
+shimmed run = the reference's OWN orchestration and in-tree arithmetic
+(pairnet_head.py:216-417, 760-924; cnn_factory.py:6-53) over restated
+third-party layers.  This is what pins oracle/head.py and what
+oracle/make_golden.py records into tests/golden/.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import torch.nn as nn
+
+from . import layers as L
+
+REF_ROOT = "/root/reference"
+
+
+def available():
+    return os.path.isfile(os.path.join(
+        REF_ROOT, "pairnet/models/relation_heads/pairnet_head.py"))
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(
+        name, os.path.join(REF_ROOT, rel))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+class _Registry:
+    def register_module(self, *a, **kw):
+        return lambda cls: cls
+
+
+class _Loss:
+    def __init__(self, cfg):
+        self.use_sigmoid = bool(cfg.get("use_sigmoid", False))
+
+
+def _passthrough_decorator(*a, **kw):
+    return lambda fn: fn
+
+
+def install():
+    """Register the stubs and load the two reference modules. Idempotent."""
+    if "pairnet.models.relation_heads.pairnet_head" in sys.modules:
+        return
+    if not available():
+        raise RuntimeError("reference tree not present at " + REF_ROOT)
+    sys.dont_write_bytecode = True
+    _mod("mmcv")
+    _mod("mmcv.cnn", Conv2d=nn.Conv2d, Linear=nn.Linear,
+         build_plugin_layer=L.build_plugin_layer,
+         caffe2_xavier_init=lambda *a, **k: None)
+    _mod("mmcv.cnn.bricks")
+    _mod("mmcv.cnn.bricks.transformer",
+         build_positional_encoding=L.build_positional_encoding,
+         build_transformer_layer_sequence=L.build_transformer_layer_sequence)
+    _mod("mmcv.ops", point_sample=None)
+    _mod("mmcv.runner", ModuleList=nn.ModuleList,
+         force_fp32=_passthrough_decorator)
+    _mod("mmdet")
+    _mod("mmdet.core", build_assigner=None, build_sampler=None,
+         multi_apply=None)
+    _mod("mmdet.datasets")
+    _mod("mmdet.datasets.coco_panoptic", INSTANCE_OFFSET=1000)
+    _mod("mmdet.models")
+    _mod("mmdet.models.builder", HEADS=_Registry(),
+         build_loss=lambda cfg: _Loss(cfg))
+
+    # super(AnchorFreeHead, self).__init__(init_cfg) (pairnet_head.py:56)
+    # resolves to the class after AnchorFreeHead in the MRO: give it one that
+    # accepts init_cfg.
+    class _Base(nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+
+    class AnchorFreeHead(_Base):
+        pass
+
+    _mod("mmdet.models.dense_heads", AnchorFreeHead=AnchorFreeHead)
+    for pkg in ("pairnet", "pairnet.models", "pairnet.models.frameworks",
+                "pairnet.models.relation_heads"):
+        _mod(pkg)
+    _load("pairnet.models.frameworks.cnn_factory",
+          "pairnet/models/frameworks/cnn_factory.py")
+    _load("pairnet.models.relation_heads.pairnet_head",
+          "pairnet/models/relation_heads/pairnet_head.py")
+
+
+def reference_head_cfg():
+    """exec the reference's own config file and return model.bbox_head."""
+    path = os.path.join(REF_ROOT, "configs/mask2former/pairnet.py")
+    scope = {}
+    with open(path) as f:
+        exec(compile(f.read(), path, "exec"), scope)
+    return L.CfgDict(scope["model"]["bbox_head"])
+
+
+def build_reference_head(cfg=None):
+    install()
+    cls = sys.modules["pairnet.models.relation_heads.pairnet_head"].CrossHead2
+    cfg = L.CfgDict(cfg if cfg is not None else reference_head_cfg())
+    cfg.pop("type", None)
+    return cls(**cfg, train_cfg=None).eval()
+
+
+def reference_conv_tiny():
+    install()
+    return sys.modules["pairnet.models.frameworks.cnn_factory"].creat_cnn(
+        "conv_tiny").eval()

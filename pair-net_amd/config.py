@@ -1,0 +1,130 @@
+"""Config boundary: the schema of the reference's configs/mask2former/pairnet.py.
+
+The reference builds its head from nested python dicts (configs/mask2former/
+pairnet.py:7-211) and reads some of them by attribute
+(pairnet_head.py:83-87: `transformer_decoder.transformerlayers.attn_cfgs.num_heads`).
+`ConfigDict` gives the same access; `pairnet_r50()` is this repo's own statement of
+that schema (same keys and values, assembled from small helpers rather than copied),
+and `load_config()` also accepts a python config file in the reference's format,
+e.g. the reference's own file when it is present.
+"""
+import os
+
+
+class ConfigDict(dict):
+    """Nested dict with attribute access (the subset of mmcv.ConfigDict used)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        for k, v in dict(*args, **kwargs).items():
+            self[k] = v
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, _to_cfg(value))
+
+    def __getattr__(self, key):
+        try:
+            return self[key]
+        except KeyError:
+            raise AttributeError(key) from None
+
+    __setattr__ = __setitem__
+
+    def update(self, *args, **kwargs):
+        for k, v in dict(*args, **kwargs).items():
+            self[k] = v
+
+    def copy(self):
+        return ConfigDict(self)
+
+
+def _to_cfg(v):
+    if isinstance(v, ConfigDict):
+        return v
+    if isinstance(v, dict):
+        return ConfigDict(v)
+    if isinstance(v, (list, tuple)):
+        return type(v)(_to_cfg(x) for x in v)
+    return v
+
+
+def _mha(embed=256, heads=8):
+    return dict(type="MultiheadAttention", embed_dims=embed, num_heads=heads,
+                attn_drop=0.0, proj_drop=0.0, dropout_layer=None, batch_first=False)
+
+
+def _decoder(num_layers, return_intermediate, ffn_drop):
+    ffn = dict(embed_dims=256, feedforward_channels=2048, num_fcs=2,
+               act_cfg=dict(type="ReLU", inplace=True), ffn_drop=ffn_drop,
+               dropout_layer=None, add_identity=True)
+    order = ("cross_attn", "norm", "self_attn", "norm", "ffn", "norm")
+    return dict(type="DetrTransformerDecoder", return_intermediate=return_intermediate,
+                num_layers=num_layers,
+                transformerlayers=dict(type="BaseTransformerLayer", attn_cfgs=_mha(),
+                                       ffn_cfgs=ffn, operation_order=order))
+
+
+def _pixel_decoder(num_levels=3, num_points=4, enc_layers=6):
+    attn = dict(type="MultiScaleDeformableAttention", embed_dims=256, num_heads=8,
+                num_levels=num_levels, num_points=num_points, im2col_step=64,
+                dropout=0.0, batch_first=False, norm_cfg=None, init_cfg=None)
+    ffn = dict(type="FFN", embed_dims=256, feedforward_channels=1024, num_fcs=2,
+               ffn_drop=0.0, act_cfg=dict(type="ReLU", inplace=True))
+    enc = dict(type="DetrTransformerEncoder", num_layers=enc_layers, init_cfg=None,
+               transformerlayers=dict(type="BaseTransformerLayer", attn_cfgs=attn,
+                                      ffn_cfgs=ffn,
+                                      operation_order=("self_attn", "norm", "ffn", "norm")))
+    return dict(type="MSDeformAttnPixelDecoder", num_outs=3,
+                norm_cfg=dict(type="GN", num_groups=32), act_cfg=dict(type="ReLU"),
+                encoder=enc, init_cfg=None,
+                positional_encoding=dict(type="SinePositionalEncoding", num_feats=128,
+                                         normalize=True))
+
+
+def pairnet_head_cfg(in_channels=(256, 512, 1024, 2048), num_obj_query=100,
+                     num_rel_query=100, num_classes=133, num_relations=56):
+    """bbox_head section (type CrossHead2) of the Pair-Net R50 config."""
+    nc = num_classes
+    return ConfigDict(
+        type="CrossHead2", num_classes=nc, num_relations=num_relations,
+        num_obj_query=num_obj_query, num_rel_query=num_rel_query, mapper="conv_tiny",
+        in_channels=list(in_channels), feat_channels=256, out_channels=256,
+        num_transformer_feat_level=3, embed_dims=256,
+        enforce_decoder_input_project=False,
+        pixel_decoder=_pixel_decoder(),
+        transformer_decoder=_decoder(9, False, 0.0),
+        relation_decoder=_decoder(6, True, 0.1),
+        positional_encoding=dict(type="SinePositionalEncoding", num_feats=128,
+                                 normalize=True),
+        rel_cls_loss=dict(type="SeesawLoss", num_classes=num_relations,
+                          return_dict=True, loss_weight=2.0),
+        subobj_cls_loss=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=4.0,
+                             reduction="mean", class_weight=[1.0] * (nc + 1)),
+        importance_match_loss=dict(type="BCEWithLogitsLoss", reduction="mean",
+                                   loss_weight=5.0),
+        loss_cls=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=2.0,
+                      reduction="mean", class_weight=[1.0] * nc + [0.1]),
+        loss_mask=dict(type="CrossEntropyLoss", use_sigmoid=True, reduction="mean",
+                       loss_weight=5.0),
+        loss_dice=dict(type="DiceLoss", use_sigmoid=True, activate=True, reduction="mean",
+                       naive_dice=True, eps=1.0, loss_weight=5.0))
+
+
+def pairnet_r50():
+    """`model` section: PSGTr(ResNet-50, CrossHead2) as the reference configures it."""
+    return ConfigDict(
+        type="PSGTr",
+        backbone=dict(type="ResNet", depth=50, num_stages=4, out_indices=(0, 1, 2, 3),
+                      frozen_stages=1, norm_cfg=dict(type="BN", requires_grad=False),
+                      norm_eval=True, style="pytorch"),
+        bbox_head=pairnet_head_cfg(),
+        test_cfg=dict(max_per_img=100))
+
+
+def load_config(path):
+    """exec a reference-format python config; returns ConfigDict of its globals
+    (without `_base_` inheritance: the model section of pairnet.py has none)."""
+    scope = {}
+    with open(path) as f:
+        exec(compile(f.read(), os.path.abspath(path), "exec"), scope)
+    return ConfigDict({k: v for k, v in scope.items() if not k.startswith("__")})

@@ -1,0 +1,368 @@
+// fp32 contractions on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
+// bitwise an fmaf chain).  Two kernels behind pn_gemm_f32 / pn_conv2d_nhwc_f32:
+//
+//   k_gemm_tile   LDS-tiled BMxBNx32, 4 waves, register-prefetched double-buffered
+//                 LDS.  A rows come from a row-major matrix, a column-major matrix
+//                 (an NCHW feature map read as [K][M]) or an on-the-fly im2col of
+//                 a channel-last image (implicit-GEMM convolution).
+//   k_gemm_skinny 32x32 output tile per workgroup, the 4 waves split K and reduce
+//                 through LDS; operands go global->VGPR directly.  For the M~100
+//                 query-side GEMMs of the decoders, where a 128-row tile would
+//                 leave the chip empty.
+//
+// LDS layout [row][32+4]: a lane's MFMA operand for four consecutive k-steps is one
+// ds_read_b128 (k-permutation: lanes 0-31 take k = kb..kb+3, lanes 32-63 take
+// kb+4..kb+7 for BOTH operands, so the pairing inside each MFMA stays consistent);
+// the 36-float stride makes the four 16-lane groups of a b128 read hit all 64 banks
+// exactly once.
+#include "common.h"
+
+struct GemmP {
+  const float* A; const float* Aadd; const float* W; const float* bias;
+  const float* Res; float* C;
+  int64_t lda, ldaadd, ldw, ldres, ldc;
+  int64_t sA, sW, sRes, sC;
+  int M, N, K, aadd_rows, relu, a_vec;
+  int H, Wd, Cin, KW, pad;  // conv mode
+};
+
+enum { A_ROW = 0, A_COL = 1, A_CONV = 2 };
+
+template <int BM, int BN, int WM, int WN, int AMODE>
+__global__ __launch_bounds__(256) void k_gemm_tile(const GemmP p) {
+  constexpr int BK = 32, LD = BK + 4;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int LDK = BM + 4;  // k-major A tile stride (A_COL)
+  constexpr int A_ELEMS = (AMODE == A_COL) ? BK * LDK : BM * LD;
+  constexpr int B_ELEMS = BN * LD;
+  constexpr int STAGE = A_ELEMS + B_ELEMS;
+  constexpr int NA = (BM * BK / 4) / 256;
+  constexpr int NB = (BN * BK / 4) / 256;
+  constexpr int QM = BM / 4;         // float4 per k-row of a column-major A tile
+  constexpr int KSTEP = 256 / QM;    // k rows covered per pass
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int bz = blockIdx.z;
+  const float* __restrict__ A = p.A + (int64_t)bz * p.sA;
+  const float* __restrict__ W = p.W + (int64_t)bz * p.sW;
+
+  // ---- per-thread loader state (row indices do not change over k) ----
+  const float* a_row[NA];
+  const float* add_row[NA];
+  int cy[NA], cx[NA];
+  bool a_ok[NA];
+  const int kc = (tid & 7) * 4;  // row-major / conv: k offset inside the tile
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    a_row[j] = nullptr; add_row[j] = nullptr; cy[j] = cx[j] = 0; a_ok[j] = false;
+    if (AMODE != A_COL) {
+      const int gm = m0 + (tid >> 3) + 32 * j;
+      a_ok[j] = gm < p.M;
+      if (AMODE == A_ROW) {
+        a_row[j] = A + (int64_t)(a_ok[j] ? gm : 0) * p.lda;
+        if (p.Aadd) add_row[j] = p.Aadd + (int64_t)((a_ok[j] ? gm : 0) % p.aadd_rows) * p.ldaadd;
+      } else {
+        cy[j] = gm / p.Wd;
+        cx[j] = gm - cy[j] * p.Wd;
+      }
+    }
+  }
+  const float* w_row[NB];
+  bool w_ok[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int gn = n0 + (tid >> 3) + 32 * j;
+    w_ok[j] = gn < p.N;
+    w_row[j] = W + (int64_t)(w_ok[j] ? gn : 0) * p.ldw;
+  }
+
+  float4 ra[NA], rb[NB];
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+    if (AMODE == A_ROW) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a_ok[j] && k0 + kc < p.K) {
+          v = ld4(a_row[j] + k0 + kc);
+          if (p.Aadd) v = add4(v, ld4(add_row[j] + k0 + kc));
+        }
+        ra[j] = v;
+      }
+    } else if (AMODE == A_CONV) {
+      const int tap = k0 / p.Cin;
+      const int ci = k0 - tap * p.Cin + kc;
+      const int dy = tap / p.KW - p.pad, dx = tap % p.KW - p.pad;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int yy = cy[j] + dy, xx = cx[j] + dx;
+        if (a_ok[j] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd && k0 + kc < p.K)
+          v = ld4(A + ((int64_t)yy * p.Wd + xx) * p.Cin + ci);
+        ra[j] = v;
+      }
+    } else {
+      const int mc = m0 + (tid % QM) * 4;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int kk = k0 + tid / QM + KSTEP * j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kk < p.K) {
+          const float* src = A + (int64_t)kk * p.lda + mc;
+          if (p.a_vec && mc + 3 < p.M) {
+            v = ld4(src);
+          } else {
+            if (mc + 0 < p.M) v.x = src[0];
+            if (mc + 1 < p.M) v.y = src[1];
+            if (mc + 2 < p.M) v.z = src[2];
+            if (mc + 3 < p.M) v.w = src[3];
+          }
+        }
+        ra[j] = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (w_ok[j] && k0 + kc < p.K) v = ld4(w_row[j] + k0 + kc);
+      rb[j] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* sA = smem + buf * STAGE;
+    float* sB = sA + A_ELEMS;
+    if (AMODE == A_COL) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j)
+        st4(sA + (tid / QM + KSTEP * j) * LDK + (tid % QM) * 4, ra[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NA; ++j)
+        st4(sA + ((tid >> 3) + 32 * j) * LD + kc, ra[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      st4(sB + ((tid >> 3) + 32 * j) * LD + kc, rb[j]);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const float* sA = smem + buf * STAGE;
+    const float* sB = sA + A_ELEMS;
+#pragma unroll
+    for (int kb = 0; kb < BK; kb += 8) {
+      float a[TM][4], b[TN][4];
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        if (AMODE == A_COL) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            a[mi][t] = sA[(kb + t + 4 * lh) * LDK + wm * WM + mi * 32 + li];
+        } else {
+          const float4 v = ld4(sA + (wm * WM + mi * 32 + li) * LD + kb + 4 * lh);
+          a[mi][0] = v.x; a[mi][1] = v.y; a[mi][2] = v.z; a[mi][3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const float4 v = ld4(sB + (wn * WN + ni * 32 + li) * LD + kb + 4 * lh);
+        b[ni][0] = v.x; b[ni][1] = v.y; b[ni][2] = v.z; b[ni][3] = v.w;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            acc[mi][ni] = mfma32(a[mi][t], b[ni][t], acc[mi][ni]);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias -> act -> residual ----
+  float* __restrict__ C = p.C + (int64_t)bz * p.sC;
+  const float* __restrict__ Res = p.Res ? p.Res + (int64_t)bz * p.sRes : nullptr;
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) {
+    const int col = n0 + wn * WN + ni * 32 + li;
+    if (col >= p.N) continue;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WM + mi * 32 + mfma32_row(r, lh);
+        if (row < p.M) {
+          float v = acc[mi][ni][r] + bv;
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (Res) v += Res[(int64_t)row * p.ldres + col];
+          C[(int64_t)row * p.ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// 32x32 output tile; wave w contracts k in [w*ks, (w+1)*ks); partial tiles are summed
+// through LDS in wave order (deterministic).
+template <int AMODE>
+__global__ __launch_bounds__(256) void k_gemm_skinny(const GemmP p) {
+  __shared__ float red[4 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32, bz = blockIdx.z;
+  const float* __restrict__ A = p.A + (int64_t)bz * p.sA;
+  const float* __restrict__ W = p.W + (int64_t)bz * p.sW;
+  const int am = min(m0 + li, p.M - 1);
+  const int wn_ = min(n0 + li, p.N - 1);
+  const float* arow = (AMODE == A_ROW) ? A + (int64_t)am * p.lda : A + am;
+  const float* addrow = p.Aadd ? p.Aadd + (int64_t)(am % p.aadd_rows) * p.ldaadd : nullptr;
+  const float* wrow = W + (int64_t)wn_ * p.ldw;
+
+  int ks = (p.K + 3) / 4;
+  ks = (ks + 7) & ~7;
+  const int kbeg = min(wave * ks, p.K), kend = min(kbeg + ks, p.K);
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const int nfull = (kend - kbeg) / 8;
+  int k = kbeg + 4 * lh;
+#pragma unroll 4
+  for (int s = 0; s < nfull; ++s, k += 8) {
+    float4 a, b = ld4(wrow + k);
+    if (AMODE == A_ROW) {
+      a = ld4(arow + k);
+      if (addrow) a = add4(a, ld4(addrow + k));
+    } else {
+      a.x = arow[(int64_t)(k + 0) * p.lda];
+      a.y = arow[(int64_t)(k + 1) * p.lda];
+      a.z = arow[(int64_t)(k + 2) * p.lda];
+      a.w = arow[(int64_t)(k + 3) * p.lda];
+    }
+    acc = mfma32(a.x, b.x, acc);
+    acc = mfma32(a.y, b.y, acc);
+    acc = mfma32(a.z, b.z, acc);
+    acc = mfma32(a.w, b.w, acc);
+  }
+  if (kbeg + nfull * 8 < kend) {  // one 4-wide remainder: lower half only
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (lh == 0) {
+      b = ld4(wrow + k);
+      if (AMODE == A_ROW) {
+        a = ld4(arow + k);
+        if (addrow) a = add4(a, ld4(addrow + k));
+      } else {
+        a.x = arow[(int64_t)(k + 0) * p.lda];
+        a.y = arow[(int64_t)(k + 1) * p.lda];
+        a.z = arow[(int64_t)(k + 2) * p.lda];
+        a.w = arow[(int64_t)(k + 3) * p.lda];
+      }
+    }
+    acc = mfma32(a.x, b.x, acc);
+    acc = mfma32(a.y, b.y, acc);
+    acc = mfma32(a.z, b.z, acc);
+    acc = mfma32(a.w, b.w, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave * 1024 + mfma32_row(r, lh) * 32 + li] = acc[r];
+  __syncthreads();
+
+  float* __restrict__ C = p.C + (int64_t)bz * p.sC;
+  const float* __restrict__ Res = p.Res ? p.Res + (int64_t)bz * p.sRes : nullptr;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + 256 * j;
+    const int row = m0 + (e >> 5), col = n0 + (e & 31);
+    if (row < p.M && col < p.N) {
+      float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+      if (p.bias) v += p.bias[col];
+      if (p.relu) v = fmaxf(v, 0.f);
+      if (Res) v += Res[(int64_t)row * p.ldres + col];
+      C[(int64_t)row * p.ldc + col] = v;
+    }
+  }
+}
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <int BM, int BN, int WM, int WN, int AMODE>
+static int launch_tile(const GemmP& p, int batch, hipStream_t s) {
+  dim3 grid(pn_cdiv(p.N, BN), pn_cdiv(p.M, BM), batch);
+  hipLaunchKernelGGL((k_gemm_tile<BM, BN, WM, WN, AMODE>), grid, dim3(256), 0, s, p);
+  return PN_LAUNCH_CHECK();
+}
+
+extern "C" int pn_gemm_f32(const pn_gemm_desc* d, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!d || !d->A || !d->W || !d->C) return PN_BAD_ARG;
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return PN_BAD_ARG;
+  const bool colmajor = d->flags & PN_GEMM_A_COLMAJOR;
+  if (d->K % 4 || d->ldw % 4 || d->strideW % 4 || !aligned16(d->W)) return PN_BAD_ARG;
+  if (!colmajor && (d->lda % 4 || d->strideA % 4 || !aligned16(d->A))) return PN_BAD_ARG;
+  if (d->Aadd && (colmajor || d->ldaadd % 4 || !aligned16(d->Aadd) || d->aadd_rows <= 0))
+    return PN_BAD_ARG;
+  GemmP p{};
+  p.A = d->A; p.Aadd = d->Aadd; p.W = d->W; p.bias = d->bias; p.Res = d->Res; p.C = d->C;
+  p.lda = d->lda; p.ldaadd = d->ldaadd; p.ldw = d->ldw; p.ldres = d->ldres; p.ldc = d->ldc;
+  p.sA = d->strideA; p.sW = d->strideW; p.sRes = d->strideRes; p.sC = d->strideC;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.aadd_rows = d->Aadd ? d->aadd_rows : 1;
+  p.relu = (d->flags & PN_GEMM_RELU) ? 1 : 0;
+  p.a_vec = colmajor && d->lda % 4 == 0 && d->strideA % 4 == 0 && aligned16(d->A);
+
+  const int64_t tiles128 = (int64_t)pn_cdiv(d->M, 128) * pn_cdiv(d->N, 128) * d->batch;
+  bool skinny = tiles128 < 96;
+  if (d->flags & PN_GEMM_FORCE_TILE) skinny = false;
+  if (d->flags & PN_GEMM_FORCE_SKINNY) skinny = true;
+  if (skinny) {
+    dim3 grid(pn_cdiv(d->N, 32), pn_cdiv(d->M, 32), d->batch);
+    if (colmajor) hipLaunchKernelGGL(k_gemm_skinny<A_COL>, grid, dim3(256), 0, s, p);
+    else          hipLaunchKernelGGL(k_gemm_skinny<A_ROW>, grid, dim3(256), 0, s, p);
+    return PN_LAUNCH_CHECK();
+  }
+  if (d->N <= 64)
+    return colmajor ? launch_tile<128, 64, 32, 64, A_COL>(p, d->batch, s)
+                    : launch_tile<128, 64, 32, 64, A_ROW>(p, d->batch, s);
+  return colmajor ? launch_tile<128, 128, 64, 64, A_COL>(p, d->batch, s)
+                  : launch_tile<128, 128, 64, 64, A_ROW>(p, d->batch, s);
+}
+
+extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float* bias,
+                                  float* out, int B, int H, int W, int Cin, int Cout,
+                                  int KH, int KW, int pad, int relu, void* stream) {
+  if (!in || !Wp || !out || B <= 0 || H <= 0 || W <= 0) return PN_BAD_ARG;
+  if (Cin % 32 || !aligned16(in) || !aligned16(Wp)) return PN_BAD_ARG;
+  GemmP p{};
+  p.A = in; p.W = Wp; p.bias = bias; p.C = out;
+  p.M = H * W; p.N = Cout; p.K = KH * KW * Cin;
+  p.lda = Cin; p.ldw = p.K; p.ldc = Cout;
+  p.sA = (int64_t)H * W * Cin; p.sW = 0; p.sC = (int64_t)H * W * Cout;
+  p.relu = relu ? 1 : 0; p.aadd_rows = 1;
+  p.H = H; p.Wd = W; p.Cin = Cin; p.KW = KW; p.pad = pad;
+  hipStream_t s = (hipStream_t)stream;
+  if (Cout <= 64) return launch_tile<64, 64, 32, 32, A_CONV>(p, B, s);
+  return launch_tile<128, 128, 64, 64, A_CONV>(p, B, s);
+}
+
+extern "C" int pn_abi_version(void) { return PN_ABI_VERSION; }

@@ -1,0 +1,116 @@
+// Multi-scale deformable attention sampling for the pixel-decoder encoder
+// (8 heads x 32 channels, P = 4 points, L <= 4 levels), HBM/L2-bound gather.
+//
+// Thread = (query, head, 4 channels): the 8 lanes of one (query, head) read one
+// 128-byte value row per bilinear tap as float4s, so every tap is a full-line
+// access; a 256-thread workgroup covers 4 consecutive queries (row-major
+// neighbours sample overlapping value rows -> L2 hits).  Softmax over the L*P
+// logits, reference point + offset / (W_l, H_l) and the grid_sample
+// un-normalisation are fused, following mmcv's CPU formula
+// (multi_scale_deformable_attn_pytorch):
+//   loc = ref + off / (W_l, H_l);  g = 2 loc - 1;  ix = ((g + 1) W_l - 1) / 2
+// with zero padding outside the map.
+#include "common.h"
+
+struct MsdaLevels {
+  int h[4], w[4], start[4];
+  int L, N;
+};
+
+__global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
+                                              const float* __restrict__ offaw,
+                                              float* __restrict__ out,
+                                              const MsdaLevels lv) {
+  const int tid = threadIdx.x;
+  const int c4 = tid & 7, head = (tid >> 3) & 7, ql = tid >> 6;
+  const int n = blockIdx.x * 4 + ql;
+  const int b = blockIdx.y;
+  if (n >= lv.N) return;
+  const int L = lv.L;
+  const int LP = L * 4;
+
+  // level and pixel of this query token
+  int ql_lvl = 0;
+#pragma unroll
+  for (int l = 1; l < 4; ++l)
+    if (l < L && n >= lv.start[l]) ql_lvl = l;
+  const int idx = n - lv.start[ql_lvl];
+  const int qy = idx / lv.w[ql_lvl], qx = idx - qy * lv.w[ql_lvl];
+  const float ref_x = ((float)qx + 0.5f) / (float)lv.w[ql_lvl];
+  const float ref_y = ((float)qy + 0.5f) / (float)lv.h[ql_lvl];
+
+  const float* oa = offaw + ((int64_t)b * lv.N + n) * (8 * LP * 3);
+  const float* offp = oa + head * LP * 2;
+  const float* awp = oa + 8 * LP * 2 + head * LP;
+
+  float logit[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    logit[i] = (i < LP) ? awp[i] : -INFINITY;
+    mx = fmaxf(mx, logit[i]);
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    logit[i] = (i < LP) ? expf(logit[i] - mx) : 0.f;
+    den += logit[i];
+  }
+
+  const float* vb = value + (int64_t)b * lv.N * 256 + head * 32 + c4 * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    if (l >= L) break;
+    const int Hl = lv.h[l], Wl = lv.w[l];
+    const float* vl = vb + (int64_t)lv.start[l] * 256;
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+      const float ox = offp[(l * 4 + pt) * 2 + 0];
+      const float oy = offp[(l * 4 + pt) * 2 + 1];
+      const float aw = logit[l * 4 + pt] / den;
+      const float locx = ref_x + ox / (float)Wl;
+      const float locy = ref_y + oy / (float)Hl;
+      const float gx = 2.f * locx - 1.f, gy = 2.f * locy - 1.f;
+      const float ix = ((gx + 1.f) * (float)Wl - 1.f) * 0.5f;
+      const float iy = ((gy + 1.f) * (float)Hl - 1.f) * 0.5f;
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int x0 = (int)fx, y0 = (int)fy;
+      const float tx = ix - fx, ty = iy - fy;
+      const float w_nw = (1.f - tx) * (1.f - ty), w_ne = tx * (1.f - ty);
+      const float w_sw = (1.f - tx) * ty, w_se = tx * ty;
+      const bool xin0 = x0 >= 0 && x0 < Wl, xin1 = x0 + 1 >= 0 && x0 + 1 < Wl;
+      const bool yin0 = y0 >= 0 && y0 < Hl, yin1 = y0 + 1 >= 0 && y0 + 1 < Hl;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v_nw = (xin0 && yin0) ? ld4(vl + ((int64_t)y0 * Wl + x0) * 256) : z;
+      const float4 v_ne = (xin1 && yin0) ? ld4(vl + ((int64_t)y0 * Wl + x0 + 1) * 256) : z;
+      const float4 v_sw = (xin0 && yin1) ? ld4(vl + ((int64_t)(y0 + 1) * Wl + x0) * 256) : z;
+      const float4 v_se = (xin1 && yin1) ? ld4(vl + ((int64_t)(y0 + 1) * Wl + x0 + 1) * 256) : z;
+      float4 s;
+      s.x = ((v_nw.x * w_nw + v_ne.x * w_ne) + v_sw.x * w_sw) + v_se.x * w_se;
+      s.y = ((v_nw.y * w_nw + v_ne.y * w_ne) + v_sw.y * w_sw) + v_se.y * w_se;
+      s.z = ((v_nw.z * w_nw + v_ne.z * w_ne) + v_sw.z * w_sw) + v_se.z * w_se;
+      s.w = ((v_nw.w * w_nw + v_ne.w * w_ne) + v_sw.w * w_sw) + v_se.w * w_se;
+      acc.x += s.x * aw; acc.y += s.y * aw; acc.z += s.z * aw; acc.w += s.w * aw;
+    }
+  }
+  st4(out + ((int64_t)b * lv.N + n) * 256 + head * 32 + c4 * 4, acc);
+}
+
+extern "C" int pn_msda_f32(const float* value, const float* offaw, float* out, int B, int L,
+                           const int32_t* level_h, const int32_t* level_w, void* stream) {
+  if (!value || !offaw || !out || B <= 0 || L <= 0 || L > 4 || !level_h || !level_w)
+    return PN_BAD_ARG;
+  MsdaLevels lv{};
+  lv.L = L;
+  int n = 0;
+  for (int l = 0; l < L; ++l) {
+    if (level_h[l] <= 0 || level_w[l] <= 0) return PN_BAD_ARG;
+    lv.h[l] = level_h[l]; lv.w[l] = level_w[l]; lv.start[l] = n;
+    n += level_h[l] * level_w[l];
+  }
+  lv.N = n;
+  hipLaunchKernelGGL(k_msda, dim3(pn_cdiv(n, 4), B), dim3(256), 0, (hipStream_t)stream, value,
+                     offaw, out, lv);
+  return PN_LAUNCH_CHECK();
+}

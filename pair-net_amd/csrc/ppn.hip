@@ -1,0 +1,211 @@
+// Pair Proposal Network kernels: Matrix Learner edge layers, top-k pair selection,
+// row gathers.  (The 64->64 middle layer of the Matrix Learner is the implicit-GEMM
+// convolution in gemm.hip.)
+#include "common.h"
+
+// ---- first layer: 1 -> C (C == 64), 7x7, pad 3, ReLU; out channel-last ----
+__global__ __launch_bounds__(256) void k_ml_first(const float* __restrict__ in,
+                                                  const float* __restrict__ w1,
+                                                  const float* __restrict__ b1,
+                                                  float* __restrict__ out, int S) {
+  __shared__ float ws[49 * 64];
+  const int tid = threadIdx.x, c = tid & 63, pl = tid >> 6;
+  for (int e = tid; e < 49 * 64; e += 256) ws[(e % 49) * 64 + (e / 49)] = w1[e];  // [tap][c]
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int pix = blockIdx.x * 4 + pl;
+  if (pix >= S * S) return;
+  const int y = pix / S, x = pix - y * S;
+  const float* ib = in + (int64_t)b * S * S;
+  float acc = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky) {
+    const int yy = y + ky - 3;
+    if (yy < 0 || yy >= S) continue;
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+      const int xx = x + kx - 3;
+      if (xx < 0 || xx >= S) continue;
+      acc += ib[yy * S + xx] * ws[(ky * 7 + kx) * 64 + c];
+    }
+  }
+  out[((int64_t)b * S * S + pix) * 64 + c] = fmaxf(acc + b1[c], 0.f);
+}
+
+extern "C" int pn_mlearner_first_f32(const float* in, const float* w1, const float* b1,
+                                     float* out, int B, int S, int C, void* stream) {
+  if (!in || !w1 || !b1 || !out || C != 64 || B <= 0 || S <= 0) return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_ml_first, dim3(pn_cdiv((int64_t)S * S, 4), B), dim3(256), 0,
+                     (hipStream_t)stream, in, w1, b1, out, S);
+  return PN_LAUNCH_CHECK();
+}
+
+// ---- last layer: C -> 1 (C == 64); one wave per pixel, lane = input channel ----
+__global__ __launch_bounds__(256) void k_ml_last(const float* __restrict__ in,
+                                                 const float* __restrict__ w3,
+                                                 const float* __restrict__ b3,
+                                                 float* __restrict__ out, int S) {
+  const int lane = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int pix = blockIdx.x * 4 + pl;
+  if (pix >= S * S) return;
+  const int y = pix / S, x = pix - y * S;
+  const float* ib = in + (int64_t)b * S * S * 64;
+  float acc = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky) {
+    const int yy = y + ky - 3;
+    if (yy < 0 || yy >= S) continue;
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+      const int xx = x + kx - 3;
+      if (xx < 0 || xx >= S) continue;
+      acc += ib[((int64_t)yy * S + xx) * 64 + lane] * w3[(ky * 7 + kx) * 64 + lane];
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[(int64_t)b * S * S + pix] = acc + b3[0];
+}
+
+extern "C" int pn_mlearner_last_f32(const float* in, const float* w3, const float* b3,
+                                    float* out, int B, int S, int C, void* stream) {
+  if (!in || !w3 || !b3 || !out || C != 64 || B <= 0 || S <= 0) return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_ml_last, dim3(pn_cdiv((int64_t)S * S, 4), B), dim3(256), 0,
+                     (hipStream_t)stream, in, w3, b3, out, S);
+  return PN_LAUNCH_CHECK();
+}
+
+// ---- top-k pair selection ------------------------------------------------------
+// 48-bit unique keys: (order-preserving float bits << 16) | (0xFFFF - flat index), so
+// "larger key" == larger score, ties -> smaller index.  MSB-first 8-bit radix select
+// (LDS histogram + one-wave suffix scan per pass) finds the key of the k-th largest;
+// the k survivors are compacted and bitonic-sorted descending in LDS.
+__device__ __forceinline__ unsigned long long topk_key(float v, int idx) {
+  uint32_t u = __float_as_uint(v + 0.0f);  // -0 -> +0
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 16) | (unsigned long long)(0xFFFF - idx);
+}
+
+__global__ __launch_bounds__(1024) void k_topk_pairs(const float* __restrict__ scores,
+                                                     int64_t* __restrict__ idx_out,
+                                                     int64_t* __restrict__ sub_out,
+                                                     int64_t* __restrict__ obj_out, int Q, int k) {
+  __shared__ int hist[256];
+  __shared__ unsigned long long sel[256];
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_remaining, s_count;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = Q * Q;
+  const float* sc = scores + (int64_t)blockIdx.x * n;
+  if (tid == 0) { s_prefix = 0ull; s_remaining = k; s_count = 0; }
+  if (tid < 256) sel[tid] = 0ull;
+  __syncthreads();
+  for (int pass = 0; pass < 6; ++pass) {
+    const int shift = 40 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned long long prefix = s_prefix;
+    for (int i = tid; i < n; i += 1024) {
+      const unsigned long long key = topk_key(sc[i], i);
+      if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8)))
+        atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int remaining = s_remaining;
+      const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1];
+      const int h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+      const int s = (h0 + h1) + (h2 + h3);
+      int suf = s;  // inclusive suffix sum over lanes >= this one
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_down(suf, o, 64);
+        if (lane + o < 64) suf += t;
+      }
+      const int above = suf - s;
+      if (above < remaining && remaining <= suf) {
+        int cum = above, digit, hb[4] = {h0, h1, h2, h3};
+        digit = 4 * lane;
+#pragma unroll
+        for (int bq = 3; bq >= 0; --bq) {
+          if (cum + hb[bq] >= remaining) { digit = 4 * lane + bq; break; }
+          cum += hb[bq];
+        }
+        s_prefix = prefix | ((unsigned long long)digit << shift);
+        s_remaining = remaining - cum;
+      }
+    }
+    __syncthreads();
+  }
+  const unsigned long long kth = s_prefix;
+  for (int i = tid; i < n; i += 1024) {
+    const unsigned long long key = topk_key(sc[i], i);
+    if (key >= kth) {
+      const int slot = atomicAdd(&s_count, 1);
+      if (slot < 256) sel[slot] = key;
+    }
+  }
+  __syncthreads();
+  // bitonic sort of 256 keys, descending (zero padding sinks to the end)
+  for (int size = 2; size <= 256; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (tid < 128) {
+        const int lo = ((tid / stride) * stride * 2) + (tid % stride);
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = sel[lo], b = sel[hi];
+        if ((a < b) == desc) { sel[lo] = b; sel[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid < k) {
+    const int64_t idx = 0xFFFF - (int)(sel[tid] & 0xFFFFull);
+    const int64_t o = (int64_t)blockIdx.x * k + tid;
+    idx_out[o] = idx;
+    sub_out[o] = idx / Q;
+    obj_out[o] = idx % Q;
+  }
+}
+
+extern "C" int pn_topk_pairs(const float* scores, int64_t* idx, int64_t* sub, int64_t* obj,
+                             int B, int Q, int k, void* stream) {
+  if (!scores || !idx || !sub || !obj || B <= 0 || Q <= 0) return PN_BAD_ARG;
+  if ((int64_t)Q * Q > 65536 || k <= 0 || k > 256 || k > Q * Q) return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_topk_pairs, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores, idx,
+                     sub, obj, Q, k);
+  return PN_LAUNCH_CHECK();
+}
+
+// ---- row gather ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ in,
+                                                     const int64_t* __restrict__ index,
+                                                     float* __restrict__ out, int rows_in,
+                                                     int rows_out, int64_t len, int vec) {
+  const int r = blockIdx.y, b = blockIdx.z;
+  int64_t src = index[(int64_t)b * rows_out + r];
+  if (src < 0) src = 0;
+  if (src >= rows_in) src = rows_in - 1;
+  const float* ip = in + ((int64_t)b * rows_in + src) * len;
+  float* op = out + ((int64_t)b * rows_out + r) * len;
+  if (vec) {
+    const int64_t n4 = len >> 2;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256)
+      st4(op + 4 * e, ld4(ip + 4 * e));
+  } else {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < len; e += (int64_t)gridDim.x * 256)
+      op[e] = ip[e];
+  }
+}
+
+extern "C" int pn_gather_rows_f32(const float* in, const int64_t* index, float* out, int B,
+                                  int rows_in, int rows_out, int64_t len, void* stream) {
+  if (!in || !index || !out || B <= 0 || rows_in <= 0 || rows_out <= 0 || len <= 0)
+    return PN_BAD_ARG;
+  const int vec = (len % 4 == 0) && (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+  int gx = pn_cdiv(vec ? len / 4 : len, 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(k_gather_rows, dim3(gx, rows_out, B), dim3(256), 0, (hipStream_t)stream,
+                     in, index, out, rows_in, rows_out, len, vec);
+  return PN_LAUNCH_CHECK();
+}

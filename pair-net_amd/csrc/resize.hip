@@ -1,0 +1,132 @@
+// Sine positional encoding and bilinear resampling (align_corners=False), HBM-bound.
+#include "common.h"
+
+// SinePositionalEncoding(num_feats = C/2, normalize=True, scale=2pi, eps=1e-6)
+// for an all-valid mask: channels [pos_y | pos_x], each
+// interleaved sin (even) / cos (odd) over dim_t[i] = T^(2*(i/2)/num_feats).
+__global__ void k_sine_pe(float* __restrict__ out, const float* __restrict__ add, int h,
+                          int w, int C, float temperature) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)h * w * C;
+  if (e >= total) return;
+  const int c = (int)(e % C);
+  const int pix = (int)(e / C);
+  const int y = pix / w, x = pix - y * w;
+  const int nf = C / 2;
+  const int i = (c < nf) ? c : c - nf;
+  const float scale = 6.283185307179586f;
+  const float embed = (c < nf) ? ((float)(y + 1) / ((float)h + 1e-6f)) * scale
+                               : ((float)(x + 1) / ((float)w + 1e-6f)) * scale;
+  const float dim_t = powf(temperature, (float)(2 * (i / 2)) / (float)nf);
+  const float v = embed / dim_t;
+  float r = (i & 1) ? cosf(v) : sinf(v);
+  if (add) r += add[c];
+  out[e] = r;
+}
+
+extern "C" int pn_sine_pe_f32(float* out, const float* add, int h, int w, int C,
+                              float temperature, void* stream) {
+  if (!out || h <= 0 || w <= 0 || C <= 0 || (C & 3)) return PN_BAD_ARG;
+  const int64_t total = (int64_t)h * w * C;
+  hipLaunchKernelGGL(k_sine_pe, dim3(pn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     out, add, h, w, C, temperature);
+  return PN_LAUNCH_CHECK();
+}
+
+// ATen's upsample_bilinear2d source index (align_corners=False, no scale factor):
+//   src = max(scale * (dst + 0.5) - 0.5, 0), scale = in / out;
+//   i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1.
+struct Tap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Tap make_tap(int dst, int in, int outn) {
+  const float scale = (float)in / (float)outn;
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  Tap t;
+  t.i0 = (int)src;
+  if (t.i0 > in - 1) t.i0 = in - 1;
+  t.i1 = t.i0 + ((t.i0 < in - 1) ? 1 : 0);
+  t.l1 = src - (float)t.i0;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+
+__global__ __launch_bounds__(256) void k_bilinear_nhwc(const float* __restrict__ in,
+                                                       float* __restrict__ out, int hi, int wi,
+                                                       int ho, int wo, int C4, int accumulate,
+                                                       int64_t ibs, int64_t obs) {
+  // thread = (output pixel, float4 channel group)
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per_img = (int64_t)ho * wo * C4;
+  if (e >= per_img) return;
+  const int b = blockIdx.y;
+  const int c4 = (int)(e % C4);
+  const int pix = (int)(e / C4);
+  const int oy = pix / wo, ox = pix - oy * wo;
+  const Tap ty = make_tap(oy, hi, ho), tx = make_tap(ox, wi, wo);
+  const float* ib = in + (int64_t)b * ibs + c4 * 4;
+  const int64_t rs = (int64_t)wi * C4 * 4, cs = (int64_t)C4 * 4;
+  const float4 v00 = ld4(ib + ty.i0 * rs + tx.i0 * cs), v01 = ld4(ib + ty.i0 * rs + tx.i1 * cs);
+  const float4 v10 = ld4(ib + ty.i1 * rs + tx.i0 * cs), v11 = ld4(ib + ty.i1 * rs + tx.i1 * cs);
+  float4 r;
+  r.x = ty.l0 * (tx.l0 * v00.x + tx.l1 * v01.x) + ty.l1 * (tx.l0 * v10.x + tx.l1 * v11.x);
+  r.y = ty.l0 * (tx.l0 * v00.y + tx.l1 * v01.y) + ty.l1 * (tx.l0 * v10.y + tx.l1 * v11.y);
+  r.z = ty.l0 * (tx.l0 * v00.z + tx.l1 * v01.z) + ty.l1 * (tx.l0 * v10.z + tx.l1 * v11.z);
+  r.w = ty.l0 * (tx.l0 * v00.w + tx.l1 * v01.w) + ty.l1 * (tx.l0 * v10.w + tx.l1 * v11.w);
+  float* o = out + (int64_t)b * obs + (int64_t)pix * C4 * 4 + c4 * 4;
+  if (accumulate) r = add4(ld4(o), r);
+  st4(o, r);
+}
+
+extern "C" int pn_bilinear_nhwc_f32(const float* in, float* out, int B, int hi, int wi, int ho,
+                                    int wo, int C, int accumulate, int64_t in_bstride,
+                                    int64_t out_bstride, void* stream) {
+  if (!in || !out || B <= 0 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0 || C <= 0 || (C & 3))
+    return PN_BAD_ARG;
+  if ((in_bstride | out_bstride) & 3) return PN_BAD_ARG;
+  const int64_t per_img = (int64_t)ho * wo * (C / 4);
+  hipLaunchKernelGGL(k_bilinear_nhwc, dim3(pn_cdiv(per_img, 256), B), dim3(256), 0,
+                     (hipStream_t)stream, in, out, hi, wi, ho, wo, C / 4, accumulate, in_bstride,
+                     out_bstride);
+  return PN_LAUNCH_CHECK();
+}
+
+template <bool GT0>
+__global__ __launch_bounds__(256) void k_bilinear_planar(const float* __restrict__ in,
+                                                         void* __restrict__ outv, int hi, int wi,
+                                                         int ho, int wo) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per_plane = (int64_t)ho * wo;
+  if (e >= per_plane) return;
+  const int64_t pl = blockIdx.y;
+  const int oy = (int)(e / wo), ox = (int)(e - (int64_t)oy * wo);
+  const Tap ty = make_tap(oy, hi, ho), tx = make_tap(ox, wi, wo);
+  const float* ib = in + pl * hi * wi;
+  const float v00 = ib[(int64_t)ty.i0 * wi + tx.i0], v01 = ib[(int64_t)ty.i0 * wi + tx.i1];
+  const float v10 = ib[(int64_t)ty.i1 * wi + tx.i0], v11 = ib[(int64_t)ty.i1 * wi + tx.i1];
+  const float r = ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11);
+  if (GT0) ((uint8_t*)outv)[pl * per_plane + e] = r > 0.f ? 1 : 0;
+  else     ((float*)outv)[pl * per_plane + e] = r;
+}
+
+static int launch_planar(const float* in, void* out, int64_t P, int hi, int wi, int ho, int wo,
+                         bool gt0, void* stream) {
+  if (!in || !out || P <= 0 || P > 65535 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0)
+    return PN_BAD_ARG;
+  dim3 grid(pn_cdiv((int64_t)ho * wo, 256), (unsigned)P);
+  if (gt0)
+    hipLaunchKernelGGL(k_bilinear_planar<true>, grid, dim3(256), 0, (hipStream_t)stream, in, out,
+                       hi, wi, ho, wo);
+  else
+    hipLaunchKernelGGL(k_bilinear_planar<false>, grid, dim3(256), 0, (hipStream_t)stream, in, out,
+                       hi, wi, ho, wo);
+  return PN_LAUNCH_CHECK();
+}
+
+extern "C" int pn_bilinear_planar_f32(const float* in, float* out, int64_t P, int hi, int wi,
+                                      int ho, int wo, void* stream) {
+  return launch_planar(in, out, P, hi, wi, ho, wo, false, stream);
+}
+extern "C" int pn_bilinear_planar_gt0_u8(const float* in, uint8_t* out, int64_t P, int hi, int wi,
+                                         int ho, int wo, void* stream) {
+  return launch_planar(in, out, P, hi, wi, ho, wo, true, stream);
+}

@@ -1,0 +1,162 @@
+"""Detector wrapper and result container: the caller side of the head.
+
+`PSGTr` mirrors pairnet/models/frameworks/psgtr.py:73-88,148-156 (backbone -> head
+-> `Result`), `triplet2Result` :15-51, `Result` the fields of
+pairnet/models/relation_heads/approaches/relation_util.py:20-97 that the PSG
+evaluator reads.  The backbone is SURVEY.md section 8 row a1 / (f)-2: a plain
+PyTorch-ROCm (MIOpen) ResNet-50 with the torchvision/mmdet key layout; it is not
+one of the hand-written kernels.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .config import ConfigDict
+from .head import CrossHead2
+
+
+class Result(object):
+    """Scene-graph result of one image (numpy on the host, like the reference)."""
+
+    FIELDS = ("refine_bboxes", "labels", "formatted_masks", "rel_pair_idxes", "rel_dists",
+              "rel_labels", "pan_results", "masks", "bboxes", "dists", "rels",
+              "refine_scores", "rel_scores", "triplet_scores", "img_shape", "sub_pos",
+              "obj_pos")
+
+    def __init__(self, **fields):
+        for k in self.FIELDS:
+            setattr(self, k, None)
+        for k, v in fields.items():
+            setattr(self, k, v)
+
+    def is_none(self):
+        return all(v is None for v in self.__dict__.values())
+
+    # mmdet's result collection treats results as sequences (relation_util.py:87-97)
+    def __len__(self):
+        return 1
+
+    def __getitem__(self, i):
+        return self
+
+    def __iter__(self):
+        yield self
+
+
+def triplet2Result(triplets, use_mask, eval_mask_rels=False):
+    """8-tuple of `CrossHead2.get_bboxes` -> Result (psgtr.py:15-51)."""
+    if not use_mask:
+        raise NotImplementedError("bbox-only triplets are not on the Pair-Net PSG path")
+    bboxes, labels, rel_pairs, masks, pan_seg, r_scores, r_labels, r_dists = triplets
+    np_ = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else t
+    pan_seg = np_(pan_seg)
+    return Result(refine_bboxes=np_(bboxes), labels=np_(labels),
+                  formatted_masks=dict(pan_results=pan_seg), rel_pair_idxes=np_(rel_pairs),
+                  rel_dists=np_(r_dists), rel_labels=np_(r_labels), pan_results=pan_seg,
+                  masks=np_(masks))
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, cin, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = None
+        if downsample:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(cin, planes * 4, 1, stride=stride, bias=False),
+                nn.BatchNorm2d(planes * 4))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = F.relu(self.bn2(self.conv2(x)))
+        return F.relu(self.bn3(self.conv3(x)) + idt)
+
+
+class ResNet50(nn.Module):
+    """depth 50, style='pytorch', out_indices (0,1,2,3), frozen BN
+    (configs/mask2former/pairnet.py:9-19)."""
+
+    def __init__(self, **unused):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        cin = 64
+        for i, (planes, blocks) in enumerate(((64, 3), (128, 4), (256, 6), (512, 3))):
+            layers = []
+            for b in range(blocks):
+                layers.append(_Bottleneck(cin, planes, 2 if (b == 0 and i > 0) else 1, b == 0))
+                cin = planes * 4
+            setattr(self, "layer%d" % (i + 1), nn.Sequential(*layers))
+        self.eval()
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    @torch.no_grad()
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)
+        outs = []
+        for i in range(4):
+            x = getattr(self, "layer%d" % (i + 1))(x)
+            outs.append(x.contiguous())
+        return tuple(outs)
+
+
+class PSGTr:
+    """`PSGTr(SingleStageDetector)` of the reference, inference half."""
+
+    def __init__(self, backbone, bbox_head, train_cfg=None, test_cfg=None, pretrained=None,
+                 init_cfg=None, neck=None):
+        assert neck is None
+        backbone = ConfigDict(backbone)
+        if backbone.get("type", "ResNet") != "ResNet" or backbone.get("depth", 50) != 50:
+            raise NotImplementedError("only the ResNet-50 backbone of pairnet.py is built")
+        self.backbone = ResNet50()
+        head_cfg = dict(bbox_head)
+        if head_cfg.pop("type", "CrossHead2") != "CrossHead2":
+            raise NotImplementedError("bbox_head.type must be CrossHead2")
+        self.bbox_head = CrossHead2(**head_cfg, train_cfg=None,
+                                    test_cfg=test_cfg or dict(max_per_img=100))
+        self.num_classes = self.bbox_head.num_classes
+
+    def to(self, device):
+        self.backbone.to(device)
+        self.bbox_head.to(device)
+        return self
+
+    def eval(self):
+        return self
+
+    def extract_feat(self, img):
+        return self.backbone(img)
+
+    @torch.no_grad()
+    def simple_test(self, img, img_metas, rescale=False):
+        """psgtr.py:148-156."""
+        feat = self.extract_feat(img)
+        results_list = self.bbox_head.simple_test(feat, img_metas, rescale=rescale)
+        return [triplet2Result(t, self.bbox_head.use_mask) for t in results_list]
+
+    def forward(self, img=None, img_metas=None, return_loss=False, rescale=False, **kw):
+        """mmdet's `model(return_loss=False, rescale=True, img=[..], img_metas=[..])`."""
+        if return_loss:
+            raise NotImplementedError("inference path only")
+        if isinstance(img, (list, tuple)):
+            img, img_metas = img[0], img_metas[0]
+        return self.simple_test(img, img_metas, rescale=rescale)
+
+    __call__ = forward
+
+
+def build_detector(cfg, train_cfg=None, test_cfg=None):
+    """`build_detector(cfg.model)` (tools/test.py:235-236)."""
+    cfg = dict(cfg)
+    if cfg.pop("type", "PSGTr") != "PSGTr":
+        raise NotImplementedError("only type='PSGTr'")
+    cfg.pop("train_cfg", None)
+    return PSGTr(cfg["backbone"], cfg["bbox_head"], test_cfg=cfg.get("test_cfg", test_cfg))

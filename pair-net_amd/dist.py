@@ -1,0 +1,65 @@
+"""Multi-GPU: shard images over ranks, all-gather the predicted triplets.
+
+The reference's only parallelism is data parallel inference: `DistributedSampler(
+shuffle=False)` hands rank r the images r, r+W, ... and mmdet's
+`collect_results_gpu` pickles whole `Result` objects (masks included, ~61 MB/img)
+through two NCCL all_gathers (tools/test.py:256-267).
+Here images are independent too (no cross-image op in pairnet_head.py:260-417), so
+ranks never talk on the data path; the single collective gathers a compact
+fixed-shape triplet record per image (~27 KB) with one RCCL all-gather over xGMI
+(`torch.distributed` backend "nccl" on ROCm; "gloo" in the CPU tests).  Masks and
+panoptic maps stay on the producing GPU.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(num_images, rank, world_size):
+    """Indices of the images rank `rank` processes (DistributedSampler(shuffle=False)
+    without padding): rank, rank + W, rank + 2W, ..."""
+    return list(range(rank, num_images, world_size))
+
+
+def triplet_record_len(num_rel_query, num_relations):
+    """float32 words per image: labels(2R) | rel_dists(R*(C+1)) | sub_pos(R) | obj_pos(R)."""
+    return 2 * num_rel_query + num_rel_query * (num_relations + 1) + 2 * num_rel_query
+
+
+def pack_triplets(labels, rel_dists, sub_pos, obj_pos):
+    """Per-image tensors -> one float32 record (indices < 2^24 are exact in fp32)."""
+    return torch.cat([labels.to(torch.float32).flatten(), rel_dists.flatten().to(torch.float32),
+                      sub_pos.to(torch.float32).flatten(), obj_pos.to(torch.float32).flatten()])
+
+
+def unpack_triplets(rec, num_rel_query, num_relations):
+    R, C = num_rel_query, num_relations + 1
+    o = 0
+    labels = rec[o:o + 2 * R].to(torch.int64); o += 2 * R
+    rel_dists = rec[o:o + R * C].view(R, C); o += R * C
+    sub_pos = rec[o:o + R].to(torch.int64); o += R
+    obj_pos = rec[o:o + R].to(torch.int64)
+    return dict(labels=labels, rel_dists=rel_dists, sub_pos=sub_pos, obj_pos=obj_pos,
+                rel_pairs=torch.arange(2 * R, dtype=torch.int32).reshape(2, -1).T)
+
+
+def all_gather_triplets(local_records, num_images, group=None):
+    """local_records: [n_local, L] float32 (rows in the order of shard_indices).
+    Returns [num_images, L] in dataset order on every rank.  Ranks with fewer images
+    pad to the per-rank maximum, like collect_results_gpu pads to the longest pickle."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_records[:num_images]
+    W, rank = dist.get_world_size(group), dist.get_rank(group)
+    per_rank = (num_images + W - 1) // W
+    L = local_records.shape[1]
+    send = local_records.new_zeros((per_rank, L))
+    send[:local_records.shape[0]] = local_records
+    recv = local_records.new_empty((W * per_rank, L))
+    try:
+        dist.all_gather_into_tensor(recv, send, group=group)
+    except (RuntimeError, NotImplementedError):  # older gloo: list form
+        parts = [torch.empty_like(send) for _ in range(W)]
+        dist.all_gather(parts, send, group=group)
+        recv = torch.cat(parts, 0)
+    # rank r's j-th row is image r + j*W: interleave (zip over ranks) and truncate
+    out = recv.view(W, per_rank, L).transpose(0, 1).reshape(W * per_rank, L)
+    return out[:num_images].contiguous()

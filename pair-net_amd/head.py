@@ -1,0 +1,656 @@
+"""CrossHead2 on MI355X: the Pair-Net head behind the reference's own interface.
+
+Mirrors pairnet/models/relation_heads/pairnet_head.py (`CrossHead2`): constructor
+keywords (:24-55), `forward(feats, img_metas)` (:260-417), `forward_head` (:216-258),
+`get_bboxes` (:760-786), `simple_test_bboxes` (:926-930) and the state-dict key names
+(SURVEY.md 8a N7), so `configs/mask2former/pairnet.py` and a reference checkpoint
+drop in.  All arithmetic runs in the hand-written gfx950 kernels of
+libpairnet_hip.so through `hip.py`; torch supplies device buffers, views, memcpys
+and the stream.  There is no CPU path: every entry raises without the library/GPU.
+
+Device data layout (fp32, batch-first, channel-last):
+  tokens X        [B, N0+N1+N2, 256]   encoder tokens, levels low->high resolution
+  mask feature    [B, H2*W2, 256]      pixel-major, so mask logits are an NT GEMM
+  queries         [B*Q, 256]
+The reference's seq-first (Q,B,C) / NCHW layouts exist only at the API boundary.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import hip
+from .config import ConfigDict
+
+INSTANCE_OFFSET = 1000
+
+
+def _decoder_param_shapes(prefix, num_layers, ffn_dim, out):
+    for i in range(num_layers):
+        p = "%s.layers.%d." % (prefix, i)
+        for a in (0, 1):
+            out[p + "attentions.%d.attn.in_proj_weight" % a] = (768, 256)
+            out[p + "attentions.%d.attn.in_proj_bias" % a] = (768,)
+            out[p + "attentions.%d.attn.out_proj.weight" % a] = (256, 256)
+            out[p + "attentions.%d.attn.out_proj.bias" % a] = (256,)
+        out[p + "ffns.0.layers.0.0.weight"] = (ffn_dim, 256)
+        out[p + "ffns.0.layers.0.0.bias"] = (ffn_dim,)
+        out[p + "ffns.0.layers.1.weight"] = (256, ffn_dim)
+        out[p + "ffns.0.layers.1.bias"] = (256,)
+        for n in range(3):
+            out[p + "norms.%d.weight" % n] = (256,)
+            out[p + "norms.%d.bias" % n] = (256,)
+    out[prefix + ".post_norm.weight"] = (256,)
+    out[prefix + ".post_norm.bias"] = (256,)
+
+
+class CrossHead2:
+    """Drop-in for the reference's `CrossHead2` (inference half)."""
+
+    def __init__(self, num_classes, in_channels, num_relations, num_obj_query=100,
+                 num_rel_query=100, mapper="conv_tiny", use_mask=True, pixel_decoder=None,
+                 transformer_decoder=None, feat_channels=256, out_channels=256,
+                 num_transformer_feat_level=3, embed_dims=256, relation_decoder=None,
+                 enforce_decoder_input_project=False, n_heads=8,
+                 positional_encoding=dict(type="SinePositionalEncoding", num_feats=128,
+                                          normalize=True),
+                 rel_cls_loss=None, subobj_cls_loss=None, importance_match_loss=None,
+                 loss_cls=None, loss_mask=None, loss_dice=None, train_cfg=None,
+                 test_cfg=dict(max_per_img=100), init_cfg=None, **kwargs):
+        pixel_decoder = ConfigDict(pixel_decoder)
+        transformer_decoder = ConfigDict(transformer_decoder)
+        relation_decoder = ConfigDict(relation_decoder)
+        if mapper != "conv_tiny":
+            raise NotImplementedError("only mapper='conv_tiny' (configs/mask2former/pairnet.py:26)")
+        if train_cfg:
+            raise NotImplementedError("inference path only (SURVEY.md section 8)")
+        # the same checks the reference makes (pairnet_head.py:72-87)
+        assert "num_feats" in positional_encoding
+        assert positional_encoding["num_feats"] * 2 == embed_dims
+        enc_attn = pixel_decoder.encoder.transformerlayers.attn_cfgs
+        assert enc_attn.num_levels == num_transformer_feat_level
+        if (feat_channels, out_channels, embed_dims, n_heads) != (256, 256, 256, 8):
+            raise NotImplementedError("kernels are built for 256 channels, 8 heads")
+        if transformer_decoder.transformerlayers.attn_cfgs.num_heads != 8 or enforce_decoder_input_project:
+            raise NotImplementedError("8-head decoder without input projection only")
+        if (enc_attn.num_heads, enc_attn.num_points, enc_attn.embed_dims) != (8, 4, 256):
+            raise NotImplementedError("MSDeformAttn kernel: 8 heads, 4 points")
+        self.num_classes = num_classes
+        self.num_relations = num_relations
+        self.num_obj_query = self.num_queries = num_obj_query
+        self.num_rel_query = num_rel_query
+        self.use_mask = use_mask
+        self.n_heads = self.num_heads = n_heads
+        self.embed_dims = embed_dims
+        self.in_channels = list(in_channels)
+        self.num_transformer_feat_level = num_transformer_feat_level
+        self.num_enc_layers = pixel_decoder.encoder.num_layers
+        self.enc_ffn = pixel_decoder.encoder.transformerlayers.ffn_cfgs.feedforward_channels
+        self.gn_groups = pixel_decoder.norm_cfg.num_groups
+        self.num_dec_layers = transformer_decoder.num_layers
+        self.dec_ffn = transformer_decoder.transformerlayers.ffn_cfgs.feedforward_channels
+        self.num_rel_layers = relation_decoder.num_layers
+        self.rel_ffn = relation_decoder.transformerlayers.ffn_cfgs.feedforward_channels
+        self.test_cfg, self.train_cfg = test_cfg, train_cfg
+        assert len(self.in_channels) == 4 and num_transformer_feat_level == 3
+        assert num_obj_query <= 256 and num_rel_query <= 128
+        self._params = OrderedDict(
+            (k, torch.zeros(s)) for k, s in self.param_shapes().items())
+        self.device = None
+        self.w = None
+        self._plans = {}
+        self.init_weights()
+
+    # ------------------------------------------------------------------ params
+    def param_shapes(self):
+        """Reference state-dict names -> shapes."""
+        s = OrderedDict()
+        Q, R = self.num_obj_query, self.num_rel_query
+        _decoder_param_shapes("relation_decoder", self.num_rel_layers, self.rel_ffn, s)
+        s["rel_query_embed.weight"] = (R, 256)
+        s["rel_query_embed2.weight"] = (2 * R, 256)
+        s["rel_query_embed3.weight"] = (2 * R, 256)  # dead weight (Appendix B)
+        s["rel_query_feat.weight"] = (R, 256)
+        for i, (ci, co) in enumerate(((1, 64), (64, 64), (64, 1))):
+            s["update_importance.conv_layers.%d.0.weight" % i] = (co, ci, 7, 7)
+            s["update_importance.conv_layers.%d.0.bias" % i] = (co,)
+        pd = "pixel_decoder."
+        for i in range(3):
+            cin = self.in_channels[3 - i]
+            s[pd + "input_convs.%d.conv.weight" % i] = (256, cin, 1, 1)
+            s[pd + "input_convs.%d.conv.bias" % i] = (256,)
+            s[pd + "input_convs.%d.gn.weight" % i] = (256,)
+            s[pd + "input_convs.%d.gn.bias" % i] = (256,)
+        for i in range(self.num_enc_layers):
+            p = pd + "encoder.layers.%d." % i
+            for name, n in (("sampling_offsets", 192), ("attention_weights", 96),
+                            ("value_proj", 256), ("output_proj", 256)):
+                s[p + "attentions.0.%s.weight" % name] = (n, 256)
+                s[p + "attentions.0.%s.bias" % name] = (n,)
+            s[p + "ffns.0.layers.0.0.weight"] = (self.enc_ffn, 256)
+            s[p + "ffns.0.layers.0.0.bias"] = (self.enc_ffn,)
+            s[p + "ffns.0.layers.1.weight"] = (256, self.enc_ffn)
+            s[p + "ffns.0.layers.1.bias"] = (256,)
+            for n in range(2):
+                s[p + "norms.%d.weight" % n] = (256,)
+                s[p + "norms.%d.bias" % n] = (256,)
+        s[pd + "level_encoding.weight"] = (3, 256)
+        s[pd + "lateral_convs.0.conv.weight"] = (256, self.in_channels[0], 1, 1)
+        s[pd + "lateral_convs.0.gn.weight"] = (256,)
+        s[pd + "lateral_convs.0.gn.bias"] = (256,)
+        s[pd + "output_convs.0.conv.weight"] = (256, 256, 3, 3)
+        s[pd + "output_convs.0.gn.weight"] = (256,)
+        s[pd + "output_convs.0.gn.bias"] = (256,)
+        s[pd + "mask_feature.weight"] = (256, 256, 1, 1)
+        s[pd + "mask_feature.bias"] = (256,)
+        _decoder_param_shapes("transformer_decoder", self.num_dec_layers, self.dec_ffn, s)
+        s["query_embed.weight"] = (Q, 256)
+        s["query_feat.weight"] = (Q, 256)
+        s["level_embed.weight"] = (3, 256)
+        s["cls_embed.weight"] = (self.num_classes + 1, 256)
+        s["cls_embed.bias"] = (self.num_classes + 1,)
+        for mlp in ("mask_embed", "sub_query_update", "obj_query_update"):
+            for j in (0, 2, 4):
+                s["%s.%d.weight" % (mlp, j)] = (256, 256)
+                s["%s.%d.bias" % (mlp, j)] = (256,)
+        s["rel_cls_embed.weight"] = (self.num_relations, 256)
+        s["rel_cls_embed.bias"] = (self.num_relations,)
+        return s
+
+    def init_weights(self, seed=0):
+        """Random init with the distributions the reference ends up with
+        (torch layer defaults, then pairnet_head.py:177-193 / mmdet pixel-decoder
+        init): not the reference's RNG stream, the same families."""
+        g = torch.Generator().manual_seed(seed)
+        U = lambda shape, b: (torch.rand(shape, generator=g) * 2 - 1) * b
+        N = lambda shape, std: torch.randn(shape, generator=g) * std
+        for k, p in self._params.items():
+            shape = tuple(p.shape)
+            leaf = k.rsplit(".", 1)[-1]
+            in_decoder = k.startswith(("transformer_decoder.", "relation_decoder.",
+                                       "pixel_decoder.encoder."))
+            if ".norms." in k or ".gn." in k or "post_norm" in k:
+                v = torch.ones(shape) if leaf == "weight" else torch.zeros(shape)
+            elif len(shape) == 1:
+                wshape = self._params[k[:-len("bias")] + "weight"].shape
+                fan_in = 1
+                for d in wshape[1:]:
+                    fan_in *= d
+                v = torch.zeros(shape) if ("in_proj" in k or "out_proj" in k) \
+                    else U(shape, 1.0 / math.sqrt(fan_in))
+            elif in_decoder:  # xavier_normal_ on every matrix
+                fan_out, fan_in = shape[0], shape[1]
+                v = N(shape, math.sqrt(2.0 / (fan_in + fan_out)))
+            elif k.endswith(("query_embed.weight", "query_feat.weight", "query_embed2.weight",
+                             "query_embed3.weight", "level_embed.weight",
+                             "level_encoding.weight")):
+                v = N(shape, 1.0)
+            else:  # Linear / Conv2d default: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                fan_in = 1
+                for d in shape[1:]:
+                    fan_in *= d
+                v = U(shape, 1.0 / math.sqrt(fan_in))
+            p.copy_(v)
+        # MultiScaleDeformableAttention.init_weights: zero weights, directional
+        # grid bias for the offsets, uniform attention
+        thetas = torch.arange(8, dtype=torch.float32) * (2.0 * math.pi / 8)
+        grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(8, 1, 1, 2).repeat(1, 3, 4, 1)
+        for i in range(4):
+            grid[:, :, i, :] *= i + 1
+        for i in range(self.num_enc_layers):
+            p = "pixel_decoder.encoder.layers.%d.attentions.0." % i
+            self._params[p + "sampling_offsets.weight"].zero_()
+            self._params[p + "sampling_offsets.bias"].copy_(grid.reshape(-1))
+            self._params[p + "attention_weights.weight"].zero_()
+            self._params[p + "attention_weights.bias"].zero_()
+            for n in ("value_proj", "output_proj"):
+                self._params[p + n + ".weight"].copy_(U((256, 256), math.sqrt(6.0 / 512)))
+                self._params[p + n + ".bias"].zero_()
+        self.w = None
+
+    def state_dict(self):
+        return OrderedDict((k, v.clone()) for k, v in self._params.items())
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self._params if k not in sd]
+        unexpected = [k for k in sd if k not in self._params]
+        if strict and (missing or unexpected):
+            raise RuntimeError("state_dict mismatch: missing %s unexpected %s"
+                               % (missing[:5], unexpected[:5]))
+        for k, p in self._params.items():
+            if k in sd:
+                if tuple(sd[k].shape) != tuple(p.shape):
+                    raise RuntimeError("shape mismatch for %s: %s vs %s"
+                                       % (k, tuple(sd[k].shape), tuple(p.shape)))
+                p.copy_(sd[k].detach().to(torch.float32).cpu())
+        self.w = None
+        return missing, unexpected
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self.w = None
+        self._plans = {}
+        return self
+
+    def cuda(self, index=0):
+        return self.to("cuda:%d" % index)
+
+    # -------------------------------------------------------------- packing
+    def _pack(self):
+        """Upload parameters in the layouts the kernels read."""
+        if self.device is None or self.device.type != "cuda":
+            raise RuntimeError("CrossHead2 runs on an MI355X only: call .to('cuda:0'); "
+                               "there is no CPU path")
+        hip.lib()
+        dev = self.device
+        w = {k: v.to(dev).contiguous() for k, v in self._params.items()}
+        pd = "pixel_decoder."
+        for i in range(3):
+            k = pd + "input_convs.%d.conv.weight" % i
+            w[k] = w[k].reshape(256, -1)
+        w[pd + "lateral_convs.0.conv.weight"] = w[pd + "lateral_convs.0.conv.weight"].reshape(256, -1)
+        w[pd + "mask_feature.weight"] = w[pd + "mask_feature.weight"].reshape(256, 256)
+        # 3x3 conv: [co][ci][ky][kx] -> [co][(ky*3+kx)*256 + ci]
+        w[pd + "output_convs.0.conv.weight"] = \
+            w[pd + "output_convs.0.conv.weight"].permute(0, 2, 3, 1).reshape(256, -1).contiguous()
+        for i in range(self.num_enc_layers):
+            p = pd + "encoder.layers.%d.attentions.0." % i
+            w[p + "offaw.weight"] = torch.cat([w[p + "sampling_offsets.weight"],
+                                               w[p + "attention_weights.weight"]], 0).contiguous()
+            w[p + "offaw.bias"] = torch.cat([w[p + "sampling_offsets.bias"],
+                                             w[p + "attention_weights.bias"]], 0).contiguous()
+        ml = "update_importance.conv_layers."
+        w[ml + "0.0.weight"] = w[ml + "0.0.weight"].reshape(64, 49).contiguous()
+        w[ml + "1.0.weight"] = w[ml + "1.0.weight"].permute(0, 2, 3, 1).reshape(64, -1).contiguous()
+        w[ml + "2.0.weight"] = w[ml + "2.0.weight"].reshape(64, 49).t().contiguous()
+        self.w = w
+
+    class _Plan:
+        pass
+
+    def _plan(self, B, shapes, hw2):
+        key = (B, tuple(shapes), tuple(hw2))
+        if key in self._plans:
+            return self._plans[key]
+        if self.w is None:
+            self._pack()
+        dev, f32 = self.device, torch.float32
+        E = lambda *s: torch.empty(*s, device=dev, dtype=f32)
+        pl = CrossHead2._Plan()
+        pl.B, pl.shapes, pl.hw2 = B, list(shapes), tuple(hw2)
+        pl.N = [h * w for h, w in shapes]
+        pl.start = [0, pl.N[0], pl.N[0] + pl.N[1]]
+        pl.SN = sum(pl.N)
+        SN, Q, R = pl.SN, self.num_obj_query, self.num_rel_query
+        HW2 = hw2[0] * hw2[1]
+        pl.HW2 = HW2
+        M = B * SN
+        # ---- shape-dependent constants: positional tables ----
+        w = self.w
+        pl.enc_pos = E(SN, 256)
+        pl.dec_kpos = []
+        for l, (h, wd) in enumerate(shapes):
+            hip.sine_pe(pl.enc_pos[pl.start[l]:pl.start[l] + pl.N[l]],
+                        w["pixel_decoder.level_encoding.weight"][l], h, wd)
+            kp = E(pl.N[l], 256)
+            hip.sine_pe(kp, w["level_embed.weight"][l], h, wd)
+            pl.dec_kpos.append(kp)
+        # ---- pixel decoder ----
+        pl.X, pl.X1, pl.Y = E(B, SN, 256), E(B, SN, 256), E(B, SN, 256)
+        pl.V, pl.S = E(B, SN, 256), E(B, SN, 256)
+        pl.offaw = E(B, SN, 288)
+        pl.H = E(M, self.enc_ffn)
+        pl.tmpconv = E(B, max(pl.N), 256)
+        nblk = max(hip.groupnorm_nblk(HW2), hip.groupnorm_nblk(max(pl.N)))
+        pl.gn_part = torch.empty(B * nblk * 32 * 2, device=dev, dtype=torch.float64)
+        pl.T1, pl.T2 = E(B, HW2, 256), E(B, HW2, 256)
+        pl.MF = E(B, HW2, 256)
+        # ---- decoder ----
+        nd = self.num_dec_layers
+        pl.Kp = [E(B, pl.N[i % 3], 256) for i in range(nd)]
+        pl.Vp = [E(B, pl.N[i % 3], 256) for i in range(nd)]
+        BQ = B * Q
+        pl.q, pl.q1, pl.q2, pl.qy = E(BQ, 256), E(BQ, 256), E(BQ, 256), E(BQ, 256)
+        pl.qn, pl.m1, pl.m2, pl.me = E(BQ, 256), E(BQ, 256), E(BQ, 256), E(BQ, 256)
+        pl.Qp, pl.att, pl.Vs = E(BQ, 256), E(BQ, 256), E(BQ, 256)
+        pl.QK = E(BQ, 512)
+        pl.hq = E(BQ, max(self.dec_ffn, self.rel_ffn))
+        pl.MP = E(B, Q, HW2)
+        pl.ML = E(BQ, max(pl.N))
+        pl.bits = torch.empty(BQ * ((max(pl.N) + 31) // 32), device=dev, dtype=torch.int32)
+        pl.rowall = torch.empty(BQ, device=dev, dtype=torch.int32)
+        scr = max(hip.attn_scratch_floats(B, Q, n) for n in pl.N + [Q])
+        scr = max(scr, hip.attn_scratch_floats(B, R, 2 * R), hip.attn_scratch_floats(B, R, R))
+        pl.scr = E(scr)
+        pl.cls = E(B, Q, self.num_classes + 1)
+        # ---- PPN ----
+        pl.s1, pl.s2, pl.sn, pl.on = E(BQ, 256), E(BQ, 256), E(BQ, 256), E(BQ, 256)
+        pl.imp_raw, pl.imp = E(B, Q, Q), E(B, Q, Q)
+        pl.c1, pl.c2 = E(B, Q * Q, 64), E(B, Q * Q, 64)
+        i64 = lambda *s: torch.empty(*s, device=dev, dtype=torch.int64)
+        pl.topk_idx, pl.sub_pos, pl.obj_pos = i64(B, R), i64(B, R), i64(B, R)
+        pl.pair_idx = i64(B, 2 * R)
+        pl.pair = E(B * 2 * R, 256)
+        # ---- relation decoder ----
+        BR = B * R
+        pl.r, pl.r1, pl.r2, pl.ry = E(BR, 256), E(BR, 256), E(BR, 256), E(BR, 256)
+        pl.rQp, pl.ratt, pl.rVs = E(BR, 256), E(BR, 256), E(BR, 256)
+        pl.rQK = E(BR, 512)
+        pl.rh = E(BR, self.rel_ffn)
+        pl.pK, pl.pV = E(B * 2 * R, 256), E(B * 2 * R, 256)
+        pl.rel = E(B, R, self.num_relations)
+        pl.sub_cls, pl.obj_cls = E(B, R, self.num_classes + 1), E(B, R, self.num_classes + 1)
+        pl.sub_seg, pl.obj_seg = E(B, R, HW2), E(B, R, HW2)
+        self._plans[key] = pl
+        return pl
+
+    # ----------------------------------------------------------- sub-graphs
+    def _pixel_decoder(self, feats, pl):
+        """MSDeformAttnPixelDecoder -> pl.X (memories), pl.MF."""
+        w, B, SN = self.w, pl.B, pl.SN
+        pd = "pixel_decoder."
+        for l in range(3):
+            f = feats[3 - l]
+            cin, n = f.shape[1], pl.N[l]
+            hip.gemm(f, w[pd + "input_convs.%d.conv.weight" % l], pl.tmpconv, M=n, N=256, K=cin,
+                     lda=n, ldw=cin, ldc=256, bias=w[pd + "input_convs.%d.conv.bias" % l],
+                     batch=B, sA=cin * n, sC=n * 256, colmajor=True)
+            hip.groupnorm_nhwc(pl.tmpconv, w[pd + "input_convs.%d.gn.weight" % l],
+                               w[pd + "input_convs.%d.gn.bias" % l], pl.X[:, pl.start[l]:],
+                               pl.gn_part, B, n, self.gn_groups, False, n * 256, SN * 256)
+        X2, X12, Y2 = pl.X.view(-1, 256), pl.X1.view(-1, 256), pl.Y.view(-1, 256)
+        for i in range(self.num_enc_layers):
+            p = pd + "encoder.layers.%d." % i
+            a = p + "attentions.0."
+            hip.linear(X2, w[a + "offaw.weight"], w[a + "offaw.bias"], pl.offaw.view(-1, 288),
+                       aadd=pl.enc_pos)
+            hip.linear(X2, w[a + "value_proj.weight"], w[a + "value_proj.bias"], pl.V.view(-1, 256))
+            hip.msda(pl.V, pl.offaw, pl.S, B, pl.shapes)
+            hip.linear(pl.S.view(-1, 256), w[a + "output_proj.weight"], w[a + "output_proj.bias"],
+                       Y2, res=X2)
+            hip.layernorm(Y2, w[p + "norms.0.weight"], w[p + "norms.0.bias"], X12)
+            hip.linear(X12, w[p + "ffns.0.layers.0.0.weight"], w[p + "ffns.0.layers.0.0.bias"],
+                       pl.H, relu=True)
+            hip.linear(pl.H, w[p + "ffns.0.layers.1.weight"], w[p + "ffns.0.layers.1.bias"], Y2,
+                       res=X12)
+            hip.layernorm(Y2, w[p + "norms.1.weight"], w[p + "norms.1.bias"], X2)
+        # FPN level (C2): lateral 1x1 + GN, + bilinear-up(finest memory), 3x3 + GN + ReLU
+        f = feats[0]
+        cin, HW2 = f.shape[1], pl.HW2
+        H2, W2 = pl.hw2
+        hip.gemm(f, w[pd + "lateral_convs.0.conv.weight"], pl.T1, M=HW2, N=256, K=cin, lda=HW2,
+                 ldw=cin, ldc=256, batch=B, sA=cin * HW2, sC=HW2 * 256, colmajor=True)
+        hip.groupnorm_nhwc(pl.T1, w[pd + "lateral_convs.0.gn.weight"],
+                           w[pd + "lateral_convs.0.gn.bias"], pl.T2, pl.gn_part, B, HW2,
+                           self.gn_groups, False, HW2 * 256, HW2 * 256)
+        h2, w2 = pl.shapes[2]
+        hip.bilinear_nhwc(pl.X[:, pl.start[2]:], pl.T2, B, h2, w2, H2, W2, 256, True, SN * 256,
+                          HW2 * 256)
+        hip.conv2d_nhwc(pl.T2, w[pd + "output_convs.0.conv.weight"], None, pl.T1, B, H2, W2, 256,
+                        256, 3, 3, 1, False)
+        hip.groupnorm_nhwc(pl.T1, w[pd + "output_convs.0.gn.weight"],
+                           w[pd + "output_convs.0.gn.bias"], pl.T2, pl.gn_part, B, HW2,
+                           self.gn_groups, True, HW2 * 256, HW2 * 256)
+        hip.linear(pl.T2.view(-1, 256), w[pd + "mask_feature.weight"], w[pd + "mask_feature.bias"],
+                   pl.MF.view(-1, 256))
+
+    def _head_embed(self, q, pl, with_cls):
+        """post_norm -> (cls_embed) -> mask_embed MLP -> mask logits pl.MP [B,Q,H2*W2]
+        (pairnet_head.py:236-243)."""
+        w, B, Q = self.w, pl.B, self.num_obj_query
+        hip.layernorm(q, w["transformer_decoder.post_norm.weight"],
+                      w["transformer_decoder.post_norm.bias"], pl.qn)
+        if with_cls:
+            hip.linear(pl.qn, w["cls_embed.weight"], w["cls_embed.bias"], pl.cls.view(B * Q, -1))
+        hip.linear(pl.qn, w["mask_embed.0.weight"], w["mask_embed.0.bias"], pl.m1, relu=True)
+        hip.linear(pl.m1, w["mask_embed.2.weight"], w["mask_embed.2.bias"], pl.m2, relu=True)
+        hip.linear(pl.m2, w["mask_embed.4.weight"], w["mask_embed.4.bias"], pl.me)
+        hip.gemm(pl.me, pl.MF, pl.MP, M=Q, N=pl.HW2, K=256, lda=256, ldw=256, ldc=pl.HW2,
+                 batch=B, sA=Q * 256, sW=pl.HW2 * 256, sC=Q * pl.HW2)
+
+    def _attn_mask(self, pl, lvl):
+        """bilinear resize of the mask logits to level `lvl`, threshold, all-masked
+        fix (pairnet_head.py:244-256, :300) -> pl.bits / pl.rowall."""
+        BQ = pl.B * self.num_obj_query
+        h, wd = pl.shapes[lvl]
+        hip.bilinear_planar(pl.MP, pl.ML, BQ, pl.hw2[0], pl.hw2[1], h, wd)
+        hip.mask_pack(pl.ML, pl.bits, pl.rowall, BQ, h * wd)
+
+    def _layer(self, pre, x, xpos, x1, x2, y, Qp, QK, Vs, att, hbuf, Kp, Vp, Nk, B, nq, bits,
+               rowall, scr, ffn):
+        """One post-norm (cross_attn, norm, self_attn, norm, ffn, norm) layer
+        (facebook_detr.py:378-432 semantics); x is updated in place."""
+        w = self.w
+        scale = 1.0 / math.sqrt(32.0)
+        a0, a1 = pre + "attentions.0.attn.", pre + "attentions.1.attn."
+        hip.linear(x, w[a0 + "in_proj_weight"][:256], w[a0 + "in_proj_bias"][:256], Qp, aadd=xpos)
+        hip.attention(Qp, 256, Kp, 256, Vp, 256, bits, rowall, att, 256, scr, B, nq, Nk, scale)
+        hip.linear(att, w[a0 + "out_proj.weight"], w[a0 + "out_proj.bias"], y, res=x)
+        hip.layernorm(y, w[pre + "norms.0.weight"], w[pre + "norms.0.bias"], x1)
+        hip.linear(x1, w[a1 + "in_proj_weight"][:512], w[a1 + "in_proj_bias"][:512], QK, aadd=xpos)
+        hip.linear(x1, w[a1 + "in_proj_weight"][512:], w[a1 + "in_proj_bias"][512:], Vs)
+        hip.attention(QK, 512, QK[:, 256:], 512, Vs, 256, None, None, att, 256, scr, B, nq, nq,
+                      scale)
+        hip.linear(att, w[a1 + "out_proj.weight"], w[a1 + "out_proj.bias"], y, res=x1)
+        hip.layernorm(y, w[pre + "norms.1.weight"], w[pre + "norms.1.bias"], x2)
+        hb = hbuf[:, :ffn]
+        hip.linear(x2, w[pre + "ffns.0.layers.0.0.weight"], w[pre + "ffns.0.layers.0.0.bias"], hb,
+                   relu=True)
+        hip.linear(hb, w[pre + "ffns.0.layers.1.weight"], w[pre + "ffns.0.layers.1.bias"], y,
+                   res=x2)
+        hip.layernorm(y, w[pre + "norms.2.weight"], w[pre + "norms.2.bias"], x)
+
+    # --------------------------------------------------------------- forward
+    @torch.no_grad()
+    def forward(self, feats, img_metas):
+        """feats: [C2, C3, C4, C5] NCHW fp32 on the GPU; returns the reference's two
+        dicts (pairnet_head.py:405-417).  Output tensors are views of per-shape
+        buffers that the next forward() of the same shape overwrites."""
+        B = len(img_metas)
+        assert len(feats) == 4 and all(f.shape[0] == B for f in feats)
+        for f, c in zip(feats, self.in_channels):
+            if not f.is_cuda or f.dtype != torch.float32 or f.shape[1] != c or not f.is_contiguous():
+                raise RuntimeError("feats must be contiguous fp32 NCHW device tensors with "
+                                   "channels %s" % self.in_channels)
+        if self.device is None:
+            self.to(feats[0].device)
+        shapes = [tuple(feats[3 - l].shape[-2:]) for l in range(3)]
+        pl = self._plan(B, shapes, tuple(feats[0].shape[-2:]))
+        w, Q, R = self.w, self.num_obj_query, self.num_rel_query
+        self._pixel_decoder(feats, pl)
+        # K / V projections of all decoder layers up front (query-independent)
+        for i in range(self.num_dec_layers):
+            l = i % 3
+            a = "transformer_decoder.layers.%d.attentions.0.attn." % i
+            mem = pl.X[:, pl.start[l]:]
+            common = dict(M=pl.N[l], N=256, K=256, lda=256, ldw=256, ldc=256, batch=B,
+                          sA=pl.SN * 256, sC=pl.N[l] * 256)
+            hip.gemm(mem, w[a + "in_proj_weight"][256:512], pl.Kp[i],
+                     bias=w[a + "in_proj_bias"][256:512], aadd=pl.dec_kpos[l], ldaadd=256,
+                     aadd_rows=pl.N[l], **common)
+            hip.gemm(mem, w[a + "in_proj_weight"][512:], pl.Vp[i],
+                     bias=w[a + "in_proj_bias"][512:], aadd=w["level_embed.weight"][l:l + 1],
+                     ldaadd=256, aadd_rows=1, **common)
+        pl.q.view(B, Q, 256).copy_(w["query_feat.weight"].unsqueeze(0).expand(B, Q, 256))
+        qpos = w["query_embed.weight"]
+        self._head_embed(pl.q, pl, False)
+        for i in range(self.num_dec_layers):
+            l = i % 3
+            self._attn_mask(pl, l)
+            self._layer("transformer_decoder.layers.%d." % i, pl.q, qpos, pl.q1, pl.q2, pl.qy,
+                        pl.Qp, pl.QK, pl.Vs, pl.att, pl.hq, pl.Kp[i], pl.Vp[i], pl.N[l], B, Q,
+                        pl.bits, pl.rowall, pl.scr, self.dec_ffn)
+            self._head_embed(pl.q, pl, i == self.num_dec_layers - 1)
+        # ---- Pair Proposal Network (pairnet_head.py:322-340) ----
+        for mlp, dst in (("sub_query_update", pl.sn), ("obj_query_update", pl.on)):
+            hip.linear(pl.q, w[mlp + ".0.weight"], w[mlp + ".0.bias"], pl.s1, relu=True)
+            hip.linear(pl.s1, w[mlp + ".2.weight"], w[mlp + ".2.bias"], pl.s2, relu=True)
+            hip.linear(pl.s2, w[mlp + ".4.weight"], w[mlp + ".4.bias"], pl.s1)
+            hip.l2normalize(pl.s1, dst)
+        hip.gemm(pl.sn, pl.on, pl.imp_raw, M=Q, N=Q, K=256, lda=256, ldw=256, ldc=Q, batch=B,
+                 sA=Q * 256, sW=Q * 256, sC=Q * Q)
+        ml = "update_importance.conv_layers."
+        hip.mlearner_first(pl.imp_raw, w[ml + "0.0.weight"], w[ml + "0.0.bias"], pl.c1, B, Q)
+        hip.conv2d_nhwc(pl.c1, w[ml + "1.0.weight"], w[ml + "1.0.bias"], pl.c2, B, Q, Q, 64, 64,
+                        7, 7, 3, True)
+        hip.mlearner_last(pl.c2, w[ml + "2.0.weight"], w[ml + "2.0.bias"], pl.imp, B, Q)
+        hip.topk_pairs(pl.imp, pl.topk_idx, pl.sub_pos, pl.obj_pos, B, Q, R)
+        # ---- pair features + Relation Fusion decoder (:342-378) ----
+        pl.pair_idx[:, :R].copy_(pl.sub_pos)
+        pl.pair_idx[:, R:].copy_(pl.obj_pos)
+        hip.gather_rows(pl.q, pl.pair_idx, pl.pair, B, Q, 2 * R, 256)
+        pl.r.view(B, R, 256).copy_(w["rel_query_feat.weight"].unsqueeze(0).expand(B, R, 256))
+        rpos, ppos = w["rel_query_embed.weight"], w["rel_query_embed2.weight"]
+        for i in range(self.num_rel_layers):
+            pre = "relation_decoder.layers.%d." % i
+            a = pre + "attentions.0.attn."
+            hip.linear(pl.pair, w[a + "in_proj_weight"][256:512], w[a + "in_proj_bias"][256:512],
+                       pl.pK, aadd=ppos)
+            hip.linear(pl.pair, w[a + "in_proj_weight"][512:], w[a + "in_proj_bias"][512:], pl.pV)
+            self._layer(pre, pl.r, rpos, pl.r1, pl.r2, pl.ry, pl.rQp, pl.rQK, pl.rVs, pl.ratt,
+                        pl.rh, pl.pK, pl.pV, 2 * R, B, R, None, None, pl.scr, self.rel_ffn)
+        hip.linear(pl.r, w["rel_cls_embed.weight"], w["rel_cls_embed.bias"], pl.rel.view(B * R, -1))
+        # ---- output gathers (:380-403) ----
+        nc = self.num_classes + 1
+        hip.gather_rows(pl.cls, pl.sub_pos, pl.sub_cls, B, Q, R, nc)
+        hip.gather_rows(pl.cls, pl.obj_pos, pl.obj_cls, B, Q, R, nc)
+        hip.gather_rows(pl.MP, pl.sub_pos, pl.sub_seg, B, Q, R, pl.HW2)
+        hip.gather_rows(pl.MP, pl.obj_pos, pl.obj_seg, B, Q, R, pl.HW2)
+        H2, W2 = pl.hw2
+        self._last_plan = pl
+        return (dict(sub=pl.sub_cls, obj=pl.obj_cls, cls=pl.cls, rel=pl.rel, importance=pl.imp),
+                dict(mask=pl.MP.view(B, Q, H2, W2), sub_seg=pl.sub_seg.view(B, R, H2, W2),
+                     obj_seg=pl.obj_seg.view(B, R, H2, W2)))
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def forward_head(self, decoder_out, mask_feature, attn_mask_target_size):
+        """Reference signature (pairnet_head.py:216): decoder_out (Q, B, C) seq-first,
+        mask_feature (B, C, h, w); returns cls_pred (B,Q,nc), mask_pred (B,Q,h,w),
+        attn_mask (B*heads, Q, th*tw) bool."""
+        if self.w is None:
+            if self.device is None:
+                self.to(decoder_out.device)
+            self._pack()
+        w = self.w
+        Q, B, _ = decoder_out.shape
+        h, wd = mask_feature.shape[-2:]
+        th, tw = attn_mask_target_size
+        dev, f32 = self.device, torch.float32
+        E = lambda *s: torch.empty(*s, device=dev, dtype=f32)
+        q = decoder_out.permute(1, 0, 2).contiguous().view(B * Q, 256)
+        mf = mask_feature.permute(0, 2, 3, 1).contiguous().view(B, h * wd, 256)
+        qn, m1, m2, me = E(B * Q, 256), E(B * Q, 256), E(B * Q, 256), E(B * Q, 256)
+        cls = E(B, Q, self.num_classes + 1)
+        mp, ml = E(B, Q, h * wd), E(B * Q, th * tw)
+        hip.layernorm(q, w["transformer_decoder.post_norm.weight"],
+                      w["transformer_decoder.post_norm.bias"], qn)
+        hip.linear(qn, w["cls_embed.weight"], w["cls_embed.bias"], cls.view(B * Q, -1))
+        hip.linear(qn, w["mask_embed.0.weight"], w["mask_embed.0.bias"], m1, relu=True)
+        hip.linear(m1, w["mask_embed.2.weight"], w["mask_embed.2.bias"], m2, relu=True)
+        hip.linear(m2, w["mask_embed.4.weight"], w["mask_embed.4.bias"], me)
+        hip.gemm(me, mf, mp, M=Q, N=h * wd, K=256, lda=256, ldw=256, ldc=h * wd, batch=B,
+                 sA=Q * 256, sW=h * wd * 256, sC=Q * h * wd)
+        hip.bilinear_planar(mp, ml, B * Q, h, wd, th, tw)
+        attn = (ml.view(B, 1, Q, th * tw) < 0).expand(B, self.n_heads, Q, th * tw)
+        return cls, mp.view(B, Q, h, wd), attn.reshape(B * self.n_heads, Q, th * tw)
+
+    # ------------------------------------------------------- post-processing
+    @torch.no_grad()
+    def get_bboxes(self, cls_scores, mask_preds, img_metas, rescale=False):
+        """pairnet_head.py:760-786."""
+        return [self._get_bboxes_single(
+            mask_preds["mask"][i], cls_scores["cls"][i], cls_scores["sub"][i],
+            cls_scores["obj"][i], cls_scores["rel"][i], mask_preds["sub_seg"][i],
+            mask_preds["obj_seg"][i], img_metas[i]["img_shape"],
+            img_metas[i]["scale_factor"], rescale) for i in range(len(img_metas))]
+
+    def _get_bboxes_single(self, all_masks, all_cls, s_cls, o_cls, r_cls, s_seg, o_seg,
+                           img_shape, scale_factor, rescale=False):
+        """pairnet_head.py:788-924 on the device; the only host traffic is the
+        per-query (label, score) table and the per-segment areas (<= Q ints each)."""
+        assert len(s_cls) == len(o_cls) == len(r_cls)
+        dev = all_cls.device
+        R, Q = self.num_rel_query, all_cls.shape[0]
+        nc = all_cls.shape[-1]
+        H0 = round(img_shape[0] / scale_factor[1])
+        W0 = round(img_shape[1] / scale_factor[0])
+        h, wd = all_masks.shape[-2:]
+        i64 = lambda *s: torch.empty(*s, device=dev, dtype=torch.int64)
+        f32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        # triplet labels and relation distributions (:811-820)
+        so_cls = torch.cat((s_cls, o_cls), 0).contiguous()
+        labels, _ = i64(2 * R), None
+        sc_tmp = f32(2 * R)
+        hip.cls_argmax(so_cls, labels, sc_tmp, 2 * R, nc)
+        labels += 1
+        r_dists = f32(R, self.num_relations + 1)
+        hip.rel_dists(r_cls.contiguous(), r_dists, R, self.num_relations)
+        # subject / object masks at the original image size (:826-843)
+        masks_u8 = torch.empty(2 * R, H0, W0, device=dev, dtype=torch.uint8)
+        hip.bilinear_planar_gt0(s_seg.contiguous(), masks_u8[:R], R, h, wd, H0, W0)
+        hip.bilinear_planar_gt0(o_seg.contiguous(), masks_u8[R:], R, h, wd, H0, W0)
+        masks = masks_u8.view(torch.bool)
+        # panoptic map (:823-825, :845-905)
+        all_labels, all_scores = i64(Q), f32(Q)
+        hip.cls_argmax(all_cls.contiguous(), all_labels, all_scores, Q, nc)
+        lab_h, sc_h = all_labels.cpu(), all_scores.cpu()
+        keep = [k for k in range(Q) if lab_h[k] != nc - 2 and sc_h[k] > 0.5]
+        if not keep:
+            pan_img = torch.ones((H0, W0), dtype=torch.long)
+        else:
+            kept = torch.tensor(keep, device=dev, dtype=torch.int64).view(1, -1)
+            n = len(keep)
+            low = f32(n, h * wd)
+            hip.gather_rows(all_masks.contiguous().view(Q, h * wd), kept, low, 1, Q, n, h * wd)
+            up = f32(n, H0 * W0)
+            hip.bilinear_planar(low, up, n, h, wd, H0, W0)
+            klab = [int(lab_h[k]) for k in keep]
+            stuff = {}
+            for j, lab in enumerate(klab):
+                if lab >= 80:
+                    stuff.setdefault(lab, []).append(j)
+            remap = list(range(n))
+            for eq in stuff.values():
+                for e in eq:
+                    remap[e] = eq[0]
+            seg = i64(H0 * W0)
+            cur = list(range(n))  # rows of `up` still alive
+            first = True
+            while True:
+                m = len(cur)
+                rows = up if m == n else up[torch.tensor(cur, device=dev)].contiguous()
+                lab_d = torch.tensor([klab[j] for j in cur], device=dev, dtype=torch.int64)
+                area = torch.zeros(m, device=dev, dtype=torch.int32)
+                rm = torch.tensor(remap, device=dev, dtype=torch.int32) if first else None
+                hip.panoptic(rows, lab_d, rm, seg, area, m, H0 * W0)
+                # the reference counts areas on the un-merged ids only after dedup has
+                # moved pixels to the first duplicate (:873-887): same as counting seg ids
+                area_h = area.cpu().tolist()
+                small = [a <= 4 for a in area_h]
+                if not any(small):
+                    break
+                cur = [j for j, s in zip(cur, small) if not s]
+                first = False
+                if not cur:
+                    raise IndexError("every panoptic segment was filtered "
+                                     "(the reference fails here too, pairnet_head.py:882)")
+            pan_img = seg.view(H0, W0).cpu()
+        det_bboxes = torch.zeros((2 * R, 5), device=dev)
+        r_scores = torch.zeros(R, device=dev)
+        r_labels = torch.zeros(R, device=dev)
+        rel_pairs = torch.arange(2 * R, dtype=torch.int).reshape(2, -1).T
+        return (det_bboxes, labels, rel_pairs, masks, pan_img, r_scores, r_labels, r_dists)
+
+    def simple_test_bboxes(self, feats, img_metas, rescale=False):
+        """pairnet_head.py:926-930."""
+        outs = self.forward(feats, img_metas)
+        return self.get_bboxes(*outs, img_metas, rescale=rescale)
+
+    def simple_test(self, feats, img_metas, rescale=False):
+        return self.simple_test_bboxes(feats, img_metas, rescale=rescale)

@@ -1,0 +1,247 @@
+"""ctypes binding of libpairnet_hip.so (include/pairnet_hip.h).
+
+torch is used here only for what the boundary needs from it: device memory
+(`Tensor.data_ptr()`) and the current HIP stream.  There is NO fallback: if the
+library is missing or a launch fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from .build import LIB_PATH
+
+_i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+GEMM_RELU, GEMM_A_COLMAJOR, GEMM_FORCE_TILE, GEMM_FORCE_SKINNY = 1, 2, 4, 8
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", _vp), ("lda", _i64), ("strideA", _i64),
+                ("Aadd", _vp), ("ldaadd", _i64), ("aadd_rows", _i32),
+                ("W", _vp), ("ldw", _i64), ("strideW", _i64),
+                ("bias", _vp),
+                ("Res", _vp), ("ldres", _i64), ("strideRes", _i64),
+                ("C", _vp), ("ldc", _i64), ("strideC", _i64),
+                ("M", _i32), ("N", _i32), ("K", _i32), ("batch", _i32),
+                ("flags", _i32)]
+
+
+_SIGS = {
+    "pn_abi_version": (C.c_int, []),
+    "pn_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "pn_conv2d_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 9 + [_vp]),
+    "pn_layernorm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "pn_groupnorm_nblk": (C.c_int, [_i64]),
+    "pn_groupnorm_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32,
+                                        _i32, _f32, _i32, _i64, _i64, _vp]),
+    "pn_l2normalize_f32": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _vp]),
+    "pn_msda_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_i32),
+                              C.POINTER(_i32), _vp]),
+    "pn_sine_pe_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "pn_bilinear_nhwc_f32": (C.c_int, [_vp, _vp] + [_i32] * 7 + [_i64, _i64, _vp]),
+    "pn_bilinear_planar_f32": (C.c_int, [_vp, _vp, _i64] + [_i32] * 4 + [_vp]),
+    "pn_bilinear_planar_gt0_u8": (C.c_int, [_vp, _vp, _i64] + [_i32] * 4 + [_vp]),
+    "pn_mask_pack": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "pn_attn_scratch_floats": (_i64, [_i32, _i32, _i32]),
+    "pn_attention_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
+                                   _i64, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "pn_mlearner_first_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "pn_mlearner_last_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "pn_topk_pairs": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "pn_gather_rows_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
+    "pn_cls_argmax_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "pn_rel_dists_f32": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "pn_panoptic_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libpairnet_hip.so is missing (%s): run __graft_entry__.build(); "
+                "there is no CPU / PyTorch fallback for the Pair-Net hot path" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.pn_abi_version() != 1:
+            raise RuntimeError("libpairnet_hip.so ABI mismatch; rebuild")
+        _lib = handle
+    return _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("pairnet_hip kernels take device tensors (got %s)" % t.device)
+    if t.dtype != dtype:
+        raise RuntimeError("expected %s, got %s" % (dtype, t.dtype))
+    return t.data_ptr()
+
+
+def _check(code, what):
+    if code != 0:
+        raise RuntimeError("%s failed: %s" % (
+            what, "argument contract violated" if code == -1 else "hipError %d" % code))
+
+
+def _rowmajor(t):
+    """(rows, ld) of a 2-D view whose last dim is contiguous."""
+    assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+    return t.shape[0], t.stride(0)
+
+
+def gemm(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaadd=0,
+         aadd_rows=0, res=None, ldres=0, batch=1, sA=0, sW=0, sC=0, sRes=0,
+         relu=False, colmajor=False, force=None):
+    """Raw pn_gemm_f32 call; tensors only supply base pointers."""
+    d = GemmDesc()
+    d.A, d.lda, d.strideA = _ptr(A), lda, sA
+    d.Aadd, d.ldaadd, d.aadd_rows = _ptr(aadd), ldaadd, aadd_rows
+    d.W, d.ldw, d.strideW = _ptr(W), ldw, sW
+    d.bias = _ptr(bias)
+    d.Res, d.ldres, d.strideRes = _ptr(res), ldres, sRes
+    d.C, d.ldc, d.strideC = _ptr(Cout), ldc, sC
+    d.M, d.N, d.K, d.batch = M, N, K, batch
+    d.flags = (GEMM_RELU if relu else 0) | (GEMM_A_COLMAJOR if colmajor else 0) | \
+        {None: 0, "tile": GEMM_FORCE_TILE, "skinny": GEMM_FORCE_SKINNY}[force]
+    _check(lib().pn_gemm_f32(C.byref(d), _stream()), "pn_gemm_f32")
+
+
+def linear(x, weight, bias, out, *, aadd=None, res=None, relu=False, force=None):
+    """out = act((x + aadd[row % len(aadd)]) @ weight.T + bias) + res on 2-D views."""
+    M, lda = _rowmajor(x)
+    N, ldw = _rowmajor(weight)
+    Mo, ldc = _rowmajor(out)
+    assert Mo == M and out.shape[1] == N and weight.shape[1] == x.shape[1]
+    kw = {}
+    if aadd is not None:
+        ra, lda2 = _rowmajor(aadd)
+        kw.update(aadd=aadd, ldaadd=lda2, aadd_rows=ra)
+    if res is not None:
+        rr, ldr = _rowmajor(res)
+        assert rr == M
+        kw.update(res=res, ldres=ldr)
+    gemm(x, weight, out, M=M, N=N, K=x.shape[1], lda=lda, ldw=ldw, ldc=ldc, bias=bias,
+         relu=relu, force=force, **kw)
+
+
+def conv2d_nhwc(x, wp, bias, out, B, H, W, Cin, Cout, KH, KW, pad, relu):
+    _check(lib().pn_conv2d_nhwc_f32(_ptr(x), _ptr(wp), _ptr(bias), _ptr(out), B, H, W,
+                                    Cin, Cout, KH, KW, pad, int(relu), _stream()),
+           "pn_conv2d_nhwc_f32")
+
+
+def layernorm(x, gamma, beta, out, eps=1e-5):
+    rows = x.numel() // 256
+    _check(lib().pn_layernorm_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), rows, 256,
+                                  eps, _stream()), "pn_layernorm_f32")
+
+
+def groupnorm_nblk(hw):
+    return lib().pn_groupnorm_nblk(hw)
+
+
+def groupnorm_nhwc(x, gamma, beta, out, partials, B, HW, G, relu, x_bstride, y_bstride,
+                   eps=1e-5):
+    _check(lib().pn_groupnorm_nhwc_f32(
+        _ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(partials, torch.float64), B, HW,
+        256, G, eps, int(relu), x_bstride, y_bstride, _stream()), "pn_groupnorm_nhwc_f32")
+
+
+def l2normalize(x, out, eps=1e-12):
+    _check(lib().pn_l2normalize_f32(_ptr(x), _ptr(out), x.numel() // 256, 256, eps,
+                                    _stream()), "pn_l2normalize_f32")
+
+
+def msda(value, offaw, out, B, shapes):
+    L = len(shapes)
+    hs = (_i32 * L)(*[s[0] for s in shapes])
+    ws = (_i32 * L)(*[s[1] for s in shapes])
+    _check(lib().pn_msda_f32(_ptr(value), _ptr(offaw), _ptr(out), B, L, hs, ws, _stream()),
+           "pn_msda_f32")
+
+
+def sine_pe(out, add, h, w, C_=256, temperature=10000.0):
+    _check(lib().pn_sine_pe_f32(_ptr(out), _ptr(add), h, w, C_, temperature, _stream()),
+           "pn_sine_pe_f32")
+
+
+def bilinear_nhwc(x, out, B, hi, wi, ho, wo, Cc, accumulate, in_bstride, out_bstride):
+    _check(lib().pn_bilinear_nhwc_f32(_ptr(x), _ptr(out), B, hi, wi, ho, wo, Cc,
+                                      int(accumulate), in_bstride, out_bstride, _stream()),
+           "pn_bilinear_nhwc_f32")
+
+
+def bilinear_planar(x, out, P, hi, wi, ho, wo):
+    _check(lib().pn_bilinear_planar_f32(_ptr(x), _ptr(out), P, hi, wi, ho, wo, _stream()),
+           "pn_bilinear_planar_f32")
+
+
+def bilinear_planar_gt0(x, out, P, hi, wi, ho, wo):
+    _check(lib().pn_bilinear_planar_gt0_u8(_ptr(x), _ptr(out, torch.uint8), P, hi, wi, ho,
+                                           wo, _stream()), "pn_bilinear_planar_gt0_u8")
+
+
+def mask_pack(logits, bits, rowall, R, Nk):
+    _check(lib().pn_mask_pack(_ptr(logits), _ptr(bits, torch.int32),
+                              _ptr(rowall, torch.int32), R, Nk, _stream()), "pn_mask_pack")
+
+
+def attn_scratch_floats(B, Q, Nk):
+    return lib().pn_attn_scratch_floats(B, Q, Nk)
+
+
+def attention(q, ldq, k, ldk, v, ldv, bits, rowall, out, ldo, scratch, B, Q, Nk, scale):
+    _check(lib().pn_attention_f32(
+        _ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(bits, torch.int32),
+        _ptr(rowall, torch.int32), _ptr(out), ldo, _ptr(scratch), B, Q, Nk, scale,
+        _stream()), "pn_attention_f32")
+
+
+def mlearner_first(x, w1, b1, out, B, S):
+    _check(lib().pn_mlearner_first_f32(_ptr(x), _ptr(w1), _ptr(b1), _ptr(out), B, S, 64,
+                                       _stream()), "pn_mlearner_first_f32")
+
+
+def mlearner_last(x, w3, b3, out, B, S):
+    _check(lib().pn_mlearner_last_f32(_ptr(x), _ptr(w3), _ptr(b3), _ptr(out), B, S, 64,
+                                      _stream()), "pn_mlearner_last_f32")
+
+
+def topk_pairs(scores, idx, sub, obj, B, Q, k):
+    _check(lib().pn_topk_pairs(_ptr(scores), _ptr(idx, torch.int64), _ptr(sub, torch.int64),
+                               _ptr(obj, torch.int64), B, Q, k, _stream()), "pn_topk_pairs")
+
+
+def gather_rows(x, index, out, B, rows_in, rows_out, length):
+    _check(lib().pn_gather_rows_f32(_ptr(x), _ptr(index, torch.int64), _ptr(out), B, rows_in,
+                                    rows_out, length, _stream()), "pn_gather_rows_f32")
+
+
+def cls_argmax(logits, label, score, rows, Cc):
+    _check(lib().pn_cls_argmax_f32(_ptr(logits), _ptr(label, torch.int64), _ptr(score), rows,
+                                   Cc, _stream()), "pn_cls_argmax_f32")
+
+
+def rel_dists(logits, out, rows, Cc):
+    _check(lib().pn_rel_dists_f32(_ptr(logits), _ptr(out), rows, Cc, _stream()),
+           "pn_rel_dists_f32")
+
+
+def panoptic(masks, labels, remap, seg, area, n, HW):
+    _check(lib().pn_panoptic_f32(_ptr(masks), _ptr(labels, torch.int64),
+                                 _ptr(remap, torch.int32), _ptr(seg, torch.int64),
+                                 _ptr(area, torch.int32), n, HW, _stream()), "pn_panoptic_f32")

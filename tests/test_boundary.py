@@ -1,0 +1,97 @@
+"""CPU: the drop-in boundary -- C ABI exports, config schema, state-dict names,
+loud failure without a GPU, and "the product never touches the oracle"."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from helpers import head_cfg
+from oracle import ref_shim
+from oracle.head import OracleCrossHead2
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    header = open(os.path.join(ROOT, "include", "pairnet_hip.h")).read()
+    declared = set(re.findall(r"\b(pn_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(built_lib)
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.pn_abi_version.restype = ctypes.c_int
+    assert lib.pn_abi_version() == 1
+    from pairnet_amd import hip
+    assert declared == set(hip.EXPORTS)
+
+
+def test_bad_arguments_are_refused_without_launching(built_lib):
+    from pairnet_amd import hip
+    lib = hip.lib()
+    d = hip.GemmDesc()  # all NULL
+    assert lib.pn_gemm_f32(ctypes.byref(d), None) == -1
+    assert lib.pn_topk_pairs(None, None, None, None, 1, 100, 100, None) == -1
+    assert lib.pn_layernorm_f32(None, None, None, None, 4, 256, 1e-5, None) == -1
+
+
+def test_state_dict_names_match_reference_layout():
+    from pairnet_amd import CrossHead2
+    cfg = head_cfg()
+    ours = {k: tuple(v.shape) for k, v in CrossHead2(**cfg).state_dict().items()}
+    theirs = {k: tuple(v.shape) for k, v in OracleCrossHead2(**cfg).state_dict().items()}
+    assert ours == theirs
+    if ref_shim.available():
+        ref = ref_shim.build_reference_head()
+        assert ours == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+def test_reference_config_file_drops_in():
+    """The reference's own configs/mask2former/pairnet.py builds our detector, and our
+    restated schema equals it key for key."""
+    from pairnet_amd import CrossHead2, load_config, pairnet_r50
+    cfg = load_config(os.path.join(ref_shim.REF_ROOT, "configs/mask2former/pairnet.py"))
+    ref_head = dict(cfg.model.bbox_head)
+    assert ref_head == dict(pairnet_r50().bbox_head)
+    ref_head.pop("type")
+    head = CrossHead2(**ref_head)
+    assert head.num_classes == 133 and head.num_rel_query == 100 and head.use_mask
+
+
+def test_no_cpu_fallback():
+    from pairnet_amd import CrossHead2
+    head = CrossHead2(**head_cfg())
+    feats = [torch.zeros(1, c, 8 // (2 ** i) or 1, 8 // (2 ** i) or 1)
+             for i, c in enumerate((256, 512, 1024, 2048))]
+    with pytest.raises(RuntimeError):
+        head.forward(feats, [dict(img_shape=(32, 32, 3), scale_factor=[1, 1, 1, 1])])
+    with pytest.raises(RuntimeError):
+        head.to("cpu")._pack()
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "pair-net_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
+                assert "/root/reference" not in text, f
+
+
+def test_detector_builds_from_config_and_result_container():
+    import numpy as np
+    from pairnet_amd import build_detector, pairnet_r50, triplet2Result
+    det = build_detector(pairnet_r50())
+    assert det.num_classes == 133
+    keys = list(det.backbone.state_dict())
+    assert "conv1.weight" in keys and "layer4.2.bn3.running_var" in keys
+    t = (torch.zeros(200, 5), torch.ones(200, dtype=torch.long),
+         torch.arange(200, dtype=torch.int).reshape(2, -1).T, torch.zeros(200, 4, 4, dtype=torch.bool),
+         torch.ones(4, 4, dtype=torch.long), torch.zeros(100), torch.zeros(100),
+         torch.zeros(100, 57))
+    r = triplet2Result(t, True)
+    assert isinstance(r.rel_dists, np.ndarray) and r.rel_pair_idxes.shape == (100, 2)
+    assert len(r) == 1 and r[0] is r and r.formatted_masks["pan_results"] is r.pan_results

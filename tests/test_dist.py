@@ -1,0 +1,72 @@
+"""CPU: the multi-GPU path (image sharding + triplet all-gather) with world_size 2
+over gloo."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pairnet_amd.dist import (all_gather_triplets, pack_triplets, shard_indices,
+                              triplet_record_len, unpack_triplets)
+
+
+def _record(i, R=100, C=56):
+    g = torch.Generator().manual_seed(1000 + i)
+    labels = torch.randint(1, 134, (2 * R,), generator=g)
+    rel = torch.rand(R, C + 1, generator=g)
+    sub = torch.randint(0, 100, (R,), generator=g)
+    obj = torch.randint(0, 100, (R,), generator=g)
+    return pack_triplets(labels, rel, sub, obj)
+
+
+def _worker(rank, world, port, n_images, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_indices(n_images, rank, world)
+    local = torch.stack([_record(i) for i in mine]) if mine else \
+        torch.zeros(0, triplet_record_len(100, 56))
+    out = all_gather_triplets(local, n_images)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_indices_cover_dataset_like_distributed_sampler():
+    for n, w in ((16, 8), (5, 2), (3, 4)):
+        seen = sorted(i for r in range(w) for i in shard_indices(n, r, w))
+        assert seen == list(range(n))
+        assert shard_indices(n, 1, w) == list(range(1, n, w))
+
+
+def test_pack_roundtrip():
+    rec = _record(3)
+    assert rec.shape[0] == triplet_record_len(100, 56)
+    d = unpack_triplets(rec, 100, 56)
+    assert d["labels"].dtype == torch.int64 and d["rel_dists"].shape == (100, 57)
+    assert torch.equal(pack_triplets(d["labels"], d["rel_dists"], d["sub_pos"], d["obj_pos"]), rec)
+
+
+def test_all_gather_triplets_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_images, world, port = 5, 2, _free_port()   # uneven split: rank 0 gets 3, rank 1 gets 2
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_images, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = torch.stack([_record(i) for i in range(n_images)])
+    for r in range(world):
+        assert torch.equal(outs[r], expect)

@@ -1,0 +1,123 @@
+"""CPU: the oracle is pinned (a) against the golden vectors recorded from the
+reference's own code and (b), when /root/reference is present (build container),
+against the reference itself run under shims."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import golden, oracle_head, overrides_of
+from oracle import layers as L
+from oracle import ref_shim, seeded
+from oracle.matrix_learner import MatrixLearnerTiny
+
+
+def test_convtiny_matches_golden():
+    fx = golden("convtiny")
+    net = MatrixLearnerTiny().eval()
+    sd = seeded.seeded_state_dict({k: v.shape for k, v in net.state_dict().items()},
+                                  int(fx["weight_seed"]))
+    assert seeded.checksum(sd) == int(fx["weight_crc"])
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        y = net(torch.from_numpy(fx["x"]))
+    assert np.array_equal(y.numpy(), fx["y"])
+
+
+def test_msda_formula_matches_golden():
+    fx = golden("msda")
+    shapes = [tuple(s) for s in fx["shapes"].tolist()]
+    value, off, logits = (torch.from_numpy(fx[k]) for k in ("value", "offsets", "logits"))
+    bs, n = value.shape[:2]
+    refs = []
+    for h, w in shapes:
+        yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32) + 0.5,
+                                torch.arange(w, dtype=torch.float32) + 0.5, indexing="ij")
+        refs.append(torch.stack([xx.reshape(-1) / w, yy.reshape(-1) / h], -1))
+    ref = torch.cat(refs, 0)[None, :, None].repeat(bs, 1, 3, 1)
+    norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
+    loc = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    out = L.msda_core(value, shapes, loc, logits.softmax(-1).view(bs, n, 8, 3, 4))
+    assert np.array_equal(out.numpy(), fx["out"])
+
+
+def test_ppn_and_reldec_match_golden():
+    fx = golden("ppn")
+    head, sd, crc = oracle_head(int(fx["weight_seed"]))
+    assert crc == int(fx["weight_crc"])
+    q = torch.from_numpy(fx["query_feat"])
+    with torch.no_grad():
+        s = F.normalize(head.sub_query_update(q).transpose(0, 1), p=2, dim=-1, eps=1e-12)
+        o = F.normalize(head.obj_query_update(q).transpose(0, 1), p=2, dim=-1, eps=1e-12)
+        raw = torch.matmul(s, o.transpose(1, 2))
+        imp = head.update_importance(raw)
+        idx = torch.topk(imp.flatten(-2, -1), k=100)[1]
+    assert np.array_equal(raw.numpy(), fx["importance_raw"])
+    assert np.array_equal(imp.numpy(), fx["importance"])
+    assert np.array_equal(idx.numpy(), fx["topk_idx"])
+    fr = golden("reldec")
+    pair = torch.from_numpy(fr["pair_feat"])
+    bs = pair.shape[1]
+    with torch.no_grad():
+        r = head.rel_query_feat.weight.unsqueeze(1).repeat((1, bs, 1))
+        e1 = head.rel_query_embed.weight.unsqueeze(1).repeat((1, bs, 1))
+        e2 = head.rel_query_embed2.weight.unsqueeze(1).repeat((1, bs, 1))
+        for layer in head.relation_decoder.layers:
+            r = layer(query=r, key=pair, value=pair, query_pos=e1, key_pos=e2)
+        rel = head.rel_cls_embed(r.transpose(0, 1))
+    assert np.array_equal(rel.numpy(), fr["rel_preds"])
+
+
+def test_e2e_small_matches_golden():
+    fx = golden("e2e_small")
+    head, sd, crc = oracle_head(int(fx["weight_seed"]), overrides_of(fx))
+    assert crc == int(fx["weight_crc"])
+    H, W, bs = int(fx["height"]), int(fx["width"]), int(fx["batch"])
+    feats = seeded.seeded_feats(int(fx["feat_seed"]), bs, H, W)
+    assert seeded.checksum(feats) == int(fx["feat_crc"])
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[2.0, 2.0, 2.0, 2.0])] * bs
+    cls, masks = head.forward(feats, metas)
+    for k, v in cls.items():
+        assert np.array_equal(v.numpy(), fx["cls_" + k]), k
+    for k, v in masks.items():
+        assert np.array_equal(v.numpy(), fx["mask_" + k]), k
+    res = head.get_bboxes(cls, masks, metas)
+    names = ("bboxes", "labels", "rel_pairs", "masks", "pan_img", "r_scores", "r_labels",
+             "r_dists")
+    for i, r in enumerate(res):
+        for name, v in zip(names, r):
+            ref = fx["res%d_%s" % (i, name)]
+            got = np.packbits(v.numpy()) if name == "masks" else v.numpy()
+            assert np.array_equal(got, ref), (i, name)
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+def test_oracle_equals_shimmed_reference():
+    """Same weights, same inputs: the restatement and the reference's own class agree
+    bit for bit (forward and get_bboxes), batch 2, reduced resolution."""
+    ref = ref_shim.build_reference_head()
+    head, sd, _ = oracle_head(7)
+    ref.load_state_dict(sd, strict=True)
+    H, W = 64, 96
+    feats = seeded.seeded_feats(8, 2, H, W)
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[1.5, 1.5, 1.5, 1.5])] * 2
+    with torch.no_grad():
+        a = ref.forward(feats, metas)
+        b = head.forward(feats, metas)
+        for da, db in zip(a, b):
+            for k in da:
+                assert torch.equal(da[k], db[k]), k
+        ra, rb = ref.get_bboxes(*a, metas), head.get_bboxes(*b, metas)
+    for ta, tb in zip(ra, rb):
+        for x, y in zip(ta, tb):
+            assert torch.equal(x, y)
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+def test_matrix_learner_equals_reference_module():
+    ref = ref_shim.reference_conv_tiny()
+    net = MatrixLearnerTiny().eval()
+    net.load_state_dict(ref.state_dict())
+    x = torch.randn(3, 37, 37)
+    with torch.no_grad():
+        assert torch.equal(ref(x), net(x))

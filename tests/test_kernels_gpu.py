@@ -1,0 +1,358 @@
+"""GPU: every C-ABI kernel against a plain torch fp32 CPU statement of the same op
+(floating point: tolerances stated per test) or bit-exactly (index / integer work)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import golden
+from oracle import layers as L
+from oracle.matrix_learner import MatrixLearnerTiny
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hip(built_lib):
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    from pairnet_amd import hip as h
+    h.lib()
+    return h
+
+
+def R(*shape, seed=0, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed + int(np.prod(shape)) % 9973)
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def close(got, ref, tol, what=""):
+    got = got.detach().cpu()
+    err = (got.double() - ref.double()).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    assert math.isfinite(err) and err <= tol * scale, "%s max|err| %.3e (scale %.2f)" % (what, err, scale)
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("force", ["tile", "skinny", None])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (100, 134, 256), (1000, 544, 260),
+                                   (37, 56, 2048), (129, 64, 96), (5, 33, 8)])
+def test_gemm_linear_variants(hip, M, N, K, force):
+    x, w, b = R(M, K, seed=1), R(N, K, seed=2), R(N, seed=3)
+    pos, res = R(50, K, seed=4), R(M, N, seed=5)
+    ref = F.relu(F.linear(x + pos.repeat((M + 49) // 50, 1)[:M], w, b)) + res
+    out = torch.empty(M, N, device=DEV)
+    hip.linear(x.to(DEV), w.to(DEV), b.to(DEV), out, aadd=pos.to(DEV), res=res.to(DEV),
+               relu=True, force=force)
+    close(out, ref, 2e-5 * math.sqrt(K / 256), "gemm %s" % force)
+    out2 = torch.empty(M, N, device=DEV)
+    hip.linear(x.to(DEV), w.to(DEV), None, out2, force=force)
+    close(out2, F.linear(x, w), 2e-5 * math.sqrt(K / 256), "gemm plain %s" % force)
+
+
+@pytest.mark.parametrize("force", ["tile", "skinny"])
+def test_gemm_batched_strided_and_colmajor(hip, force):
+    B, M, N, K = 3, 210, 256, 64          # M % 4 != 0: scalar column-major path
+    a = R(B, K, M, seed=7)                # NCHW-like: [b][k][m]
+    w, bias = R(N, K, seed=8), R(N, seed=9)
+    ref = torch.einsum("bkm,nk->bmn", a, w) + bias
+    out = torch.empty(B, M, N, device=DEV)
+    hip.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, lda=M, ldw=K, ldc=N, bias=bias.to(DEV),
+             batch=B, sA=K * M, sC=M * N, colmajor=True, force=force)
+    close(out, ref, 2e-5, "colmajor scalar")
+    M2 = 400                               # vector path
+    a2 = R(B, K, M2, seed=10)
+    out = torch.empty(B, M2, N, device=DEV)
+    hip.gemm(a2.to(DEV), w.to(DEV), out, M=M2, N=N, K=K, lda=M2, ldw=K, ldc=N, batch=B,
+             sA=K * M2, sC=M2 * N, colmajor=True, force=force)
+    close(out, torch.einsum("bkm,nk->bmn", a2, w), 2e-5, "colmajor vec")
+    # per-batch W (mask logits: W = mask feature of image b), output with a wide ldc
+    q, mf = R(B, 100, 256, seed=11), R(B, 530, 256, seed=12)
+    out = torch.empty(B, 100, 530, device=DEV)
+    hip.gemm(q.to(DEV), mf.to(DEV), out, M=100, N=530, K=256, lda=256, ldw=256, ldc=530,
+             batch=B, sA=100 * 256, sW=530 * 256, sC=100 * 530, force=force)
+    close(out, torch.einsum("bqc,bpc->bqp", q, mf), 2e-5, "batched W")
+
+
+def test_gemm_is_an_fmaf_chain(hip):
+    """The f32 MFMA is exact fp32: with integer-valued operands the result is exact."""
+    x = torch.randint(-8, 9, (256, 512)).float()
+    w = torch.randint(-8, 9, (256, 512)).float()
+    for force in ("tile", "skinny"):
+        out = torch.empty(256, 256, device=DEV)
+        hip.linear(x.to(DEV), w.to(DEV), None, out, force=force)
+        assert torch.equal(out.cpu(), x @ w.t())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,relu", [(2, 13, 17, 256, 256, 3, False),
+                                                  (1, 20, 20, 64, 64, 7, True),
+                                                  (2, 9, 40, 32, 64, 7, True)])
+def test_conv2d_nhwc(hip, B, H, W, Cin, Cout, k, relu):
+    x, w, b = R(B, Cin, H, W, seed=1), R(Cout, Cin, k, k, seed=2, lo=-0.05, hi=0.05), R(Cout, seed=3)
+    ref = F.conv2d(x, w, b, padding=k // 2)
+    ref = F.relu(ref) if relu else ref
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+    out = torch.empty(B, H, W, Cout, device=DEV)
+    hip.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), wp.to(DEV), b.to(DEV), out, B, H,
+                    W, Cin, Cout, k, k, k // 2, relu)
+    close(out.permute(0, 3, 1, 2), ref, 3e-5, "conv%dx%d" % (k, k))
+
+
+# ----------------------------------------------------------------------------- norms
+def test_layernorm_l2norm(hip):
+    x, g, b = R(1003, 256, seed=1, lo=-3, hi=5), R(256, seed=2), R(256, seed=3)
+    out = torch.empty(1003, 256, device=DEV)
+    hip.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), out)
+    close(out, F.layer_norm(x, (256,), g, b, 1e-5), 2e-6, "layernorm")
+    hip.l2normalize(x.to(DEV), out)
+    close(out, F.normalize(x, p=2, dim=-1, eps=1e-12), 1e-6, "l2norm")
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_groupnorm_nhwc_with_batch_strides(hip, relu):
+    B, HW = 2, 1050
+    x = R(B, 256, HW, seed=4, lo=-2, hi=6)
+    g, b = R(256, seed=5), R(256, seed=6)
+    ref = F.group_norm(x, 32, g, b, 1e-5)
+    ref = F.relu(ref) if relu else ref
+    xin = x.permute(0, 2, 1).contiguous().to(DEV)
+    big = torch.zeros(B, HW + 77, 256, device=DEV)      # output embedded in a token buffer
+    part = torch.empty(B * hip.groupnorm_nblk(HW) * 64, device=DEV, dtype=torch.float64)
+    hip.groupnorm_nhwc(xin, g.to(DEV), b.to(DEV), big[:, 77:], part, B, HW, 32, relu, HW * 256,
+                       (HW + 77) * 256)
+    close(big[:, 77:].permute(0, 2, 1), ref, 3e-6, "groupnorm")
+    assert float(big[:, :77].abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------- MSDA
+def _msda_ref(value, off, logits, shapes):
+    bs, n = value.shape[:2]
+    refs = []
+    for h, w in shapes:
+        yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32) + 0.5,
+                                torch.arange(w, dtype=torch.float32) + 0.5, indexing="ij")
+        refs.append(torch.stack([xx.reshape(-1) / w, yy.reshape(-1) / h], -1))
+    ref = torch.cat(refs, 0)[None, :, None].repeat(bs, 1, len(shapes), 1)
+    norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
+    loc = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    aw = logits.softmax(-1).view(bs, n, 8, len(shapes), 4)
+    return L.msda_core(value, shapes, loc, aw)
+
+
+def _run_msda(hip, value, off, logits, shapes):
+    bs, n = value.shape[:2]
+    offaw = torch.cat([off.reshape(bs, n, -1), logits.reshape(bs, n, -1)], -1).contiguous()
+    out = torch.empty(bs, n, 256, device=DEV)
+    hip.msda(value.reshape(bs, n, 256).to(DEV), offaw.to(DEV), out, bs, shapes)
+    return out
+
+
+def test_msda_golden_and_random(hip):
+    fx = golden("msda")
+    shapes = [tuple(s) for s in fx["shapes"].tolist()]
+    value, off, logits = (torch.from_numpy(fx[k]) for k in ("value", "offsets", "logits"))
+    out = _run_msda(hip, value, off, logits, shapes)
+    close(out, torch.from_numpy(fx["out"]), 2e-6, "msda golden")
+    shapes = [(7, 11), (13, 21), (25, 42)]
+    n = sum(h * w for h, w in shapes)
+    value, off = R(1, n, 8, 32, seed=1), R(1, n, 8, 3, 4, 2, seed=2, lo=-6, hi=6)
+    logits = R(1, n, 8, 12, seed=3, lo=-3, hi=3)
+    close(_run_msda(hip, value, off, logits, shapes), _msda_ref(value, off, logits, shapes), 2e-6,
+          "msda random")
+
+
+# ----------------------------------------------------------------------------- PE / resize
+def test_sine_pe(hip):
+    pe = L.SinePositionalEncoding(128, normalize=True)
+    for h, w in ((25, 42), (3, 4)):
+        ref = pe(torch.zeros(1, h, w, dtype=torch.bool))[0].permute(1, 2, 0).reshape(h * w, 256)
+        add = R(256, seed=1)
+        out = torch.empty(h * w, 256, device=DEV)
+        hip.sine_pe(out, add.to(DEV), h, w)
+        close(out, ref + add, 2e-5, "sine pe")   # sinf/powf differ by a few ulp between libms
+
+
+def test_bilinear(hip):
+    x = R(2, 256, 12, 21, seed=1)
+    base = R(2, 24, 42, 256, seed=2)
+    ref = base.permute(0, 3, 1, 2) + F.interpolate(x, (24, 42), mode="bilinear", align_corners=False)
+    out = base.clone().to(DEV)
+    hip.bilinear_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), out, 2, 12, 21, 24, 42, 256, True,
+                      12 * 21 * 256, 24 * 42 * 256)
+    close(out.permute(0, 3, 1, 2), ref, 2e-6, "bilinear nhwc")
+    m = R(7, 40, 67, seed=3, lo=-4, hi=4)
+    for size in ((5, 9), (10, 17), (20, 34), (77, 131)):
+        ref = F.interpolate(m[None], size, mode="bilinear", align_corners=False)[0]
+        out = torch.empty(7, *size, device=DEV)
+        hip.bilinear_planar(m.to(DEV), out, 7, 40, 67, size[0], size[1])
+        close(out, ref, 2e-6, "bilinear planar %s" % (size,))
+        o8 = torch.empty(7, *size, device=DEV, dtype=torch.uint8)
+        hip.bilinear_planar_gt0(m.to(DEV), o8, 7, 40, 67, size[0], size[1])
+        mism = (o8.cpu().bool() != (torch.sigmoid(ref) > 0.5)) & (ref.abs() > 1e-5)
+        assert int(mism.sum()) == 0
+
+
+# ----------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, mask, scale):
+    B, Qn, _ = q.shape
+    qh = q.view(B, Qn, 8, 32).transpose(1, 2) * scale
+    kh = k.view(B, -1, 8, 32).transpose(1, 2)
+    vh = v.view(B, -1, 8, 32).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2)
+    if mask is not None:
+        s = s.masked_fill(mask[:, None], float("-inf"))
+    return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, Qn, 256)
+
+
+@pytest.mark.parametrize("B,Qn,Nk,masked", [(1, 100, 1050, True), (2, 100, 4200, True),
+                                            (1, 100, 16700, True), (2, 100, 100, False),
+                                            (1, 100, 200, False), (1, 37, 333, True),
+                                            (1, 200, 777, True)])
+def test_attention_and_mask_pack(hip, B, Qn, Nk, masked):
+    q, k, v = R(B, Qn, 256, seed=1, lo=-2, hi=2), R(B, Nk, 256, seed=2), R(B, Nk, 256, seed=3)
+    scale = 1 / math.sqrt(32)
+    mask = bits = rowall = None
+    if masked:
+        logits = R(B * Qn, Nk, seed=4)
+        logits[3] = -logits[3].abs() - 0.1          # an all-masked row -> un-masked (:300)
+        logits[5, : Nk - 1] = -1.0                   # exactly one key survives
+        logits[5, Nk - 1] = 1.0
+        mask = (logits < 0).view(B, Qn, Nk).clone()
+        mask[mask.all(-1)] = False
+        bits = torch.empty(B * Qn * ((Nk + 31) // 32), device=DEV, dtype=torch.int32)
+        rowall = torch.empty(B * Qn, device=DEV, dtype=torch.int32)
+        hip.mask_pack(logits.to(DEV), bits, rowall, B * Qn, Nk)
+        ra = rowall.cpu()
+        assert int(ra[3]) == 1 and int(ra.sum()) == int((logits < 0).all(-1).sum())
+        words = bits.cpu().view(B * Qn, -1).numpy().view(np.uint32)
+        unpacked = np.unpackbits(words.view(np.uint8), axis=1, bitorder="little")[:, :Nk]
+        assert np.array_equal(unpacked.astype(bool), (logits < 0).numpy())
+    scr = torch.empty(hip.attn_scratch_floats(B, Qn, Nk), device=DEV)
+    out = torch.empty(B, Qn, 256, device=DEV)
+    hip.attention(q.to(DEV), 256, k.to(DEV), 256, v.to(DEV), 256, bits, rowall, out, 256, scr, B, Qn,
+                  Nk, scale)
+    close(out, _attn_ref(q, k, v, mask, scale), 3e-6, "attention")
+
+
+def test_attention_strided_qk_matches_nn_multiheadattention(hip):
+    """Self-attention as the decoder layer issues it: packed [Q|K] projection buffer with
+    ld 512; checked against torch.nn.MultiheadAttention itself."""
+    mha = torch.nn.MultiheadAttention(256, 8).eval()
+    with torch.no_grad():
+        mha.in_proj_bias.copy_(R(768, seed=1))
+    x, pos = R(100, 2, 256, seed=2, lo=-2, hi=2), R(100, 1, 256, seed=3)
+    with torch.no_grad():
+        ref = mha(x + pos, x + pos, x, need_weights=False)[0]      # (Q, B, C)
+    W, b = mha.in_proj_weight.detach(), mha.in_proj_bias.detach()
+    xb = x.transpose(0, 1).reshape(200, 256).contiguous().to(DEV)
+    QK, V = torch.empty(200, 512, device=DEV), torch.empty(200, 256, device=DEV)
+    hip.linear(xb, W[:512].to(DEV), b[:512].to(DEV), QK, aadd=pos[:, 0].contiguous().to(DEV))
+    hip.linear(xb, W[512:].to(DEV), b[512:].to(DEV), V)
+    att, out = torch.empty(200, 256, device=DEV), torch.empty(200, 256, device=DEV)
+    scr = torch.empty(hip.attn_scratch_floats(2, 100, 100), device=DEV)
+    hip.attention(QK, 512, QK[:, 256:], 512, V, 256, None, None, att, 256, scr, 2, 100, 100,
+                  1 / math.sqrt(32))
+    hip.linear(att, mha.out_proj.weight.detach().to(DEV), mha.out_proj.bias.detach().to(DEV), out)
+    close(out.view(2, 100, 256).transpose(0, 1), ref, 5e-6, "mha")
+
+
+# ----------------------------------------------------------------------------- PPN
+def test_matrix_learner_golden(hip):
+    fx = golden("convtiny")
+    net = MatrixLearnerTiny().eval()
+    from oracle import seeded
+    sd = seeded.seeded_state_dict({k: v.shape for k, v in net.state_dict().items()},
+                                  int(fx["weight_seed"]))
+    x = torch.from_numpy(fx["x"])
+    B, S = x.shape[0], x.shape[1]
+    w1 = sd["conv_layers.0.0.weight"].reshape(64, 49).contiguous().to(DEV)
+    w2 = sd["conv_layers.1.0.weight"].permute(0, 2, 3, 1).reshape(64, -1).contiguous().to(DEV)
+    w3 = sd["conv_layers.2.0.weight"].reshape(64, 49).t().contiguous().to(DEV)
+    c1, c2 = torch.empty(B, S * S, 64, device=DEV), torch.empty(B, S * S, 64, device=DEV)
+    out = torch.empty(B, S, S, device=DEV)
+    hip.mlearner_first(x.to(DEV), w1, sd["conv_layers.0.0.bias"].to(DEV), c1, B, S)
+    hip.conv2d_nhwc(c1, w2, sd["conv_layers.1.0.bias"].to(DEV), c2, B, S, S, 64, 64, 7, 7, 3, True)
+    hip.mlearner_last(c2, w3, sd["conv_layers.2.0.bias"].to(DEV), out, B, S)
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        c1_ref = F.relu(net.conv_layers[0][0](x[:, None]))
+    close(c1.view(B, S, S, 64).permute(0, 3, 1, 2), c1_ref, 2e-6, "ml first")
+    close(out, torch.from_numpy(fx["y"]), 1e-5, "matrix learner (reference ConvTiny golden)")
+
+
+def _topk_ref(scores, k):
+    """value descending, index ascending on ties."""
+    order = np.lexsort((np.arange(scores.size), -scores.astype(np.float64)))
+    return order[:k]
+
+
+@pytest.mark.parametrize("Q,k", [(100, 100), (200, 100), (37, 7), (16, 256), (256, 128)])
+def test_topk_pairs_bit_exact(hip, Q, k):
+    B = 3
+    s = R(B, Q * Q, seed=Q)
+    s[1] = torch.round(s[1] * 20) / 20             # massive ties
+    s[2, :50] = s[2].max() + 1.0                   # tied maxima at the head
+    s[0, 17] = -0.0
+    idx = torch.empty(B, k, device=DEV, dtype=torch.int64)
+    sub, obj = torch.empty_like(idx), torch.empty_like(idx)
+    hip.topk_pairs(s.to(DEV), idx, sub, obj, B, Q, k)
+    idx, sub, obj = idx.cpu(), sub.cpu(), obj.cpu()
+    for b in range(B):
+        assert np.array_equal(idx[b].numpy(), _topk_ref(s[b].numpy(), k)), b
+    assert torch.equal(sub, torch.div(idx, Q, rounding_mode="trunc"))
+    assert torch.equal(obj, torch.remainder(idx, Q))
+    # tie-free row: identical to torch.topk (sorted descending), as the reference calls it
+    assert torch.equal(idx[0], torch.topk(s[0], k)[1]) or len(set(s[0].tolist())) < Q * Q
+
+
+def test_topk_on_reference_importance_is_bit_exact(hip):
+    """PPN golden: fed the reference's own importance tensor, the selector reproduces the
+    reference's top-k indices, sub_pos and obj_pos bit for bit."""
+    fx = golden("ppn")
+    imp = torch.from_numpy(fx["importance"])
+    idx = torch.empty(1, 100, device=DEV, dtype=torch.int64)
+    sub, obj = torch.empty_like(idx), torch.empty_like(idx)
+    hip.topk_pairs(imp.to(DEV), idx, sub, obj, 1, 100, 100)
+    assert np.array_equal(idx.cpu().numpy(), fx["topk_idx"])
+    assert np.array_equal(sub.cpu().numpy(), fx["sub_pos"])
+    assert np.array_equal(obj.cpu().numpy(), fx["obj_pos"])
+
+
+def test_gather_rows(hip):
+    B, rin, rout = 2, 100, 64
+    for length in (256, 134, 66800):
+        x = R(B, rin, length, seed=length)
+        index = torch.randint(0, rin, (B, rout))
+        out = torch.empty(B, rout, length, device=DEV)
+        hip.gather_rows(x.to(DEV), index.to(DEV), out, B, rin, rout, length)
+        ref = torch.gather(x, 1, index[..., None].expand(-1, -1, length))
+        assert torch.equal(out.cpu(), ref)
+
+
+# ----------------------------------------------------------------------------- post-processing
+def test_cls_argmax_rel_dists_panoptic(hip):
+    logits = R(200, 134, seed=1, lo=-4, hi=4)
+    lab = torch.empty(200, device=DEV, dtype=torch.int64)
+    sc = torch.empty(200, device=DEV)
+    hip.cls_argmax(logits.to(DEV), lab, sc, 200, 134)
+    p = F.softmax(logits, -1)[..., :-1]
+    assert torch.equal(lab.cpu(), p.argmax(-1))
+    close(sc, p.max(-1)[0], 1e-6, "score")
+    rl = R(100, 56, seed=2, lo=-3, hi=3)
+    out = torch.empty(100, 57, device=DEV)
+    hip.rel_dists(rl.to(DEV), out, 100, 56)
+    close(out, torch.cat([torch.zeros(100, 1), F.softmax(rl, -1)], -1), 1e-6, "rel dists")
+    n, HW = 9, 5000
+    m = R(n, HW, seed=3, lo=-5, hi=5)
+    labels = torch.randint(0, 133, (n,))
+    remap = torch.arange(n, dtype=torch.int32)
+    remap[4] = 2
+    seg = torch.empty(HW, device=DEV, dtype=torch.int64)
+    area = torch.zeros(n, device=DEV, dtype=torch.int32)
+    hip.panoptic(m.to(DEV), labels.to(DEV), remap.to(DEV), seg, area, n, HW)
+    ids = m.t().softmax(-1).argmax(-1)
+    ids = remap.long()[ids]
+    assert torch.equal(seg.cpu(), ids * 1000 + labels[ids])
+    assert torch.equal(area.cpu().long(), torch.bincount(ids, minlength=n))

@@ -61,6 +61,13 @@ typedef struct pn_gemm_desc {
 
 int pn_gemm_f32(const pn_gemm_desc* d, void* stream);
 
+/* Which kernel pn_gemm_f32 would launch for `d` (for profiling / roofline
+ * attribution; +1 = the column-major-A instantiation). */
+#define PN_GEMM_VARIANT_SKINNY        0  /* k_gemm_skinny<A>                 */
+#define PN_GEMM_VARIANT_TILE_128x64   2  /* k_gemm_tile<128,64,32,64,A>      */
+#define PN_GEMM_VARIANT_TILE_128x128  4  /* k_gemm_tile<128,128,64,64,A>     */
+int pn_gemm_variant(const pn_gemm_desc* d);
+
 /* Implicit-GEMM KHxKW convolution, stride 1, zero padding, channel-last:
  *   out[b][y][x][co] = act(sum_{ky,kx,ci} in[b][y+ky-pad][x+kx-pad][ci]
  *                          * Wp[co][(ky*KW+kx)*Cin+ci] + bias[co])

@@ -314,6 +314,21 @@ static int launch_tile(const GemmP& p, int batch, hipStream_t s) {
   return PN_LAUNCH_CHECK();
 }
 
+static bool gemm_use_skinny(const pn_gemm_desc* d) {
+  const int64_t tiles128 = (int64_t)pn_cdiv(d->M, 128) * pn_cdiv(d->N, 128) * d->batch;
+  bool skinny = tiles128 < 96;
+  if (d->flags & PN_GEMM_FORCE_TILE) skinny = false;
+  if (d->flags & PN_GEMM_FORCE_SKINNY) skinny = true;
+  return skinny;
+}
+
+extern "C" int pn_gemm_variant(const pn_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->batch <= 0) return PN_BAD_ARG;
+  const int col = (d->flags & PN_GEMM_A_COLMAJOR) ? 1 : 0;
+  if (gemm_use_skinny(d)) return PN_GEMM_VARIANT_SKINNY + col;
+  return (d->N <= 64 ? PN_GEMM_VARIANT_TILE_128x64 : PN_GEMM_VARIANT_TILE_128x128) + col;
+}
+
 extern "C" int pn_gemm_f32(const pn_gemm_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!d || !d->A || !d->W || !d->C) return PN_BAD_ARG;
@@ -331,11 +346,7 @@ extern "C" int pn_gemm_f32(const pn_gemm_desc* d, void* stream) {
   p.relu = (d->flags & PN_GEMM_RELU) ? 1 : 0;
   p.a_vec = colmajor && d->lda % 4 == 0 && d->strideA % 4 == 0 && aligned16(d->A);
 
-  const int64_t tiles128 = (int64_t)pn_cdiv(d->M, 128) * pn_cdiv(d->N, 128) * d->batch;
-  bool skinny = tiles128 < 96;
-  if (d->flags & PN_GEMM_FORCE_TILE) skinny = false;
-  if (d->flags & PN_GEMM_FORCE_SKINNY) skinny = true;
-  if (skinny) {
+  if (gemm_use_skinny(d)) {
     dim3 grid(pn_cdiv(d->N, 32), pn_cdiv(d->M, 32), d->batch);
     if (colmajor) hipLaunchKernelGGL(k_gemm_skinny<A_COL>, grid, dim3(256), 0, s, p);
     else          hipLaunchKernelGGL(k_gemm_skinny<A_ROW>, grid, dim3(256), 0, s, p);

@@ -601,8 +601,11 @@ class CrossHead2:
         hip.cls_argmax(all_cls.contiguous(), all_labels, all_scores, Q, nc)
         lab_h, sc_h = all_labels.cpu(), all_scores.cpu()
         keep = [k for k in range(Q) if lab_h[k] != nc - 2 and sc_h[k] > 0.5]
+        # pan_img stays on the device (the reference returns a host tensor, :883): a fresh
+        # multi-MB host allocation per image is an mmap/munmap pair, and on ROCm every
+        # munmap runs the amdgpu MMU notifier against the busy GPU (~75 ms stalls measured).
         if not keep:
-            pan_img = torch.ones((H0, W0), dtype=torch.long)
+            pan_img = torch.ones((H0, W0), dtype=torch.long, device=dev)
         else:
             kept = torch.tensor(keep, device=dev, dtype=torch.int64).view(1, -1)
             n = len(keep)
@@ -640,7 +643,7 @@ class CrossHead2:
                 if not cur:
                     raise IndexError("every panoptic segment was filtered "
                                      "(the reference fails here too, pairnet_head.py:882)")
-            pan_img = seg.view(H0, W0).cpu()
+            pan_img = seg.view(H0, W0)
         det_bboxes = torch.zeros((2 * R, 5), device=dev)
         r_scores = torch.zeros(R, device=dev)
         r_labels = torch.zeros(R, device=dev)

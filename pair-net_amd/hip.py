@@ -30,6 +30,7 @@ class GemmDesc(C.Structure):
 _SIGS = {
     "pn_abi_version": (C.c_int, []),
     "pn_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "pn_gemm_variant": (C.c_int, [C.POINTER(GemmDesc)]),
     "pn_conv2d_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 9 + [_vp]),
     "pn_layernorm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "pn_groupnorm_nblk": (C.c_int, [_i64]),
@@ -81,6 +82,47 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+GEMM_KERNELS = {0: "k_gemm_skinny<A_ROW>", 1: "k_gemm_skinny<A_COL>",
+                2: "k_gemm_tile<128,64,32,64,A_ROW>", 3: "k_gemm_tile<128,64,32,64,A_COL>",
+                4: "k_gemm_tile<128,128,64,64,A_ROW>", 5: "k_gemm_tile<128,128,64,64,A_COL>"}
+
+
+class KernelTimer:
+    """Optional per-launch HIP-event timing (bench.py's roofline leg).  Events are
+    recorded on the stream the kernels are launched on (torch's current stream).
+    `only`: kernel names to bracket (None = all instrumented launches)."""
+
+    def __init__(self, only=None):
+        self.only = set(only) if only else None
+        self.records = []   # (name, flops, bytes, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, nbytes, s, e in self.records:
+            a = agg.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            a["launches"] += 1
+            a["ms"] += s.elapsed_time(e)
+            a["flops"] += flops
+            a["bytes"] += nbytes
+        return agg
+
+
+TIMER = None
+
+
+def _launch(name, flops, nbytes, fn):
+    t = TIMER
+    if t is None or (t.only is not None and name not in t.only):
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    t.records.append((name, flops, nbytes, s, e))
+    return r
+
+
 def _ptr(t, dtype=torch.float32):
     if t is None:
         return None
@@ -117,7 +159,13 @@ def gemm(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaadd=0,
     d.M, d.N, d.K, d.batch = M, N, K, batch
     d.flags = (GEMM_RELU if relu else 0) | (GEMM_A_COLMAJOR if colmajor else 0) | \
         {None: 0, "tile": GEMM_FORCE_TILE, "skinny": GEMM_FORCE_SKINNY}[force]
-    _check(lib().pn_gemm_f32(C.byref(d), _stream()), "pn_gemm_f32")
+    if TIMER is None:
+        _check(lib().pn_gemm_f32(C.byref(d), _stream()), "pn_gemm_f32")
+        return
+    name = GEMM_KERNELS[lib().pn_gemm_variant(C.byref(d))]
+    nbytes = 4.0 * batch * (M * K + N * K + M * N)
+    _check(_launch(name, 2.0 * M * N * K * batch, nbytes,
+                   lambda: lib().pn_gemm_f32(C.byref(d), _stream())), "pn_gemm_f32")
 
 
 def linear(x, weight, bias, out, *, aadd=None, res=None, relu=False, force=None):
@@ -139,9 +187,12 @@ def linear(x, weight, bias, out, *, aadd=None, res=None, relu=False, force=None)
 
 
 def conv2d_nhwc(x, wp, bias, out, B, H, W, Cin, Cout, KH, KW, pad, relu):
-    _check(lib().pn_conv2d_nhwc_f32(_ptr(x), _ptr(wp), _ptr(bias), _ptr(out), B, H, W,
-                                    Cin, Cout, KH, KW, pad, int(relu), _stream()),
-           "pn_conv2d_nhwc_f32")
+    name = "k_gemm_tile<64,64,32,32,A_CONV>" if Cout <= 64 else "k_gemm_tile<128,128,64,64,A_CONV>"
+    flops = 2.0 * B * H * W * Cout * KH * KW * Cin
+    nbytes = 4.0 * (B * H * W * (Cin + Cout) + Cout * KH * KW * Cin)
+    _check(_launch(name, flops, nbytes, lambda: lib().pn_conv2d_nhwc_f32(
+        _ptr(x), _ptr(wp), _ptr(bias), _ptr(out), B, H, W, Cin, Cout, KH, KW, pad, int(relu),
+        _stream())), "pn_conv2d_nhwc_f32")
 
 
 def layernorm(x, gamma, beta, out, eps=1e-5):
@@ -170,8 +221,12 @@ def msda(value, offaw, out, B, shapes):
     L = len(shapes)
     hs = (_i32 * L)(*[s[0] for s in shapes])
     ws = (_i32 * L)(*[s[1] for s in shapes])
-    _check(lib().pn_msda_f32(_ptr(value), _ptr(offaw), _ptr(out), B, L, hs, ws, _stream()),
-           "pn_msda_f32")
+    n = sum(h * w for h, w in shapes)
+    # algorithmic bytes: value read + offsets/logits read + output write
+    nbytes = 4.0 * B * n * (256 + 8 * L * 4 * 3 + 256)
+    _check(_launch("k_msda", 2.0 * B * n * 8 * L * 4 * 4 * 32 * 2, nbytes,
+                   lambda: lib().pn_msda_f32(_ptr(value), _ptr(offaw), _ptr(out), B, L, hs, ws,
+                                             _stream())), "pn_msda_f32")
 
 
 def sine_pe(out, add, h, w, C_=256, temperature=10000.0):

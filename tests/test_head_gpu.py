@@ -70,9 +70,9 @@ def test_e2e_small_against_reference_golden():
         assert got.shape == shape and got.dtype == np.bool_
         mism = (got[both] != ref_masks[both].astype(bool)).mean()
         print("image %d: mask bit mismatch %.2e, pan mismatch %.2e" % (
-            i, mism, (r[4].numpy() != fx["res%d_pan_img" % i]).mean()))
+            i, mism, (r[4].cpu().numpy() != fx["res%d_pan_img" % i]).mean()))
         assert mism < 1e-3
-        assert (r[4].numpy() != fx["res%d_pan_img" % i]).mean() < 5e-3
+        assert (r[4].cpu().numpy() != fx["res%d_pan_img" % i]).mean() < 5e-3
         assert np.array_equal(r[2].numpy(), fx["res%d_rel_pairs" % i])
         assert r[0].shape == (200, 5) and float(r[0].abs().sum()) == 0.0
 

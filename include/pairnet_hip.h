@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 1
+#define PN_ABI_VERSION 2
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -46,12 +46,16 @@ int pn_abi_version(void);
  * ------------------------------------------------------------------------- */
 #define PN_GEMM_RELU       1   /* act = ReLU (else identity)                        */
 #define PN_GEMM_A_COLMAJOR 2   /* A is stored [K][lda] (an NCHW feature map)        */
-#define PN_GEMM_FORCE_TILE 4   /* testing: force the 128x128 LDS-tiled kernel       */
+#define PN_GEMM_FORCE_TILE 4   /* testing: force the 128x128 tile of the LDS kernel */
 #define PN_GEMM_FORCE_SKINNY 8 /* testing: force the 32x32 split-K-in-block kernel  */
+#define PN_GEMM_FORCE_TILE64 16     /* tuning: 64x64 tile (row-major A)             */
+#define PN_GEMM_FORCE_TILE128x64 32 /* tuning: 128x64 tile                          */
 
 typedef struct pn_gemm_desc {
   const float* A;     int64_t lda;    int64_t strideA;    /* [M][K] (or [K][M])    */
   const float* Aadd;  int64_t ldaadd; int32_t aadd_rows;  /* optional, may be NULL */
+  int32_t aadd_from_col;  /* Aadd only feeds output columns >= this (multiple of 64;
+                             0 = all): one GEMM for [value_proj | offsets+logits]       */
   const float* W;     int64_t ldw;    int64_t strideW;    /* [N][K]                */
   const float* bias;                                      /* [N] or NULL           */
   const float* Res;   int64_t ldres;  int64_t strideRes;  /* optional residual     */
@@ -61,11 +65,17 @@ typedef struct pn_gemm_desc {
 
 int pn_gemm_f32(const pn_gemm_desc* d, void* stream);
 
+/* `count` (<= 16) independent row-major problems in ONE launch of the 128x128 tile
+ * kernel (all their tiles share the grid): used for the 18 key/value projections of
+ * the 9 decoder layers, whose per-problem tile counts do not fill 256 CUs evenly. */
+int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream);
+
 /* Which kernel pn_gemm_f32 would launch for `d` (for profiling / roofline
  * attribution; +1 = the column-major-A instantiation). */
 #define PN_GEMM_VARIANT_SKINNY        0  /* k_gemm_skinny<A>                 */
 #define PN_GEMM_VARIANT_TILE_128x64   2  /* k_gemm_tile<128,64,32,64,A>      */
 #define PN_GEMM_VARIANT_TILE_128x128  4  /* k_gemm_tile<128,128,64,64,A>     */
+#define PN_GEMM_VARIANT_TILE_64x64    6  /* k_gemm_tile<64,64,32,32,A> (default) */
 int pn_gemm_variant(const pn_gemm_desc* d);
 
 /* Implicit-GEMM KHxKW convolution, stride 1, zero padding, channel-last:
@@ -107,16 +117,19 @@ int pn_l2normalize_f32(const float* x, float* y, int64_t rows, int C, float eps,
  * level_start_index, sampling_locations, attention_weights, im2col_step)` and
  * fuses what precedes it in MultiScaleDeformableAttention.forward: softmax over
  * the L*P logits and reference_point + offset / (W_l, H_l).
- *   value   [B][N][H*D]      projected value tokens, levels concatenated
- *   offaw   [B][N][H*L*P*3]  raw Linear outputs: H*L*P*2 offsets (x,y) followed
- *                            by H*L*P attention logits
+ *   value   [B][N][ld_value]  projected value tokens (first H*D floats of each
+ *                             row), levels concatenated
+ *   offaw   [B][N][ld_offaw]  raw Linear outputs: H*L*P*2 offsets (x,y) followed
+ *                             by H*L*P attention logits
+ *   (row strides let both live in one [value | offsets | logits] GEMM output)
  *   out     [B][N][H*D]
  * Queries are the N tokens themselves (encoder self-attention); the reference
  * point of token n is its own pixel centre ((x+.5)/w, (y+.5)/h).
  * H == 8, D == 32, P == 4, L <= 4. */
-int pn_msda_f32(const float* value, const float* offaw, float* out, int B,
-                int L, const int32_t* level_h /* host */,
-                const int32_t* level_w /* host */, void* stream);
+int pn_msda_f32(const float* value, int64_t ld_value, const float* offaw,
+                int64_t ld_offaw, float* out, int B, int L,
+                const int32_t* level_h /* host */, const int32_t* level_w /* host */,
+                void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Positional encoding / resampling

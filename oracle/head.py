@@ -128,17 +128,7 @@ class OracleCrossHead2(nn.Module):
         _, idx = torch.topk(importance.flatten(-2, -1), k=self.num_rel_query)
         sub_pos = torch.div(idx, self.num_obj_query, rounding_mode="trunc")
         obj_pos = torch.remainder(idx, self.num_obj_query)
-        ex = lambda p: p.unsqueeze(-1).repeat(1, 1, self.embed_dims).transpose(0, 1)
-        pair_feat = torch.cat([torch.gather(q, 0, ex(sub_pos)),
-                               torch.gather(q, 0, ex(obj_pos))], dim=0)
-        r = self.rel_query_feat.weight.unsqueeze(1).repeat((1, bs, 1))
-        r_pos = self.rel_query_embed.weight.unsqueeze(1).repeat((1, bs, 1))
-        p_pos = self.rel_query_embed2.weight.unsqueeze(1).repeat((1, bs, 1))
-        for layer in self.relation_decoder.layers:
-            r = layer(query=r, key=pair_feat, value=pair_feat, query_pos=r_pos,
-                      key_pos=p_pos, query_key_padding_mask=None,
-                      key_padding_mask=None)
-        rel_preds = self.rel_cls_embed(r.transpose(0, 1))
+        pair_feat, rel_preds = self.relation_logits(q, sub_pos, obj_pos)
         nc = cls_pred.shape[-1]
         hw = mask_pred.shape[-2:]
         g_cls = lambda p: torch.gather(cls_pred, 1, p.unsqueeze(-1).expand(-1, -1, nc))
@@ -152,6 +142,24 @@ class OracleCrossHead2(nn.Module):
                      rel=rel_preds, importance=importance),
                 dict(mask=mask_pred, sub_seg=g_seg(sub_pos),
                      obj_seg=g_seg(obj_pos)))
+
+    # pairnet_head.py:342-378: pair features of the selected (sub, obj) queries ->
+    # Relation Fusion decoder -> relation logits.  Separate so that tests can evaluate
+    # it for the pair list the GPU selected when a near-tie reorders the top-k.
+    @torch.no_grad()
+    def relation_logits(self, q, sub_pos, obj_pos):
+        bs = q.shape[1]
+        ex = lambda p: p.unsqueeze(-1).repeat(1, 1, self.embed_dims).transpose(0, 1)
+        pair_feat = torch.cat([torch.gather(q, 0, ex(sub_pos)),
+                               torch.gather(q, 0, ex(obj_pos))], dim=0)
+        r = self.rel_query_feat.weight.unsqueeze(1).repeat((1, bs, 1))
+        r_pos = self.rel_query_embed.weight.unsqueeze(1).repeat((1, bs, 1))
+        p_pos = self.rel_query_embed2.weight.unsqueeze(1).repeat((1, bs, 1))
+        for layer in self.relation_decoder.layers:
+            r = layer(query=r, key=pair_feat, value=pair_feat, query_pos=r_pos,
+                      key_pos=p_pos, query_key_padding_mask=None,
+                      key_padding_mask=None)
+        return pair_feat, self.rel_cls_embed(r.transpose(0, 1))
 
     # pairnet_head.py:760-786
     def get_bboxes(self, cls_scores, mask_preds, img_metas, rescale=False):

@@ -54,8 +54,8 @@ extern "C" int pn_mask_pack(const float* logits, uint32_t* bits, int32_t* rowall
 struct AttnP {
   const float* q; const float* k; const float* v;
   const uint32_t* bits; const int32_t* rowall;
-  float* opart; float* ml;
-  int64_t ldq, ldk, ldv;
+  float* opart; float* ml; float* out;
+  int64_t ldq, ldk, ldv, ldo;
   int Q, Nk, chunk, nchunks, nwords;
   float scale;
 };
@@ -160,48 +160,80 @@ __global__ __launch_bounds__(256) void k_attn_chunk(const AttnP p) {
       o = mfma32(a, s[t], o);
     }
   }
-  // ---- write the partial: O^T register r is d = mfma32_row(r, lh) of query lane&31 ----
+  // ---- O^T register r is d = mfma32_row(r, lh) of query lane&31 ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  if (q_ok) {
-    const int64_t slot = (((int64_t)b * 8 + head) * p.nchunks + c) * p.Q + myq;
-    float* op = p.opart + slot * 32;
+  if (!q_ok) return;
+  if (p.nchunks == 1) {  // single chunk: normalise and write the final rows directly
+    const float inv = 1.f / l_tot;
+    float* op = p.out + ((int64_t)b * p.Q + myq) * p.ldo + head * 32;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      st4(op + 8 * g + 4 * lh, make_float4(o[4 * g + 0], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]));
-    if (lh == 0) {
-      p.ml[slot * 2 + 0] = m_run;
-      p.ml[slot * 2 + 1] = l_tot;
-    }
+      st4(op + 8 * g + 4 * lh, make_float4(o[4 * g + 0] * inv, o[4 * g + 1] * inv,
+                                           o[4 * g + 2] * inv, o[4 * g + 3] * inv));
+    return;
+  }
+  const int64_t slot = (((int64_t)b * 8 + head) * p.nchunks + c) * p.Q + myq;
+  float* op = p.opart + slot * 32;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    st4(op + 8 * g + 4 * lh, make_float4(o[4 * g + 0], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]));
+  if (lh == 0) {
+    p.ml[slot * 2 + 0] = m_run;
+    p.ml[slot * 2 + 1] = l_tot;
   }
 }
 
-// out[b][q][h*32+d] = sum_c e^{m_c-M} O_c[d] / sum_c e^{m_c-M} l_c
+// out[b][q][h*32+d] = sum_c e^{m_c-M} O_c[d] / sum_c e^{m_c-M} l_c.
+// One workgroup per (b, q); the 32 lanes of head h first sweep the chunk statistics
+// in parallel (lane = chunk) to get M, the weights (kept in LDS) and the denominator,
+// then lane d accumulates the weighted partials with independent loads.
+#define ATT_MAXCH 256
 __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ opart,
                                                       const float* __restrict__ ml,
                                                       float* __restrict__ out, int64_t ldo, int Q,
                                                       int nchunks) {
+  __shared__ float wts[8][ATT_MAXCH];
   const int q = blockIdx.x, b = blockIdx.y;
   const int head = threadIdx.x >> 5, d = threadIdx.x & 31;
   const int64_t base = ((int64_t)b * 8 + head) * nchunks;
   float M = -INFINITY;
-  for (int c = 0; c < nchunks; ++c) M = fmaxf(M, ml[((base + c) * Q + q) * 2]);
-  float num = 0.f, den = 0.f;
-  for (int c = 0; c < nchunks; ++c) {
+  for (int c = d; c < nchunks; c += 32) M = fmaxf(M, ml[((base + c) * Q + q) * 2]);
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 32));
+  float den = 0.f;
+  for (int c = d; c < nchunks; c += 32) {
     const int64_t slot = (base + c) * Q + q;
     const float m = ml[slot * 2];
-    if (m == -INFINITY) continue;
-    const float w = expf(m - M);
-    num += w * opart[slot * 32 + d];
+    const float w = (m == -INFINITY) ? 0.f : expf(m - M);
+    wts[head][c] = w;
     den += w * ml[slot * 2 + 1];
   }
-  out[((int64_t)b * Q + q) * ldo + head * 32 + d] = num / den;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) den += __shfl_xor(den, o, 32);
+  __syncthreads();
+  float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+  int c = 0;
+  for (; c + 4 <= nchunks; c += 4) {
+    n0 += wts[head][c + 0] * opart[((base + c + 0) * Q + q) * 32 + d];
+    n1 += wts[head][c + 1] * opart[((base + c + 1) * Q + q) * 32 + d];
+    n2 += wts[head][c + 2] * opart[((base + c + 2) * Q + q) * 32 + d];
+    n3 += wts[head][c + 3] * opart[((base + c + 3) * Q + q) * 32 + d];
+  }
+  for (; c < nchunks; ++c) n0 += wts[head][c] * opart[((base + c) * Q + q) * 32 + d];
+  out[((int64_t)b * Q + q) * ldo + head * 32 + d] = ((n0 + n1) + (n2 + n3)) / den;
 }
 
 static int attn_chunking(int Nk, int B, int Q, int* chunk) {
-  // aim for >= ~512 workgroups, chunk a multiple of 32 keys, >= 64 keys
+  // short key sets (self-attention, relation decoder): one chunk, no combine pass;
+  // long ones: ~1000 workgroups, chunk a multiple of 32 keys, at most ATT_MAXCH chunks
   const int qgroups = (Q + 127) / 128;
-  int want = 512 / (8 * B * qgroups);
+  if (Nk <= 512) {
+    *chunk = (Nk + 31) & ~31;
+    return 1;
+  }
+  int want = 1024 / (8 * B * qgroups);
   if (want < 1) want = 1;
+  if (want > ATT_MAXCH) want = ATT_MAXCH;
   int ch = ((Nk + want - 1) / want + 31) & ~31;
   if (ch < 64) ch = 64;
   *chunk = ch;
@@ -219,7 +251,7 @@ extern "C" int pn_attention_f32(const float* q, int64_t ldq, const float* k, int
                                 const int32_t* rowall, float* out, int64_t ldo, float* scratch,
                                 int B, int Q, int Nk, float scale, void* stream) {
   if (!q || !k || !v || !out || !scratch || B <= 0 || Q <= 0 || Nk <= 0) return PN_BAD_ARG;
-  if ((ldq | ldk | ldv) & 3) return PN_BAD_ARG;
+  if ((ldq | ldk | ldv | ldo) & 3) return PN_BAD_ARG;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)scratch) & 15) return PN_BAD_ARG;
   if ((maskbits == nullptr) != (rowall == nullptr)) return PN_BAD_ARG;
   AttnP p{};
@@ -229,10 +261,13 @@ extern "C" int pn_attention_f32(const float* q, int64_t ldq, const float* k, int
   p.nwords = (Nk + 31) / 32;
   p.opart = scratch;
   p.ml = scratch + (int64_t)B * 8 * p.nchunks * Q * 32;
+  p.out = out;
+  p.ldo = ldo;
   hipStream_t s = (hipStream_t)stream;
   const int qgroups = (Q + 127) / 128;
   hipLaunchKernelGGL(k_attn_chunk, dim3(p.nchunks, 8, B * qgroups), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(k_attn_combine, dim3(Q, B), dim3(256), 0, s, p.opart, p.ml, out, ldo, Q,
-                     p.nchunks);
+  if (p.nchunks > 1)
+    hipLaunchKernelGGL(k_attn_combine, dim3(Q, B), dim3(256), 0, s, p.opart, p.ml, out, ldo, Q,
+                       p.nchunks);
   return PN_LAUNCH_CHECK();
 }

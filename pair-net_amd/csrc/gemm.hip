@@ -22,14 +22,15 @@ struct GemmP {
   const float* Res; float* C;
   int64_t lda, ldaadd, ldw, ldres, ldc;
   int64_t sA, sW, sRes, sC;
-  int M, N, K, aadd_rows, relu, a_vec;
+  int M, N, K, aadd_rows, aadd_from_col, relu, a_vec;
   int H, Wd, Cin, KW, pad;  // conv mode
 };
 
 enum { A_ROW = 0, A_COL = 1, A_CONV = 2 };
 
 template <int BM, int BN, int WM, int WN, int AMODE>
-__global__ __launch_bounds__(256) void k_gemm_tile(const GemmP p) {
+__device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int m0, const int n0,
+                                               const int bz, float* smem) {
   constexpr int BK = 32, LD = BK + 4;
   constexpr int WAVES_N = BN / WN;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -42,13 +43,11 @@ __global__ __launch_bounds__(256) void k_gemm_tile(const GemmP p) {
   constexpr int QM = BM / 4;         // float4 per k-row of a column-major A tile
   constexpr int KSTEP = 256 / QM;    // k rows covered per pass
   static_assert((BM / WM) * WAVES_N == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int bz = blockIdx.z;
+  const float* __restrict__ Aadd = (p.Aadd && n0 >= p.aadd_from_col) ? p.Aadd : nullptr;
   const float* __restrict__ A = p.A + (int64_t)bz * p.sA;
   const float* __restrict__ W = p.W + (int64_t)bz * p.sW;
 
@@ -66,7 +65,7 @@ __global__ __launch_bounds__(256) void k_gemm_tile(const GemmP p) {
       a_ok[j] = gm < p.M;
       if (AMODE == A_ROW) {
         a_row[j] = A + (int64_t)(a_ok[j] ? gm : 0) * p.lda;
-        if (p.Aadd) add_row[j] = p.Aadd + (int64_t)((a_ok[j] ? gm : 0) % p.aadd_rows) * p.ldaadd;
+        if (Aadd) add_row[j] = Aadd + (int64_t)((a_ok[j] ? gm : 0) % p.aadd_rows) * p.ldaadd;
       } else {
         cy[j] = gm / p.Wd;
         cx[j] = gm - cy[j] * p.Wd;
@@ -91,7 +90,7 @@ __global__ __launch_bounds__(256) void k_gemm_tile(const GemmP p) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a_ok[j] && k0 + kc < p.K) {
           v = ld4(a_row[j] + k0 + kc);
-          if (p.Aadd) v = add4(v, ld4(add_row[j] + k0 + kc));
+          if (Aadd) v = add4(v, ld4(add_row[j] + k0 + kc));
         }
         ra[j] = v;
       }
@@ -223,11 +222,52 @@ __global__ __launch_bounds__(256) void k_gemm_tile(const GemmP p) {
   }
 }
 
-// 32x32 output tile; wave w contracts k in [w*ks, (w+1)*ks); partial tiles are summed
-// through LDS in wave order (deterministic).
-template <int AMODE>
-__global__ __launch_bounds__(256) void k_gemm_skinny(const GemmP p) {
-  __shared__ float red[4 * 1024];
+template <int BM, int BN, int AMODE>
+struct TileSmem {
+  static constexpr int A_ELEMS = (AMODE == A_COL) ? 32 * (BM + 4) : BM * 36;
+  static constexpr int FLOATS = 2 * (A_ELEMS + BN * 36);
+};
+
+template <int BM, int BN, int WM, int WN, int AMODE>
+__global__ __launch_bounds__(256) void k_gemm_tile(const GemmP p) {
+  __shared__ __attribute__((aligned(16))) float smem[TileSmem<BM, BN, AMODE>::FLOATS];
+  gemm_tile_body<BM, BN, WM, WN, AMODE>(p, blockIdx.y * BM, blockIdx.x * BN, blockIdx.z, smem);
+}
+
+// Several independent row-major GEMMs in ONE launch: the 64x64 tiles of all
+// problems are enumerated together (n-tile fastest, so blocks that share an A panel
+// are neighbours), which fills the chip where a single M x 256 problem leaves a
+// ragged second round of workgroups.
+#define GEMM_GROUP_MAX 16
+struct GroupP {
+  int n;
+  int tile_start[GEMM_GROUP_MAX + 1];
+  int mt[GEMM_GROUP_MAX], nt[GEMM_GROUP_MAX];
+  GemmP p[GEMM_GROUP_MAX];
+};
+
+__global__ __launch_bounds__(256) void k_gemm_group(const GroupP g) {
+  __shared__ __attribute__((aligned(16))) float smem[TileSmem<64, 64, A_ROW>::FLOATS];
+  const int bid = blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < GEMM_GROUP_MAX; ++j)
+    if (j < g.n && bid >= g.tile_start[j]) i = j;
+  const int local = bid - g.tile_start[i];
+  const int per = g.mt[i] * g.nt[i];
+  const int bz = local / per, r = local - bz * per;
+  const int tm = r / g.nt[i], tn = r - tm * g.nt[i];
+  gemm_tile_body<64, 64, 32, 32, A_ROW>(g.p[i], tm * 64, tn * 64, bz, smem);
+}
+
+// 32x32 output tile per workgroup; NW waves split K (wave w contracts a contiguous
+// K/NW slice, rounded to 32) and the partial tiles are summed through LDS in wave
+// order (deterministic).  Operands go global -> VGPR directly, one 32-deep chunk
+// (4 float4 per operand per lane) prefetched ahead of the 16 MFMAs that consume the
+// previous one, so a wave never waits on a single load round trip per MFMA group.
+template <int AMODE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gemm_skinny(const GemmP p) {
+  __shared__ float red[NW * 1024];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32, bz = blockIdx.z;
@@ -236,54 +276,58 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const GemmP p) {
   const int am = min(m0 + li, p.M - 1);
   const int wn_ = min(n0 + li, p.N - 1);
   const float* arow = (AMODE == A_ROW) ? A + (int64_t)am * p.lda : A + am;
-  const float* addrow = p.Aadd ? p.Aadd + (int64_t)(am % p.aadd_rows) * p.ldaadd : nullptr;
+  const float* addrow = (p.Aadd && n0 >= p.aadd_from_col)
+                            ? p.Aadd + (int64_t)(am % p.aadd_rows) * p.ldaadd : nullptr;
   const float* wrow = W + (int64_t)wn_ * p.ldw;
 
-  int ks = (p.K + 3) / 4;
-  ks = (ks + 7) & ~7;
+  int ks = (p.K + NW - 1) / NW;
+  ks = (ks + 31) & ~31;
   const int kbeg = min(wave * ks, p.K), kend = min(kbeg + ks, p.K);
 
+  auto load_chunk = [&](int kc, float4 (&a)[4], float4 (&b)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int kk = kc + 8 * s + 4 * lh;
+      const bool ok = kk < kend;
+      float4 av = make_float4(0.f, 0.f, 0.f, 0.f), bv = av;
+      if (ok) {
+        bv = ld4(wrow + kk);
+        if (AMODE == A_ROW) {
+          av = ld4(arow + kk);
+          if (addrow) av = add4(av, ld4(addrow + kk));
+        } else {
+          av.x = arow[(int64_t)(kk + 0) * p.lda];
+          av.y = arow[(int64_t)(kk + 1) * p.lda];
+          av.z = arow[(int64_t)(kk + 2) * p.lda];
+          av.w = arow[(int64_t)(kk + 3) * p.lda];
+        }
+      }
+      a[s] = av; b[s] = bv;
+    }
+  };
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  auto mma_chunk = [&](const float4 (&a)[4], const float4 (&b)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      acc = mfma32(a[s].x, b[s].x, acc);
+      acc = mfma32(a[s].y, b[s].y, acc);
+      acc = mfma32(a[s].z, b[s].z, acc);
+      acc = mfma32(a[s].w, b[s].w, acc);
+    }
+  };
 
-  const int nfull = (kend - kbeg) / 8;
-  int k = kbeg + 4 * lh;
-#pragma unroll 4
-  for (int s = 0; s < nfull; ++s, k += 8) {
-    float4 a, b = ld4(wrow + k);
-    if (AMODE == A_ROW) {
-      a = ld4(arow + k);
-      if (addrow) a = add4(a, ld4(addrow + k));
-    } else {
-      a.x = arow[(int64_t)(k + 0) * p.lda];
-      a.y = arow[(int64_t)(k + 1) * p.lda];
-      a.z = arow[(int64_t)(k + 2) * p.lda];
-      a.w = arow[(int64_t)(k + 3) * p.lda];
+  float4 a0[4], b0[4], a1[4], b1[4];
+  if (kbeg < kend) load_chunk(kbeg, a0, b0);
+  for (int kc = kbeg; kc < kend; kc += 64) {
+    const bool more1 = kc + 32 < kend;
+    if (more1) load_chunk(kc + 32, a1, b1);
+    mma_chunk(a0, b0);
+    if (more1) {
+      if (kc + 64 < kend) load_chunk(kc + 64, a0, b0);
+      mma_chunk(a1, b1);
     }
-    acc = mfma32(a.x, b.x, acc);
-    acc = mfma32(a.y, b.y, acc);
-    acc = mfma32(a.z, b.z, acc);
-    acc = mfma32(a.w, b.w, acc);
-  }
-  if (kbeg + nfull * 8 < kend) {  // one 4-wide remainder: lower half only
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (lh == 0) {
-      b = ld4(wrow + k);
-      if (AMODE == A_ROW) {
-        a = ld4(arow + k);
-        if (addrow) a = add4(a, ld4(addrow + k));
-      } else {
-        a.x = arow[(int64_t)(k + 0) * p.lda];
-        a.y = arow[(int64_t)(k + 1) * p.lda];
-        a.z = arow[(int64_t)(k + 2) * p.lda];
-        a.w = arow[(int64_t)(k + 3) * p.lda];
-      }
-    }
-    acc = mfma32(a.x, b.x, acc);
-    acc = mfma32(a.y, b.y, acc);
-    acc = mfma32(a.z, b.z, acc);
-    acc = mfma32(a.w, b.w, acc);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave * 1024 + mfma32_row(r, lh) * 32 + li] = acc[r];
@@ -291,18 +335,30 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const GemmP p) {
 
   float* __restrict__ C = p.C + (int64_t)bz * p.sC;
   const float* __restrict__ Res = p.Res ? p.Res + (int64_t)bz * p.sRes : nullptr;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e = tid + 256 * j;
+  for (int e = tid; e < 1024; e += 64 * NW) {
     const int row = m0 + (e >> 5), col = n0 + (e & 31);
     if (row < p.M && col < p.N) {
-      float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+      float v = red[e];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) v += red[w * 1024 + e];
       if (p.bias) v += p.bias[col];
       if (p.relu) v = fmaxf(v, 0.f);
       if (Res) v += Res[(int64_t)row * p.ldres + col];
       C[(int64_t)row * p.ldc + col] = v;
     }
   }
+}
+
+template <int AMODE>
+static int launch_skinny(const GemmP& p, int batch, hipStream_t s) {
+  dim3 grid(pn_cdiv(p.N, 32), pn_cdiv(p.M, 32), batch);
+  if (p.K <= 128)
+    hipLaunchKernelGGL((k_gemm_skinny<AMODE, 4>), grid, dim3(256), 0, s, p);
+  else if (p.K <= 256)
+    hipLaunchKernelGGL((k_gemm_skinny<AMODE, 8>), grid, dim3(512), 0, s, p);
+  else
+    hipLaunchKernelGGL((k_gemm_skinny<AMODE, 16>), grid, dim3(1024), 0, s, p);
+  return PN_LAUNCH_CHECK();
 }
 
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -317,7 +373,8 @@ static int launch_tile(const GemmP& p, int batch, hipStream_t s) {
 static bool gemm_use_skinny(const pn_gemm_desc* d) {
   const int64_t tiles128 = (int64_t)pn_cdiv(d->M, 128) * pn_cdiv(d->N, 128) * d->batch;
   bool skinny = tiles128 < 96;
-  if (d->flags & PN_GEMM_FORCE_TILE) skinny = false;
+  if (d->flags & (PN_GEMM_FORCE_TILE | PN_GEMM_FORCE_TILE64 | PN_GEMM_FORCE_TILE128x64))
+    skinny = false;
   if (d->flags & PN_GEMM_FORCE_SKINNY) skinny = true;
   return skinny;
 }
@@ -326,11 +383,12 @@ extern "C" int pn_gemm_variant(const pn_gemm_desc* d) {
   if (!d || d->M <= 0 || d->N <= 0 || d->batch <= 0) return PN_BAD_ARG;
   const int col = (d->flags & PN_GEMM_A_COLMAJOR) ? 1 : 0;
   if (gemm_use_skinny(d)) return PN_GEMM_VARIANT_SKINNY + col;
-  return (d->N <= 64 ? PN_GEMM_VARIANT_TILE_128x64 : PN_GEMM_VARIANT_TILE_128x128) + col;
+  if (d->flags & PN_GEMM_FORCE_TILE128x64) return PN_GEMM_VARIANT_TILE_128x64 + col;
+  if (d->flags & PN_GEMM_FORCE_TILE) return PN_GEMM_VARIANT_TILE_128x128 + col;
+  return PN_GEMM_VARIANT_TILE_64x64 + col;
 }
 
-extern "C" int pn_gemm_f32(const pn_gemm_desc* d, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+static int fill_params(const pn_gemm_desc* d, GemmP* out) {
   if (!d || !d->A || !d->W || !d->C) return PN_BAD_ARG;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return PN_BAD_ARG;
   const bool colmajor = d->flags & PN_GEMM_A_COLMAJOR;
@@ -338,25 +396,57 @@ extern "C" int pn_gemm_f32(const pn_gemm_desc* d, void* stream) {
   if (!colmajor && (d->lda % 4 || d->strideA % 4 || !aligned16(d->A))) return PN_BAD_ARG;
   if (d->Aadd && (colmajor || d->ldaadd % 4 || !aligned16(d->Aadd) || d->aadd_rows <= 0))
     return PN_BAD_ARG;
+  if (d->Aadd && (d->aadd_from_col < 0 || d->aadd_from_col % 64)) return PN_BAD_ARG;
   GemmP p{};
   p.A = d->A; p.Aadd = d->Aadd; p.W = d->W; p.bias = d->bias; p.Res = d->Res; p.C = d->C;
   p.lda = d->lda; p.ldaadd = d->ldaadd; p.ldw = d->ldw; p.ldres = d->ldres; p.ldc = d->ldc;
   p.sA = d->strideA; p.sW = d->strideW; p.sRes = d->strideRes; p.sC = d->strideC;
   p.M = d->M; p.N = d->N; p.K = d->K; p.aadd_rows = d->Aadd ? d->aadd_rows : 1;
+  p.aadd_from_col = d->Aadd ? d->aadd_from_col : 0;
   p.relu = (d->flags & PN_GEMM_RELU) ? 1 : 0;
   p.a_vec = colmajor && d->lda % 4 == 0 && d->strideA % 4 == 0 && aligned16(d->A);
+  *out = p;
+  return 0;
+}
 
+extern "C" int pn_gemm_f32(const pn_gemm_desc* d, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GemmP p;
+  if (int rc = fill_params(d, &p)) return rc;
+  const bool colmajor = d->flags & PN_GEMM_A_COLMAJOR;
   if (gemm_use_skinny(d)) {
-    dim3 grid(pn_cdiv(d->N, 32), pn_cdiv(d->M, 32), d->batch);
-    if (colmajor) hipLaunchKernelGGL(k_gemm_skinny<A_COL>, grid, dim3(256), 0, s, p);
-    else          hipLaunchKernelGGL(k_gemm_skinny<A_ROW>, grid, dim3(256), 0, s, p);
-    return PN_LAUNCH_CHECK();
+    return colmajor ? launch_skinny<A_COL>(p, d->batch, s) : launch_skinny<A_ROW>(p, d->batch, s);
   }
-  if (d->N <= 64)
+  // Tile choice (measured on MI355X, tools/gemm_sweep.py): with K = 256..1024 and
+  // M x N of a few hundred 128x128 tiles, the 64x64 tile wins everywhere (75-94 vs
+  // 58-80 TFLOP/s): 4x more workgroups even out the last round over 256 CUs and four
+  // of them fit a CU (36.8 KB LDS, 58 VGPRs).
+  if (d->flags & PN_GEMM_FORCE_TILE128x64)
     return colmajor ? launch_tile<128, 64, 32, 64, A_COL>(p, d->batch, s)
                     : launch_tile<128, 64, 32, 64, A_ROW>(p, d->batch, s);
-  return colmajor ? launch_tile<128, 128, 64, 64, A_COL>(p, d->batch, s)
-                  : launch_tile<128, 128, 64, 64, A_ROW>(p, d->batch, s);
+  if (d->flags & PN_GEMM_FORCE_TILE)
+    return colmajor ? launch_tile<128, 128, 64, 64, A_COL>(p, d->batch, s)
+                    : launch_tile<128, 128, 64, 64, A_ROW>(p, d->batch, s);
+  return colmajor ? launch_tile<64, 64, 32, 32, A_COL>(p, d->batch, s)
+                  : launch_tile<64, 64, 32, 32, A_ROW>(p, d->batch, s);
+}
+
+extern "C" int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream) {
+  if (!d || count <= 0 || count > GEMM_GROUP_MAX) return PN_BAD_ARG;
+  GroupP g{};
+  g.n = count;
+  int tiles = 0;
+  for (int i = 0; i < count; ++i) {
+    if (d[i].flags & PN_GEMM_A_COLMAJOR) return PN_BAD_ARG;
+    if (int rc = fill_params(&d[i], &g.p[i])) return rc;
+    g.tile_start[i] = tiles;
+    g.mt[i] = pn_cdiv(d[i].M, 64);
+    g.nt[i] = pn_cdiv(d[i].N, 64);
+    tiles += g.mt[i] * g.nt[i] * d[i].batch;
+  }
+  for (int i = count; i <= GEMM_GROUP_MAX; ++i) g.tile_start[i] = tiles;
+  hipLaunchKernelGGL(k_gemm_group, dim3(tiles), dim3(256), 0, (hipStream_t)stream, g);
+  return PN_LAUNCH_CHECK();
 }
 
 extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float* bias,
@@ -372,8 +462,7 @@ extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float*
   p.relu = relu ? 1 : 0; p.aadd_rows = 1;
   p.H = H; p.Wd = W; p.Cin = Cin; p.KW = KW; p.pad = pad;
   hipStream_t s = (hipStream_t)stream;
-  if (Cout <= 64) return launch_tile<64, 64, 32, 32, A_CONV>(p, B, s);
-  return launch_tile<128, 128, 64, 64, A_CONV>(p, B, s);
+  return launch_tile<64, 64, 32, 32, A_CONV>(p, B, s);
 }
 
 extern "C" int pn_abi_version(void) { return PN_ABI_VERSION; }

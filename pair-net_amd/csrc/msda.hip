@@ -20,7 +20,8 @@ struct MsdaLevels {
 __global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
                                               const float* __restrict__ offaw,
                                               float* __restrict__ out,
-                                              const MsdaLevels lv) {
+                                              const MsdaLevels lv, const int64_t ldv,
+                                              const int64_t ldo) {
   const int tid = threadIdx.x;
   const int c4 = tid & 7, head = (tid >> 3) & 7, ql = tid >> 6;
   const int n = blockIdx.x * 4 + ql;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
   const float ref_x = ((float)qx + 0.5f) / (float)lv.w[ql_lvl];
   const float ref_y = ((float)qy + 0.5f) / (float)lv.h[ql_lvl];
 
-  const float* oa = offaw + ((int64_t)b * lv.N + n) * (8 * LP * 3);
+  const float* oa = offaw + ((int64_t)b * lv.N + n) * ldo;
   const float* offp = oa + head * LP * 2;
   const float* awp = oa + 8 * LP * 2 + head * LP;
 
@@ -57,13 +58,13 @@ __global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
     den += logit[i];
   }
 
-  const float* vb = value + (int64_t)b * lv.N * 256 + head * 32 + c4 * 4;
+  const float* vb = value + (int64_t)b * lv.N * ldv + head * 32 + c4 * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int l = 0; l < 4; ++l) {
     if (l >= L) break;
     const int Hl = lv.h[l], Wl = lv.w[l];
-    const float* vl = vb + (int64_t)lv.start[l] * 256;
+    const float* vl = vb + (int64_t)lv.start[l] * ldv;
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
       const float ox = offp[(l * 4 + pt) * 2 + 0];
@@ -82,10 +83,10 @@ __global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
       const bool xin0 = x0 >= 0 && x0 < Wl, xin1 = x0 + 1 >= 0 && x0 + 1 < Wl;
       const bool yin0 = y0 >= 0 && y0 < Hl, yin1 = y0 + 1 >= 0 && y0 + 1 < Hl;
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 v_nw = (xin0 && yin0) ? ld4(vl + ((int64_t)y0 * Wl + x0) * 256) : z;
-      const float4 v_ne = (xin1 && yin0) ? ld4(vl + ((int64_t)y0 * Wl + x0 + 1) * 256) : z;
-      const float4 v_sw = (xin0 && yin1) ? ld4(vl + ((int64_t)(y0 + 1) * Wl + x0) * 256) : z;
-      const float4 v_se = (xin1 && yin1) ? ld4(vl + ((int64_t)(y0 + 1) * Wl + x0 + 1) * 256) : z;
+      const float4 v_nw = (xin0 && yin0) ? ld4(vl + ((int64_t)y0 * Wl + x0) * ldv) : z;
+      const float4 v_ne = (xin1 && yin0) ? ld4(vl + ((int64_t)y0 * Wl + x0 + 1) * ldv) : z;
+      const float4 v_sw = (xin0 && yin1) ? ld4(vl + ((int64_t)(y0 + 1) * Wl + x0) * ldv) : z;
+      const float4 v_se = (xin1 && yin1) ? ld4(vl + ((int64_t)(y0 + 1) * Wl + x0 + 1) * ldv) : z;
       float4 s;
       s.x = ((v_nw.x * w_nw + v_ne.x * w_ne) + v_sw.x * w_sw) + v_se.x * w_se;
       s.y = ((v_nw.y * w_nw + v_ne.y * w_ne) + v_sw.y * w_sw) + v_se.y * w_se;
@@ -97,9 +98,12 @@ __global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
   st4(out + ((int64_t)b * lv.N + n) * 256 + head * 32 + c4 * 4, acc);
 }
 
-extern "C" int pn_msda_f32(const float* value, const float* offaw, float* out, int B, int L,
-                           const int32_t* level_h, const int32_t* level_w, void* stream) {
+extern "C" int pn_msda_f32(const float* value, int64_t ld_value, const float* offaw,
+                           int64_t ld_offaw, float* out, int B, int L, const int32_t* level_h,
+                           const int32_t* level_w, void* stream) {
   if (!value || !offaw || !out || B <= 0 || L <= 0 || L > 4 || !level_h || !level_w)
+    return PN_BAD_ARG;
+  if (ld_value < 256 || (ld_value & 3) || ld_offaw < 8 * L * 12 || ((uintptr_t)value & 15))
     return PN_BAD_ARG;
   MsdaLevels lv{};
   lv.L = L;
@@ -111,6 +115,6 @@ extern "C" int pn_msda_f32(const float* value, const float* offaw, float* out, i
   }
   lv.N = n;
   hipLaunchKernelGGL(k_msda, dim3(pn_cdiv(n, 4), B), dim3(256), 0, (hipStream_t)stream, value,
-                     offaw, out, lv);
+                     offaw, out, lv, ld_value, ld_offaw);
   return PN_LAUNCH_CHECK();
 }

@@ -259,10 +259,14 @@ class CrossHead2:
             w[pd + "output_convs.0.conv.weight"].permute(0, 2, 3, 1).reshape(256, -1).contiguous()
         for i in range(self.num_enc_layers):
             p = pd + "encoder.layers.%d.attentions.0." % i
-            w[p + "offaw.weight"] = torch.cat([w[p + "sampling_offsets.weight"],
-                                               w[p + "attention_weights.weight"]], 0).contiguous()
-            w[p + "offaw.bias"] = torch.cat([w[p + "sampling_offsets.bias"],
-                                             w[p + "attention_weights.bias"]], 0).contiguous()
+            # one GEMM per layer: columns [value_proj 256 | sampling_offsets 192 |
+            # attention_weights 96]; the positional add feeds only columns >= 256
+            w[p + "voa.weight"] = torch.cat([w[p + "value_proj.weight"],
+                                             w[p + "sampling_offsets.weight"],
+                                             w[p + "attention_weights.weight"]], 0).contiguous()
+            w[p + "voa.bias"] = torch.cat([w[p + "value_proj.bias"],
+                                           w[p + "sampling_offsets.bias"],
+                                           w[p + "attention_weights.bias"]], 0).contiguous()
         ml = "update_importance.conv_layers."
         w[ml + "0.0.weight"] = w[ml + "0.0.weight"].reshape(64, 49).contiguous()
         w[ml + "1.0.weight"] = w[ml + "1.0.weight"].permute(0, 2, 3, 1).reshape(64, -1).contiguous()
@@ -301,8 +305,8 @@ class CrossHead2:
             pl.dec_kpos.append(kp)
         # ---- pixel decoder ----
         pl.X, pl.X1, pl.Y = E(B, SN, 256), E(B, SN, 256), E(B, SN, 256)
-        pl.V, pl.S = E(B, SN, 256), E(B, SN, 256)
-        pl.offaw = E(B, SN, 288)
+        pl.S = E(B, SN, 256)
+        pl.VOA = E(B, SN, 544)          # [value | offsets | logits] per token
         pl.H = E(M, self.enc_ffn)
         pl.tmpconv = E(B, max(pl.N), 256)
         nblk = max(hip.groupnorm_nblk(HW2), hip.groupnorm_nblk(max(pl.N)))
@@ -366,10 +370,10 @@ class CrossHead2:
         for i in range(self.num_enc_layers):
             p = pd + "encoder.layers.%d." % i
             a = p + "attentions.0."
-            hip.linear(X2, w[a + "offaw.weight"], w[a + "offaw.bias"], pl.offaw.view(-1, 288),
-                       aadd=pl.enc_pos)
-            hip.linear(X2, w[a + "value_proj.weight"], w[a + "value_proj.bias"], pl.V.view(-1, 256))
-            hip.msda(pl.V, pl.offaw, pl.S, B, pl.shapes)
+            hip.gemm(X2, w[a + "voa.weight"], pl.VOA, M=B * SN, N=544, K=256, lda=256, ldw=256,
+                     ldc=544, bias=w[a + "voa.bias"], aadd=pl.enc_pos, ldaadd=256, aadd_rows=SN,
+                     aadd_from_col=256)
+            hip.msda(pl.VOA, 544, pl.VOA.view(-1)[256:], 544, pl.S, B, pl.shapes)
             hip.linear(pl.S.view(-1, 256), w[a + "output_proj.weight"], w[a + "output_proj.bias"],
                        Y2, res=X2)
             hip.layernorm(Y2, w[p + "norms.0.weight"], w[p + "norms.0.bias"], X12)
@@ -462,19 +466,24 @@ class CrossHead2:
         pl = self._plan(B, shapes, tuple(feats[0].shape[-2:]))
         w, Q, R = self.w, self.num_obj_query, self.num_rel_query
         self._pixel_decoder(feats, pl)
-        # K / V projections of all decoder layers up front (query-independent)
+        # K / V projections of all decoder layers up front (query-independent), as grouped
+        # launches: 18 problems whose tile counts (9/33/131 x 2 per image) would each
+        # leave most of the 256 CUs idle on their own
+        probs = []
         for i in range(self.num_dec_layers):
             l = i % 3
             a = "transformer_decoder.layers.%d.attentions.0.attn." % i
             mem = pl.X[:, pl.start[l]:]
-            common = dict(M=pl.N[l], N=256, K=256, lda=256, ldw=256, ldc=256, batch=B,
-                          sA=pl.SN * 256, sC=pl.N[l] * 256)
-            hip.gemm(mem, w[a + "in_proj_weight"][256:512], pl.Kp[i],
-                     bias=w[a + "in_proj_bias"][256:512], aadd=pl.dec_kpos[l], ldaadd=256,
-                     aadd_rows=pl.N[l], **common)
-            hip.gemm(mem, w[a + "in_proj_weight"][512:], pl.Vp[i],
-                     bias=w[a + "in_proj_bias"][512:], aadd=w["level_embed.weight"][l:l + 1],
-                     ldaadd=256, aadd_rows=1, **common)
+            common = dict(A=mem, M=pl.N[l], N=256, K=256, lda=256, ldw=256, ldc=256, batch=B,
+                          sA=pl.SN * 256, sC=pl.N[l] * 256, ldaadd=256)
+            probs.append(dict(W=w[a + "in_proj_weight"][256:512], C=pl.Kp[i],
+                              bias=w[a + "in_proj_bias"][256:512], aadd=pl.dec_kpos[l],
+                              aadd_rows=pl.N[l], **common))
+            probs.append(dict(W=w[a + "in_proj_weight"][512:], C=pl.Vp[i],
+                              bias=w[a + "in_proj_bias"][512:],
+                              aadd=w["level_embed.weight"][l:l + 1], aadd_rows=1, **common))
+        for j in range(0, len(probs), 16):
+            hip.gemm_group(probs[j:j + 16])
         pl.q.view(B, Q, 256).copy_(w["query_feat.weight"].unsqueeze(0).expand(B, Q, 256))
         qpos = w["query_embed.weight"]
         self._head_embed(pl.q, pl, False)

@@ -19,6 +19,7 @@ GEMM_RELU, GEMM_A_COLMAJOR, GEMM_FORCE_TILE, GEMM_FORCE_SKINNY = 1, 2, 4, 8
 class GemmDesc(C.Structure):
     _fields_ = [("A", _vp), ("lda", _i64), ("strideA", _i64),
                 ("Aadd", _vp), ("ldaadd", _i64), ("aadd_rows", _i32),
+                ("aadd_from_col", _i32),
                 ("W", _vp), ("ldw", _i64), ("strideW", _i64),
                 ("bias", _vp),
                 ("Res", _vp), ("ldres", _i64), ("strideRes", _i64),
@@ -31,13 +32,14 @@ _SIGS = {
     "pn_abi_version": (C.c_int, []),
     "pn_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "pn_gemm_variant": (C.c_int, [C.POINTER(GemmDesc)]),
+    "pn_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
     "pn_conv2d_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 9 + [_vp]),
     "pn_layernorm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "pn_groupnorm_nblk": (C.c_int, [_i64]),
     "pn_groupnorm_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32,
                                         _i32, _f32, _i32, _i64, _i64, _vp]),
     "pn_l2normalize_f32": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _vp]),
-    "pn_msda_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_i32),
+    "pn_msda_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, C.POINTER(_i32),
                               C.POINTER(_i32), _vp]),
     "pn_sine_pe_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "pn_bilinear_nhwc_f32": (C.c_int, [_vp, _vp] + [_i32] * 7 + [_i64, _i64, _vp]),
@@ -72,7 +74,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.pn_abi_version() != 1:
+        if handle.pn_abi_version() != 2:
             raise RuntimeError("libpairnet_hip.so ABI mismatch; rebuild")
         _lib = handle
     return _lib
@@ -84,7 +86,8 @@ def _stream():
 
 GEMM_KERNELS = {0: "k_gemm_skinny<A_ROW>", 1: "k_gemm_skinny<A_COL>",
                 2: "k_gemm_tile<128,64,32,64,A_ROW>", 3: "k_gemm_tile<128,64,32,64,A_COL>",
-                4: "k_gemm_tile<128,128,64,64,A_ROW>", 5: "k_gemm_tile<128,128,64,64,A_COL>"}
+                4: "k_gemm_tile<128,128,64,64,A_ROW>", 5: "k_gemm_tile<128,128,64,64,A_COL>",
+                6: "k_gemm_tile<64,64,32,32,A_ROW>", 7: "k_gemm_tile<64,64,32,32,A_COL>"}
 
 
 class KernelTimer:
@@ -145,27 +148,49 @@ def _rowmajor(t):
     return t.shape[0], t.stride(0)
 
 
-def gemm(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaadd=0,
-         aadd_rows=0, res=None, ldres=0, batch=1, sA=0, sW=0, sC=0, sRes=0,
-         relu=False, colmajor=False, force=None):
-    """Raw pn_gemm_f32 call; tensors only supply base pointers."""
-    d = GemmDesc()
+def gemm_desc(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaadd=0,
+              aadd_rows=0, aadd_from_col=0, res=None, ldres=0, batch=1, sA=0, sW=0, sC=0,
+              sRes=0, relu=False, colmajor=False, force=None, into=None):
+    """Fill a pn_gemm_desc; tensors only supply base pointers."""
+    d = into if into is not None else GemmDesc()
     d.A, d.lda, d.strideA = _ptr(A), lda, sA
-    d.Aadd, d.ldaadd, d.aadd_rows = _ptr(aadd), ldaadd, aadd_rows
+    d.Aadd, d.ldaadd, d.aadd_rows, d.aadd_from_col = _ptr(aadd), ldaadd, aadd_rows, aadd_from_col
     d.W, d.ldw, d.strideW = _ptr(W), ldw, sW
     d.bias = _ptr(bias)
     d.Res, d.ldres, d.strideRes = _ptr(res), ldres, sRes
     d.C, d.ldc, d.strideC = _ptr(Cout), ldc, sC
     d.M, d.N, d.K, d.batch = M, N, K, batch
     d.flags = (GEMM_RELU if relu else 0) | (GEMM_A_COLMAJOR if colmajor else 0) | \
-        {None: 0, "tile": GEMM_FORCE_TILE, "skinny": GEMM_FORCE_SKINNY}[force]
+        {None: 0, "tile": GEMM_FORCE_TILE, "skinny": GEMM_FORCE_SKINNY, "tile64": 16,
+         "tile128x64": 32}[force]
+    return d
+
+
+def gemm(A, W, Cout, **kw):
+    """Raw pn_gemm_f32 call."""
+    d = gemm_desc(A, W, Cout, **kw)
     if TIMER is None:
         _check(lib().pn_gemm_f32(C.byref(d), _stream()), "pn_gemm_f32")
         return
     name = GEMM_KERNELS[lib().pn_gemm_variant(C.byref(d))]
-    nbytes = 4.0 * batch * (M * K + N * K + M * N)
-    _check(_launch(name, 2.0 * M * N * K * batch, nbytes,
+    nbytes = 4.0 * d.batch * (d.M * d.K + d.N * d.K + d.M * d.N)
+    _check(_launch(name, 2.0 * d.M * d.N * d.K * d.batch, nbytes,
                    lambda: lib().pn_gemm_f32(C.byref(d), _stream())), "pn_gemm_f32")
+
+
+def gemm_group(problems):
+    """`problems`: list of kwargs dicts for gemm_desc (+ 'A','W','C'), <= 16, row-major:
+    one launch of the grouped 128x128 tile kernel."""
+    n = len(problems)
+    arr = (GemmDesc * n)()
+    flops = nbytes = 0.0
+    for i, pr in enumerate(problems):
+        pr = dict(pr)
+        d = gemm_desc(pr.pop("A"), pr.pop("W"), pr.pop("C"), into=arr[i], **pr)
+        flops += 2.0 * d.M * d.N * d.K * d.batch
+        nbytes += 4.0 * d.batch * (d.M * d.K + d.N * d.K + d.M * d.N)
+    _check(_launch("k_gemm_group", flops, nbytes,
+                   lambda: lib().pn_gemm_group_f32(arr, n, _stream())), "pn_gemm_group_f32")
 
 
 def linear(x, weight, bias, out, *, aadd=None, res=None, relu=False, force=None):
@@ -187,7 +212,7 @@ def linear(x, weight, bias, out, *, aadd=None, res=None, relu=False, force=None)
 
 
 def conv2d_nhwc(x, wp, bias, out, B, H, W, Cin, Cout, KH, KW, pad, relu):
-    name = "k_gemm_tile<64,64,32,32,A_CONV>" if Cout <= 64 else "k_gemm_tile<128,128,64,64,A_CONV>"
+    name = "k_gemm_tile<64,64,32,32,A_CONV>"
     flops = 2.0 * B * H * W * Cout * KH * KW * Cin
     nbytes = 4.0 * (B * H * W * (Cin + Cout) + Cout * KH * KW * Cin)
     _check(_launch(name, flops, nbytes, lambda: lib().pn_conv2d_nhwc_f32(
@@ -217,7 +242,7 @@ def l2normalize(x, out, eps=1e-12):
                                     _stream()), "pn_l2normalize_f32")
 
 
-def msda(value, offaw, out, B, shapes):
+def msda(value, ld_value, offaw, ld_offaw, out, B, shapes):
     L = len(shapes)
     hs = (_i32 * L)(*[s[0] for s in shapes])
     ws = (_i32 * L)(*[s[1] for s in shapes])
@@ -225,8 +250,9 @@ def msda(value, offaw, out, B, shapes):
     # algorithmic bytes: value read + offsets/logits read + output write
     nbytes = 4.0 * B * n * (256 + 8 * L * 4 * 3 + 256)
     _check(_launch("k_msda", 2.0 * B * n * 8 * L * 4 * 4 * 32 * 2, nbytes,
-                   lambda: lib().pn_msda_f32(_ptr(value), _ptr(offaw), _ptr(out), B, L, hs, ws,
-                                             _stream())), "pn_msda_f32")
+                   lambda: lib().pn_msda_f32(_ptr(value), ld_value, _ptr(offaw), ld_offaw,
+                                             _ptr(out), B, L, hs, ws, _stream())),
+           "pn_msda_f32")
 
 
 def sine_pe(out, add, h, w, C_=256, temperature=10000.0):

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     missing = [n for n in declared if not hasattr(lib, n)]
     assert not missing, missing
     lib.pn_abi_version.restype = ctypes.c_int
-    assert lib.pn_abi_version() == 1
+    assert lib.pn_abi_version() == 2
     from pairnet_amd import hip
     assert declared == set(hip.EXPORTS)
 
@@ -33,6 +33,7 @@ def test_bad_arguments_are_refused_without_launching(built_lib):
     d = hip.GemmDesc()  # all NULL
     assert lib.pn_gemm_f32(ctypes.byref(d), None) == -1
     assert lib.pn_topk_pairs(None, None, None, None, 1, 100, 100, None) == -1
+    assert lib.pn_gemm_group_f32(None, 3, None) == -1
     assert lib.pn_layernorm_f32(None, None, None, None, 4, 256, 1e-5, None) == -1
 
 

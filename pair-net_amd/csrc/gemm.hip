@@ -462,7 +462,10 @@ extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float*
   p.relu = relu ? 1 : 0; p.aadd_rows = 1;
   p.H = H; p.Wd = W; p.Cin = Cin; p.KW = KW; p.pad = pad;
   hipStream_t s = (hipStream_t)stream;
-  return launch_tile<64, 64, 32, 32, A_CONV>(p, B, s);
+  // 3x3 x 256 channels (K = 2304): the long k-loop amortises the 128x128 tile (922 vs
+  // 974 us measured); the 64-channel Matrix Learner layer has N = 64
+  if (Cout <= 64) return launch_tile<64, 64, 32, 32, A_CONV>(p, B, s);
+  return launch_tile<128, 128, 64, 64, A_CONV>(p, B, s);
 }
 
 extern "C" int pn_abi_version(void) { return PN_ABI_VERSION; }

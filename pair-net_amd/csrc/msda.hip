@@ -1,12 +1,14 @@
 // Multi-scale deformable attention sampling for the pixel-decoder encoder
 // (8 heads x 32 channels, P = 4 points, L <= 4 levels), HBM/L2-bound gather.
 //
-// Thread = (query, head, 4 channels): the 8 lanes of one (query, head) read one
-// 128-byte value row per bilinear tap as float4s, so every tap is a full-line
-// access; a 256-thread workgroup covers 4 consecutive queries (row-major
-// neighbours sample overlapping value rows -> L2 hits).  Softmax over the L*P
-// logits, reference point + offset / (W_l, H_l) and the grid_sample
-// un-normalisation are fused, following mmcv's CPU formula
+// Thread = (query, head, sampling point, 4 channels): one 256-thread workgroup per
+// query token, 32 lanes per head = 4 points x 8 lanes; the 8 lanes of a point read
+// one 128-byte value row per bilinear tap as float4s (every tap is a full line) and
+// each lane has only L x 4 = 12 independent loads in flight, which keeps the VGPR
+// count low enough for 6+ waves/SIMD on this latency-bound gather.  The softmax over
+// the L*P logits and the sum over points are xor-8 / xor-16 shuffles inside the
+// 32-lane group.  Reference point + offset / (W_l, H_l) and the grid_sample
+// un-normalisation follow mmcv's CPU formula
 // (multi_scale_deformable_attn_pytorch):
 //   loc = ref + off / (W_l, H_l);  g = 2 loc - 1;  ix = ((g + 1) W_l - 1) / 2
 // with zero padding outside the map.
@@ -17,46 +19,55 @@ struct MsdaLevels {
   int L, N;
 };
 
+__device__ __forceinline__ float grp_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 8, 64));
+  return fmaxf(v, __shfl_xor(v, 16, 64));
+}
+__device__ __forceinline__ float grp_sum(float v) {
+  v += __shfl_xor(v, 8, 64);
+  return v + __shfl_xor(v, 16, 64);
+}
+
 __global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
                                               const float* __restrict__ offaw,
                                               float* __restrict__ out,
                                               const MsdaLevels lv, const int64_t ldv,
                                               const int64_t ldo) {
   const int tid = threadIdx.x;
-  const int c4 = tid & 7, head = (tid >> 3) & 7, ql = tid >> 6;
-  const int n = blockIdx.x * 4 + ql;
-  const int b = blockIdx.y;
-  if (n >= lv.N) return;
+  const int c4 = tid & 7, pt = (tid >> 3) & 3, head = tid >> 5;
+  const int n = blockIdx.x, b = blockIdx.y;
   const int L = lv.L;
   const int LP = L * 4;
 
-  // level and pixel of this query token
-  int ql_lvl = 0;
+  // level and pixel of this query token (wave-uniform)
+  int qw = lv.w[0], qh = lv.h[0], qs = 0;
 #pragma unroll
   for (int l = 1; l < 4; ++l)
-    if (l < L && n >= lv.start[l]) ql_lvl = l;
-  const int idx = n - lv.start[ql_lvl];
-  const int qy = idx / lv.w[ql_lvl], qx = idx - qy * lv.w[ql_lvl];
-  const float ref_x = ((float)qx + 0.5f) / (float)lv.w[ql_lvl];
-  const float ref_y = ((float)qy + 0.5f) / (float)lv.h[ql_lvl];
+    if (l < L && n >= lv.start[l]) { qw = lv.w[l]; qh = lv.h[l]; qs = lv.start[l]; }
+  const int idx = n - qs;
+  const int qy = idx / qw, qx = idx - qy * qw;
+  const float ref_x = ((float)qx + 0.5f) / (float)qw;
+  const float ref_y = ((float)qy + 0.5f) / (float)qh;
 
   const float* oa = offaw + ((int64_t)b * lv.N + n) * ldo;
-  const float* offp = oa + head * LP * 2;
-  const float* awp = oa + 8 * LP * 2 + head * LP;
+  const float* offp = oa + head * LP * 2 + pt * 2;
+  const float* awp = oa + 8 * LP * 2 + head * LP + pt;
 
-  float logit[16];
+  float e[4];
   float mx = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    logit[i] = (i < LP) ? awp[i] : -INFINITY;
-    mx = fmaxf(mx, logit[i]);
+  for (int l = 0; l < 4; ++l) {
+    e[l] = (l < L) ? awp[l * 4] : -INFINITY;
+    mx = fmaxf(mx, e[l]);
   }
+  mx = grp_max(mx);
   float den = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    logit[i] = (i < LP) ? expf(logit[i] - mx) : 0.f;
-    den += logit[i];
+  for (int l = 0; l < 4; ++l) {
+    e[l] = (l < L) ? expf(e[l] - mx) : 0.f;
+    den += e[l];
   }
+  den = grp_sum(den);
 
   const float* vb = value + (int64_t)b * lv.N * ldv + head * 32 + c4 * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -65,37 +76,35 @@ __global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
     if (l >= L) break;
     const int Hl = lv.h[l], Wl = lv.w[l];
     const float* vl = vb + (int64_t)lv.start[l] * ldv;
-#pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-      const float ox = offp[(l * 4 + pt) * 2 + 0];
-      const float oy = offp[(l * 4 + pt) * 2 + 1];
-      const float aw = logit[l * 4 + pt] / den;
-      const float locx = ref_x + ox / (float)Wl;
-      const float locy = ref_y + oy / (float)Hl;
-      const float gx = 2.f * locx - 1.f, gy = 2.f * locy - 1.f;
-      const float ix = ((gx + 1.f) * (float)Wl - 1.f) * 0.5f;
-      const float iy = ((gy + 1.f) * (float)Hl - 1.f) * 0.5f;
-      const float fx = floorf(ix), fy = floorf(iy);
-      const int x0 = (int)fx, y0 = (int)fy;
-      const float tx = ix - fx, ty = iy - fy;
-      const float w_nw = (1.f - tx) * (1.f - ty), w_ne = tx * (1.f - ty);
-      const float w_sw = (1.f - tx) * ty, w_se = tx * ty;
-      const bool xin0 = x0 >= 0 && x0 < Wl, xin1 = x0 + 1 >= 0 && x0 + 1 < Wl;
-      const bool yin0 = y0 >= 0 && y0 < Hl, yin1 = y0 + 1 >= 0 && y0 + 1 < Hl;
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 v_nw = (xin0 && yin0) ? ld4(vl + ((int64_t)y0 * Wl + x0) * ldv) : z;
-      const float4 v_ne = (xin1 && yin0) ? ld4(vl + ((int64_t)y0 * Wl + x0 + 1) * ldv) : z;
-      const float4 v_sw = (xin0 && yin1) ? ld4(vl + ((int64_t)(y0 + 1) * Wl + x0) * ldv) : z;
-      const float4 v_se = (xin1 && yin1) ? ld4(vl + ((int64_t)(y0 + 1) * Wl + x0 + 1) * ldv) : z;
-      float4 s;
-      s.x = ((v_nw.x * w_nw + v_ne.x * w_ne) + v_sw.x * w_sw) + v_se.x * w_se;
-      s.y = ((v_nw.y * w_nw + v_ne.y * w_ne) + v_sw.y * w_sw) + v_se.y * w_se;
-      s.z = ((v_nw.z * w_nw + v_ne.z * w_ne) + v_sw.z * w_sw) + v_se.z * w_se;
-      s.w = ((v_nw.w * w_nw + v_ne.w * w_ne) + v_sw.w * w_sw) + v_se.w * w_se;
-      acc.x += s.x * aw; acc.y += s.y * aw; acc.z += s.z * aw; acc.w += s.w * aw;
-    }
+    const float2 off = *reinterpret_cast<const float2*>(offp + l * 8);
+    const float aw = e[l] / den;
+    const float locx = ref_x + off.x / (float)Wl;
+    const float locy = ref_y + off.y / (float)Hl;
+    const float gx = 2.f * locx - 1.f, gy = 2.f * locy - 1.f;
+    const float ix = ((gx + 1.f) * (float)Wl - 1.f) * 0.5f;
+    const float iy = ((gy + 1.f) * (float)Hl - 1.f) * 0.5f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float tx = ix - fx, ty = iy - fy;
+    const float w_nw = (1.f - tx) * (1.f - ty), w_ne = tx * (1.f - ty);
+    const float w_sw = (1.f - tx) * ty, w_se = tx * ty;
+    const bool xin0 = x0 >= 0 && x0 < Wl, xin1 = x0 + 1 >= 0 && x0 + 1 < Wl;
+    const bool yin0 = y0 >= 0 && y0 < Hl, yin1 = y0 + 1 >= 0 && y0 + 1 < Hl;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v_nw = (xin0 && yin0) ? ld4(vl + ((int64_t)y0 * Wl + x0) * ldv) : z;
+    const float4 v_ne = (xin1 && yin0) ? ld4(vl + ((int64_t)y0 * Wl + x0 + 1) * ldv) : z;
+    const float4 v_sw = (xin0 && yin1) ? ld4(vl + ((int64_t)(y0 + 1) * Wl + x0) * ldv) : z;
+    const float4 v_se = (xin1 && yin1) ? ld4(vl + ((int64_t)(y0 + 1) * Wl + x0 + 1) * ldv) : z;
+    float4 s;
+    s.x = ((v_nw.x * w_nw + v_ne.x * w_ne) + v_sw.x * w_sw) + v_se.x * w_se;
+    s.y = ((v_nw.y * w_nw + v_ne.y * w_ne) + v_sw.y * w_sw) + v_se.y * w_se;
+    s.z = ((v_nw.z * w_nw + v_ne.z * w_ne) + v_sw.z * w_sw) + v_se.z * w_se;
+    s.w = ((v_nw.w * w_nw + v_ne.w * w_ne) + v_sw.w * w_sw) + v_se.w * w_se;
+    acc.x += s.x * aw; acc.y += s.y * aw; acc.z += s.z * aw; acc.w += s.w * aw;
   }
-  st4(out + ((int64_t)b * lv.N + n) * 256 + head * 32 + c4 * 4, acc);
+  acc.x = grp_sum(acc.x); acc.y = grp_sum(acc.y);
+  acc.z = grp_sum(acc.z); acc.w = grp_sum(acc.w);
+  if (pt == 0) st4(out + ((int64_t)b * lv.N + n) * 256 + head * 32 + c4 * 4, acc);
 }
 
 extern "C" int pn_msda_f32(const float* value, int64_t ld_value, const float* offaw,
@@ -103,7 +112,8 @@ extern "C" int pn_msda_f32(const float* value, int64_t ld_value, const float* of
                            const int32_t* level_w, void* stream) {
   if (!value || !offaw || !out || B <= 0 || L <= 0 || L > 4 || !level_h || !level_w)
     return PN_BAD_ARG;
-  if (ld_value < 256 || (ld_value & 3) || ld_offaw < 8 * L * 12 || ((uintptr_t)value & 15))
+  if (ld_value < 256 || (ld_value & 3) || ld_offaw < 8 * L * 12 || (ld_offaw & 1) ||
+      ((uintptr_t)value & 15) || ((uintptr_t)offaw & 7))
     return PN_BAD_ARG;
   MsdaLevels lv{};
   lv.L = L;
@@ -114,7 +124,7 @@ extern "C" int pn_msda_f32(const float* value, int64_t ld_value, const float* of
     n += level_h[l] * level_w[l];
   }
   lv.N = n;
-  hipLaunchKernelGGL(k_msda, dim3(pn_cdiv(n, 4), B), dim3(256), 0, (hipStream_t)stream, value,
+  hipLaunchKernelGGL(k_msda, dim3(n, B), dim3(256), 0, (hipStream_t)stream, value,
                      offaw, out, lv, ld_value, ld_offaw);
   return PN_LAUNCH_CHECK();
 }

@@ -99,6 +99,9 @@ class CrossHead2:
         self.device = None
         self.w = None
         self._plans = {}
+        # True: compute attention masks in the reference's operation order (full-size mask
+        # logits -> bilinear resize); False: resample the mask feature once (see _attn_mask)
+        self.exact_mask_order = False
         self.init_weights()
 
     # ------------------------------------------------------------------ params
@@ -267,6 +270,20 @@ class CrossHead2:
             w[p + "voa.bias"] = torch.cat([w[p + "value_proj.bias"],
                                            w[p + "sampling_offsets.bias"],
                                            w[p + "attention_weights.bias"]], 0).contiguous()
+        # self-attention: one [V | Q | K] projection (positional add feeds Q and K only);
+        # relation cross-attention keys/values: one [V | K] projection
+        for dec, n in (("transformer_decoder", self.num_dec_layers),
+                       ("relation_decoder", self.num_rel_layers)):
+            for i in range(n):
+                a = "%s.layers.%d.attentions.1.attn." % (dec, i)
+                W, b = w[a + "in_proj_weight"], w[a + "in_proj_bias"]
+                w[a + "vqk.weight"] = torch.cat([W[512:], W[:512]], 0).contiguous()
+                w[a + "vqk.bias"] = torch.cat([b[512:], b[:512]], 0).contiguous()
+        for i in range(self.num_rel_layers):
+            a = "relation_decoder.layers.%d.attentions.0.attn." % i
+            W, b = w[a + "in_proj_weight"], w[a + "in_proj_bias"]
+            w[a + "vk.weight"] = torch.cat([W[512:], W[256:512]], 0).contiguous()
+            w[a + "vk.bias"] = torch.cat([b[512:], b[256:512]], 0).contiguous()
         ml = "update_importance.conv_layers."
         w[ml + "0.0.weight"] = w[ml + "0.0.weight"].reshape(64, 49).contiguous()
         w[ml + "1.0.weight"] = w[ml + "1.0.weight"].permute(0, 2, 3, 1).reshape(64, -1).contiguous()
@@ -320,9 +337,10 @@ class CrossHead2:
         BQ = B * Q
         pl.q, pl.q1, pl.q2, pl.qy = E(BQ, 256), E(BQ, 256), E(BQ, 256), E(BQ, 256)
         pl.qn, pl.m1, pl.m2, pl.me = E(BQ, 256), E(BQ, 256), E(BQ, 256), E(BQ, 256)
-        pl.Qp, pl.att, pl.Vs = E(BQ, 256), E(BQ, 256), E(BQ, 256)
-        pl.QK = E(BQ, 512)
-        pl.hq = E(BQ, max(self.dec_ffn, self.rel_ffn))
+        pl.Qp, pl.att = E(BQ, 256), E(BQ, 256)
+        pl.VQK = E(BQ, 768)
+        pl.MFd = [E(B, n, 256) for n in pl.N]   # mask feature resampled to each level
+        pl.hq = E(hip.ffn_scratch_floats(BQ, self.dec_ffn))
         pl.MP = E(B, Q, HW2)
         pl.ML = E(BQ, max(pl.N))
         pl.bits = torch.empty(BQ * ((max(pl.N) + 31) // 32), device=dev, dtype=torch.int32)
@@ -342,10 +360,10 @@ class CrossHead2:
         # ---- relation decoder ----
         BR = B * R
         pl.r, pl.r1, pl.r2, pl.ry = E(BR, 256), E(BR, 256), E(BR, 256), E(BR, 256)
-        pl.rQp, pl.ratt, pl.rVs = E(BR, 256), E(BR, 256), E(BR, 256)
-        pl.rQK = E(BR, 512)
-        pl.rh = E(BR, self.rel_ffn)
-        pl.pK, pl.pV = E(B * 2 * R, 256), E(B * 2 * R, 256)
+        pl.rQp, pl.ratt = E(BR, 256), E(BR, 256)
+        pl.rVQK = E(BR, 768)
+        pl.rh = E(hip.ffn_scratch_floats(BR, self.rel_ffn))
+        pl.pVK = E(B * 2 * R, 512)
         pl.rel = E(B, R, self.num_relations)
         pl.sub_cls, pl.obj_cls = E(B, R, self.num_classes + 1), E(B, R, self.num_classes + 1)
         pl.sub_seg, pl.obj_seg = E(B, R, HW2), E(B, R, HW2)
@@ -401,10 +419,14 @@ class CrossHead2:
                            self.gn_groups, True, HW2 * 256, HW2 * 256)
         hip.linear(pl.T2.view(-1, 256), w[pd + "mask_feature.weight"], w[pd + "mask_feature.bias"],
                    pl.MF.view(-1, 256))
+        if not self.exact_mask_order:
+            for l, (h, wd) in enumerate(pl.shapes):
+                hip.bilinear_nhwc(pl.MF, pl.MFd[l], B, H2, W2, h, wd, 256, False, HW2 * 256,
+                                  pl.N[l] * 256)
 
-    def _head_embed(self, q, pl, with_cls):
-        """post_norm -> (cls_embed) -> mask_embed MLP -> mask logits pl.MP [B,Q,H2*W2]
-        (pairnet_head.py:236-243)."""
+    def _head_embed(self, q, pl, with_cls, full_mask):
+        """post_norm -> (cls_embed) -> mask_embed MLP -> pl.me; with `full_mask` also the
+        mask logits pl.MP [B,Q,H2*W2] (pairnet_head.py:236-243)."""
         w, B, Q = self.w, pl.B, self.num_obj_query
         hip.layernorm(q, w["transformer_decoder.post_norm.weight"],
                       w["transformer_decoder.post_norm.bias"], pl.qn)
@@ -413,40 +435,48 @@ class CrossHead2:
         hip.linear(pl.qn, w["mask_embed.0.weight"], w["mask_embed.0.bias"], pl.m1, relu=True)
         hip.linear(pl.m1, w["mask_embed.2.weight"], w["mask_embed.2.bias"], pl.m2, relu=True)
         hip.linear(pl.m2, w["mask_embed.4.weight"], w["mask_embed.4.bias"], pl.me)
-        hip.gemm(pl.me, pl.MF, pl.MP, M=Q, N=pl.HW2, K=256, lda=256, ldw=256, ldc=pl.HW2,
-                 batch=B, sA=Q * 256, sW=pl.HW2 * 256, sC=Q * pl.HW2)
+        if full_mask:
+            hip.gemm(pl.me, pl.MF, pl.MP, M=Q, N=pl.HW2, K=256, lda=256, ldw=256, ldc=pl.HW2,
+                     batch=B, sA=Q * 256, sW=pl.HW2 * 256, sC=Q * pl.HW2)
 
     def _attn_mask(self, pl, lvl):
-        """bilinear resize of the mask logits to level `lvl`, threshold, all-masked
-        fix (pairnet_head.py:244-256, :300) -> pl.bits / pl.rowall."""
-        BQ = pl.B * self.num_obj_query
-        h, wd = pl.shapes[lvl]
-        hip.bilinear_planar(pl.MP, pl.ML, BQ, pl.hw2[0], pl.hw2[1], h, wd)
-        hip.mask_pack(pl.ML, pl.bits, pl.rowall, BQ, h * wd)
+        """Boolean attention mask of level `lvl` + all-masked fix (pairnet_head.py:244-256,
+        :300) -> pl.bits / pl.rowall.
 
-    def _layer(self, pre, x, xpos, x1, x2, y, Qp, QK, Vs, att, hbuf, Kp, Vp, Nk, B, nq, bits,
-               rowall, scr, ffn):
+        The reference resizes the full-resolution mask logits bilinearly and thresholds.
+        Bilinear resampling is linear, so resize(me . MF) == me . resize(MF): the mask
+        feature is resampled once per image (pl.MFd) and each layer's logits are a
+        Q x N_l GEMM instead of a Q x 66 800 GEMM plus a resize (same values up to fp32
+        re-association; `exact_mask_order=True` keeps the reference's operation order)."""
+        B, Q = pl.B, self.num_obj_query
+        h, wd = pl.shapes[lvl]
+        n = h * wd
+        if self.exact_mask_order:
+            hip.bilinear_planar(pl.MP, pl.ML, B * Q, pl.hw2[0], pl.hw2[1], h, wd)
+        else:
+            hip.gemm(pl.me, pl.MFd[lvl], pl.ML, M=Q, N=n, K=256, lda=256, ldw=256, ldc=n,
+                     batch=B, sA=Q * 256, sW=n * 256, sC=Q * n)
+        hip.mask_pack(pl.ML, pl.bits, pl.rowall, B * Q, n)
+
+    def _layer(self, pre, x, xpos, x1, x2, y, Qp, VQK, att, hbuf, Kp, ldk, Vp, ldv, Nk, B, nq,
+               bits, rowall, scr, ffn):
         """One post-norm (cross_attn, norm, self_attn, norm, ffn, norm) layer
         (facebook_detr.py:378-432 semantics); x is updated in place."""
         w = self.w
         scale = 1.0 / math.sqrt(32.0)
         a0, a1 = pre + "attentions.0.attn.", pre + "attentions.1.attn."
         hip.linear(x, w[a0 + "in_proj_weight"][:256], w[a0 + "in_proj_bias"][:256], Qp, aadd=xpos)
-        hip.attention(Qp, 256, Kp, 256, Vp, 256, bits, rowall, att, 256, scr, B, nq, Nk, scale)
+        hip.attention(Qp, 256, Kp, ldk, Vp, ldv, bits, rowall, att, 256, scr, B, nq, Nk, scale)
         hip.linear(att, w[a0 + "out_proj.weight"], w[a0 + "out_proj.bias"], y, res=x)
         hip.layernorm(y, w[pre + "norms.0.weight"], w[pre + "norms.0.bias"], x1)
-        hip.linear(x1, w[a1 + "in_proj_weight"][:512], w[a1 + "in_proj_bias"][:512], QK, aadd=xpos)
-        hip.linear(x1, w[a1 + "in_proj_weight"][512:], w[a1 + "in_proj_bias"][512:], Vs)
-        hip.attention(QK, 512, QK[:, 256:], 512, Vs, 256, None, None, att, 256, scr, B, nq, nq,
-                      scale)
+        hip.linear(x1, w[a1 + "vqk.weight"], w[a1 + "vqk.bias"], VQK, aadd=xpos, aadd_from_col=256)
+        hip.attention(VQK[:, 256:], 768, VQK[:, 512:], 768, VQK, 768, None, None, att, 256, scr,
+                      B, nq, nq, scale)
         hip.linear(att, w[a1 + "out_proj.weight"], w[a1 + "out_proj.bias"], y, res=x1)
         hip.layernorm(y, w[pre + "norms.1.weight"], w[pre + "norms.1.bias"], x2)
-        hb = hbuf[:, :ffn]
-        hip.linear(x2, w[pre + "ffns.0.layers.0.0.weight"], w[pre + "ffns.0.layers.0.0.bias"], hb,
-                   relu=True)
-        hip.linear(hb, w[pre + "ffns.0.layers.1.weight"], w[pre + "ffns.0.layers.1.bias"], y,
-                   res=x2)
-        hip.layernorm(y, w[pre + "norms.2.weight"], w[pre + "norms.2.bias"], x)
+        hip.ffn_ln(x2, w[pre + "ffns.0.layers.0.0.weight"], w[pre + "ffns.0.layers.0.0.bias"],
+                   w[pre + "ffns.0.layers.1.weight"], w[pre + "ffns.0.layers.1.bias"],
+                   w[pre + "norms.2.weight"], w[pre + "norms.2.bias"], x, hbuf, B * nq, ffn)
 
     # --------------------------------------------------------------- forward
     @torch.no_grad()
@@ -486,14 +516,16 @@ class CrossHead2:
             hip.gemm_group(probs[j:j + 16])
         pl.q.view(B, Q, 256).copy_(w["query_feat.weight"].unsqueeze(0).expand(B, Q, 256))
         qpos = w["query_embed.weight"]
-        self._head_embed(pl.q, pl, False)
+        exact = self.exact_mask_order
+        self._head_embed(pl.q, pl, False, exact)
+        last = self.num_dec_layers - 1
         for i in range(self.num_dec_layers):
             l = i % 3
             self._attn_mask(pl, l)
             self._layer("transformer_decoder.layers.%d." % i, pl.q, qpos, pl.q1, pl.q2, pl.qy,
-                        pl.Qp, pl.QK, pl.Vs, pl.att, pl.hq, pl.Kp[i], pl.Vp[i], pl.N[l], B, Q,
-                        pl.bits, pl.rowall, pl.scr, self.dec_ffn)
-            self._head_embed(pl.q, pl, i == self.num_dec_layers - 1)
+                        pl.Qp, pl.VQK, pl.att, pl.hq, pl.Kp[i], 256, pl.Vp[i], 256, pl.N[l], B,
+                        Q, pl.bits, pl.rowall, pl.scr, self.dec_ffn)
+            self._head_embed(pl.q, pl, i == last, exact or i == last)
         # ---- Pair Proposal Network (pairnet_head.py:322-340) ----
         for mlp, dst in (("sub_query_update", pl.sn), ("obj_query_update", pl.on)):
             hip.linear(pl.q, w[mlp + ".0.weight"], w[mlp + ".0.bias"], pl.s1, relu=True)
@@ -517,11 +549,11 @@ class CrossHead2:
         for i in range(self.num_rel_layers):
             pre = "relation_decoder.layers.%d." % i
             a = pre + "attentions.0.attn."
-            hip.linear(pl.pair, w[a + "in_proj_weight"][256:512], w[a + "in_proj_bias"][256:512],
-                       pl.pK, aadd=ppos)
-            hip.linear(pl.pair, w[a + "in_proj_weight"][512:], w[a + "in_proj_bias"][512:], pl.pV)
-            self._layer(pre, pl.r, rpos, pl.r1, pl.r2, pl.ry, pl.rQp, pl.rQK, pl.rVs, pl.ratt,
-                        pl.rh, pl.pK, pl.pV, 2 * R, B, R, None, None, pl.scr, self.rel_ffn)
+            hip.linear(pl.pair, w[a + "vk.weight"], w[a + "vk.bias"], pl.pVK, aadd=ppos,
+                       aadd_from_col=256)
+            self._layer(pre, pl.r, rpos, pl.r1, pl.r2, pl.ry, pl.rQp, pl.rVQK, pl.ratt, pl.rh,
+                        pl.pVK[:, 256:], 512, pl.pVK, 512, 2 * R, B, R, None, None, pl.scr,
+                        self.rel_ffn)
         hip.linear(pl.r, w["rel_cls_embed.weight"], w["rel_cls_embed.bias"], pl.rel.view(B * R, -1))
         # ---- output gathers (:380-403) ----
         nc = self.num_classes + 1

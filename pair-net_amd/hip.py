@@ -39,6 +39,8 @@ _SIGS = {
     "pn_groupnorm_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32,
                                         _i32, _f32, _i32, _i64, _i64, _vp]),
     "pn_l2normalize_f32": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _vp]),
+    "pn_ffn_scratch_floats": (_i64, [_i32, _i32]),
+    "pn_ffn_ln_f32": (C.c_int, [_vp] * 9 + [_i32, _i32, _i32, _f32, _vp]),
     "pn_msda_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, C.POINTER(_i32),
                               C.POINTER(_i32), _vp]),
     "pn_sine_pe_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp]),
@@ -193,8 +195,10 @@ def gemm_group(problems):
                    lambda: lib().pn_gemm_group_f32(arr, n, _stream())), "pn_gemm_group_f32")
 
 
-def linear(x, weight, bias, out, *, aadd=None, res=None, relu=False, force=None):
-    """out = act((x + aadd[row % len(aadd)]) @ weight.T + bias) + res on 2-D views."""
+def linear(x, weight, bias, out, *, aadd=None, aadd_from_col=0, res=None, relu=False,
+           force=None):
+    """out = act((x + aadd[row % len(aadd)]) @ weight.T + bias) + res on 2-D views
+    (aadd only feeds output columns >= aadd_from_col)."""
     M, lda = _rowmajor(x)
     N, ldw = _rowmajor(weight)
     Mo, ldc = _rowmajor(out)
@@ -202,7 +206,7 @@ def linear(x, weight, bias, out, *, aadd=None, res=None, relu=False, force=None)
     kw = {}
     if aadd is not None:
         ra, lda2 = _rowmajor(aadd)
-        kw.update(aadd=aadd, ldaadd=lda2, aadd_rows=ra)
+        kw.update(aadd=aadd, ldaadd=lda2, aadd_rows=ra, aadd_from_col=aadd_from_col)
     if res is not None:
         rr, ldr = _rowmajor(res)
         assert rr == M
@@ -212,7 +216,7 @@ def linear(x, weight, bias, out, *, aadd=None, res=None, relu=False, force=None)
 
 
 def conv2d_nhwc(x, wp, bias, out, B, H, W, Cin, Cout, KH, KW, pad, relu):
-    name = "k_gemm_tile<64,64,32,32,A_CONV>"
+    name = "k_gemm_tile<64,64,32,32,A_CONV>" if Cout <= 64 else "k_gemm_tile<128,128,64,64,A_CONV>"
     flops = 2.0 * B * H * W * Cout * KH * KW * Cin
     nbytes = 4.0 * (B * H * W * (Cin + Cout) + Cout * KH * KW * Cin)
     _check(_launch(name, flops, nbytes, lambda: lib().pn_conv2d_nhwc_f32(
@@ -235,6 +239,18 @@ def groupnorm_nhwc(x, gamma, beta, out, partials, B, HW, G, relu, x_bstride, y_b
     _check(lib().pn_groupnorm_nhwc_f32(
         _ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(partials, torch.float64), B, HW,
         256, G, eps, int(relu), x_bstride, y_bstride, _stream()), "pn_groupnorm_nhwc_f32")
+
+
+def ffn_scratch_floats(M, hidden):
+    return lib().pn_ffn_scratch_floats(M, hidden)
+
+
+def ffn_ln(x, W1, b1, W2, b2, gamma, beta, out, scratch, M, hidden, eps=1e-5):
+    _check(_launch("k_ffn_partial+k_reduce_ln", 4.0 * M * 256 * hidden,
+                   4.0 * (2 * 256 * hidden + 2 * M * 256),
+                   lambda: lib().pn_ffn_ln_f32(_ptr(x), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
+                                               _ptr(gamma), _ptr(beta), _ptr(out), _ptr(scratch),
+                                               M, 256, hidden, eps, _stream())), "pn_ffn_ln_f32")
 
 
 def l2normalize(x, out, eps=1e-12):

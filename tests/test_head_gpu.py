@@ -130,7 +130,8 @@ def test_e2e_full_800x1333_against_reference_golden():
     assert float((res[0][7].sum(-1) - 1).abs().max()) < 1e-5
 
 
-def test_against_oracle_other_seed_and_batch_consistency():
+@pytest.mark.parametrize("exact_mask_order", [False, True])
+def test_against_oracle_other_seed_and_batch_consistency(exact_mask_order):
     head_o, sd, _ = oracle_head(1234)
     H, W = 64, 96
     feats = seeded.seeded_feats(99, 2, H, W)
@@ -139,6 +140,7 @@ def test_against_oracle_other_seed_and_batch_consistency():
     trace = {}
     ref_cls, ref_masks = head_o.forward(feats, metas, trace=trace)
     head = _hip_head(sd)
+    head.exact_mask_order = exact_mask_order
     cls, masks = head.forward([f.to(DEV) for f in feats], metas)
     torch.cuda.synchronize()
     for k in ("cls", "importance"):

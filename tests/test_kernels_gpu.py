@@ -141,6 +141,20 @@ def test_layernorm_l2norm(hip):
     close(out, F.normalize(x, p=2, dim=-1, eps=1e-12), 1e-6, "l2norm")
 
 
+@pytest.mark.parametrize("M,hidden", [(100, 2048), (200, 2048), (37, 128)])
+def test_fused_ffn_layernorm(hip, M, hidden):
+    x = R(M, 256, seed=1, lo=-2, hi=2)
+    W1, b1 = R(hidden, 256, seed=2, lo=-0.1, hi=0.1), R(hidden, seed=3)
+    W2, b2 = R(256, hidden, seed=4, lo=-0.05, hi=0.05), R(256, seed=5)
+    g, b = R(256, seed=6), R(256, seed=7)
+    ref = F.layer_norm(x + F.linear(F.relu(F.linear(x, W1, b1)), W2, b2), (256,), g, b, 1e-5)
+    out = torch.empty(M, 256, device=DEV)
+    scr = torch.empty(hip.ffn_scratch_floats(M, hidden), device=DEV)
+    hip.ffn_ln(x.to(DEV), W1.to(DEV), b1.to(DEV), W2.to(DEV), b2.to(DEV), g.to(DEV), b.to(DEV),
+               out, scr, M, hidden)
+    close(out, ref, 5e-6, "ffn+ln")
+
+
 @pytest.mark.parametrize("relu", [False, True])
 def test_groupnorm_nhwc_with_batch_strides(hip, relu):
     B, HW = 2, 1050

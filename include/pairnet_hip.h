@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 2
+#define PN_ABI_VERSION 3
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -50,6 +50,10 @@ int pn_abi_version(void);
 #define PN_GEMM_FORCE_SKINNY 8 /* testing: force the 32x32 split-K-in-block kernel  */
 #define PN_GEMM_FORCE_TILE64 16     /* tuning: 64x64 tile (row-major A)             */
 #define PN_GEMM_FORCE_TILE128x64 32 /* tuning: 128x64 tile                          */
+#define PN_GEMM_SPLIT_BF16 64  /* opt-in: fp32-accurate 3 x bf16 operand split on the
+                                  bf16 MFMA (6 partial products, fp32 accumulate;
+                                  error <= 3*2^-24 |a||b| per product, not bitwise the
+                                  fp32 fmaf chain).  Large row-major / conv problems. */
 
 typedef struct pn_gemm_desc {
   const float* A;     int64_t lda;    int64_t strideA;    /* [M][K] (or [K][M])    */
@@ -76,6 +80,7 @@ int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream);
 #define PN_GEMM_VARIANT_TILE_128x64   2  /* k_gemm_tile<128,64,32,64,A>      */
 #define PN_GEMM_VARIANT_TILE_128x128  4  /* k_gemm_tile<128,128,64,64,A>     */
 #define PN_GEMM_VARIANT_TILE_64x64    6  /* k_gemm_tile<64,64,32,32,A> (default) */
+#define PN_GEMM_VARIANT_SPLIT         8  /* k_gemm_split<A_ROW>                  */
 int pn_gemm_variant(const pn_gemm_desc* d);
 
 /* Implicit-GEMM KHxKW convolution, stride 1, zero padding, channel-last:
@@ -86,7 +91,8 @@ int pn_gemm_variant(const pn_gemm_desc* d);
  * Cin % 32 == 0. */
 int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float* bias,
                        float* out, int B, int H, int W, int Cin, int Cout,
-                       int KH, int KW, int pad, int relu, void* stream);
+                       int KH, int KW, int pad, int relu, int flags /* 0 or
+                       PN_GEMM_SPLIT_BF16, | PN_GEMM_FORCE_TILE */, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Normalisation

@@ -16,17 +16,7 @@
 // the 36-float stride makes the four 16-lane groups of a b128 read hit all 64 banks
 // exactly once.
 #include "common.h"
-
-struct GemmP {
-  const float* A; const float* Aadd; const float* W; const float* bias;
-  const float* Res; float* C;
-  int64_t lda, ldaadd, ldw, ldres, ldc;
-  int64_t sA, sW, sRes, sC;
-  int M, N, K, aadd_rows, aadd_from_col, relu, a_vec;
-  int H, Wd, Cin, KW, pad;  // conv mode
-};
-
-enum { A_ROW = 0, A_COL = 1, A_CONV = 2 };
+#include "gemm_common.h"
 
 template <int BM, int BN, int WM, int WN, int AMODE>
 __device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int m0, const int n0,
@@ -361,7 +351,6 @@ static int launch_skinny(const GemmP& p, int batch, hipStream_t s) {
   return PN_LAUNCH_CHECK();
 }
 
-static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <int BM, int BN, int WM, int WN, int AMODE>
 static int launch_tile(const GemmP& p, int batch, hipStream_t s) {
@@ -383,12 +372,13 @@ extern "C" int pn_gemm_variant(const pn_gemm_desc* d) {
   if (!d || d->M <= 0 || d->N <= 0 || d->batch <= 0) return PN_BAD_ARG;
   const int col = (d->flags & PN_GEMM_A_COLMAJOR) ? 1 : 0;
   if (gemm_use_skinny(d)) return PN_GEMM_VARIANT_SKINNY + col;
+  if ((d->flags & PN_GEMM_SPLIT_BF16) && !col) return PN_GEMM_VARIANT_SPLIT;
   if (d->flags & PN_GEMM_FORCE_TILE128x64) return PN_GEMM_VARIANT_TILE_128x64 + col;
   if (d->flags & PN_GEMM_FORCE_TILE) return PN_GEMM_VARIANT_TILE_128x128 + col;
   return PN_GEMM_VARIANT_TILE_64x64 + col;
 }
 
-static int fill_params(const pn_gemm_desc* d, GemmP* out) {
+int pn_fill_params(const pn_gemm_desc* d, GemmP* out) {
   if (!d || !d->A || !d->W || !d->C) return PN_BAD_ARG;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return PN_BAD_ARG;
   const bool colmajor = d->flags & PN_GEMM_A_COLMAJOR;
@@ -412,11 +402,13 @@ static int fill_params(const pn_gemm_desc* d, GemmP* out) {
 extern "C" int pn_gemm_f32(const pn_gemm_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   GemmP p;
-  if (int rc = fill_params(d, &p)) return rc;
+  if (int rc = pn_fill_params(d, &p)) return rc;
   const bool colmajor = d->flags & PN_GEMM_A_COLMAJOR;
   if (gemm_use_skinny(d)) {
     return colmajor ? launch_skinny<A_COL>(p, d->batch, s) : launch_skinny<A_ROW>(p, d->batch, s);
   }
+  if ((d->flags & PN_GEMM_SPLIT_BF16) && !colmajor)
+    return pn_launch_gemm_split(p, d->batch, /*conv=*/false, (d->flags & PN_GEMM_FORCE_TILE) != 0, s);
   // Tile choice (measured on MI355X, tools/gemm_sweep.py): with K = 256..1024 and
   // M x N of a few hundred 128x128 tiles, the 64x64 tile wins everywhere (75-94 vs
   // 58-80 TFLOP/s): 4x more workgroups even out the last round over 256 CUs and four
@@ -438,7 +430,7 @@ extern "C" int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream)
   int tiles = 0;
   for (int i = 0; i < count; ++i) {
     if (d[i].flags & PN_GEMM_A_COLMAJOR) return PN_BAD_ARG;
-    if (int rc = fill_params(&d[i], &g.p[i])) return rc;
+    if (int rc = pn_fill_params(&d[i], &g.p[i])) return rc;
     g.tile_start[i] = tiles;
     g.mt[i] = pn_cdiv(d[i].M, 64);
     g.nt[i] = pn_cdiv(d[i].N, 64);
@@ -451,7 +443,8 @@ extern "C" int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream)
 
 extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float* bias,
                                   float* out, int B, int H, int W, int Cin, int Cout,
-                                  int KH, int KW, int pad, int relu, void* stream) {
+                                  int KH, int KW, int pad, int relu, int flags,
+                                  void* stream) {
   if (!in || !Wp || !out || B <= 0 || H <= 0 || W <= 0) return PN_BAD_ARG;
   if (Cin % 32 || !aligned16(in) || !aligned16(Wp)) return PN_BAD_ARG;
   GemmP p{};
@@ -462,6 +455,9 @@ extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float*
   p.relu = relu ? 1 : 0; p.aadd_rows = 1;
   p.H = H; p.Wd = W; p.Cin = Cin; p.KW = KW; p.pad = pad;
   hipStream_t s = (hipStream_t)stream;
+  if (flags & PN_GEMM_SPLIT_BF16) {
+    return pn_launch_gemm_split(p, B, /*conv=*/true, (flags & PN_GEMM_FORCE_TILE) != 0, s);
+  }
   // 3x3 x 256 channels (K = 2304): the long k-loop amortises the 128x128 tile (922 vs
   // 974 us measured); the 64-channel Matrix Learner layer has N = 64
   if (Cout <= 64) return launch_tile<64, 64, 32, 32, A_CONV>(p, B, s);

@@ -1,0 +1,20 @@
+// Shared between gemm.hip and gemm_split.hip.
+#pragma once
+#include "common.h"
+
+struct GemmP {
+  const float* A; const float* Aadd; const float* W; const float* bias;
+  const float* Res; float* C;
+  int64_t lda, ldaadd, ldw, ldres, ldc;
+  int64_t sA, sW, sRes, sC;
+  int M, N, K, aadd_rows, aadd_from_col, relu, a_vec;
+  int H, Wd, Cin, KW, pad;  // conv mode
+};
+
+enum { A_ROW = 0, A_COL = 1, A_CONV = 2 };
+
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+int pn_fill_params(const pn_gemm_desc* d, GemmP* out);
+int pn_launch_gemm_split(const GemmP& p, int batch, bool conv, bool big_tile, hipStream_t s);

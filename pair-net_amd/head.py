@@ -102,6 +102,10 @@ class CrossHead2:
         # True: compute attention masks in the reference's operation order (full-size mask
         # logits -> bilinear resize); False: resample the mask feature once (see _attn_mask)
         self.exact_mask_order = False
+        # "f32": every contraction on the exact-fp32 MFMA (default, the measured headline).
+        # "bf16x3": the large GEMMs / the 3x3 conv use the fp32-accurate 3 x bf16 operand
+        # split (csrc/gemm_split.hip): same error class, not bitwise the fp32 chain.
+        self.gemm_mode = "f32"
         self.init_weights()
 
     # ------------------------------------------------------------------ params
@@ -374,6 +378,7 @@ class CrossHead2:
     def _pixel_decoder(self, feats, pl):
         """MSDeformAttnPixelDecoder -> pl.X (memories), pl.MF."""
         w, B, SN = self.w, pl.B, pl.SN
+        sp = self.gemm_mode == "bf16x3"
         pd = "pixel_decoder."
         for l in range(3):
             f = feats[3 - l]
@@ -390,15 +395,15 @@ class CrossHead2:
             a = p + "attentions.0."
             hip.gemm(X2, w[a + "voa.weight"], pl.VOA, M=B * SN, N=544, K=256, lda=256, ldw=256,
                      ldc=544, bias=w[a + "voa.bias"], aadd=pl.enc_pos, ldaadd=256, aadd_rows=SN,
-                     aadd_from_col=256)
+                     aadd_from_col=256, split=sp)
             hip.msda(pl.VOA, 544, pl.VOA.view(-1)[256:], 544, pl.S, B, pl.shapes)
             hip.linear(pl.S.view(-1, 256), w[a + "output_proj.weight"], w[a + "output_proj.bias"],
-                       Y2, res=X2)
+                       Y2, res=X2, split=sp)
             hip.layernorm(Y2, w[p + "norms.0.weight"], w[p + "norms.0.bias"], X12)
             hip.linear(X12, w[p + "ffns.0.layers.0.0.weight"], w[p + "ffns.0.layers.0.0.bias"],
-                       pl.H, relu=True)
+                       pl.H, relu=True, split=sp)
             hip.linear(pl.H, w[p + "ffns.0.layers.1.weight"], w[p + "ffns.0.layers.1.bias"], Y2,
-                       res=X12)
+                       res=X12, split=sp)
             hip.layernorm(Y2, w[p + "norms.1.weight"], w[p + "norms.1.bias"], X2)
         # FPN level (C2): lateral 1x1 + GN, + bilinear-up(finest memory), 3x3 + GN + ReLU
         f = feats[0]
@@ -413,12 +418,12 @@ class CrossHead2:
         hip.bilinear_nhwc(pl.X[:, pl.start[2]:], pl.T2, B, h2, w2, H2, W2, 256, True, SN * 256,
                           HW2 * 256)
         hip.conv2d_nhwc(pl.T2, w[pd + "output_convs.0.conv.weight"], None, pl.T1, B, H2, W2, 256,
-                        256, 3, 3, 1, False)
+                        256, 3, 3, 1, False, split=sp, big_tile=sp)
         hip.groupnorm_nhwc(pl.T1, w[pd + "output_convs.0.gn.weight"],
                            w[pd + "output_convs.0.gn.bias"], pl.T2, pl.gn_part, B, HW2,
                            self.gn_groups, True, HW2 * 256, HW2 * 256)
         hip.linear(pl.T2.view(-1, 256), w[pd + "mask_feature.weight"], w[pd + "mask_feature.bias"],
-                   pl.MF.view(-1, 256))
+                   pl.MF.view(-1, 256), split=sp)
         if not self.exact_mask_order:
             for l, (h, wd) in enumerate(pl.shapes):
                 hip.bilinear_nhwc(pl.MF, pl.MFd[l], B, H2, W2, h, wd, 256, False, HW2 * 256,
@@ -437,7 +442,8 @@ class CrossHead2:
         hip.linear(pl.m2, w["mask_embed.4.weight"], w["mask_embed.4.bias"], pl.me)
         if full_mask:
             hip.gemm(pl.me, pl.MF, pl.MP, M=Q, N=pl.HW2, K=256, lda=256, ldw=256, ldc=pl.HW2,
-                     batch=B, sA=Q * 256, sW=pl.HW2 * 256, sC=Q * pl.HW2)
+                     batch=B, sA=Q * 256, sW=pl.HW2 * 256, sC=Q * pl.HW2,
+                     split=self.gemm_mode == "bf16x3")
 
     def _attn_mask(self, pl, lvl):
         """Boolean attention mask of level `lvl` + all-masked fix (pairnet_head.py:244-256,

@@ -33,7 +33,7 @@ _SIGS = {
     "pn_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "pn_gemm_variant": (C.c_int, [C.POINTER(GemmDesc)]),
     "pn_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
-    "pn_conv2d_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 9 + [_vp]),
+    "pn_conv2d_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp]),
     "pn_layernorm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "pn_groupnorm_nblk": (C.c_int, [_i64]),
     "pn_groupnorm_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32,
@@ -76,7 +76,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.pn_abi_version() != 2:
+        if handle.pn_abi_version() != 3:
             raise RuntimeError("libpairnet_hip.so ABI mismatch; rebuild")
         _lib = handle
     return _lib
@@ -89,7 +89,9 @@ def _stream():
 GEMM_KERNELS = {0: "k_gemm_skinny<A_ROW>", 1: "k_gemm_skinny<A_COL>",
                 2: "k_gemm_tile<128,64,32,64,A_ROW>", 3: "k_gemm_tile<128,64,32,64,A_COL>",
                 4: "k_gemm_tile<128,128,64,64,A_ROW>", 5: "k_gemm_tile<128,128,64,64,A_COL>",
-                6: "k_gemm_tile<64,64,32,32,A_ROW>", 7: "k_gemm_tile<64,64,32,32,A_COL>"}
+                6: "k_gemm_tile<64,64,32,32,A_ROW>", 7: "k_gemm_tile<64,64,32,32,A_COL>",
+                8: "k_gemm_split<A_ROW>"}
+GEMM_SPLIT_BF16 = 64
 
 
 class KernelTimer:
@@ -152,7 +154,7 @@ def _rowmajor(t):
 
 def gemm_desc(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaadd=0,
               aadd_rows=0, aadd_from_col=0, res=None, ldres=0, batch=1, sA=0, sW=0, sC=0,
-              sRes=0, relu=False, colmajor=False, force=None, into=None):
+              sRes=0, relu=False, colmajor=False, force=None, split=False, into=None):
     """Fill a pn_gemm_desc; tensors only supply base pointers."""
     d = into if into is not None else GemmDesc()
     d.A, d.lda, d.strideA = _ptr(A), lda, sA
@@ -164,7 +166,7 @@ def gemm_desc(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaad
     d.M, d.N, d.K, d.batch = M, N, K, batch
     d.flags = (GEMM_RELU if relu else 0) | (GEMM_A_COLMAJOR if colmajor else 0) | \
         {None: 0, "tile": GEMM_FORCE_TILE, "skinny": GEMM_FORCE_SKINNY, "tile64": 16,
-         "tile128x64": 32}[force]
+         "tile128x64": 32}[force] | (GEMM_SPLIT_BF16 if split else 0)
     return d
 
 
@@ -196,7 +198,7 @@ def gemm_group(problems):
 
 
 def linear(x, weight, bias, out, *, aadd=None, aadd_from_col=0, res=None, relu=False,
-           force=None):
+           force=None, split=False):
     """out = act((x + aadd[row % len(aadd)]) @ weight.T + bias) + res on 2-D views
     (aadd only feeds output columns >= aadd_from_col)."""
     M, lda = _rowmajor(x)
@@ -212,15 +214,18 @@ def linear(x, weight, bias, out, *, aadd=None, aadd_from_col=0, res=None, relu=F
         assert rr == M
         kw.update(res=res, ldres=ldr)
     gemm(x, weight, out, M=M, N=N, K=x.shape[1], lda=lda, ldw=ldw, ldc=ldc, bias=bias,
-         relu=relu, force=force, **kw)
+         relu=relu, force=force, split=split, **kw)
 
 
-def conv2d_nhwc(x, wp, bias, out, B, H, W, Cin, Cout, KH, KW, pad, relu):
-    name = "k_gemm_tile<64,64,32,32,A_CONV>" if Cout <= 64 else "k_gemm_tile<128,128,64,64,A_CONV>"
+def conv2d_nhwc(x, wp, bias, out, B, H, W, Cin, Cout, KH, KW, pad, relu, split=False,
+                big_tile=False):
+    name = "k_gemm_split<A_CONV>" if split else (
+        "k_gemm_tile<64,64,32,32,A_CONV>" if Cout <= 64 else "k_gemm_tile<128,128,64,64,A_CONV>")
     flops = 2.0 * B * H * W * Cout * KH * KW * Cin
     nbytes = 4.0 * (B * H * W * (Cin + Cout) + Cout * KH * KW * Cin)
     _check(_launch(name, flops, nbytes, lambda: lib().pn_conv2d_nhwc_f32(
         _ptr(x), _ptr(wp), _ptr(bias), _ptr(out), B, H, W, Cin, Cout, KH, KW, pad, int(relu),
+        (GEMM_SPLIT_BF16 if split else 0) | (GEMM_FORCE_TILE if big_tile else 0),
         _stream())), "pn_conv2d_nhwc_f32")
 
 

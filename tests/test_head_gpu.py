@@ -93,7 +93,8 @@ def test_e2e_small_against_reference_golden():
         assert r[0].shape == (200, 5) and float(r[0].abs().sum()) == 0.0
 
 
-def test_e2e_full_800x1333_against_reference_golden():
+@pytest.mark.parametrize("gemm_mode", ["f32", "bf16x3"])
+def test_e2e_full_800x1333_against_reference_golden(gemm_mode):
     fx = golden("e2e_full")
     head_o, sd, crc = oracle_head(int(fx["weight_seed"]), overrides_of(fx))
     assert crc == int(fx["weight_crc"])
@@ -103,6 +104,7 @@ def test_e2e_full_800x1333_against_reference_golden():
     assert [tuple(f.shape) for f in feats] == [tuple(s) for s in fx["feat_shapes"].tolist()]
     metas = [dict(img_shape=(H, W, 3), scale_factor=[2.083] * 4)]
     head = _hip_head(sd)
+    head.gemm_mode = gemm_mode
     cls, masks = head.forward([f.to(DEV) for f in feats], metas)
     torch.cuda.synchronize()
     trace = {}
@@ -130,8 +132,9 @@ def test_e2e_full_800x1333_against_reference_golden():
     assert float((res[0][7].sum(-1) - 1).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("exact_mask_order", [False, True])
-def test_against_oracle_other_seed_and_batch_consistency(exact_mask_order):
+@pytest.mark.parametrize("exact_mask_order,gemm_mode", [(False, "f32"), (True, "f32"),
+                                                        (False, "bf16x3")])
+def test_against_oracle_other_seed_and_batch_consistency(exact_mask_order, gemm_mode):
     head_o, sd, _ = oracle_head(1234)
     H, W = 64, 96
     feats = seeded.seeded_feats(99, 2, H, W)
@@ -141,6 +144,7 @@ def test_against_oracle_other_seed_and_batch_consistency(exact_mask_order):
     ref_cls, ref_masks = head_o.forward(feats, metas, trace=trace)
     head = _hip_head(sd)
     head.exact_mask_order = exact_mask_order
+    head.gemm_mode = gemm_mode
     cls, masks = head.forward([f.to(DEV) for f in feats], metas)
     torch.cuda.synchronize()
     for k in ("cls", "importance"):

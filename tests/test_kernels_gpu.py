@@ -107,6 +107,40 @@ def test_gemm_group_and_column_split_add(hip):
     close(out, ref, 2e-5, "column-split add")
 
 
+@pytest.mark.parametrize("big", [False, True])
+def test_gemm_bf16x3_split_is_fp32_accurate(hip, big):
+    """The opt-in 3 x bf16 operand split: error vs an fp64 reference no larger than the
+    exact-fp32 MFMA path's (both ~K * 2^-24 relative), on a wide dynamic range."""
+    M, N, K = 1000, 320, 512
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g) * 3)
+    w = torch.randn(N, K, generator=g) * 0.1
+    b, res, pos = R(N, seed=1), R(M, N, seed=2), R(250, K, seed=3)
+    ref = F.relu((x + pos.repeat(4, 1)).double() @ w.double().t() + b.double()) + res.double()
+    outs = {}
+    for name, kw in (("f32", dict(force="tile64")), ("split", dict(split=True, force="tile" if big else None))):
+        out = torch.empty(M, N, device=DEV)
+        hip.linear(x.to(DEV), w.to(DEV), b.to(DEV), out, aadd=pos.to(DEV), res=res.to(DEV),
+                   relu=True, **kw)
+        outs[name] = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    print(outs)
+    assert outs["split"] <= max(2 * outs["f32"], 2e-6)
+    # exact on integer-valued operands, like the fp32 chain
+    xi = torch.randint(-8, 9, (256, 512)).float()
+    wi = torch.randint(-8, 9, (256, 512)).float()
+    out = torch.empty(256, 256, device=DEV)
+    hip.linear(xi.to(DEV), wi.to(DEV), None, out, split=True, force="tile" if big else None)
+    assert torch.equal(out.cpu(), xi @ wi.t())
+    # conv path
+    xc, wc = R(1, 32, 17, 23, seed=5), R(64, 32, 3, 3, seed=6, lo=-0.1, hi=0.1)
+    refc = F.conv2d(xc.double(), wc.double(), padding=1)
+    o = torch.empty(1, 17, 23, 64, device=DEV)
+    hip.conv2d_nhwc(xc.permute(0, 2, 3, 1).contiguous().to(DEV),
+                    wc.permute(0, 2, 3, 1).reshape(64, -1).contiguous().to(DEV), None, o, 1, 17, 23,
+                    32, 64, 3, 3, 1, False, split=True, big_tile=big)
+    assert (o.permute(0, 3, 1, 2).cpu().double() - refc).abs().max().item() < 5e-6
+
+
 def test_gemm_is_an_fmaf_chain(hip):
     """The f32 MFMA is exact fp32: with integer-valued operands the result is exact."""
     x = torch.randint(-8, 9, (256, 512)).float()

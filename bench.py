@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default="f32",
                     help="f32: exact-fp32 MFMA everywhere (headline); bf16x3: fp32-accurate "
                          "3 x bf16 operand split for the large GEMMs / 3x3 conv")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run the two stages of consecutive batches back to back on one stream")
+    ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -73,7 +76,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    from pairnet_amd import CrossHead2, hip, pairnet_head_cfg
+    from pairnet_amd import CrossHead2, PipelinedHead, hip, pairnet_head_cfg
     from pairnet_amd.dist import all_gather_triplets, pack_triplets
 
     cfg = pairnet_head_cfg()
@@ -82,6 +85,8 @@ def main():
     head.init_weights(seed=0)
     head.to(dev)
     head.gemm_mode = args.gemm
+    head.use_graphs = not args.no_graphs
+    engine = None if args.no_pipeline else PipelinedHead(head)
     B, H, W = args.batch, args.height, args.width
     g = torch.Generator().manual_seed(1000 + rank)
     feats_cpu = [torch.relu(torch.randn(B, c, h, w, generator=g))
@@ -91,18 +96,36 @@ def main():
     metas = [dict(img_shape=(H, W, 3), scale_factor=[sf, sf, sf, sf])] * B
     R = head.num_rel_query
 
-    def step():
-        res = head.simple_test_bboxes(feats, metas)
-        if world > 1:
-            pl = head._last_plan
-            rec = torch.stack([pack_triplets(r[1], r[7], pl.sub_pos[i], pl.obj_pos[i])
+    def gather(res, sub_pos, obj_pos):
+        if world > 1 and res is not None:
+            rec = torch.stack([pack_triplets(r[1], r[7], sub_pos[i], obj_pos[i])
                                for i, r in enumerate(res)])
             all_gather_triplets(rec, world * B)
+
+    def step():
+        """One batch through simple_test_bboxes.  Pipelined: stage A of this batch is
+        queued next to stage B + post-processing of the previous one (results arrive one
+        step late; drain() completes the last batch)."""
+        if engine is None:
+            res = head.simple_test_bboxes(feats, metas)
+        else:
+            res = engine.submit(feats, metas)
+        if res is not None:
+            pl = head._last_plan
+            gather(res, pl.sub_pos, pl.obj_pos)
         return res
+
+    def drain():
+        if engine is not None:
+            res = engine.flush()
+            if res is not None:
+                pl = head._last_plan
+                gather(res, pl.sub_pos, pl.obj_pos)
 
     # ---- warm-up ----
     for _ in range(args.warmup):
         step()
+    drain()
     # Python's cyclic GC (gen-2 passes of 50-100 ms over torch's object graph) would
     # land inside the timed region at random: collect now, then keep it off, as a
     # serving loop would.
@@ -117,6 +140,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()                      # the K-th batch finishes inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -131,11 +155,13 @@ def main():
     # timed region above because ~100 event pairs per step cost host time there. ----
     timer = dominant = prof = None
     if rank == 0:
+        head.use_graphs = False   # events need eager, single-stream launches
         hip.TIMER = timer = hip.KernelTimer()
         for _ in range(min(args.steps, 10)):
-            step()
+            head.simple_test_bboxes(feats, metas)
         prof = timer.summary()
         hip.TIMER = None
+        head.use_graphs = not args.no_graphs
         dominant = max(prof, key=lambda k: prof[k]["ms"]) if prof else None
     gc.enable()
 
@@ -160,6 +186,9 @@ def main():
                             % (B, H, W),
                 "global_batch": world * B, "per_gpu_batch": B, "image": [H, W],
                 "parallelism": "dp%d" % world,
+                "schedule": ("eager" if args.no_graphs else "hipGraph replay per stage") + (
+                    ", single stream" if args.no_pipeline else
+                    ", 2-stream pipeline (stage A of batch i+1 beside stage B of batch i)"),
                 "collective": "all-gather of triplet records" if world > 1 else "none"},
         }
         if timer and dominant:
@@ -177,8 +206,8 @@ def main():
                 "launches_per_step": agg["launches"] // nprof,
                 "avg_launch_us": 1e3 * agg["ms"] / agg["launches"],
                 "ms_per_step": agg["ms"] / nprof,
-                "measured": "HIP events around each launch, %d steps right after the timed "
-                            "region" % nprof}
+                "measured": "HIP events around each launch on the launching stream, %d "
+                            "eager single-stream steps right after the timed region" % nprof}
             out["kernel_profile"] = {
                 k: {"ms_per_step": v["ms"] / nprof, "launches_per_step": v["launches"] // nprof,
                     "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0.0,
@@ -194,11 +223,27 @@ def main():
                 fn()
             torch.cuda.synchronize()
             return 1e3 * (time.perf_counter() - t) / n
+        def run_steps(n=10):
+            for _ in range(n):
+                step()
+            drain()
+        out["latency_ms_single_stream_eager"] = None
+        head.use_graphs = False
+        out["latency_ms_single_stream_eager"] = timeit(
+            lambda: head.simple_test_bboxes(feats, metas), 10)
+        head.use_graphs = not args.no_graphs
         if args.gemm == "f32":   # the opt-in mode, for comparison (not the headline)
             head.gemm_mode = "bf16x3"
-            t_split = timeit(lambda: head.simple_test_bboxes(feats, metas), 10)
+            run_steps(6)         # re-capture graphs for this mode
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            run_steps(10)
+            torch.cuda.synchronize()
+            t_split = 1e3 * (time.perf_counter() - t) / 10
             head.gemm_mode = "f32"
+            run_steps(6)
             out["opt_in_bf16x3_split"] = {"images_per_s": B * 1e3 / t_split, "ms_per_step": t_split}
+        head.use_graphs = False
         outs = head.forward(feats, metas)
         out["breakdown_ms"] = {
             "forward": timeit(lambda: head.forward(feats, metas)),

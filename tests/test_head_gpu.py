@@ -173,3 +173,39 @@ def test_forward_head_signature_and_values():
     assert _err(out[0], ref[0]) < 1e-4 and _err(out[1], ref[1]) < 1e-3
     assert out[2].shape == ref[2].shape == (16, 100, 48) and out[2].dtype == torch.bool
     assert float((out[2].cpu() != ref[2]).float().mean()) < 1e-3
+
+
+def test_graph_replay_and_two_stream_pipeline_are_bitwise_the_eager_path():
+    """hipGraph replay per stage and the 2-stream pipeline reorder launches, never
+    arithmetic: every output must equal the eager single-stream call bit for bit."""
+    from pairnet_amd import PipelinedHead
+    head_o, sd, _ = oracle_head(77)
+    head = _hip_head(sd)
+    H, W = 64, 96
+    batches = [[f.to(DEV) for f in seeded.seeded_feats(200 + i, 2, H, W)] for i in range(5)]
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[1.5] * 4)] * 2
+    names = ("bboxes", "labels", "rel_pairs", "masks", "pan", "r_scores", "r_labels", "r_dists")
+
+    def snap(res):
+        return [[t.cpu().clone() if isinstance(t, torch.Tensor) else t for t in r] for r in res]
+    eager = [snap(head.simple_test_bboxes(b, metas)) for b in batches]
+    head.use_graphs = True
+    for rep in range(3):                                   # eager -> capture -> replay
+        got = [snap(head.simple_test_bboxes(b, metas)) for b in batches]
+        for e, g in zip(eager, got):
+            for re_, rg in zip(e, g):
+                for n, x, y in zip(names, re_, rg):
+                    assert torch.equal(x, y), (rep, n)
+    eng = PipelinedHead(head)
+    for rep in range(3):
+        outs = []
+        for b in batches:
+            r = eng.submit(b, metas)
+            if r is not None:
+                outs.append(snap(r))
+        outs.append(snap(eng.flush()))
+        assert len(outs) == len(batches)
+        for e, g in zip(eager, outs):
+            for re_, rg in zip(e, g):
+                for n, x, y in zip(names, re_, rg):
+                    assert torch.equal(x, y), (rep, n)

@@ -47,7 +47,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
@@ -56,6 +56,7 @@ def main():
                          "3 x bf16 operand split for the large GEMMs / 3x3 conv")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two stages of consecutive batches back to back on one stream")
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight in the pipeline")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -86,7 +87,7 @@ def main():
     head.to(dev)
     head.gemm_mode = args.gemm
     head.use_graphs = not args.no_graphs
-    engine = None if args.no_pipeline else PipelinedHead(head)
+    engine = None if args.no_pipeline else PipelinedHead(head, depth=args.depth)
     B, H, W = args.batch, args.height, args.width
     g = torch.Generator().manual_seed(1000 + rank)
     feats_cpu = [torch.relu(torch.randn(B, c, h, w, generator=g))
@@ -103,9 +104,9 @@ def main():
             all_gather_triplets(rec, world * B)
 
     def step():
-        """One batch through simple_test_bboxes.  Pipelined: stage A of this batch is
-        queued next to stage B + post-processing of the previous one (results arrive one
-        step late; drain() completes the last batch)."""
+        """One batch through simple_test_bboxes.  Pipelined: stage A of this batch is queued
+        beside the query chains of the two previous ones (results arrive two steps late;
+        drain() completes the batches still in flight)."""
         if engine is None:
             res = head.simple_test_bboxes(feats, metas)
         else:
@@ -117,8 +118,8 @@ def main():
 
     def drain():
         if engine is not None:
-            res = engine.flush()
-            if res is not None:
+            while engine.queue:
+                res = engine._finish(engine.queue.pop(0))
                 pl = head._last_plan
                 gather(res, pl.sub_pos, pl.obj_pos)
 
@@ -188,7 +189,8 @@ def main():
                 "parallelism": "dp%d" % world,
                 "schedule": ("eager" if args.no_graphs else "hipGraph replay per stage") + (
                     ", single stream" if args.no_pipeline else
-                    ", 2-stream pipeline (stage A of batch i+1 beside stage B of batch i)"),
+                    ", %d-stream pipeline (stage A of batch i beside the query chains of "
+                    "the %d previous batches)" % (args.depth, args.depth - 1)),
                 "collective": "all-gather of triplet records" if world > 1 else "none"},
         }
         if timer and dominant:
@@ -234,14 +236,14 @@ def main():
         head.use_graphs = not args.no_graphs
         if args.gemm == "f32":   # the opt-in mode, for comparison (not the headline)
             head.gemm_mode = "bf16x3"
-            run_steps(6)         # re-capture graphs for this mode
+            run_steps(8)         # re-capture graphs for this mode
             torch.cuda.synchronize()
             t = time.perf_counter()
             run_steps(10)
             torch.cuda.synchronize()
             t_split = 1e3 * (time.perf_counter() - t) / 10
             head.gemm_mode = "f32"
-            run_steps(6)
+            run_steps(8)
             out["opt_in_bf16x3_split"] = {"images_per_s": B * 1e3 / t_split, "ms_per_step": t_split}
         head.use_graphs = False
         outs = head.forward(feats, metas)

@@ -1,74 +1,95 @@
-"""Two-stream software pipeline over consecutive batches.
+"""Multi-stream software pipeline over consecutive batches.
 
 The head has two very different halves (head.py): stage A (pixel decoder + K/V
-projections) is a few dozen chip-filling GEMM / gather launches, stage B (the
-sequential query chain of the two decoders, PPN, top-k, post-processing) is ~200
-latency-bound launches that each occupy a handful of CUs.  Run back to back, stage B
-leaves most of the 256 CUs idle.  `PipelinedHead` runs stage B of batch i on one HIP
-stream while stage A of batch i+1 runs on another, with two buffer sets (`slot` 0/1)
-so the stages never share mutable state:
+projections) is a few dozen chip-filling GEMM / gather launches; stage B (the
+sequential query chain of the two decoders, PPN, top-k) is ~200 latency-bound launches
+that each occupy a handful of CUs, followed by the post-processing (`get_bboxes`).
+Run back to back, stage B leaves most of the 256 CUs idle; run beside stage A, each of
+its small kernels queues behind resident GEMM workgroups, so its chain stretches to
+about twice its stand-alone time.  `PipelinedHead(depth=3)` therefore keeps THREE
+batches in flight on three HIP streams and three buffer sets ("slots"):
 
-    stream A:  A(0) A(1)       A(2)       A(3) ...
-    stream B:       B(0)+post  B(1)+post  B(2)+post ...
+    stream A :  A(i)                      stage A of the newest batch
+    stream B0:  B(i-1)                    query chain of the previous batch ...
+    stream B1:  B(i-2), get_bboxes(i-2)   ... and of the one before, whose results
+                                          submit(i) returns (its host syncs only wait
+                                          for work queued two submissions ago)
 
-Results are those of `CrossHead2.simple_test_bboxes`, returned one submission late;
-`flush()` returns the last one.  Images are independent (pairnet_head.py:260-417 has
-no cross-image op), so this is the same computation, only scheduled for throughput.
+Results are exactly those of `CrossHead2.simple_test_bboxes` (bitwise: scheduling
+only), returned `depth-1` submissions late; `flush()` drains the rest.  Images are
+independent (pairnet_head.py:260-417 has no cross-image op).
 """
 import torch
 
 
 class PipelinedHead:
-    def __init__(self, head):
+    def __init__(self, head, depth=3):
         if head.device is None or head.device.type != "cuda":
             raise RuntimeError("PipelinedHead needs a head on an MI355X (.to('cuda:N'))")
-        self.head = head
+        if depth < 2:
+            raise ValueError("depth >= 2")
+        self.head, self.depth = head, depth
         with torch.cuda.device(head.device):
-            # stage B's small dependent kernels must not queue behind stage A's thousands
-            # of workgroups: give its stream the high hardware-queue priority
             self.stream_a = torch.cuda.Stream(priority=0)
-            self.stream_b = torch.cuda.Stream(priority=-1)
-            self.a_done = [torch.cuda.Event(), torch.cuda.Event()]
-            self.b_done = [torch.cuda.Event(), torch.cuda.Event()]
+            # the query chains' small dependent kernels get the high-priority queues
+            self.streams_b = [torch.cuda.Stream(priority=-1) for _ in range(depth - 1)]
+            self.a_done = [torch.cuda.Event() for _ in range(depth)]
+            self.b_done = [torch.cuda.Event() for _ in range(depth)]
         self.count = 0
-        self.pending = None       # (slot, plan, img_metas, rescale) whose stage B has not run
+        self.queue = []   # per in-flight batch: dict(slot, pl, metas, rescale, b_started)
+
+    def _stream_b(self, index):
+        return self.streams_b[index % (self.depth - 1)]
 
     @torch.no_grad()
     def submit(self, feats, img_metas, rescale=False):
-        """Queue one batch; returns the previous batch's result list (None the first time)."""
+        """Queue one batch; returns the result list of the batch submitted depth-1 calls
+        earlier (None while the pipeline fills)."""
         head = self.head
         B, shapes, hw2 = head._check_feats(feats, img_metas)
-        slot = self.count & 1
+        idx = self.count
+        slot = idx % self.depth
         pl = head._plan(B, shapes, hw2, slot)
         cur = torch.cuda.current_stream(head.device)
-        self.stream_a.wait_stream(cur)               # feats produced on the caller's stream
-        if self.count >= 2:
-            self.stream_a.wait_event(self.b_done[slot])   # slot's buffers free again
+        self.stream_a.wait_stream(cur)                    # feats produced on the caller's stream
+        if idx >= self.depth:
+            self.stream_a.wait_event(self.b_done[slot])   # slot's buffers are free again
         with torch.cuda.stream(self.stream_a):
             head._run_stage("a", pl, feats)
             self.a_done[slot].record(self.stream_a)
-        for f in feats:                               # keep feats alive until A has read them
+        for f in feats:                                    # keep feats alive until A has read them
             f.record_stream(self.stream_a)
-        prev = self._finish()
-        self.pending = (slot, pl, img_metas, rescale)
+        self.queue.append(dict(idx=idx, slot=slot, pl=pl, metas=img_metas, rescale=rescale,
+                               b_started=False))
         self.count += 1
-        return prev
+        # start the query chain of every batch but the newest
+        for item in self.queue[:-1]:
+            self._start_b(item)
+        if len(self.queue) >= self.depth:
+            return self._finish(self.queue.pop(0))
+        return None
 
-    def _finish(self):
-        if self.pending is None:
-            return None
+    def _start_b(self, item):
+        if item["b_started"]:
+            return
+        sb = self._stream_b(item["idx"])
+        with torch.cuda.stream(sb):
+            sb.wait_event(self.a_done[item["slot"]])
+            self.head._run_stage("b", item["pl"])
+        item["b_started"] = True
+
+    def _finish(self, item):
         head = self.head
-        slot, pl, metas, rescale = self.pending
-        self.pending = None
-        with torch.cuda.stream(self.stream_b):
-            self.stream_b.wait_event(self.a_done[slot])
-            head._run_stage("b", pl)
-            head._last_plan = pl
-            res = head.get_bboxes(*head._outputs(pl), metas, rescale=rescale)
-            self.b_done[slot].record(self.stream_b)
+        self._start_b(item)
+        sb = self._stream_b(item["idx"])
+        with torch.cuda.stream(sb):
+            head._last_plan = item["pl"]
+            res = head.get_bboxes(*head._outputs(item["pl"]), item["metas"],
+                                  rescale=item["rescale"])
+            self.b_done[item["slot"]].record(sb)
         # the caller consumes the results on its own stream
         cur = torch.cuda.current_stream(head.device)
-        cur.wait_event(self.b_done[slot])
+        cur.wait_event(self.b_done[item["slot"]])
         for tup in res:
             for t in tup:
                 if isinstance(t, torch.Tensor) and t.is_cuda:
@@ -77,7 +98,9 @@ class PipelinedHead:
 
     @torch.no_grad()
     def flush(self):
-        """Finish the batch still in flight and return its results (or None)."""
-        res = self._finish()
-        torch.cuda.current_stream(self.head.device).wait_stream(self.stream_b)
-        return res
+        """Finish every batch still in flight; returns the list of their result lists
+        (oldest first)."""
+        out = []
+        while self.queue:
+            out.append(self._finish(self.queue.pop(0)))
+        return out

@@ -196,16 +196,17 @@ def test_graph_replay_and_two_stream_pipeline_are_bitwise_the_eager_path():
             for re_, rg in zip(e, g):
                 for n, x, y in zip(names, re_, rg):
                     assert torch.equal(x, y), (rep, n)
-    eng = PipelinedHead(head)
-    for rep in range(3):
-        outs = []
-        for b in batches:
-            r = eng.submit(b, metas)
-            if r is not None:
-                outs.append(snap(r))
-        outs.append(snap(eng.flush()))
-        assert len(outs) == len(batches)
-        for e, g in zip(eager, outs):
-            for re_, rg in zip(e, g):
-                for n, x, y in zip(names, re_, rg):
-                    assert torch.equal(x, y), (rep, n)
+    for depth in (2, 3):
+        eng = PipelinedHead(head, depth=depth)
+        for rep in range(3):
+            outs = []
+            for b in batches:
+                r = eng.submit(b, metas)
+                if r is not None:
+                    outs.append(snap(r))
+            outs.extend(snap(r) for r in eng.flush())
+            assert len(outs) == len(batches)
+            for e, g in zip(eager, outs):
+                for re_, rg in zip(e, g):
+                    for n, x, y in zip(names, re_, rg):
+                        assert torch.equal(x, y), (depth, rep, n)

@@ -47,3 +47,15 @@ __device__ __forceinline__ void st4(float* p, float4 v) {
 __device__ __forceinline__ float4 add4(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
+
+// XCD-aware tile order.  MI355X has 8 XCDs with private 4 MB L2s and the dispatcher
+// places workgroup L on XCD L % 8, so consecutive workgroups (which want to share an
+// operand panel) land on eight different L2s.  Map the launch index L to the logical
+// tile index T so that each XCD walks a CONTIGUOUS range of T (bijective for any
+// count; performance only -- any placement is correct).
+__device__ __forceinline__ int xcd_tile_index(int L, int ntiles) {
+  const int xcd = L & 7, j = L >> 3;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + j;
+}

@@ -221,7 +221,12 @@ struct TileSmem {
 template <int BM, int BN, int WM, int WN, int AMODE>
 __global__ __launch_bounds__(256) void k_gemm_tile(const GemmP p) {
   __shared__ __attribute__((aligned(16))) float smem[TileSmem<BM, BN, AMODE>::FLOATS];
-  gemm_tile_body<BM, BN, WM, WN, AMODE>(p, blockIdx.y * BM, blockIdx.x * BN, blockIdx.z, smem);
+  // 1-D launch over tiles; T enumerates tiles n-fastest, so one XCD's contiguous range
+  // of T shares A row-panels (and, for the conv, image rows with their halo) in its L2
+  const int nt = (p.N + BN - 1) / BN, mt = (p.M + BM - 1) / BM;
+  const int T = xcd_tile_index(blockIdx.x, nt * mt);
+  const int tm = T / nt, tn = T - tm * nt;
+  gemm_tile_body<BM, BN, WM, WN, AMODE>(p, tm * BM, tn * BN, blockIdx.z, smem);
 }
 
 // Several independent row-major GEMMs in ONE launch: the 64x64 tiles of all
@@ -238,7 +243,7 @@ struct GroupP {
 
 __global__ __launch_bounds__(256) void k_gemm_group(const GroupP g) {
   __shared__ __attribute__((aligned(16))) float smem[TileSmem<64, 64, A_ROW>::FLOATS];
-  const int bid = blockIdx.x;
+  const int bid = xcd_tile_index(blockIdx.x, gridDim.x);
   int i = 0;
 #pragma unroll
   for (int j = 1; j < GEMM_GROUP_MAX; ++j)
@@ -354,7 +359,7 @@ static int launch_skinny(const GemmP& p, int batch, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int AMODE>
 static int launch_tile(const GemmP& p, int batch, hipStream_t s) {
-  dim3 grid(pn_cdiv(p.N, BN), pn_cdiv(p.M, BM), batch);
+  dim3 grid(pn_cdiv(p.N, BN) * pn_cdiv(p.M, BM), 1, batch);
   hipLaunchKernelGGL((k_gemm_tile<BM, BN, WM, WN, AMODE>), grid, dim3(256), 0, s, p);
   return PN_LAUNCH_CHECK();
 }

@@ -55,7 +55,9 @@ __global__ __launch_bounds__(256) void k_gemm_split(const GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, bz = blockIdx.z;
+  const int nt = (p.N + BN - 1) / BN, mt = (p.M + BM - 1) / BM;
+  const int T = xcd_tile_index(blockIdx.x, nt * mt);   // see common.h
+  const int m0 = (T / nt) * BM, n0 = (T % nt) * BN, bz = blockIdx.z;
   const float* __restrict__ A = p.A + (int64_t)bz * p.sA;
   const float* __restrict__ W = p.W + (int64_t)bz * p.sW;
   const float* __restrict__ Aadd = (p.Aadd && n0 >= p.aadd_from_col) ? p.Aadd : nullptr;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void k_gemm_split(const GemmP p) {
 
 template <int BM, int BN, int WM, int WN, int AMODE>
 static int launch(const GemmP& p, int batch, hipStream_t s) {
-  dim3 grid(pn_cdiv(p.N, BN), pn_cdiv(p.M, BM), batch);
+  dim3 grid(pn_cdiv(p.N, BN) * pn_cdiv(p.M, BM), 1, batch);
   hipLaunchKernelGGL((k_gemm_split<BM, BN, WM, WN, AMODE>), grid, dim3(256), 0, s, p);
   return PN_LAUNCH_CHECK();
 }

@@ -70,12 +70,16 @@ def main():
                          "--nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; (for a functional check of the multi-rank control flow on a
+    # single-GPU box: PAIRNET_DIST_BACKEND=gloo lets several ranks share cuda:0)
+    backend = os.environ.get("PAIRNET_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     from pairnet_amd import CrossHead2, PipelinedHead, hip, pairnet_head_cfg
     from pairnet_amd.dist import all_gather_triplets, pack_triplets
@@ -101,7 +105,7 @@ def main():
         if world > 1 and res is not None:
             rec = torch.stack([pack_triplets(r[1], r[7], sub_pos[i], obj_pos[i])
                                for i, r in enumerate(res)])
-            all_gather_triplets(rec, world * B)
+            all_gather_triplets(rec if backend == "nccl" else rec.cpu(), world * B)
 
     def step():
         """One batch through simple_test_bboxes.  Pipelined: stage A of this batch is queued
@@ -147,7 +151,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu",
+                         dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

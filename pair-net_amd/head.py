@@ -620,7 +620,9 @@ class CrossHead2:
     def _capture(fn):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: other threads (e.g. the RCCL watchdog) may touch the runtime
+        # while this thread captures
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             fn()
         return g
 

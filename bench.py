@@ -207,9 +207,19 @@ def main():
             else:
                 ach, peak, unit = agg["flops"] / sec / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
                 bound = "mfma"
+            traffic, traffic_src = None, None
+            try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE
+                # doubled per MI355X_MICROARCH.md + WRITE_SIZE), same workload, same kernel
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                for v in pmc["kernels"].values():
+                    if v.get("bench_name") == dominant:
+                        traffic, traffic_src = v["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+            except (OSError, ValueError, KeyError):
+                pass
             out["roofline"] = {
                 "kernel": dominant, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                "frac": ach / peak, "traffic": None,
+                "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": agg["bytes"] / agg["launches"],
                 "launches_per_step": agg["launches"] // nprof,
                 "avg_launch_us": 1e3 * agg["ms"] / agg["launches"],
                 "ms_per_step": agg["ms"] / nprof,

@@ -210,3 +210,38 @@ def test_graph_replay_and_two_stream_pipeline_are_bitwise_the_eager_path():
                 for re_, rg in zip(e, g):
                     for n, x, y in zip(names, re_, rg):
                         assert torch.equal(x, y), (depth, rep, n)
+
+
+def test_swin_l_200_query_configuration():
+    """BASELINE.json configs[3]: Swin-L channel widths, 200 object queries (200x200
+    importance matrix, top-k over 40 000), batch 2 -- against the CPU oracle."""
+    from collections import OrderedDict
+    from oracle.head import OracleCrossHead2
+    from pairnet_amd import CrossHead2, pairnet_head_cfg
+    cfg = pairnet_head_cfg(in_channels=(192, 384, 768, 1536), num_obj_query=200)
+    cfg.pop("type")
+    head_o = OracleCrossHead2(**cfg).eval()
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in head_o.state_dict().items())
+    sd = seeded.seeded_state_dict(shapes, 4242)
+    head_o.load_state_dict(sd)
+    head = CrossHead2(**cfg)
+    head.load_state_dict(sd)
+    head.to(DEV)
+    H, W = 64, 80
+    feats = seeded.seeded_feats(17, 2, H, W, channels=(192, 384, 768, 1536))
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[1.0] * 4)] * 2
+    trace = {}
+    ref_cls, ref_masks = head_o.forward(feats, metas, trace=trace)
+    cls, masks = head.forward([f.to(DEV) for f in feats], metas)
+    assert cls["importance"].shape == (2, 200, 200) and cls["rel"].shape == (2, 100, 56)
+    assert _err(cls["cls"], ref_cls["cls"]) < 1e-3
+    assert _err(cls["importance"], ref_cls["importance"]) < 1e-3
+    e, same = _rel_err(head_o, head, cls, ref_cls["rel"], trace["topk_idx"], trace["query_feat"])
+    assert e < 1e-3
+    for b in range(2):
+        ok, exact = tie_aware_topk_match(ref_cls["importance"][b].numpy(),
+                                         trace["topk_idx"][b].numpy(),
+                                         head._last_plan.topk_idx[b].cpu().numpy(), TIE_TOL)
+        assert ok
+    res = head.get_bboxes(cls, masks, metas)
+    assert res[0][3].shape == (200, H, W) and res[0][1].shape == (200,)

@@ -237,6 +237,33 @@ int pn_panoptic_f32(const float* masks, const int64_t* labels,
                     const int32_t* remap, int64_t* seg, int32_t* area, int n,
                     int64_t HW, void* stream);
 
+/* The whole panoptic branch of _get_bboxes_single (:845-905) with no host round trip:
+ * keep = (label != num_classes-1) & (score > 0.5) in query order, duplicate stuff
+ * classes (label >= 80) merged into their first occurrence, kept masks resized to
+ * (ho, wo), per-pixel argmax -> seg = id*1000 + label, then `passes` rounds of "drop
+ * segments with area <= 4 and redo the argmax" (a round whose predecessor dropped
+ * nothing returns immediately; the reference loops until nothing is dropped, which in
+ * practice takes <= 2 rounds).  No kept query -> seg = 1 everywhere (:850).
+ *   masks [Q][hi][wi] mask logits; labels/scores from pn_cls_argmax_f32 over all_cls
+ *   state: pn_panoptic_state_bytes() bytes, readable afterwards: int32 nkeep,
+ *          changed[8], all_gone (every segment dropped: the reference raises),
+ *          overflow (still dropping after the last round)
+ *   up_scratch Q*ho*wo floats; area_scratch 256*passes int32; seg [ho*wo] int64 */
+int64_t pn_panoptic_state_bytes(void);
+int pn_panoptic_device_f32(const float* masks, const int64_t* labels, const float* scores,
+                           int Q, int num_classes, int hi, int wi, int ho, int wo,
+                           void* state, float* up_scratch, int32_t* area_scratch,
+                           int64_t* seg, int passes, void* stream);
+
+/* Evaluator feed (pairnet/evaluation/sgg_metrics.py:1276-1380, mask_iou :1374-1380):
+ * masks as bit rows (bit i of word w = pixel 64w+i) and the exact integer counts
+ * behind IoU: inter[i][j] = |pred_i & gt_j|, area_pred[i], area_gt[j]. */
+int pn_pack_mask_bits(const uint8_t* masks, uint64_t* words, int64_t rows, int64_t HW,
+                      void* stream);
+int pn_mask_iou_counts(const uint64_t* pred_words, int P, const uint64_t* gt_words, int G,
+                       int64_t nwords, int32_t* inter, int32_t* area_pred, int32_t* area_gt,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

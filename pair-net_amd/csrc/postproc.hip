@@ -122,3 +122,229 @@ extern "C" int pn_panoptic_f32(const float* masks, const int64_t* labels, const 
                      masks, labels, remap, seg, area, n, HW);
   return PN_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------
+// Sync-free panoptic post-processing (pairnet_head.py:845-905 without host round
+// trips).  The reference filters queries on the host (`keep`), merges duplicate stuff
+// classes, and re-runs the per-pixel argmax while any segment has area <= 4, reading
+// areas back with .item() each time.  Here the keep list, the duplicate map, the alive
+// flags and the compact ranks live in device memory; a FIXED number of argmax/filter
+// passes is enqueued and a pass whose predecessor changed nothing returns at once.
+// ---------------------------------------------------------------------------------
+struct PanState {      // device-resident, Q <= 256
+  int32_t nkeep;       // number of kept queries
+  int32_t changed[8];  // changed[p]: filter pass p removed something
+  int32_t all_gone;    // every kept segment was filtered (the reference raises here)
+  int32_t overflow;    // still changing after the last enqueued pass
+  int32_t pad[5];
+  int32_t kept[256];   // kept position -> query index
+  int32_t remap[256];  // kept position -> first kept position of the same stuff class
+  int32_t alive[256];
+  int32_t rank[256];   // compact index among alive positions
+  int64_t klab[256];   // label of kept position
+};
+
+__global__ __launch_bounds__(256) void k_pan_select(const int64_t* __restrict__ labels,
+                                                    const float* __restrict__ scores, int Q,
+                                                    int last_real_class, PanState* st) {
+  __shared__ int flag[256], pos[256];
+  const int t = threadIdx.x;
+  const bool keep = t < Q && labels[t] != last_real_class && scores[t] > 0.5f;
+  flag[t] = keep ? 1 : 0;
+  __syncthreads();
+  if (t == 0) {
+    int c = 0;
+    for (int i = 0; i < 256; ++i) { pos[i] = c; c += flag[i]; }
+    st->nkeep = c;
+    for (int p = 0; p < 8; ++p) st->changed[p] = 0;
+    st->all_gone = 0;
+    st->overflow = 0;
+  }
+  __syncthreads();
+  if (keep) {
+    st->kept[pos[t]] = t;
+    st->klab[pos[t]] = labels[t];
+  }
+  __syncthreads();
+  const int n = st->nkeep;
+  if (t < n) {
+    const int64_t lab = st->klab[t];
+    int first = t;
+    if (lab >= 80)
+      for (int i = 0; i < t; ++i)
+        if (st->klab[i] == lab) { first = i; break; }
+    st->remap[t] = first;
+    st->alive[t] = 1;
+    st->rank[t] = t;
+  }
+}
+
+// bilinear resize of the kept planes only: out[j] = resize(in[kept[j]]), j < nkeep
+__global__ __launch_bounds__(256) void k_resize_kept(const float* __restrict__ in,
+                                                     float* __restrict__ out,
+                                                     const PanState* __restrict__ st, int hi,
+                                                     int wi, int ho, int wo) {
+  const int j = blockIdx.y;
+  if (j >= st->nkeep) return;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per_plane = (int64_t)ho * wo;
+  if (e >= per_plane) return;
+  const int oy = (int)(e / wo), ox = (int)(e - (int64_t)oy * wo);
+  // same index / lambda arithmetic as k_bilinear_planar (resize.hip)
+  const float sy = (float)hi / (float)ho, sx = (float)wi / (float)wo;
+  float fy = sy * ((float)oy + 0.5f) - 0.5f, fx = sx * ((float)ox + 0.5f) - 0.5f;
+  if (fy < 0.f) fy = 0.f;
+  if (fx < 0.f) fx = 0.f;
+  int y0 = (int)fy, x0 = (int)fx;
+  if (y0 > hi - 1) y0 = hi - 1;
+  if (x0 > wi - 1) x0 = wi - 1;
+  const int y1 = y0 + (y0 < hi - 1 ? 1 : 0), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
+  const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
+  const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  const float* ib = in + (int64_t)st->kept[j] * hi * wi;
+  const float v00 = ib[(int64_t)y0 * wi + x0], v01 = ib[(int64_t)y0 * wi + x1];
+  const float v10 = ib[(int64_t)y1 * wi + x0], v11 = ib[(int64_t)y1 * wi + x1];
+  out[(int64_t)j * per_plane + e] = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+}
+
+__global__ __launch_bounds__(256) void k_pan_argmax(const float* __restrict__ up,
+                                                    PanState* __restrict__ st,
+                                                    int64_t* __restrict__ seg,
+                                                    int32_t* __restrict__ area, int64_t HW,
+                                                    int pass) {
+  if (pass > 0 && st->changed[pass - 1] == 0) return;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const int n = st->nkeep;
+  if (n == 0) { seg[p] = 1; return; }   // torch.ones(mask_size) (:850)
+  float best = 0.f;
+  int bi = -1;
+  for (int i = 0; i < n; ++i) {
+    if (!st->alive[i]) continue;
+    const float v = up[(int64_t)i * HW + p];
+    if (bi < 0 || v > best) { best = v; bi = i; }
+  }
+  if (bi < 0) return;                   // nothing alive: all_gone is set by the filter
+  if (pass == 0) bi = st->remap[bi];    // merge duplicate stuff classes (:873-878)
+  seg[p] = (int64_t)st->rank[bi] * 1000 + st->klab[bi];
+  atomicAdd(&area[pass * 256 + bi], 1);
+}
+
+__global__ __launch_bounds__(256) void k_pan_filter(PanState* st, const int32_t* __restrict__ area,
+                                                    int pass, int last_pass) {
+  __shared__ int any_small, nalive;
+  if (pass > 0 && st->changed[pass - 1] == 0) return;
+  const int t = threadIdx.x, n = st->nkeep;
+  if (t == 0) { any_small = 0; nalive = 0; }
+  __syncthreads();
+  bool a = t < n && st->alive[t] != 0;
+  if (a && area[pass * 256 + t] <= 4) { a = false; any_small = 1; }
+  __syncthreads();
+  if (!any_small) return;               // converged: changed[pass] stays 0
+  if (t < n) st->alive[t] = a ? 1 : 0;
+  __syncthreads();
+  if (t == 0) {
+    int c = 0;
+    for (int i = 0; i < n; ++i) { st->rank[i] = c; c += st->alive[i]; }
+    st->changed[pass] = 1;
+    if (c == 0) st->all_gone = 1;
+    if (last_pass) st->overflow = 1;
+  }
+}
+
+extern "C" int64_t pn_panoptic_state_bytes(void) { return (int64_t)sizeof(PanState); }
+
+extern "C" int pn_panoptic_device_f32(const float* masks, const int64_t* labels,
+                                      const float* scores, int Q, int num_classes, int hi,
+                                      int wi, int ho, int wo, void* state, float* up_scratch,
+                                      int32_t* area_scratch, int64_t* seg, int passes,
+                                      void* stream) {
+  if (!masks || !labels || !scores || !state || !up_scratch || !area_scratch || !seg)
+    return PN_BAD_ARG;
+  if (Q <= 0 || Q > 256 || passes < 1 || passes > 8 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0)
+    return PN_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  PanState* st = (PanState*)state;
+  const int64_t HW = (int64_t)ho * wo;
+  (void)hipMemsetAsync(area_scratch, 0, sizeof(int32_t) * 256 * passes, s);
+  hipLaunchKernelGGL(k_pan_select, dim3(1), dim3(256), 0, s, labels, scores, Q, num_classes - 1,
+                     st);
+  hipLaunchKernelGGL(k_resize_kept, dim3(pn_cdiv(HW, 256), Q), dim3(256), 0, s, masks, up_scratch,
+                     st, hi, wi, ho, wo);
+  for (int p = 0; p < passes; ++p) {
+    hipLaunchKernelGGL(k_pan_argmax, dim3(pn_cdiv(HW, 256)), dim3(256), 0, s, up_scratch, st, seg,
+                       area_scratch, HW, p);
+    hipLaunchKernelGGL(k_pan_filter, dim3(1), dim3(256), 0, s, st, area_scratch, p,
+                       p == passes - 1 ? 1 : 0);
+  }
+  return PN_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------
+// Evaluator feed (pairnet/evaluation/sgg_metrics.py:1276-1380): bit-packed masks and
+// the integer counts behind mask_iou (intersection and areas), exact.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_bits(const uint8_t* __restrict__ m,
+                                                   unsigned long long* __restrict__ words,
+                                                   int64_t HW, int64_t nwords) {
+  const int64_t row = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool on = i < HW && m[row * HW + i] != 0;
+  const unsigned long long bal = __ballot(on);
+  const int64_t w = i >> 6;
+  if ((threadIdx.x & 63) == 0 && w < nwords) words[row * nwords + w] = bal;
+}
+
+extern "C" int pn_pack_mask_bits(const uint8_t* masks, uint64_t* words, int64_t rows, int64_t HW,
+                                 void* stream) {
+  if (!masks || !words || rows <= 0 || rows > 65535 || HW <= 0) return PN_BAD_ARG;
+  const int64_t nwords = (HW + 63) / 64;
+  hipLaunchKernelGGL(k_pack_bits, dim3(pn_cdiv(nwords * 64, 256), (unsigned)rows), dim3(256), 0,
+                     (hipStream_t)stream, masks, (unsigned long long*)words, HW, nwords);
+  return PN_LAUNCH_CHECK();
+}
+
+// inter[i][j] = popcount(pred_i & gt_j); area_p[i], area_g[j].  One wave per (i, j).
+__global__ __launch_bounds__(256) void k_mask_iou_counts(const unsigned long long* __restrict__ pw,
+                                                         const unsigned long long* __restrict__ gw,
+                                                         int P, int G, int64_t nwords,
+                                                         int32_t* __restrict__ inter,
+                                                         int32_t* __restrict__ area_p,
+                                                         int32_t* __restrict__ area_g) {
+  const int lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= P * G) return;
+  const int i = pair / G, j = pair - i * G;
+  const unsigned long long* a = pw + (int64_t)i * nwords;
+  const unsigned long long* b = gw + (int64_t)j * nwords;
+  int ci = 0, ca = 0, cb = 0;
+  for (int64_t w = lane; w < nwords; w += 64) {
+    const unsigned long long x = a[w], y = b[w];
+    ci += __popcll(x & y);
+    ca += __popcll(x);
+    cb += __popcll(y);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ci += __shfl_xor(ci, o, 64);
+    ca += __shfl_xor(ca, o, 64);
+    cb += __shfl_xor(cb, o, 64);
+  }
+  if (lane == 0) {
+    inter[pair] = ci;
+    if (j == 0) area_p[i] = ca;
+    if (i == 0) area_g[j] = cb;
+  }
+}
+
+extern "C" int pn_mask_iou_counts(const uint64_t* pred_words, int P, const uint64_t* gt_words,
+                                  int G, int64_t nwords, int32_t* inter, int32_t* area_pred,
+                                  int32_t* area_gt, void* stream) {
+  if (!pred_words || !gt_words || !inter || !area_pred || !area_gt || P <= 0 || G <= 0 ||
+      nwords <= 0)
+    return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_mask_iou_counts, dim3(pn_cdiv((int64_t)P * G, 4)), dim3(256), 0,
+                     (hipStream_t)stream, (const unsigned long long*)pred_words,
+                     (const unsigned long long*)gt_words, P, G, nwords, inter, area_pred, area_gt);
+  return PN_LAUNCH_CHECK();
+}

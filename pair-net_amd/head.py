@@ -684,8 +684,8 @@ class CrossHead2:
 
     def _get_bboxes_single(self, all_masks, all_cls, s_cls, o_cls, r_cls, s_seg, o_seg,
                            img_shape, scale_factor, rescale=False):
-        """pairnet_head.py:788-924 on the device; the only host traffic is the
-        per-query (label, score) table and the per-segment areas (<= Q ints each)."""
+        """pairnet_head.py:788-924 on the device, without any host round trip (every
+        launch is asynchronous; `panoptic_status()` reads the flags back on demand)."""
         assert len(s_cls) == len(o_cls) == len(r_cls)
         dev = all_cls.device
         R, Q = self.num_rel_query, all_cls.shape[0]
@@ -708,59 +708,42 @@ class CrossHead2:
         hip.bilinear_planar_gt0(s_seg.contiguous(), masks_u8[:R], R, h, wd, H0, W0)
         hip.bilinear_planar_gt0(o_seg.contiguous(), masks_u8[R:], R, h, wd, H0, W0)
         masks = masks_u8.view(torch.bool)
-        # panoptic map (:823-825, :845-905)
+        # panoptic map (:823-825, :845-905), entirely on the device and without a host
+        # round trip: keep list, stuff-class merging, argmax and the "drop segments of
+        # area <= 4 and redo" loop are enqueued as a fixed number of passes
+        # (csrc/postproc.hip).  pan_img stays on the device (the reference returns a
+        # host tensor, :883): a fresh multi-MB host allocation per image is an
+        # mmap/munmap pair, and on ROCm every munmap runs the amdgpu MMU notifier against
+        # the busy GPU (~75 ms stalls measured).
         all_labels, all_scores = i64(Q), f32(Q)
         hip.cls_argmax(all_cls.contiguous(), all_labels, all_scores, Q, nc)
-        lab_h, sc_h = all_labels.cpu(), all_scores.cpu()
-        keep = [k for k in range(Q) if lab_h[k] != nc - 2 and sc_h[k] > 0.5]
-        # pan_img stays on the device (the reference returns a host tensor, :883): a fresh
-        # multi-MB host allocation per image is an mmap/munmap pair, and on ROCm every
-        # munmap runs the amdgpu MMU notifier against the busy GPU (~75 ms stalls measured).
-        if not keep:
-            pan_img = torch.ones((H0, W0), dtype=torch.long, device=dev)
-        else:
-            kept = torch.tensor(keep, device=dev, dtype=torch.int64).view(1, -1)
-            n = len(keep)
-            low = f32(n, h * wd)
-            hip.gather_rows(all_masks.contiguous().view(Q, h * wd), kept, low, 1, Q, n, h * wd)
-            up = f32(n, H0 * W0)
-            hip.bilinear_planar(low, up, n, h, wd, H0, W0)
-            klab = [int(lab_h[k]) for k in keep]
-            stuff = {}
-            for j, lab in enumerate(klab):
-                if lab >= 80:
-                    stuff.setdefault(lab, []).append(j)
-            remap = list(range(n))
-            for eq in stuff.values():
-                for e in eq:
-                    remap[e] = eq[0]
-            seg = i64(H0 * W0)
-            cur = list(range(n))  # rows of `up` still alive
-            first = True
-            while True:
-                m = len(cur)
-                rows = up if m == n else up[torch.tensor(cur, device=dev)].contiguous()
-                lab_d = torch.tensor([klab[j] for j in cur], device=dev, dtype=torch.int64)
-                area = torch.zeros(m, device=dev, dtype=torch.int32)
-                rm = torch.tensor(remap, device=dev, dtype=torch.int32) if first else None
-                hip.panoptic(rows, lab_d, rm, seg, area, m, H0 * W0)
-                # the reference counts areas on the un-merged ids only after dedup has
-                # moved pixels to the first duplicate (:873-887): same as counting seg ids
-                area_h = area.cpu().tolist()
-                small = [a <= 4 for a in area_h]
-                if not any(small):
-                    break
-                cur = [j for j, s in zip(cur, small) if not s]
-                first = False
-                if not cur:
-                    raise IndexError("every panoptic segment was filtered "
-                                     "(the reference fails here too, pairnet_head.py:882)")
-            pan_img = seg.view(H0, W0)
+        state = torch.empty(hip.panoptic_state_bytes(), device=dev, dtype=torch.uint8)
+        up = f32(Q, H0 * W0)
+        area = torch.empty(256 * hip.PAN_PASSES, device=dev, dtype=torch.int32)
+        seg = i64(H0 * W0)
+        hip.panoptic_device(all_masks.contiguous(), all_labels, all_scores, Q, nc - 1, h, wd, H0,
+                            W0, state, up, area, seg)
+        pan_img = seg.view(H0, W0)
+        self.last_panoptic_state = state
         det_bboxes = torch.zeros((2 * R, 5), device=dev)
         r_scores = torch.zeros(R, device=dev)
         r_labels = torch.zeros(R, device=dev)
         rel_pairs = torch.arange(2 * R, dtype=torch.int).reshape(2, -1).T
         return (det_bboxes, labels, rel_pairs, masks, pan_img, r_scores, r_labels, r_dists)
+
+    def panoptic_status(self):
+        """Host check of the last image's panoptic pass (one small D2H): dict with
+        nkeep and the two flags the sync-free loop cannot raise on its own."""
+        st = self.last_panoptic_state[:44].cpu().view(torch.int32)
+        out = dict(nkeep=int(st[0]), passes_that_dropped=int(st[1:9].sum()),
+                   all_gone=bool(st[9]), overflow=bool(st[10]))
+        if out["all_gone"]:
+            raise IndexError("every panoptic segment was filtered (the reference fails here "
+                             "too, pairnet_head.py:882)")
+        if out["overflow"]:
+            raise RuntimeError("panoptic area filter did not converge in %d passes"
+                               % hip.PAN_PASSES)
+        return out
 
     def simple_test_bboxes(self, feats, img_metas, rescale=False):
         """pairnet_head.py:926-930."""

@@ -58,6 +58,11 @@ _SIGS = {
     "pn_cls_argmax_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "pn_rel_dists_f32": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "pn_panoptic_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp]),
+    "pn_panoptic_state_bytes": (_i64, []),
+    "pn_panoptic_device_f32": (C.c_int, [_vp, _vp, _vp] + [_i32] * 6 + [_vp, _vp, _vp, _vp,
+                                                                        _i32, _vp]),
+    "pn_pack_mask_bits": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
+    "pn_mask_iou_counts": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -347,3 +352,30 @@ def panoptic(masks, labels, remap, seg, area, n, HW):
     _check(lib().pn_panoptic_f32(_ptr(masks), _ptr(labels, torch.int64),
                                  _ptr(remap, torch.int32), _ptr(seg, torch.int64),
                                  _ptr(area, torch.int32), n, HW, _stream()), "pn_panoptic_f32")
+
+
+PAN_PASSES = 4
+
+
+def panoptic_state_bytes():
+    return lib().pn_panoptic_state_bytes()
+
+
+def panoptic_device(masks, labels, scores, Q, num_classes, hi, wi, ho, wo, state, up, area, seg,
+                    passes=PAN_PASSES):
+    _check(lib().pn_panoptic_device_f32(
+        _ptr(masks), _ptr(labels, torch.int64), _ptr(scores), Q, num_classes, hi, wi, ho, wo,
+        _ptr(state, torch.uint8), _ptr(up), _ptr(area, torch.int32), _ptr(seg, torch.int64),
+        passes, _stream()), "pn_panoptic_device_f32")
+
+
+def pack_mask_bits(masks_u8, words, rows, HW):
+    _check(lib().pn_pack_mask_bits(_ptr(masks_u8, torch.uint8), _ptr(words, torch.int64), rows, HW,
+                                   _stream()), "pn_pack_mask_bits")
+
+
+def mask_iou_counts(pred_words, P, gt_words, G, nwords, inter, area_p, area_g):
+    _check(lib().pn_mask_iou_counts(_ptr(pred_words, torch.int64), P, _ptr(gt_words, torch.int64),
+                                    G, nwords, _ptr(inter, torch.int32),
+                                    _ptr(area_p, torch.int32), _ptr(area_g, torch.int32),
+                                    _stream()), "pn_mask_iou_counts")

@@ -245,3 +245,79 @@ def test_swin_l_200_query_configuration():
         assert ok
     res = head.get_bboxes(cls, masks, metas)
     assert res[0][3].shape == (200, H, W) and res[0][1].shape == (200,)
+
+
+def _crafted_postproc_inputs(seed, Q=100, h=24, w=32, empty=False):
+    """Confident class logits for a handful of queries (stuff duplicates, the excluded
+    class 132, one query whose mask wins only a few pixels) so that every branch of
+    _get_bboxes_single runs: keep filter, stuff merging, the area <= 4 drop-and-redo."""
+    g = torch.Generator().manual_seed(seed)
+    all_cls = torch.randn(Q, 134, generator=g) * 0.3
+    if not empty:
+        conf = {3: 17, 8: 100, 15: 100, 21: 132, 30: 5, 41: 90, 55: 90, 56: 90, 70: 2, 88: 119}
+        for q, lab in conf.items():
+            all_cls[q, lab] += 12.0
+    ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+    all_masks = torch.randn(Q, h, w, generator=g) * 0.5
+    for q in range(Q):   # smooth blobs, different centre per query
+        cy, cx = (q * 7) % h, (q * 13) % w
+        all_masks[q] += 6.0 * torch.exp(-((ys - cy) ** 2 + (xs - cx) ** 2) / (2 * (2.0 + q % 5) ** 2))
+    all_masks[30] = -5.0
+    all_masks[30, 5, 5] = 30.0          # wins ~1 low-res pixel -> area <= 4 after upsampling? no:
+    all_masks[70] = -20.0               # never wins: area 0 -> dropped, forces a second pass
+    s_cls, o_cls = torch.randn(100, 134, generator=g), torch.randn(100, 134, generator=g)
+    r_cls = torch.randn(100, 56, generator=g)
+    s_seg, o_seg = torch.randn(100, h, w, generator=g), torch.randn(100, h, w, generator=g)
+    return all_masks, all_cls, s_cls, o_cls, r_cls, s_seg, o_seg
+
+
+@pytest.mark.parametrize("case", ["rich", "empty"])
+def test_device_postprocessing_equals_reference_loop(case):
+    """get_bboxes on crafted inputs vs the oracle's restatement of the reference's host
+    loop (pairnet_head.py:788-924): labels, r_dists, masks, pan_img, including stuff
+    merging and the small-area re-run.  No host sync inside the device version."""
+    head_o, sd, _ = oracle_head(5)
+    head = _hip_head(sd)
+    args = _crafted_postproc_inputs(11, empty=(case == "empty"))
+    img_shape, sf = (48, 64, 3), [1.0, 1.0, 1.0, 1.0]
+    ref = head_o._get_bboxes_single(*args, img_shape, sf)
+    got = head._get_bboxes_single(*[a.to(DEV) for a in args], img_shape, sf)
+    st = head.panoptic_status()
+    print(st)
+    assert torch.equal(got[1].cpu(), ref[1])                       # labels
+    assert _err(got[7], ref[7]) < 1e-6                              # r_dists
+    assert float((got[3].cpu() != ref[3]).float().mean()) < 1e-3    # masks (|logit|~0 pixels)
+    assert torch.equal(got[4].cpu(), ref[4])                        # pan_img, exact
+    if case == "rich":
+        assert st["nkeep"] == 9 and st["passes_that_dropped"] >= 1
+        assert len(torch.unique(ref[4])) >= 4
+    else:
+        assert st["nkeep"] == 0 and int(got[4].min()) == 1 and int(got[4].max()) == 1
+
+
+def test_evaluator_feed_mask_iou_counts_are_exact():
+    from pairnet_amd import hip
+    g = torch.Generator().manual_seed(1)
+    P, G, H, W = 37, 11, 61, 83                  # HW not a multiple of 64
+    pred = torch.rand(P, H, W, generator=g) > 0.6
+    gt = torch.rand(G, H, W, generator=g) > 0.7
+    gt[3] = False
+    pred[5] = gt[2]
+    nw = (H * W + 63) // 64
+    pw = torch.empty(P, nw, device=DEV, dtype=torch.int64)
+    gw = torch.empty(G, nw, device=DEV, dtype=torch.int64)
+    hip.pack_mask_bits(pred.to(DEV).view(torch.uint8), pw, P, H * W)
+    hip.pack_mask_bits(gt.to(DEV).view(torch.uint8), gw, G, H * W)
+    bits = np.unpackbits(pw.cpu().numpy().view(np.uint8), axis=1, bitorder="little")[:, :H * W]
+    assert np.array_equal(bits.astype(bool), pred.flatten(1).numpy())
+    inter = torch.empty(P, G, device=DEV, dtype=torch.int32)
+    ap = torch.empty(P, device=DEV, dtype=torch.int32)
+    ag = torch.empty(G, device=DEV, dtype=torch.int32)
+    hip.mask_iou_counts(pw, P, gw, G, nw, inter, ap, ag)
+    pf, gf = pred.flatten(1).long(), gt.flatten(1).long()
+    assert torch.equal(inter.cpu().long(), pf @ gf.t())
+    assert torch.equal(ap.cpu().long(), pf.sum(1)) and torch.equal(ag.cpu().long(), gf.sum(1))
+    # mask_iou (sgg_metrics.py:1374-1380) from the counts, in float64 like numpy
+    i, a, b = inter.cpu().double(), ap.cpu().double()[:, None], ag.cpu().double()[None]
+    iou = i / (a + b - i)
+    assert float(iou[5, 2]) == 1.0

@@ -442,9 +442,11 @@ extern "C" int pn_gemm_f32(const pn_gemm_desc* d, void* stream) {
   // ... and with ONE LDS stage (18 KB, two barriers per k-tile) seven workgroups fit a
   // CU instead of four: +3-9 % on the same shapes (more waves to fill the matrix pipe
   // while others sit in their load / barrier phases).
-  if (colmajor) return launch_tile<64, 64, 32, 32, A_COL>(p, d->batch, s);
   dim3 grid(pn_cdiv(p.N, 64) * pn_cdiv(p.M, 64), 1, d->batch);
-  hipLaunchKernelGGL((k_gemm_tile<64, 64, 32, 32, A_ROW, false>), grid, dim3(256), 0, s, p);
+  if (colmajor)
+    hipLaunchKernelGGL((k_gemm_tile<64, 64, 32, 32, A_COL, false>), grid, dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((k_gemm_tile<64, 64, 32, 32, A_ROW, false>), grid, dim3(256), 0, s, p);
   return PN_LAUNCH_CHECK();
 }
 
@@ -483,10 +485,16 @@ extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float*
   if (flags & PN_GEMM_SPLIT_BF16) {
     return pn_launch_gemm_split(p, B, /*conv=*/true, (flags & PN_GEMM_FORCE_TILE) != 0, s);
   }
-  // 3x3 x 256 channels (K = 2304): the long k-loop amortises the 128x128 tile (922 vs
-  // 974 us measured); the 64-channel Matrix Learner layer has N = 64
-  if (Cout <= 64) return launch_tile<64, 64, 32, 32, A_CONV>(p, B, s);
-  return launch_tile<128, 128, 64, 64, A_CONV>(p, B, s);
+  // single LDS stage everywhere (more resident workgroups; 817 vs 944 us on the 3x3 FPN
+  // conv); 128x128 for the 256-channel conv, 64x64 for the 64-channel Matrix Learner layer
+  if (Cout <= 64) {
+    dim3 grid(pn_cdiv(p.N, 64) * pn_cdiv(p.M, 64), 1, B);
+    hipLaunchKernelGGL((k_gemm_tile<64, 64, 32, 32, A_CONV, false>), grid, dim3(256), 0, s, p);
+  } else {
+    dim3 grid(pn_cdiv(p.N, 128) * pn_cdiv(p.M, 128), 1, B);
+    hipLaunchKernelGGL((k_gemm_tile<128, 128, 64, 64, A_CONV, false>), grid, dim3(256), 0, s, p);
+  }
+  return PN_LAUNCH_CHECK();
 }
 
 extern "C" int pn_abi_version(void) { return PN_ABI_VERSION; }

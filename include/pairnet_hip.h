@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 3
+#define PN_ABI_VERSION 4
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -214,6 +214,10 @@ int pn_mlearner_last_f32(const float* in, const float* w3, const float* b3,
  * sub = idx / Q (trunc), obj = idx % Q.  n <= 65536, k <= 256. */
 int pn_topk_pairs(const float* scores, int64_t* idx, int64_t* sub, int64_t* obj,
                   int B, int Q, int k, void* stream);
+/* General form: k largest of n scores per row; quot = idx / div, rem = idx % div
+ * (triplet ranking of the sibling head, relation_heads/baseline.py:1033-1037). */
+int pn_topk_f32(const float* scores, int64_t* idx, int64_t* quot, int64_t* rem, int B,
+                int n, int div, int k, void* stream);
 
 /* out[b][r][:] = in[b][index[b][r]][:], rows of `len` floats
  * (torch.gather at pairnet_head.py:342-351, 380-403). */
@@ -230,6 +234,19 @@ int pn_cls_argmax_f32(const float* logits, int64_t* label, float* score,
 /* r_dists[r][0] = 0, r_dists[r][1:] = softmax(logits[r][:])  (:817-820) */
 int pn_rel_dists_f32(const float* logits, float* out, int64_t rows, int C,
                      void* stream);
+/* CrossHeadBaseline triplet ranking (pairnet/models/relation_heads/baseline.py).
+ * probs [rows][C] = softmax(logits); fg [rows][C-1] = probs[:, 1:]  (:1033-1034) */
+int pn_softmax_fg_f32(const float* logits, float* probs, float* fg, int64_t rows,
+                      int C, void* stream);
+/* idx[r] = first index of max(x[r][:])  (torch.max(-1)[1], :398-399) */
+int pn_row_argmax_f32(const float* x, int64_t* idx, int64_t rows, int n,
+                      void* stream);
+/* labels [2k] = [s_label[tri]+1 | o_label[tri]+1]; r_labels = rem+1;
+ * r_scores = probs[tri][rem+1]; r_dists [k][C] = probs[tri]  (:1035-1046) */
+int pn_triplet_finish(const int64_t* s_label, const int64_t* o_label,
+                      const float* probs, const int64_t* tri, const int64_t* rem,
+                      int64_t* labels, int64_t* r_labels, float* r_scores,
+                      float* r_dists, int k, int C, void* stream);
 /* Panoptic id map (:866-871): masks [n][HW] fp32 logits ->
  * m_id[p] = argmax_i softmax_i(masks[:, p]); remap[i] merges stuff duplicates
  * (:873-878); seg[p] = id*1000 + labels[id]; area[i] = #pixels with id i. */

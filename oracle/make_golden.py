@@ -18,6 +18,8 @@ Fixtures
   e2e_small  G7  whole head + get_bboxes on a 96x128 image, batch 2
   e2e_full   G8  whole head on the 800x1333 north-star shape, batch 1 (statistics,
                  logits and indices only)
+  baseline_small  the sibling head CrossHeadBaseline (relation_heads/baseline.py):
+                 forward + get_bboxes on a 96x128 image, batch 2
 """
 import argparse
 import os
@@ -197,6 +199,46 @@ def gen_e2e_full(head, sd):
     print("e2e_full: reference forward %.1f s on %d threads" % (dt, torch.get_num_threads()))
 
 
+RES_NAMES = ("bboxes", "labels", "rel_pairs", "masks", "pan_img", "r_scores", "r_labels",
+             "r_dists")
+
+
+def gen_baseline_small():
+    head = ref_shim.build_reference_baseline_head()
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in head.state_dict().items())
+    sd = seeded.seeded_state_dict(shapes, WEIGHT_SEED + 1)
+    head.load_state_dict(sd, strict=True)
+    H, W, bs = 96, 128, 2
+    feats = seeded.seeded_feats(71, bs, H, W)
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[2.0, 2.0, 2.0, 2.0])] * bs
+    mf_bias = calibrate_mask_bias(head, feats)
+    with torch.no_grad():
+        cls, masks = head.forward(feats, metas)
+        res = head.get_bboxes(cls, masks, metas)
+    m = masks["mask"]                                   # (9, bs, Q, h, w)
+    probe = torch.from_numpy(np.random.default_rng(72).integers(0, m[0].numel(), 4096))
+    top2 = lambda x: (lambda v: (v[..., 0] - v[..., 1]).min())(x.topk(2, dim=-1)[0])
+    fg = F.softmax(cls["rel"], -1)[..., 1:].flatten(1)
+    out = dict(weight_seed=WEIGHT_SEED + 1, weight_crc=seeded.checksum(sd), feat_seed=71,
+               feat_crc=seeded.checksum(feats), height=H, width=W, batch=bs,
+               mask_last=_np(m[-1]), mask_probe_idx=_np(probe),
+               mask_probe=_np(m.flatten(1)[:, probe]),
+               sub_ids=_np(cls["subject_scores"].max(-1)[1]),
+               obj_ids=_np(cls["object_scores"].max(-1)[1]),
+               match_gap=float(min(top2(cls["subject_scores"]), top2(cls["object_scores"]))),
+               rank_gap=_np(topk_gaps(fg.unsqueeze(1), 100)),
+               mask_neg_frac=float((m < 0).float().mean()))
+    out["override_" + MF_BIAS] = _np(mf_bias)
+    for k, v in cls.items():
+        out["cls_" + k] = _np(v)
+    for i, r in enumerate(res):
+        for name, v in zip(RES_NAMES, r):
+            if name != "bboxes":                        # torch.rand dummies in the reference
+                out["res%d_%s" % (i, name)] = np.packbits(_np(v)) if name == "masks" else _np(v)
+        out["res%d_masks_shape" % i] = np.array(r[3].shape)
+    np.savez_compressed(os.path.join(OUT, "baseline_small.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -218,6 +260,8 @@ def main():
             gen_e2e_small(head, sd)
         if want("e2e_full"):
             gen_e2e_full(head, sd)
+    if want("baseline_small"):
+        gen_baseline_small()
     for f in sorted(os.listdir(OUT)):
         print("%-16s %8.1f KB" % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))
 

@@ -80,7 +80,8 @@ def install():
          force_fp32=_passthrough_decorator)
     _mod("mmdet")
     _mod("mmdet.core", build_assigner=None, build_sampler=None,
-         multi_apply=None)
+         multi_apply=None, reduce_mean=None)
+    _mod("mmdet.models.utils", get_uncertain_point_coords_with_randomness=None)
     _mod("mmdet.datasets")
     _mod("mmdet.datasets.coco_panoptic", INSTANCE_OFFSET=1000)
     _mod("mmdet.models")
@@ -105,6 +106,8 @@ def install():
           "pairnet/models/frameworks/cnn_factory.py")
     _load("pairnet.models.relation_heads.pairnet_head",
           "pairnet/models/relation_heads/pairnet_head.py")
+    _load("pairnet.models.relation_heads.baseline",
+          "pairnet/models/relation_heads/baseline.py")
 
 
 def reference_head_cfg():
@@ -120,6 +123,23 @@ def build_reference_head(cfg=None):
     install()
     cls = sys.modules["pairnet.models.relation_heads.pairnet_head"].CrossHead2
     cfg = L.CfgDict(cfg if cfg is not None else reference_head_cfg())
+    cfg.pop("type", None)
+    return cls(**cfg, train_cfg=None).eval()
+
+
+def reference_baseline_cfg():
+    """model.bbox_head of the reference's configs/mask2former/baseline_r50_psg.py."""
+    path = os.path.join(REF_ROOT, "configs/mask2former/baseline_r50_psg.py")
+    scope = {}
+    with open(path) as f:
+        exec(compile(f.read(), path, "exec"), scope)
+    return L.CfgDict(scope["model"]["bbox_head"])
+
+
+def build_reference_baseline_head(cfg=None):
+    install()
+    cls = sys.modules["pairnet.models.relation_heads.baseline"].CrossHeadBaseline
+    cfg = L.CfgDict(cfg if cfg is not None else reference_baseline_cfg())
     cfg.pop("type", None)
     return cls(**cfg, train_cfg=None).eval()
 

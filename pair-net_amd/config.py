@@ -53,14 +53,17 @@ def _mha(embed=256, heads=8):
                 attn_drop=0.0, proj_drop=0.0, dropout_layer=None, batch_first=False)
 
 
-def _decoder(num_layers, return_intermediate, ffn_drop):
+CROSS_FIRST = ("cross_attn", "norm", "self_attn", "norm", "ffn", "norm")
+SELF_FIRST = ("self_attn", "norm", "cross_attn", "norm", "ffn", "norm")
+
+
+def _decoder(num_layers, return_intermediate, ffn_drop, order=CROSS_FIRST, attn=None):
     ffn = dict(embed_dims=256, feedforward_channels=2048, num_fcs=2,
                act_cfg=dict(type="ReLU", inplace=True), ffn_drop=ffn_drop,
                dropout_layer=None, add_identity=True)
-    order = ("cross_attn", "norm", "self_attn", "norm", "ffn", "norm")
     return dict(type="DetrTransformerDecoder", return_intermediate=return_intermediate,
                 num_layers=num_layers,
-                transformerlayers=dict(type="BaseTransformerLayer", attn_cfgs=_mha(),
+                transformerlayers=dict(type="BaseTransformerLayer", attn_cfgs=attn or _mha(),
                                        ffn_cfgs=ffn, operation_order=order))
 
 
@@ -110,6 +113,36 @@ def pairnet_head_cfg(in_channels=(256, 512, 1024, 2048), num_obj_query=100,
                        naive_dice=True, eps=1.0, loss_weight=5.0))
 
 
+def baseline_head_cfg(in_channels=(256, 512, 1024, 2048), num_obj_query=100,
+                      num_rel_query=100, num_classes=133, num_relations=56):
+    """bbox_head section (type CrossHeadBaseline) of configs/mask2former/baseline_r50_psg.py:
+    the same trunk; the relation decoder runs self-attention first and cross-attends the
+    pixel memories."""
+    nc = num_classes
+    return ConfigDict(
+        type="CrossHeadBaseline", num_classes=nc, num_relations=num_relations,
+        num_obj_query=num_obj_query, num_rel_query=num_rel_query,
+        in_channels=list(in_channels), strides=[4, 8, 16, 32], feat_channels=256,
+        out_channels=256, num_transformer_feat_level=3, embed_dims=256,
+        enforce_decoder_input_project=False,
+        pixel_decoder=_pixel_decoder(),
+        transformer_decoder=_decoder(9, False, 0.0),
+        relation_decoder=_decoder(6, True, 0.1, SELF_FIRST,
+                                  dict(type="MultiheadAttention", embed_dims=256, num_heads=8)),
+        positional_encoding=dict(type="SinePositionalEncoding", num_feats=128,
+                                 normalize=True),
+        rel_loss_cls=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=2.0,
+                          reduction="mean", class_weight=[0.02] + [1.0] * num_relations),
+        sub_id_loss=dict(type="MultilabelCrossEntropy", loss_weight=2.0),
+        obj_id_loss=dict(type="MultilabelCrossEntropy", loss_weight=2.0),
+        loss_cls=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=2.0,
+                      reduction="mean", class_weight=[1.0] * nc + [0.1]),
+        loss_mask=dict(type="CrossEntropyLoss", use_sigmoid=True, reduction="mean",
+                       loss_weight=5.0),
+        loss_dice=dict(type="DiceLoss", use_sigmoid=True, activate=True, reduction="mean",
+                       naive_dice=True, eps=1.0, loss_weight=5.0))
+
+
 def pairnet_r50():
     """`model` section: PSGTr(ResNet-50, CrossHead2) as the reference configures it."""
     return ConfigDict(
@@ -119,6 +152,13 @@ def pairnet_r50():
                       norm_eval=True, style="pytorch"),
         bbox_head=pairnet_head_cfg(),
         test_cfg=dict(max_per_img=100))
+
+
+def baseline_r50():
+    """`model` section: PSGTr(ResNet-50, CrossHeadBaseline)."""
+    cfg = pairnet_r50()
+    cfg["bbox_head"] = baseline_head_cfg()
+    return cfg
 
 
 def load_config(path):

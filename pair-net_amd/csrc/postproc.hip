@@ -94,6 +94,118 @@ extern "C" int pn_rel_dists_f32(const float* logits, float* out, int64_t rows, i
   return PN_LAUNCH_CHECK();
 }
 
+// ---- CrossHeadBaseline triplet ranking (baseline.py:1025-1046) -----------------
+// probs = softmax over all C logits; fg = probs without column 0 (the "no relation"
+// class), packed [rows][C-1] so the flat top-k index is row*(C-1) + (label-1).
+__global__ __launch_bounds__(256) void k_softmax_fg(const float* __restrict__ logits,
+                                                    float* __restrict__ probs,
+                                                    float* __restrict__ fg, int64_t rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* x = logits + row * C;
+  float v[4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = lane + 64 * j;
+    v[j] = (c < C) ? x[c] : -INFINITY;
+    mx = fmaxf(mx, v[j]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = (lane + 64 * j < C) ? expf(v[j] - mx) : 0.f;
+    sum += v[j];
+  }
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = lane + 64 * j;
+    if (c < C) {
+      const float pr = v[j] / sum;
+      probs[row * C + c] = pr;
+      if (c > 0) fg[row * (C - 1) + c - 1] = pr;
+    }
+  }
+}
+
+extern "C" int pn_softmax_fg_f32(const float* logits, float* probs, float* fg, int64_t rows,
+                                 int C, void* stream) {
+  if (!logits || !probs || !fg || rows <= 0 || C < 2 || C > 256) return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_softmax_fg, dim3(pn_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                     logits, probs, fg, rows, C);
+  return PN_LAUNCH_CHECK();
+}
+
+// First-index argmax of each row (torch.max(-1)[1] on the matching scores,
+// baseline.py:398-399).  One wave per row.
+__global__ __launch_bounds__(256) void k_row_argmax(const float* __restrict__ x,
+                                                    int64_t* __restrict__ idx, int64_t rows,
+                                                    int n) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* r = x + row * n;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < n; c += 64) {
+    const float v = r[c];
+    if (v > best || bi == 0x7fffffff) { best = v; bi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) {
+      best = ob; bi = oi;
+    }
+  }
+  if (lane == 0) idx[row] = bi;
+}
+
+extern "C" int pn_row_argmax_f32(const float* x, int64_t* idx, int64_t rows, int n,
+                                 void* stream) {
+  if (!x || !idx || rows <= 0 || n <= 0) return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_row_argmax, dim3(pn_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x,
+                     idx, rows, n);
+  return PN_LAUNCH_CHECK();
+}
+
+// Ranked triplets: tri[j] = relation query of the j-th best (query, predicate) pair,
+// rem[j] its predicate - 1.  labels = [s_label[tri]+1 | o_label[tri]+1],
+// r_labels = rem + 1, r_scores[j] = probs[tri[j]][rem[j]+1], r_dists[j] = probs[tri[j]]
+// (baseline.py:1035-1046).
+__global__ __launch_bounds__(256) void k_triplet_finish(
+    const int64_t* __restrict__ s_label, const int64_t* __restrict__ o_label,
+    const float* __restrict__ probs, const int64_t* __restrict__ tri,
+    const int64_t* __restrict__ rem, int64_t* __restrict__ labels,
+    int64_t* __restrict__ r_labels, float* __restrict__ r_scores, float* __restrict__ r_dists,
+    int k, int C) {
+  const int j = blockIdx.x;
+  const int64_t t = tri[j];
+  if (threadIdx.x == 0) {
+    labels[j] = s_label[t] + 1;
+    labels[k + j] = o_label[t] + 1;
+    r_labels[j] = rem[j] + 1;
+    r_scores[j] = probs[t * C + rem[j] + 1];
+  }
+  for (int c = threadIdx.x; c < C; c += 256) r_dists[(int64_t)j * C + c] = probs[t * C + c];
+}
+
+extern "C" int pn_triplet_finish(const int64_t* s_label, const int64_t* o_label,
+                                 const float* probs, const int64_t* tri, const int64_t* rem,
+                                 int64_t* labels, int64_t* r_labels, float* r_scores,
+                                 float* r_dists, int k, int C, void* stream) {
+  if (!s_label || !o_label || !probs || !tri || !rem || !labels || !r_labels || !r_scores ||
+      !r_dists || k <= 0 || C <= 0)
+    return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_triplet_finish, dim3(k), dim3(256), 0, (hipStream_t)stream, s_label,
+                     o_label, probs, tri, rem, labels, r_labels, r_scores, r_dists, k, C);
+  return PN_LAUNCH_CHECK();
+}
+
 // Panoptic id map.  softmax over the n kept masks is monotone, so the per-pixel
 // argmax is taken on the logits (first index on ties).  `area` must be zeroed by the
 // caller; integer atomics keep it deterministic.

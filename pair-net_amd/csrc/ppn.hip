@@ -89,13 +89,13 @@ __device__ __forceinline__ unsigned long long topk_key(float v, int idx) {
 __global__ __launch_bounds__(1024) void k_topk_pairs(const float* __restrict__ scores,
                                                      int64_t* __restrict__ idx_out,
                                                      int64_t* __restrict__ sub_out,
-                                                     int64_t* __restrict__ obj_out, int Q, int k) {
+                                                     int64_t* __restrict__ obj_out, int n, int Q,
+                                                     int k) {
   __shared__ int hist[256];
   __shared__ unsigned long long sel[256];
   __shared__ unsigned long long s_prefix;
   __shared__ int s_remaining, s_count;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = Q * Q;
   const float* sc = scores + (int64_t)blockIdx.x * n;
   if (tid == 0) { s_prefix = 0ull; s_remaining = k; s_count = 0; }
   if (tid < 256) sel[tid] = 0ull;
@@ -173,7 +173,19 @@ extern "C" int pn_topk_pairs(const float* scores, int64_t* idx, int64_t* sub, in
   if (!scores || !idx || !sub || !obj || B <= 0 || Q <= 0) return PN_BAD_ARG;
   if ((int64_t)Q * Q > 65536 || k <= 0 || k > 256 || k > Q * Q) return PN_BAD_ARG;
   hipLaunchKernelGGL(k_topk_pairs, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores, idx,
-                     sub, obj, Q, k);
+                     sub, obj, Q * Q, Q, k);
+  return PN_LAUNCH_CHECK();
+}
+
+// General form: the k largest of n scores per row, sorted descending (ties -> smaller
+// index); quot = idx / div, rem = idx % div.  (CrossHeadBaseline's triplet ranking,
+// pairnet/models/relation_heads/baseline.py:1033-1037: n = R * num_relations.)
+extern "C" int pn_topk_f32(const float* scores, int64_t* idx, int64_t* quot, int64_t* rem, int B,
+                           int n, int div, int k, void* stream) {
+  if (!scores || !idx || !quot || !rem || B <= 0 || n <= 0 || div <= 0) return PN_BAD_ARG;
+  if (n > 65536 || k <= 0 || k > 256 || k > n) return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_topk_pairs, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores, idx,
+                     quot, rem, n, div, k);
   return PN_LAUNCH_CHECK();
 }
 

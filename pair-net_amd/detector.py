@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .config import ConfigDict
+from .baseline_head import CrossHeadBaseline
 from .head import CrossHead2
 
 
@@ -118,10 +119,12 @@ class PSGTr:
             raise NotImplementedError("only the ResNet-50 backbone of pairnet.py is built")
         self.backbone = ResNet50()
         head_cfg = dict(bbox_head)
-        if head_cfg.pop("type", "CrossHead2") != "CrossHead2":
-            raise NotImplementedError("bbox_head.type must be CrossHead2")
-        self.bbox_head = CrossHead2(**head_cfg, train_cfg=None,
-                                    test_cfg=test_cfg or dict(max_per_img=100))
+        heads = dict(CrossHead2=CrossHead2, CrossHeadBaseline=CrossHeadBaseline)
+        head_type = head_cfg.pop("type", "CrossHead2")
+        if head_type not in heads:
+            raise NotImplementedError("bbox_head.type must be one of %s" % sorted(heads))
+        self.bbox_head = heads[head_type](**head_cfg, train_cfg=None,
+                                          test_cfg=test_cfg or dict(max_per_img=100))
         self.num_classes = self.bbox_head.num_classes
 
     def to(self, device):

@@ -47,6 +47,9 @@ def _decoder_param_shapes(prefix, num_layers, ffn_dim, out):
 class CrossHead2:
     """Drop-in for the reference's `CrossHead2` (inference half)."""
 
+    # operation order of the relation decoder's layers this head is built for
+    RELATION_ORDER = ("cross_attn", "norm", "self_attn", "norm", "ffn", "norm")
+
     def __init__(self, num_classes, in_channels, num_relations, num_obj_query=100,
                  num_rel_query=100, mapper="conv_tiny", use_mask=True, pixel_decoder=None,
                  transformer_decoder=None, feat_channels=256, out_channels=256,
@@ -75,6 +78,11 @@ class CrossHead2:
             raise NotImplementedError("8-head decoder without input projection only")
         if (enc_attn.num_heads, enc_attn.num_points, enc_attn.embed_dims) != (8, 4, 256):
             raise NotImplementedError("MSDeformAttn kernel: 8 heads, 4 points")
+        for dec, want in ((transformer_decoder, CrossHead2.RELATION_ORDER),
+                          (relation_decoder, self.RELATION_ORDER)):
+            got = tuple(dec.transformerlayers.get("operation_order", want))
+            if got != want:
+                raise NotImplementedError("operation_order %s (built for %s)" % (got, want))
         self.num_classes = num_classes
         self.num_relations = num_relations
         self.num_obj_query = self.num_queries = num_obj_query
@@ -276,15 +284,23 @@ class CrossHead2:
             w[p + "voa.bias"] = torch.cat([w[p + "value_proj.bias"],
                                            w[p + "sampling_offsets.bias"],
                                            w[p + "attention_weights.bias"]], 0).contiguous()
-        # self-attention: one [V | Q | K] projection (positional add feeds Q and K only);
-        # relation cross-attention keys/values: one [V | K] projection
+        self._pack_relation(w)
+        self.w = w
+
+    @staticmethod
+    def _pack_vqk(w, attn_prefix):
+        """Self-attention as one [V | Q | K] projection (the positional add feeds only
+        the Q and K columns)."""
+        W, b = w[attn_prefix + "in_proj_weight"], w[attn_prefix + "in_proj_bias"]
+        w[attn_prefix + "vqk.weight"] = torch.cat([W[512:], W[:512]], 0).contiguous()
+        w[attn_prefix + "vqk.bias"] = torch.cat([b[512:], b[:512]], 0).contiguous()
+
+    def _pack_relation(self, w):
         for dec, n in (("transformer_decoder", self.num_dec_layers),
                        ("relation_decoder", self.num_rel_layers)):
             for i in range(n):
-                a = "%s.layers.%d.attentions.1.attn." % (dec, i)
-                W, b = w[a + "in_proj_weight"], w[a + "in_proj_bias"]
-                w[a + "vqk.weight"] = torch.cat([W[512:], W[:512]], 0).contiguous()
-                w[a + "vqk.bias"] = torch.cat([b[512:], b[:512]], 0).contiguous()
+                self._pack_vqk(w, "%s.layers.%d.attentions.1.attn." % (dec, i))
+        # relation cross-attention keys/values: one [V | K] projection
         for i in range(self.num_rel_layers):
             a = "relation_decoder.layers.%d.attentions.0.attn." % i
             W, b = w[a + "in_proj_weight"], w[a + "in_proj_bias"]
@@ -294,13 +310,12 @@ class CrossHead2:
         w[ml + "0.0.weight"] = w[ml + "0.0.weight"].reshape(64, 49).contiguous()
         w[ml + "1.0.weight"] = w[ml + "1.0.weight"].permute(0, 2, 3, 1).reshape(64, -1).contiguous()
         w[ml + "2.0.weight"] = w[ml + "2.0.weight"].reshape(64, 49).t().contiguous()
-        self.w = w
 
     class _Plan:
         pass
 
     def _plan(self, B, shapes, hw2, slot=0):
-        key = (B, tuple(shapes), tuple(hw2), slot)
+        key = (B, tuple(shapes), tuple(hw2), slot, getattr(self, "return_all_layers", False))
         if key in self._plans:
             return self._plans[key]
         if self.w is None:
@@ -353,10 +368,18 @@ class CrossHead2:
         pl.ML = E(BQ, max(pl.N))
         pl.bits = torch.empty(BQ * ((max(pl.N) + 31) // 32), device=dev, dtype=torch.int32)
         pl.rowall = torch.empty(BQ, device=dev, dtype=torch.int32)
+        pl.cls = E(B, Q, self.num_classes + 1)
+        self._plan_relation(pl, E)
+        self._plans[key] = pl
+        return pl
+
+    def _plan_relation(self, pl, E):
+        """Buffers of the Pair Proposal Network and the Relation Fusion decoder."""
+        B, Q, R, dev = pl.B, self.num_obj_query, self.num_rel_query, self.device
+        BQ, HW2 = B * Q, pl.HW2
         scr = max(hip.attn_scratch_floats(B, Q, n) for n in pl.N + [Q])
         scr = max(scr, hip.attn_scratch_floats(B, R, 2 * R), hip.attn_scratch_floats(B, R, R))
         pl.scr = E(scr)
-        pl.cls = E(B, Q, self.num_classes + 1)
         # ---- PPN ----
         pl.s1, pl.s2, pl.sn, pl.on = E(BQ, 256), E(BQ, 256), E(BQ, 256), E(BQ, 256)
         pl.imp_raw, pl.imp = E(B, Q, Q), E(B, Q, Q)
@@ -375,8 +398,6 @@ class CrossHead2:
         pl.rel = E(B, R, self.num_relations)
         pl.sub_cls, pl.obj_cls = E(B, R, self.num_classes + 1), E(B, R, self.num_classes + 1)
         pl.sub_seg, pl.obj_seg = E(B, R, HW2), E(B, R, HW2)
-        self._plans[key] = pl
-        return pl
 
     # ----------------------------------------------------------- sub-graphs
     def _pixel_decoder(self, feats, pl):
@@ -433,23 +454,26 @@ class CrossHead2:
                 hip.bilinear_nhwc(pl.MF, pl.MFd[l], B, H2, W2, h, wd, 256, False, HW2 * 256,
                                   pl.N[l] * 256)
 
-    def _head_embed(self, q, pl, with_cls, full_mask):
+    def _head_embed(self, q, pl, with_cls, full_mask, cls_out=None, mp_out=None):
         """post_norm -> (cls_embed) -> mask_embed MLP -> pl.me; with `full_mask` also the
-        mask logits pl.MP [B,Q,H2*W2] (pairnet_head.py:236-243)."""
+        mask logits [B,Q,H2*W2] (pairnet_head.py:236-243).  Outputs go to pl.cls / pl.MP
+        unless other destinations are given."""
         w, B, Q = self.w, pl.B, self.num_obj_query
+        cls_out = pl.cls if cls_out is None else cls_out
+        mp_out = pl.MP if mp_out is None else mp_out
         hip.layernorm(q, w["transformer_decoder.post_norm.weight"],
                       w["transformer_decoder.post_norm.bias"], pl.qn)
         if with_cls:
-            hip.linear(pl.qn, w["cls_embed.weight"], w["cls_embed.bias"], pl.cls.view(B * Q, -1))
+            hip.linear(pl.qn, w["cls_embed.weight"], w["cls_embed.bias"], cls_out.view(B * Q, -1))
         hip.linear(pl.qn, w["mask_embed.0.weight"], w["mask_embed.0.bias"], pl.m1, relu=True)
         hip.linear(pl.m1, w["mask_embed.2.weight"], w["mask_embed.2.bias"], pl.m2, relu=True)
         hip.linear(pl.m2, w["mask_embed.4.weight"], w["mask_embed.4.bias"], pl.me)
         if full_mask:
-            hip.gemm(pl.me, pl.MF, pl.MP, M=Q, N=pl.HW2, K=256, lda=256, ldw=256, ldc=pl.HW2,
+            hip.gemm(pl.me, pl.MF, mp_out, M=Q, N=pl.HW2, K=256, lda=256, ldw=256, ldc=pl.HW2,
                      batch=B, sA=Q * 256, sW=pl.HW2 * 256, sC=Q * pl.HW2,
                      split=self.gemm_mode == "bf16x3")
 
-    def _attn_mask(self, pl, lvl):
+    def _attn_mask(self, pl, lvl, mp=None):
         """Boolean attention mask of level `lvl` + all-masked fix (pairnet_head.py:244-256,
         :300) -> pl.bits / pl.rowall.
 
@@ -462,28 +486,46 @@ class CrossHead2:
         h, wd = pl.shapes[lvl]
         n = h * wd
         if self.exact_mask_order:
-            hip.bilinear_planar(pl.MP, pl.ML, B * Q, pl.hw2[0], pl.hw2[1], h, wd)
+            hip.bilinear_planar(pl.MP if mp is None else mp, pl.ML, B * Q, pl.hw2[0], pl.hw2[1],
+                                h, wd)
         else:
             hip.gemm(pl.me, pl.MFd[lvl], pl.ML, M=Q, N=n, K=256, lda=256, ldw=256, ldc=n,
                      batch=B, sA=Q * 256, sW=n * 256, sC=Q * n)
         hip.mask_pack(pl.ML, pl.bits, pl.rowall, B * Q, n)
 
     def _layer(self, pre, x, xpos, x1, x2, y, Qp, VQK, att, hbuf, Kp, ldk, Vp, ldv, Nk, B, nq,
-               bits, rowall, scr, ffn):
-        """One post-norm (cross_attn, norm, self_attn, norm, ffn, norm) layer
-        (facebook_detr.py:378-432 semantics); x is updated in place."""
+               bits, rowall, scr, ffn, self_first=False):
+        """One post-norm decoder layer (facebook_detr.py:378-432 semantics); x is updated
+        in place.  Operation order (cross_attn, norm, self_attn, norm, ffn, norm), or with
+        `self_first` (self_attn, norm, cross_attn, norm, ffn, norm); attentions.<j> is the
+        j-th attention in that order, as mmcv's BaseTransformerLayer numbers them."""
         w = self.w
         scale = 1.0 / math.sqrt(32.0)
-        a0, a1 = pre + "attentions.0.attn.", pre + "attentions.1.attn."
-        hip.linear(x, w[a0 + "in_proj_weight"][:256], w[a0 + "in_proj_bias"][:256], Qp, aadd=xpos)
-        hip.attention(Qp, 256, Kp, ldk, Vp, ldv, bits, rowall, att, 256, scr, B, nq, Nk, scale)
-        hip.linear(att, w[a0 + "out_proj.weight"], w[a0 + "out_proj.bias"], y, res=x)
-        hip.layernorm(y, w[pre + "norms.0.weight"], w[pre + "norms.0.bias"], x1)
-        hip.linear(x1, w[a1 + "vqk.weight"], w[a1 + "vqk.bias"], VQK, aadd=xpos, aadd_from_col=256)
-        hip.attention(VQK[:, 256:], 768, VQK[:, 512:], 768, VQK, 768, None, None, att, 256, scr,
-                      B, nq, nq, scale)
-        hip.linear(att, w[a1 + "out_proj.weight"], w[a1 + "out_proj.bias"], y, res=x1)
-        hip.layernorm(y, w[pre + "norms.1.weight"], w[pre + "norms.1.bias"], x2)
+        ac = pre + "attentions.%d.attn." % (1 if self_first else 0)
+        as_ = pre + "attentions.%d.attn." % (0 if self_first else 1)
+        nc, ns = ("norms.1.", "norms.0.") if self_first else ("norms.0.", "norms.1.")
+
+        def cross(src, dst):
+            hip.linear(src, w[ac + "in_proj_weight"][:256], w[ac + "in_proj_bias"][:256], Qp,
+                       aadd=xpos)
+            hip.attention(Qp, 256, Kp, ldk, Vp, ldv, bits, rowall, att, 256, scr, B, nq, Nk, scale)
+            hip.linear(att, w[ac + "out_proj.weight"], w[ac + "out_proj.bias"], y, res=src)
+            hip.layernorm(y, w[pre + nc + "weight"], w[pre + nc + "bias"], dst)
+
+        def self_attn(src, dst):
+            hip.linear(src, w[as_ + "vqk.weight"], w[as_ + "vqk.bias"], VQK, aadd=xpos,
+                       aadd_from_col=256)
+            hip.attention(VQK[:, 256:], 768, VQK[:, 512:], 768, VQK, 768, None, None, att, 256,
+                          scr, B, nq, nq, scale)
+            hip.linear(att, w[as_ + "out_proj.weight"], w[as_ + "out_proj.bias"], y, res=src)
+            hip.layernorm(y, w[pre + ns + "weight"], w[pre + ns + "bias"], dst)
+
+        if self_first:
+            self_attn(x, x1)
+            cross(x1, x2)
+        else:
+            cross(x, x1)
+            self_attn(x1, x2)
         hip.ffn_ln(x2, w[pre + "ffns.0.layers.0.0.weight"], w[pre + "ffns.0.layers.0.0.bias"],
                    w[pre + "ffns.0.layers.1.weight"], w[pre + "ffns.0.layers.1.bias"],
                    w[pre + "norms.2.weight"], w[pre + "norms.2.bias"], x, hbuf, B * nq, ffn)
@@ -493,43 +535,65 @@ class CrossHead2:
     # mask-feature resampling, the K/V projections of all nine decoder layers): a few
     # dozen large, chip-filling launches.
     def _stage_a(self, feats, pl):
-        w, B = self.w, pl.B
         self._pixel_decoder(feats, pl)
         # K / V projections of all decoder layers up front (query-independent), as grouped
         # launches: 18 problems whose tile counts (9/33/131 x 2 per image) would each
         # leave most of the 256 CUs idle on their own
-        probs = []
-        for i in range(self.num_dec_layers):
-            l = i % 3
-            a = "transformer_decoder.layers.%d.attentions.0.attn." % i
-            mem = pl.X[:, pl.start[l]:]
-            common = dict(A=mem, M=pl.N[l], N=256, K=256, lda=256, ldw=256, ldc=256, batch=B,
-                          sA=pl.SN * 256, sC=pl.N[l] * 256, ldaadd=256)
-            probs.append(dict(W=w[a + "in_proj_weight"][256:512], C=pl.Kp[i],
-                              bias=w[a + "in_proj_bias"][256:512], aadd=pl.dec_kpos[l],
-                              aadd_rows=pl.N[l], **common))
-            probs.append(dict(W=w[a + "in_proj_weight"][512:], C=pl.Vp[i],
-                              bias=w[a + "in_proj_bias"][512:],
-                              aadd=w["level_embed.weight"][l:l + 1], aadd_rows=1, **common))
+        probs = self._kv_problems(pl)
         for j in range(0, len(probs), 16):
             hip.gemm_group(probs[j:j + 16])
+
+    def _memory_kv(self, pl, attn_prefix, l, Kp, Vp):
+        """The two GEMM problems K = (mem_l + level_embed_l + pe_l) Wk^T + bk and
+        V = (mem_l + level_embed_l) Wv^T + bv of one cross-attention over level l."""
+        w, B = self.w, pl.B
+        mem = pl.X[:, pl.start[l]:]
+        common = dict(A=mem, M=pl.N[l], N=256, K=256, lda=256, ldw=256, ldc=256, batch=B,
+                      sA=pl.SN * 256, sC=pl.N[l] * 256, ldaadd=256)
+        return [dict(W=w[attn_prefix + "in_proj_weight"][256:512], C=Kp,
+                     bias=w[attn_prefix + "in_proj_bias"][256:512], aadd=pl.dec_kpos[l],
+                     aadd_rows=pl.N[l], **common),
+                dict(W=w[attn_prefix + "in_proj_weight"][512:], C=Vp,
+                     bias=w[attn_prefix + "in_proj_bias"][512:],
+                     aadd=w["level_embed.weight"][l:l + 1], aadd_rows=1, **common)]
+
+    def _kv_problems(self, pl):
+        probs = []
+        for i in range(self.num_dec_layers):
+            probs += self._memory_kv(pl, "transformer_decoder.layers.%d.attentions.0.attn." % i,
+                                     i % 3, pl.Kp[i], pl.Vp[i])
+        return probs
 
     # Stage B: the sequential query chain (9 masked decoder layers, PPN, top-k, 6 relation
     # layers, output gathers): ~200 small latency-bound launches.
     def _stage_b(self, pl):
-        w, B, Q, R = self.w, pl.B, self.num_obj_query, self.num_rel_query
+        self._object_decoder(pl)
+        self._relation_stage(pl)
+
+    def _object_decoder(self, pl, all_layers=False):
+        """The 9 masked-attention layers (pairnet_head.py:289-320) -> pl.q, pl.cls, pl.MP;
+        with `all_layers` every layer's class / mask logits go to pl.cls_all / pl.MP_all."""
+        w, B, Q = self.w, pl.B, self.num_obj_query
         pl.q.view(B, Q, 256).copy_(w["query_feat.weight"].unsqueeze(0).expand(B, Q, 256))
         qpos = w["query_embed.weight"]
         exact = self.exact_mask_order
         self._head_embed(pl.q, pl, False, exact)
         last = self.num_dec_layers - 1
+        mp = None
         for i in range(self.num_dec_layers):
             l = i % 3
-            self._attn_mask(pl, l)
+            self._attn_mask(pl, l, mp)
             self._layer("transformer_decoder.layers.%d." % i, pl.q, qpos, pl.q1, pl.q2, pl.qy,
                         pl.Qp, pl.VQK, pl.att, pl.hq, pl.Kp[i], 256, pl.Vp[i], 256, pl.N[l], B,
                         Q, pl.bits, pl.rowall, pl.scr, self.dec_ffn)
-            self._head_embed(pl.q, pl, i == last, exact or i == last)
+            if all_layers:
+                mp = pl.MP_all[i]
+                self._head_embed(pl.q, pl, True, True, pl.cls_all[i], mp)
+            else:
+                self._head_embed(pl.q, pl, i == last, exact or i == last)
+
+    def _relation_stage(self, pl):
+        w, B, Q, R = self.w, pl.B, self.num_obj_query, self.num_rel_query
         # ---- Pair Proposal Network (pairnet_head.py:322-340) ----
         for mlp, dst in (("sub_query_update", pl.sn), ("obj_query_update", pl.on)):
             hip.linear(pl.q, w[mlp + ".0.weight"], w[mlp + ".0.bias"], pl.s1, relu=True)

@@ -54,9 +54,13 @@ _SIGS = {
     "pn_mlearner_first_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_mlearner_last_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_topk_pairs": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "pn_topk_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_gather_rows_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     "pn_cls_argmax_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "pn_rel_dists_f32": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "pn_softmax_fg_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "pn_row_argmax_f32": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "pn_triplet_finish": (C.c_int, [_vp] * 9 + [_i32, _i32, _vp]),
     "pn_panoptic_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp]),
     "pn_panoptic_state_bytes": (_i64, []),
     "pn_panoptic_device_f32": (C.c_int, [_vp, _vp, _vp] + [_i32] * 6 + [_vp, _vp, _vp, _vp,
@@ -65,6 +69,7 @@ _SIGS = {
     "pn_mask_iou_counts": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGS)
+ABI_VERSION = 4   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -81,7 +86,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.pn_abi_version() != 3:
+        if handle.pn_abi_version() != ABI_VERSION:
             raise RuntimeError("libpairnet_hip.so ABI mismatch; rebuild")
         _lib = handle
     return _lib
@@ -333,6 +338,11 @@ def topk_pairs(scores, idx, sub, obj, B, Q, k):
                                _ptr(obj, torch.int64), B, Q, k, _stream()), "pn_topk_pairs")
 
 
+def topk(scores, idx, quot, rem, B, n, div, k):
+    _check(lib().pn_topk_f32(_ptr(scores), _ptr(idx, torch.int64), _ptr(quot, torch.int64),
+                             _ptr(rem, torch.int64), B, n, div, k, _stream()), "pn_topk_f32")
+
+
 def gather_rows(x, index, out, B, rows_in, rows_out, length):
     _check(lib().pn_gather_rows_f32(_ptr(x), _ptr(index, torch.int64), _ptr(out), B, rows_in,
                                     rows_out, length, _stream()), "pn_gather_rows_f32")
@@ -346,6 +356,26 @@ def cls_argmax(logits, label, score, rows, Cc):
 def rel_dists(logits, out, rows, Cc):
     _check(lib().pn_rel_dists_f32(_ptr(logits), _ptr(out), rows, Cc, _stream()),
            "pn_rel_dists_f32")
+
+
+def softmax_fg(logits, probs, fg, rows, Cc):
+    _check(lib().pn_softmax_fg_f32(_ptr(logits), _ptr(probs), _ptr(fg), rows, Cc, _stream()),
+           "pn_softmax_fg_f32")
+
+
+def row_argmax(x, idx, rows, n):
+    _check(lib().pn_row_argmax_f32(_ptr(x), _ptr(idx, torch.int64), rows, n, _stream()),
+           "pn_row_argmax_f32")
+
+
+def triplet_finish(s_label, o_label, probs, tri, rem, labels, r_labels, r_scores, r_dists, k,
+                   Cc):
+    i64 = torch.int64
+    _check(lib().pn_triplet_finish(_ptr(s_label, i64), _ptr(o_label, i64), _ptr(probs),
+                                   _ptr(tri, i64), _ptr(rem, i64), _ptr(labels, i64),
+                                   _ptr(r_labels, i64), _ptr(r_scores), _ptr(r_dists), k, Cc,
+                                   _stream()),
+           "pn_triplet_finish")
 
 
 def panoptic(masks, labels, remap, seg, area, n, HW):

@@ -121,3 +121,59 @@ def test_matrix_learner_equals_reference_module():
     x = torch.randn(3, 37, 37)
     with torch.no_grad():
         assert torch.equal(ref(x), net(x))
+
+
+# ---- sibling head CrossHeadBaseline (relation_heads/baseline.py) -----------------
+RES_NAMES = ("bboxes", "labels", "rel_pairs", "masks", "pan_img", "r_scores", "r_labels",
+             "r_dists")
+
+
+def test_baseline_small_matches_golden():
+    from helpers import oracle_baseline_head
+    fx = golden("baseline_small")
+    head, sd, crc = oracle_baseline_head(int(fx["weight_seed"]), overrides_of(fx))
+    assert crc == int(fx["weight_crc"])
+    H, W, bs = int(fx["height"]), int(fx["width"]), int(fx["batch"])
+    feats = seeded.seeded_feats(int(fx["feat_seed"]), bs, H, W)
+    assert seeded.checksum(feats) == int(fx["feat_crc"])
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[2.0, 2.0, 2.0, 2.0])] * bs
+    cls, masks = head.forward(feats, metas)
+    for k, v in cls.items():
+        assert np.array_equal(v.numpy(), fx["cls_" + k]), k
+    m = masks["mask"]
+    assert np.array_equal(m[-1].numpy(), fx["mask_last"])
+    assert np.array_equal(m.flatten(1)[:, torch.from_numpy(fx["mask_probe_idx"])].numpy(),
+                          fx["mask_probe"])
+    res = head.get_bboxes(cls, masks, metas)
+    for i, r in enumerate(res):
+        for name, v in zip(RES_NAMES, r):
+            if name == "bboxes":
+                continue
+            got = np.packbits(v.numpy()) if name == "masks" else v.numpy()
+            assert np.array_equal(got, fx["res%d_%s" % (i, name)]), (i, name)
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+def test_baseline_oracle_equals_shimmed_reference():
+    """The restatement of CrossHeadBaseline and the reference's own class agree bit for
+    bit (forward and get_bboxes; det_bboxes are torch.rand dummies in the reference)."""
+    from helpers import oracle_baseline_head
+    ref = ref_shim.build_reference_baseline_head()
+    head, sd, _ = oracle_baseline_head(5)
+    ref.load_state_dict(sd, strict=True)
+    H, W = 64, 96
+    feats = seeded.seeded_feats(8, 2, H, W)
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[1.5, 1.5, 1.5, 1.5])] * 2
+    with torch.no_grad():
+        a, b = ref.forward(feats, metas), head.forward(feats, metas)
+        for da, db in zip(a, b):
+            assert set(da) == set(db)
+            for k in da:
+                assert torch.equal(da[k], db[k]), k
+        ra, rb = ref.get_bboxes(*a, metas), head.get_bboxes(*b, metas)
+    for ta, tb in zip(ra, rb):
+        for name, x, y in zip(RES_NAMES, ta, tb):
+            if name == "bboxes":
+                assert x.shape == y.shape
+            else:
+                assert x.dtype == y.dtype and torch.equal(x, y), name

@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default="f32",
                     help="f32: exact-fp32 MFMA everywhere (headline); bf16x3: fp32-accurate "
                          "3 x bf16 operand split for the large GEMMs / 3x3 conv")
+    ap.add_argument("--head", choices=["pairnet", "baseline"], default="pairnet",
+                    help="pairnet = CrossHead2 (the headline); baseline = the sibling head "
+                         "CrossHeadBaseline on the same trunk (not the headline metric)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two stages of consecutive batches back to back on one stream")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight in the pipeline")
@@ -81,12 +84,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from pairnet_amd import CrossHead2, PipelinedHead, hip, pairnet_head_cfg
+    from pairnet_amd import (CrossHead2, CrossHeadBaseline, PipelinedHead, baseline_head_cfg, hip,
+                             pairnet_head_cfg)
     from pairnet_amd.dist import all_gather_triplets, pack_triplets
 
-    cfg = pairnet_head_cfg()
+    sibling = args.head == "baseline"
+    cfg = baseline_head_cfg() if sibling else pairnet_head_cfg()
     cfg.pop("type")
-    head = CrossHead2(**cfg)
+    head = (CrossHeadBaseline if sibling else CrossHead2)(**cfg)
+    pair_ids = (lambda pl: (pl.sub_ids, pl.obj_ids)) if sibling else \
+        (lambda pl: (pl.sub_pos, pl.obj_pos))
     head.init_weights(seed=0)
     head.to(dev)
     head.gemm_mode = args.gemm
@@ -116,16 +123,14 @@ def main():
         else:
             res = engine.submit(feats, metas)
         if res is not None:
-            pl = head._last_plan
-            gather(res, pl.sub_pos, pl.obj_pos)
+            gather(res, *pair_ids(head._last_plan))
         return res
 
     def drain():
         if engine is not None:
             while engine.queue:
                 res = engine._finish(engine.queue.pop(0))
-                pl = head._last_plan
-                gather(res, pl.sub_pos, pl.obj_pos)
+                gather(res, *pair_ids(head._last_plan))
 
     # ---- warm-up ----
     for _ in range(args.warmup):
@@ -184,12 +189,16 @@ def main():
                                                       "MFMA for the large GEMMs, fp32 accumulate)",
             "data": "synthetic",
             "config": {
-                "workload": "Pair-Net R50 + Mask2Former head hot path (CrossHead2."
-                            "simple_test_bboxes: pixel decoder -> 9-layer masked decoder -> "
-                            "PPN/Matrix Learner/top-k -> 6-layer relation decoder -> "
-                            "get_bboxes), 100 object / 100 relation queries, bs=%d per GPU, "
-                            "%dx%d, R50 feature pyramid resident in HBM, default-init weights"
-                            % (B, H, W),
+                "workload": ("SIBLING HEAD (not the headline): CrossHeadBaseline."
+                             "simple_test_bboxes: pixel decoder -> 9-layer masked decoder -> "
+                             "6-layer relation decoder over the pixel memories -> argmax "
+                             "matching -> get_bboxes" if sibling else
+                             "Pair-Net R50 + Mask2Former head hot path (CrossHead2."
+                             "simple_test_bboxes: pixel decoder -> 9-layer masked decoder -> "
+                             "PPN/Matrix Learner/top-k -> 6-layer relation decoder -> "
+                             "get_bboxes") + ", 100 object / 100 relation queries, bs=%d per "
+                            "GPU, %dx%d, R50 feature pyramid resident in HBM, default-init "
+                            "weights" % (B, H, W),
                 "global_batch": world * B, "per_gpu_batch": B, "image": [H, W],
                 "parallelism": "dp%d" % world,
                 "schedule": ("eager" if args.no_graphs else "hipGraph replay per stage") + (
@@ -276,9 +285,10 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.head import OracleCrossHead2
+        from oracle.baseline_head import OracleCrossHeadBaseline
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") \
             else (os.cpu_count() or 1)
-        oracle = OracleCrossHead2(**cfg).eval()
+        oracle = (OracleCrossHeadBaseline if sibling else OracleCrossHead2)(**cfg).eval()
         oracle.load_state_dict(head.state_dict())
         # torch's CPU kernels stop scaling (and then collapse) long before 256 threads on
         # these shapes: pick the thread count by timing the Matrix Learner + one decoder
@@ -293,7 +303,8 @@ def main():
                 oracle.pixel_decoder.encoder.layers[0].ffns[0](torch.randn(4096, 1, 256))
                 t = time.perf_counter()
                 oracle.pixel_decoder.encoder.layers[0].ffns[0](torch.randn(21950, 1, 256))
-                oracle.update_importance(torch.randn(B, 100, 100))
+                if not sibling:
+                    oracle.update_importance(torch.randn(B, 100, 100))
                 oracle.sub_query_update(probe_q)
                 dt = time.perf_counter() - t
             if best is None or dt < best:
@@ -310,7 +321,7 @@ def main():
         out["cpu_baseline"] = {
             "value": B / cpu_s, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": "%d timed + 1 warm-up pass of the same batch (%d image(s), same weights) "
-                      "through oracle/head.py simple_test_bboxes, torch CPU fp32, %d threads "
+                      "through the oracle's simple_test_bboxes, torch CPU fp32, %d threads "
                       "(best of a 8..128 thread probe; host exposes %d)"
                       % (n, B, torch.get_num_threads(), avail)}
 

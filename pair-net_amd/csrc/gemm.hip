@@ -1,10 +1,12 @@
 // fp32 contractions on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
 // bitwise an fmaf chain).  Two kernels behind pn_gemm_f32 / pn_conv2d_nhwc_f32:
 //
-//   k_gemm_tile   LDS-tiled BMxBNx32, 4 waves, register-prefetched double-buffered
-//                 LDS.  A rows come from a row-major matrix, a column-major matrix
-//                 (an NCHW feature map read as [K][M]) or an on-the-fly im2col of
-//                 a channel-last image (implicit-GEMM convolution).
+//   k_gemm_tile   persistent workgroups (4 waves) walking BMxBN output tiles, 32-deep
+//                 k-chunks staged global -> registers -> one LDS stage, MFMA operand
+//                 fragments double-buffered in registers.  A rows come from a
+//                 row-major matrix, a column-major matrix (an NCHW feature map read as
+//                 [K][M]) or an on-the-fly im2col of a channel-last image
+//                 (implicit-GEMM convolution).
 //   k_gemm_skinny 32x32 output tile per workgroup, the 4 waves split K and reduce
 //                 through LDS; operands go global->VGPR directly.  For the M~100
 //                 query-side GEMMs of the decoders, where a 128-row tile would
@@ -18,234 +20,386 @@
 #include "common.h"
 #include "gemm_common.h"
 
-template <int BM, int BN, int WM, int WN, int AMODE, bool DB = true>
-__device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int m0, const int n0,
-                                               const int bz, float* smem) {
+// 16-byte load through a buffer descriptor: address = rsrc.base + voff (per lane, bytes)
+// + soff (wave-uniform SGPR, bytes).  The k advance of the GEMM loops rides in soff, so
+// the loop issues NO per-lane address arithmetic (flat loads need a 64-bit VALU add per
+// load, and VALU issued between MFMAs on one accumulator costs ~43 cycles a piece).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
+  // raw buffer, no bounds clamp (callers keep offsets inside the operand)
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes,
+                                         int soff_bytes) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff_bytes, soff_bytes, 0));
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes,
+                                          int soff_bytes) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, soff_bytes, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                     __uint_as_float(v.w));
+}
+
+struct TileRef {
+  int pi;  // problem index (grouped launches), resolved through Locator::P
+  int bz, tm, tn;
+};
+
+// Persistent tile loop.  A workgroup walks a strided subsequence of its XCD's contiguous
+// tile range (xcd_tile_index's partition: neighbouring tiles share operand panels in that
+// XCD's L2).  Per 32-deep k-chunk: barrier, registers -> LDS, barrier, global loads of
+// the NEXT chunk into registers, 16*TM*TN MFMAs fed by register-double-buffered
+// ds_read_b128 fragments.  The next chunk after a tile's last one is the first chunk of
+// the workgroup's next tile, so there is no per-tile load prologue, and the epilogue's
+// stores drain under the next tile's MFMAs.  (Measured on MI355X with
+// tools/gemm_probe.hip: 83-96 -> 99-112 TFLOP/s on the encoder shapes versus one
+// workgroup per tile; the matrix pipe alone peaks at ~140.)
+template <int BM, int BN, int WM, int WN, int AMODE, bool ADD, typename Locator>
+__device__ __forceinline__ void gemm_persistent(const Locator& loc, const int ntiles,
+                                                float* smem) {
   constexpr int BK = 32, LD = BK + 4;
   constexpr int WAVES_N = BN / WN;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int LDK = BM + 4;  // k-major A tile stride (A_COL)
   constexpr int A_ELEMS = (AMODE == A_COL) ? BK * LDK : BM * LD;
-  constexpr int B_ELEMS = BN * LD;
-  constexpr int STAGE = A_ELEMS + B_ELEMS;
   constexpr int NA = (BM * BK / 4) / 256;
   constexpr int NB = (BN * BK / 4) / 256;
   constexpr int QM = BM / 4;         // float4 per k-row of a column-major A tile
   constexpr int KSTEP = 256 / QM;    // k rows covered per pass
   static_assert((BM / WM) * WAVES_N == 4, "4 waves");
 
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int base = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int cnt = q8 + (xcd < r8 ? 1 : 0);
+  if (slot >= cnt) return;
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const float* __restrict__ Aadd = (p.Aadd && n0 >= p.aadd_from_col) ? p.Aadd : nullptr;
-  const float* __restrict__ A = p.A + (int64_t)bz * p.sA;
-  const float* __restrict__ W = p.W + (int64_t)bz * p.sW;
+  const int kc = (tid & 7) * 4;  // row-major / conv: k offset inside the chunk
+  float* const sA = smem;
+  float* const sB = smem + A_ELEMS;
 
-  // ---- per-thread loader state (row indices do not change over k) ----
-  const float* a_row[NA];
-  const float* add_row[NA];
+  // ---- loader state: describes the tile whose chunks are being LOADED ----
+  // Addresses are (buffer descriptor on the per-batch operand base) + (per-lane 32-bit
+  // byte offset, fixed per tile) + (wave-uniform k offset): the K loop carries no
+  // per-lane address arithmetic.  pn_fill_params guarantees that every per-batch
+  // operand spans < 2^29 elements.
+  // Every load is UNCONDITIONAL (hipcc serialises predicated loads: a branch and a full
+  // vmcnt wait per element): out-of-range rows are clamped to the last valid row (their
+  // products land in output rows / columns that are never stored); a ragged K tail and
+  // the conv halo read a clamped address and are zeroed when the chunk goes to LDS.
+  int lpi = 0, lK = 0;
+  const float* bA = nullptr;      // batch base of A
+  const float* bW = nullptr;
+  const float* bAdd = nullptr;
+  __amdgpu_buffer_rsrc_t rA = make_rsrc(nullptr), rW = rA, rAdd = rA;
+  unsigned a_off[NA], add_off[ADD ? NA : 1], w_off[NB];   // BYTE offsets (A_COL: element m)
   int cy[NA], cx[NA];
-  bool a_ok[NA];
-  const int kc = (tid & 7) * 4;  // row-major / conv: k offset inside the tile
-#pragma unroll
-  for (int j = 0; j < NA; ++j) {
-    a_row[j] = nullptr; add_row[j] = nullptr; cy[j] = cx[j] = 0; a_ok[j] = false;
-    if (AMODE != A_COL) {
-      const int gm = m0 + (tid >> 3) + 32 * j;
-      a_ok[j] = gm < p.M;
-      if (AMODE == A_ROW) {
-        a_row[j] = A + (int64_t)(a_ok[j] ? gm : 0) * p.lda;
-        if (Aadd) add_row[j] = Aadd + (int64_t)((a_ok[j] ? gm : 0) % p.aadd_rows) * p.ldaadd;
-      } else {
-        cy[j] = gm / p.Wd;
-        cx[j] = gm - cy[j] * p.Wd;
-      }
-    }
-  }
-  const float* w_row[NB];
-  bool w_ok[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int gn = n0 + (tid >> 3) + 32 * j;
-    w_ok[j] = gn < p.N;
-    w_row[j] = W + (int64_t)(w_ok[j] ? gn : 0) * p.ldw;
-  }
-
-  float4 ra[NA], rb[NB];
-  auto load_tile = [&](int kt) {
-    const int k0 = kt * BK;
-    if (AMODE == A_ROW) {
+  unsigned a_tap[AMODE == A_CONV ? NA : 1];   // conv: a_off shifted to the current tap
+  unsigned a_off1[AMODE == A_COL ? NA : 1][4];  // column-major, unaligned rows: per element
+  unsigned in_mask = 0;  // conv: bit j = the current tap of row j lies inside the image
+  bool l_add = false;   // the positional add feeds this tile's columns
+  bool l_vec = false;   // column-major A: whole tile inside M and 16-byte aligned rows
+  auto set_tile = [&](const TileRef& tr) {
+    const GemmP& p = loc.P(tr.pi);
+    lpi = tr.pi;
+    lK = p.K;
+    const int m0 = tr.tm * BM, n0 = tr.tn * BN;
+    bA = p.A + (int64_t)tr.bz * p.sA;
+    bW = p.W + (int64_t)tr.bz * p.sW;
+    bAdd = p.Aadd ? p.Aadd : bA;   // (without an addend it only has to be readable)
+    rA = make_rsrc(bA);
+    rW = make_rsrc(bW);
+    if (ADD) rAdd = make_rsrc(bAdd);
+    l_add = p.Aadd && n0 >= p.aadd_from_col;
+    l_vec = p.a_vec && m0 + BM <= p.M;
+    if (AMODE == A_COL) {
+      // lane covers 4 consecutive m of k-row (tid / QM + KSTEP * j) of the chunk
+      const int mq = m0 + (tid % QM) * 4;
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a_ok[j] && k0 + kc < p.K) {
-          v = ld4(a_row[j] + k0 + kc);
-          if (Aadd) v = add4(v, ld4(add_row[j] + k0 + kc));
-        }
-        ra[j] = v;
-      }
-    } else if (AMODE == A_CONV) {
-      const int tap = k0 / p.Cin;
-      const int ci = k0 - tap * p.Cin + kc;
-      const int dy = tap / p.KW - p.pad, dx = tap % p.KW - p.pad;
+        const unsigned krow = (unsigned)(min(tid / QM + KSTEP * j, p.K - 1)) * (unsigned)p.lda;
+        a_off[j] = (krow + (unsigned)min(mq, p.M - 1)) * 4u;
 #pragma unroll
-      for (int j = 0; j < NA; ++j) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int yy = cy[j] + dy, xx = cx[j] + dx;
-        if (a_ok[j] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd && k0 + kc < p.K)
-          v = ld4(A + ((int64_t)yy * p.Wd + xx) * p.Cin + ci);
-        ra[j] = v;
+        for (int e = 0; e < 4; ++e) a_off1[j][e] = (krow + (unsigned)min(mq + e, p.M - 1)) * 4u;
       }
     } else {
-      const int mc = m0 + (tid % QM) * 4;
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
-        const int kk = k0 + tid / QM + KSTEP * j;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kk < p.K) {
-          const float* src = A + (int64_t)kk * p.lda + mc;
-          if (p.a_vec && mc + 3 < p.M) {
-            v = ld4(src);
-          } else {
-            if (mc + 0 < p.M) v.x = src[0];
-            if (mc + 1 < p.M) v.y = src[1];
-            if (mc + 2 < p.M) v.z = src[2];
-            if (mc + 3 < p.M) v.w = src[3];
-          }
+        const int gm = min(m0 + (tid >> 3) + 32 * j, p.M - 1);
+        a_off[j] = ((unsigned)gm * (unsigned)p.lda + kc) * 4u;
+        if (ADD) add_off[j] = ((unsigned)(p.Aadd ? gm % p.aadd_rows : gm) *
+                                   (unsigned)(p.Aadd ? p.ldaadd : p.lda) + kc) * 4u;
+        if (AMODE == A_CONV) {
+          cy[j] = gm / p.Wd;
+          cx[j] = gm - cy[j] * p.Wd;
         }
-        ra[j] = v;
       }
     }
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (w_ok[j] && k0 + kc < p.K) v = ld4(w_row[j] + k0 + kc);
-      rb[j] = v;
-    }
+    for (int j = 0; j < NB; ++j)
+      w_off[j] = ((unsigned)min(n0 + (tid >> 3) + 32 * j, p.N - 1) * (unsigned)p.ldw + kc) * 4u;
   };
-  auto store_tile = [&](int buf) {
-    float* sA = smem + buf * STAGE;
-    float* sB = sA + A_ELEMS;
+
+  // Raw loaded chunk + what store_chunk has to do to it.  Nothing here may CONSUME a
+  // loaded value at load time (a select or add right after the load makes the wave wait
+  // out the whole memory latency before its MFMAs): the positional add, the K-tail and
+  // halo zeroing all happen when the chunk is written to LDS, one chunk later.
+  float4 ra[NA], rad[ADD ? NA : 1], rb[NB];
+  bool st_ragged = false, st_add = false;
+  int st_k0 = 0;
+  unsigned st_in = 0;
+  auto load_chunk = [&](int kt) {
+    const int k0 = kt * BK;
+    // a ragged last chunk (K % 32 != 0, rare) re-reads the previous 32 columns' address
+    // range shifted back to stay in bounds; store_chunk zeroes what lies past K
+    const bool ragged = k0 + BK > lK;
+    st_ragged = ragged;
+    st_add = l_add;
+    st_k0 = k0;
+    if (AMODE == A_COL) {
+      // element (k, m) at k * lda + m: voffset = (k row inside the chunk) * lda + m,
+      // soffset = k0 * lda (a ragged last chunk loads chunk 0 instead and is re-read
+      // with bounds in store_chunk)
+      const GemmP& p = loc.P(lpi);
+      const int soff = (ragged ? 0 : k0) * (int)p.lda * 4;
+      if (l_vec) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) ra[j] = buf_ld4(rA, a_off[j], soff);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          ra[j].x = buf_ld1(rA, a_off1[j][0], soff);
+          ra[j].y = buf_ld1(rA, a_off1[j][1], soff);
+          ra[j].z = buf_ld1(rA, a_off1[j][2], soff);
+          ra[j].w = buf_ld1(rA, a_off1[j][3], soff);
+        }
+      }
+    } else if (AMODE == A_CONV) {
+      const GemmP& p = loc.P(lpi);
+      const int tap = k0 / p.Cin;
+      const int ci0 = k0 - tap * p.Cin;
+      const int dy = tap / p.KW - p.pad, dx = tap % p.KW - p.pad;
+      if (ci0 == 0) {   // new tap (uniform): which rows' taps fall inside the image, and
+                        // their per-lane offsets; the channel advance rides in soffset
+        in_mask = 0;
+        const int tap_off = (dy * p.Wd + dx) * p.Cin;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          const int yy = cy[j] + dy, xx = cx[j] + dx;
+          const bool in = yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+          in_mask |= (in ? 1u : 0u) << j;
+          // outside: read the (valid) centre pixel, zeroed when the chunk goes to LDS
+          a_tap[j] = a_off[j] + (unsigned)(in ? tap_off : 0) * 4u;
+        }
+      }
+      st_in = in_mask;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) ra[j] = buf_ld4(rA, a_tap[j], ci0 * 4);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) ra[j] = buf_ld4(rA, a_off[j], ragged ? 0 : k0 * 4);
+      if (ADD) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+          rad[j] = buf_ld4(rAdd, add_off[j], ragged ? 0 : k0 * 4);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rb[j] = buf_ld4(rW, w_off[j], ragged ? 0 : k0 * 4);
+  };
+  auto store_chunk = [&]() {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      if (ADD && st_add) ra[j] = add4(ra[j], rad[j]);
+      if (AMODE == A_CONV && !((st_in >> j) & 1u)) ra[j] = zero4;
+    }
+    if (st_ragged) {   // uniform, rare: the ragged chunk was loaded from k = 0; reload it
+      // synchronously with per-element bounds (slow path, correctness only)
+      const GemmP& p = loc.P(lpi);
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        if (AMODE == A_COL) {
+          const int kk = st_k0 + tid / QM + KSTEP * j;
+          const int mq = (int)(a_off1[j][0] / 4u) - (int)min(tid / QM + KSTEP * j, lK - 1) * (int)p.lda;
+          float4 v = zero4;
+          if (kk < lK) {
+            const float* src = bA + (int64_t)kk * p.lda;
+            v.x = src[min(mq + 0, p.M - 1)];
+            v.y = src[min(mq + 1, p.M - 1)];
+            v.z = src[min(mq + 2, p.M - 1)];
+            v.w = src[min(mq + 3, p.M - 1)];
+          }
+          ra[j] = v;
+        } else if (AMODE == A_ROW) {
+          const bool ok = st_k0 + kc < lK;
+          float4 v = ok ? ld4(bA + st_k0 + a_off[j] / 4u) : zero4;
+          if (ADD && st_add && ok) v = add4(v, ld4(bAdd + st_k0 + add_off[j] / 4u));
+          ra[j] = v;
+        } else {
+          ra[j] = zero4;   // conv: Cin % 32 == 0 is required, so K is never ragged
+        }
+      }
+      (void)p;
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        rb[j] = st_k0 + kc < lK ? ld4(bW + st_k0 + w_off[j] / 4u) : zero4;
+    }
     if (AMODE == A_COL) {
 #pragma unroll
       for (int j = 0; j < NA; ++j)
         st4(sA + (tid / QM + KSTEP * j) * LDK + (tid % QM) * 4, ra[j]);
     } else {
 #pragma unroll
-      for (int j = 0; j < NA; ++j)
-        st4(sA + ((tid >> 3) + 32 * j) * LD + kc, ra[j]);
+      for (int j = 0; j < NA; ++j) st4(sA + ((tid >> 3) + 32 * j) * LD + kc, ra[j]);
     }
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
-      st4(sB + ((tid >> 3) + 32 * j) * LD + kc, rb[j]);
+    for (int j = 0; j < NB; ++j) st4(sB + ((tid >> 3) + 32 * j) * LD + kc, rb[j]);
   };
 
   f32x16 acc[TM][TN];
+  // MFMA operand fragments, double-buffered in registers: the ds_reads of k-step kb+1
+  // are in flight while the MFMAs of kb issue
+  const float* fA = (AMODE == A_COL) ? sA + (4 * lh) * LDK + wm * WM + li
+                                     : sA + (wm * WM + li) * LD + 4 * lh;
+  const float* fB = sB + (wn * WN + li) * LD + 4 * lh;
+  auto read_frag = [&](int kb, float4 (&fa)[TM], float4 (&fb)[TN]) {
 #pragma unroll
-  for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-  const int nk = (p.K + BK - 1) / BK;
-  auto compute = [&](int buf) {
-    const float* sA = smem + buf * STAGE;
-    const float* sB = sA + A_ELEMS;
-#pragma unroll
-    for (int kb = 0; kb < BK; kb += 8) {
-      float a[TM][4], b[TN][4];
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi) {
-        if (AMODE == A_COL) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            a[mi][t] = sA[(kb + t + 4 * lh) * LDK + wm * WM + mi * 32 + li];
-        } else {
-          const float4 v = ld4(sA + (wm * WM + mi * 32 + li) * LD + kb + 4 * lh);
-          a[mi][0] = v.x; a[mi][1] = v.y; a[mi][2] = v.z; a[mi][3] = v.w;
-        }
+    for (int mi = 0; mi < TM; ++mi) {
+      if (AMODE == A_COL) {
+        const float* s = fA + (kb * 8) * LDK + mi * 32;
+        fa[mi] = make_float4(s[0], s[LDK], s[2 * LDK], s[3 * LDK]);
+      } else {
+        fa[mi] = ld4(fA + mi * 32 * LD + kb * 8);
       }
+    }
 #pragma unroll
-      for (int ni = 0; ni < TN; ++ni) {
-        const float4 v = ld4(sB + (wn * WN + ni * 32 + li) * LD + kb + 4 * lh);
-        b[ni][0] = v.x; b[ni][1] = v.y; b[ni][2] = v.z; b[ni][3] = v.w;
-      }
+    for (int ni = 0; ni < TN; ++ni) fb[ni] = ld4(fB + ni * 32 * LD + kb * 8);
+  };
+  auto compute = [&]() {
+    float4 fa[2][TM], fb[2][TN];
+    read_frag(0, fa[0], fb[0]);
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      const int cur = kb & 1;
+      if (kb + 1 < BK / 8) read_frag(kb + 1, fa[cur ^ 1], fb[cur ^ 1]);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < TN; ++ni)
-            acc[mi][ni] = mfma32(a[mi][t], b[ni][t], acc[mi][ni]);
+          for (int ni = 0; ni < TN; ++ni) {
+            const float4 av = fa[cur][mi], bv = fb[cur][ni];
+            acc[mi][ni] = mfma32(t == 0 ? av.x : t == 1 ? av.y : t == 2 ? av.z : av.w,
+                                 t == 0 ? bv.x : t == 1 ? bv.y : t == 2 ? bv.z : bv.w,
+                                 acc[mi][ni]);
+          }
     }
   };
-  load_tile(0);
-  if (DB) {
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk) load_tile(kt + 1);
-      compute(buf);
-      if (kt + 1 < nk) store_tile(buf ^ 1);
-      __syncthreads();
-    }
-  } else {
-    // one LDS stage: half the LDS, so twice as many workgroups are resident per CU to
-    // fill the matrix pipe while others sit in their load / barrier phases
-    for (int kt = 0; kt < nk; ++kt) {
-      __syncthreads();
-      store_tile(0);
-      __syncthreads();
-      if (kt + 1 < nk) load_tile(kt + 1);
-      compute(0);
-    }
-  }
 
-  // ---- epilogue: bias -> act -> residual ----
-  float* __restrict__ C = p.C + (int64_t)bz * p.sC;
-  const float* __restrict__ Res = p.Res ? p.Res + (int64_t)bz * p.sRes : nullptr;
+  TileRef cur = loc(base + slot);
+  set_tile(cur);
+  load_chunk(0);
+  for (int t = slot; t < cnt; t += per) {
+    const GemmP& p = loc.P(cur.pi);
+    // the tile after this one (clamped: the last tile re-loads its own first chunk, unused)
+    const TileRef nxt = loc(base + min(t + per, cnt - 1));
+    const int nk = (p.K + BK - 1) / BK;
 #pragma unroll
-  for (int ni = 0; ni < TN; ++ni) {
-    const int col = n0 + wn * WN + ni * 32 + li;
-    if (col >= p.N) continue;
-    const float bv = p.bias ? p.bias[col] : 0.f;
+    for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
+      for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WM + mi * 32 + mfma32_row(r, lh);
-        if (row < p.M) {
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();
+      store_chunk();
+      __syncthreads();
+      const bool last = kt + 1 == nk;
+      if (last) set_tile(nxt);
+      load_chunk(last ? 0 : kt + 1);
+      compute();
+    }
+    // ---- epilogue: bias -> act -> residual.  The residual values of a 32x32
+    // accumulator are fetched as 16 independent loads (clamped, unconditional) before
+    // any is used: one memory round trip per accumulator instead of sixteen. ----
+    const int m0 = cur.tm * BM, n0 = cur.tn * BN;
+    float* __restrict__ C = p.C + (int64_t)cur.bz * p.sC;
+    const float* __restrict__ Res = p.Res ? p.Res + (int64_t)cur.bz * p.sRes : nullptr;
+    const bool full = m0 + BM <= p.M && n0 + BN <= p.N;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int col = n0 + wn * WN + ni * 32 + li;
+      const int colc = min(col, p.N - 1);
+      const float bv = p.bias ? p.bias[colc] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int rbase = m0 + wm * WM + mi * 32;
+        float rv[16];
+        if (Res) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            rv[r] = Res[(int64_t)min(rbase + mfma32_row(r, lh), p.M - 1) * p.ldres + colc];
+        }
+        float ov[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
           float v = acc[mi][ni][r] + bv;
           if (p.relu) v = fmaxf(v, 0.f);
-          if (Res) v += Res[(int64_t)row * p.ldres + col];
-          C[(int64_t)row * p.ldc + col] = v;
+          if (Res) v += rv[r];
+          ov[r] = v;
+        }
+        // interior tiles store without per-element predicates (hipcc puts a full
+        // vmcnt(0) -- which on gfx9 also waits for the previous STORE -- in front of
+        // every predicated store)
+        float* cp = C + (int64_t)(rbase + 4 * lh) * p.ldc + col;
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cp[(int64_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = ov[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (rbase + mfma32_row(r, lh) < p.M && col < p.N)
+              cp[(int64_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = ov[r];
         }
       }
     }
+    cur = nxt;
   }
 }
 
-template <int BM, int BN, int AMODE, bool DB = true>
+template <int BM, int BN, int AMODE>
 struct TileSmem {
   static constexpr int A_ELEMS = (AMODE == A_COL) ? 32 * (BM + 4) : BM * 36;
-  static constexpr int FLOATS = (DB ? 2 : 1) * (A_ELEMS + BN * 36);
+  static constexpr int FLOATS = A_ELEMS + BN * 36;
 };
 
-template <int BM, int BN, int WM, int WN, int AMODE, bool DB = true>
-__global__ __launch_bounds__(256) void k_gemm_tile(const GemmP p) {
-  __shared__ __attribute__((aligned(16))) float smem[TileSmem<BM, BN, AMODE, DB>::FLOATS];
-  // 1-D launch over tiles; T enumerates tiles n-fastest, so one XCD's contiguous range
-  // of T shares A row-panels (and, for the conv, image rows with their halo) in its L2
-  const int nt = (p.N + BN - 1) / BN, mt = (p.M + BM - 1) / BM;
-  const int T = xcd_tile_index(blockIdx.x, nt * mt);
-  const int tm = T / nt, tn = T - tm * nt;
-  gemm_tile_body<BM, BN, WM, WN, AMODE, DB>(p, tm * BM, tn * BN, blockIdx.z, smem);
+// One problem (optionally batched): tiles enumerated batch-major, then m, n fastest.
+struct SingleLocator {
+  const GemmP& p;
+  int mt, nt;
+  __device__ __forceinline__ const GemmP& P(int) const { return p; }
+  __device__ __forceinline__ TileRef operator()(int T) const {
+    const int per_b = mt * nt;
+    const int bz = T / per_b, r = T - bz * per_b;
+    const int tm = r / nt;
+    return TileRef{0, bz, tm, r - tm * nt};
+  }
+};
+
+// ADD: the launch has a row-periodic addend on A (positional encodings), pn_gemm_desc.Aadd
+template <int BM, int BN, int WM, int WN, int AMODE, bool ADD = false>
+__global__ __launch_bounds__(256) void k_gemm_tile(const GemmP p, const int batch) {
+  __shared__ __attribute__((aligned(16))) float smem[TileSmem<BM, BN, AMODE>::FLOATS];
+  const SingleLocator loc{p, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN};
+  gemm_persistent<BM, BN, WM, WN, AMODE, ADD>(loc, loc.mt * loc.nt * batch, smem);
 }
 
 // Several independent row-major GEMMs in ONE launch: the 64x64 tiles of all
-// problems are enumerated together (n-tile fastest, so blocks that share an A panel
+// problems are enumerated together (n-tile fastest, so workgroups that share an A panel
 // are neighbours), which fills the chip where a single M x 256 problem leaves a
 // ragged second round of workgroups.
 #define GEMM_GROUP_MAX 16
@@ -256,18 +410,26 @@ struct GroupP {
   GemmP p[GEMM_GROUP_MAX];
 };
 
-__global__ __launch_bounds__(256) void k_gemm_group(const GroupP g) {
-  __shared__ __attribute__((aligned(16))) float smem[TileSmem<64, 64, A_ROW, false>::FLOATS];
-  const int bid = xcd_tile_index(blockIdx.x, gridDim.x);
-  int i = 0;
+struct GroupLocator {
+  const GroupP& g;
+  __device__ __forceinline__ const GemmP& P(int i) const { return g.p[i]; }
+  __device__ __forceinline__ TileRef operator()(int T) const {
+    int i = 0;
 #pragma unroll
-  for (int j = 1; j < GEMM_GROUP_MAX; ++j)
-    if (j < g.n && bid >= g.tile_start[j]) i = j;
-  const int local = bid - g.tile_start[i];
-  const int per = g.mt[i] * g.nt[i];
-  const int bz = local / per, r = local - bz * per;
-  const int tm = r / g.nt[i], tn = r - tm * g.nt[i];
-  gemm_tile_body<64, 64, 32, 32, A_ROW, false>(g.p[i], tm * 64, tn * 64, bz, smem);
+    for (int j = 1; j < GEMM_GROUP_MAX; ++j)
+      if (j < g.n && T >= g.tile_start[j]) i = j;
+    const int local = T - g.tile_start[i];
+    const int per_b = g.mt[i] * g.nt[i];
+    const int bz = local / per_b, r = local - bz * per_b;
+    const int tm = r / g.nt[i];
+    return TileRef{i, bz, tm, r - tm * g.nt[i]};
+  }
+};
+
+__global__ __launch_bounds__(256) void k_gemm_group(const GroupP g) {
+  __shared__ __attribute__((aligned(16))) float smem[TileSmem<64, 64, A_ROW>::FLOATS];
+  const GroupLocator loc{g};
+  gemm_persistent<64, 64, 32, 32, A_ROW, true>(loc, g.tile_start[GEMM_GROUP_MAX], smem);
 }
 
 // 32x32 output tile per workgroup; NW waves split K (wave w contracts a contiguous
@@ -372,10 +534,25 @@ static int launch_skinny(const GemmP& p, int batch, hipStream_t s) {
 }
 
 
+// Persistent launch: at most `wg_per_cu` workgroups per CU (256 CUs), a multiple of 8 so
+// that every XCD gets the same number of them.
+static int persistent_grid(int64_t ntiles, int wg_per_cu) {
+  const int64_t cap = 256 * wg_per_cu;
+  const int64_t want = (ntiles + 7) / 8 * 8;
+  return (int)(want < cap ? want : cap);
+}
+
 template <int BM, int BN, int WM, int WN, int AMODE>
 static int launch_tile(const GemmP& p, int batch, hipStream_t s) {
-  dim3 grid(pn_cdiv(p.N, BN) * pn_cdiv(p.M, BM), 1, batch);
-  hipLaunchKernelGGL((k_gemm_tile<BM, BN, WM, WN, AMODE>), grid, dim3(256), 0, s, p);
+  const int64_t ntiles = (int64_t)pn_cdiv(p.N, BN) * pn_cdiv(p.M, BM) * batch;
+  constexpr int wg_per_cu = (BM * BN <= 64 * 64) ? 4 : (BM * BN <= 128 * 64) ? 3 : 2;
+  const dim3 grid(persistent_grid(ntiles, wg_per_cu));
+  if (AMODE == A_ROW && p.Aadd)
+    hipLaunchKernelGGL((k_gemm_tile<BM, BN, WM, WN, AMODE, AMODE == A_ROW>), grid, dim3(256), 0,
+                       s, p, batch);
+  else
+    hipLaunchKernelGGL((k_gemm_tile<BM, BN, WM, WN, AMODE, false>), grid, dim3(256), 0, s, p,
+                       batch);
   return PN_LAUNCH_CHECK();
 }
 
@@ -407,6 +584,11 @@ int pn_fill_params(const pn_gemm_desc* d, GemmP* out) {
   if (d->Aadd && (colmajor || d->ldaadd % 4 || !aligned16(d->Aadd) || d->aadd_rows <= 0))
     return PN_BAD_ARG;
   if (d->Aadd && (d->aadd_from_col < 0 || d->aadd_from_col % 64)) return PN_BAD_ARG;
+  // the tile kernels address each per-batch operand with 32-bit element offsets
+  const int64_t lim = (int64_t)1 << 29;
+  if (!colmajor && (int64_t)(d->M - 1) * d->lda + d->K >= lim) return PN_BAD_ARG;
+  if ((int64_t)(d->N - 1) * d->ldw + d->K >= lim) return PN_BAD_ARG;
+  if (d->Aadd && (int64_t)d->aadd_rows * d->ldaadd >= lim) return PN_BAD_ARG;
   GemmP p{};
   p.A = d->A; p.Aadd = d->Aadd; p.W = d->W; p.bias = d->bias; p.Res = d->Res; p.C = d->C;
   p.lda = d->lda; p.ldaadd = d->ldaadd; p.ldw = d->ldw; p.ldres = d->ldres; p.ldc = d->ldc;
@@ -429,25 +611,18 @@ extern "C" int pn_gemm_f32(const pn_gemm_desc* d, void* stream) {
   }
   if ((d->flags & PN_GEMM_SPLIT_BF16) && !colmajor)
     return pn_launch_gemm_split(p, d->batch, /*conv=*/false, (d->flags & PN_GEMM_FORCE_TILE) != 0, s);
-  // Tile choice (measured on MI355X, tools/gemm_sweep.py): with K = 256..1024 and
-  // M x N of a few hundred 128x128 tiles, the 64x64 tile wins everywhere (75-94 vs
-  // 58-80 TFLOP/s): 4x more workgroups even out the last round over 256 CUs and four
-  // of them fit a CU (36.8 KB LDS, 58 VGPRs).
+  // Tile choice (measured on MI355X, tools/gemm_probe.hip / gemm_sweep.py): with
+  // K = 256..1024 the persistent 64x64 tile at 4 workgroups per CU is best or within 3 %
+  // of the best on every encoder shape (99-112 TFLOP/s); 128x64 and 128x128 stay
+  // selectable for sweeps.
   if (d->flags & PN_GEMM_FORCE_TILE128x64)
-    return colmajor ? launch_tile<128, 64, 32, 64, A_COL>(p, d->batch, s)
-                    : launch_tile<128, 64, 32, 64, A_ROW>(p, d->batch, s);
+    return colmajor ? launch_tile<128, 64, 64, 32, A_COL>(p, d->batch, s)
+                    : launch_tile<128, 64, 64, 32, A_ROW>(p, d->batch, s);
   if (d->flags & PN_GEMM_FORCE_TILE)
     return colmajor ? launch_tile<128, 128, 64, 64, A_COL>(p, d->batch, s)
                     : launch_tile<128, 128, 64, 64, A_ROW>(p, d->batch, s);
-  // ... and with ONE LDS stage (18 KB, two barriers per k-tile) seven workgroups fit a
-  // CU instead of four: +3-9 % on the same shapes (more waves to fill the matrix pipe
-  // while others sit in their load / barrier phases).
-  dim3 grid(pn_cdiv(p.N, 64) * pn_cdiv(p.M, 64), 1, d->batch);
-  if (colmajor)
-    hipLaunchKernelGGL((k_gemm_tile<64, 64, 32, 32, A_COL, false>), grid, dim3(256), 0, s, p);
-  else
-    hipLaunchKernelGGL((k_gemm_tile<64, 64, 32, 32, A_ROW, false>), grid, dim3(256), 0, s, p);
-  return PN_LAUNCH_CHECK();
+  return colmajor ? launch_tile<64, 64, 32, 32, A_COL>(p, d->batch, s)
+                  : launch_tile<64, 64, 32, 32, A_ROW>(p, d->batch, s);
 }
 
 extern "C" int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream) {
@@ -464,7 +639,8 @@ extern "C" int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream)
     tiles += g.mt[i] * g.nt[i] * d[i].batch;
   }
   for (int i = count; i <= GEMM_GROUP_MAX; ++i) g.tile_start[i] = tiles;
-  hipLaunchKernelGGL(k_gemm_group, dim3(tiles), dim3(256), 0, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(k_gemm_group, dim3(persistent_grid(tiles, 4)), dim3(256), 0,
+                     (hipStream_t)stream, g);
   return PN_LAUNCH_CHECK();
 }
 
@@ -474,6 +650,7 @@ extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float*
                                   void* stream) {
   if (!in || !Wp || !out || B <= 0 || H <= 0 || W <= 0) return PN_BAD_ARG;
   if (Cin % 32 || !aligned16(in) || !aligned16(Wp)) return PN_BAD_ARG;
+  if ((int64_t)H * W * Cin >= ((int64_t)1 << 29)) return PN_BAD_ARG;
   GemmP p{};
   p.A = in; p.W = Wp; p.bias = bias; p.C = out;
   p.M = H * W; p.N = Cout; p.K = KH * KW * Cin;
@@ -485,16 +662,12 @@ extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float*
   if (flags & PN_GEMM_SPLIT_BF16) {
     return pn_launch_gemm_split(p, B, /*conv=*/true, (flags & PN_GEMM_FORCE_TILE) != 0, s);
   }
-  // single LDS stage everywhere (more resident workgroups; 817 vs 944 us on the 3x3 FPN
-  // conv); 128x128 for the 256-channel conv, 64x64 for the 64-channel Matrix Learner layer
-  if (Cout <= 64) {
-    dim3 grid(pn_cdiv(p.N, 64) * pn_cdiv(p.M, 64), 1, B);
-    hipLaunchKernelGGL((k_gemm_tile<64, 64, 32, 32, A_CONV, false>), grid, dim3(256), 0, s, p);
-  } else {
-    dim3 grid(pn_cdiv(p.N, 128) * pn_cdiv(p.M, 128), 1, B);
-    hipLaunchKernelGGL((k_gemm_tile<128, 128, 64, 64, A_CONV, false>), grid, dim3(256), 0, s, p);
-  }
-  return PN_LAUNCH_CHECK();
+  // 64x64 tiles everywhere (3x3 FPN conv on MI355X: 625 us / 126 TFLOP/s, against 730
+  // with 128x64 and 845 with 128x128 tiles, tools/gemm_probe.hip); the larger tiles stay
+  // selectable for sweeps
+  if (flags & PN_GEMM_FORCE_TILE128x64) return launch_tile<128, 64, 64, 32, A_CONV>(p, B, s);
+  if (flags & PN_GEMM_FORCE_TILE) return launch_tile<128, 128, 64, 64, A_CONV>(p, B, s);
+  return launch_tile<64, 64, 32, 32, A_CONV>(p, B, s);
 }
 
 extern "C" int pn_abi_version(void) { return PN_ABI_VERSION; }

@@ -14,6 +14,7 @@ from .build import LIB_PATH
 _i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 GEMM_RELU, GEMM_A_COLMAJOR, GEMM_FORCE_TILE, GEMM_FORCE_SKINNY = 1, 2, 4, 8
+GEMM_FORCE_TILE64, GEMM_FORCE_TILE128x64 = 16, 32
 
 
 class GemmDesc(C.Structure):
@@ -97,7 +98,7 @@ def _stream():
 
 
 GEMM_KERNELS = {0: "k_gemm_skinny<A_ROW>", 1: "k_gemm_skinny<A_COL>",
-                2: "k_gemm_tile<128,64,32,64,A_ROW>", 3: "k_gemm_tile<128,64,32,64,A_COL>",
+                2: "k_gemm_tile<128,64,64,32,A_ROW>", 3: "k_gemm_tile<128,64,64,32,A_COL>",
                 4: "k_gemm_tile<128,128,64,64,A_ROW>", 5: "k_gemm_tile<128,128,64,64,A_COL>",
                 6: "k_gemm_tile<64,64,32,32,A_ROW>", 7: "k_gemm_tile<64,64,32,32,A_COL>",
                 8: "k_gemm_split<A_ROW>"}
@@ -228,14 +229,18 @@ def linear(x, weight, bias, out, *, aadd=None, aadd_from_col=0, res=None, relu=F
 
 
 def conv2d_nhwc(x, wp, bias, out, B, H, W, Cin, Cout, KH, KW, pad, relu, split=False,
-                big_tile=False):
+                big_tile=False, tile=None):
+    """tile: None (library default: 64x64), "128x64" or "128" (sweeps)."""
+    tflag = {None: 0, "128": GEMM_FORCE_TILE, "128x64": GEMM_FORCE_TILE128x64}[tile]
     name = "k_gemm_split<A_CONV>" if split else (
-        "k_gemm_tile<64,64,32,32,A_CONV>" if Cout <= 64 else "k_gemm_tile<128,128,64,64,A_CONV>")
+        "k_gemm_tile<128,64,64,32,A_CONV>" if tile == "128x64" else
+        "k_gemm_tile<128,128,64,64,A_CONV>" if tile == "128" else
+        "k_gemm_tile<64,64,32,32,A_CONV>")
     flops = 2.0 * B * H * W * Cout * KH * KW * Cin
     nbytes = 4.0 * (B * H * W * (Cin + Cout) + Cout * KH * KW * Cin)
     _check(_launch(name, flops, nbytes, lambda: lib().pn_conv2d_nhwc_f32(
         _ptr(x), _ptr(wp), _ptr(bias), _ptr(out), B, H, W, Cin, Cout, KH, KW, pad, int(relu),
-        (GEMM_SPLIT_BF16 if split else 0) | (GEMM_FORCE_TILE if big_tile else 0),
+        (GEMM_SPLIT_BF16 if split else 0) | (GEMM_FORCE_TILE if big_tile else 0) | tflag,
         _stream())), "pn_conv2d_nhwc_f32")
 
 

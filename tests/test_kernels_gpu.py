@@ -36,7 +36,7 @@ def close(got, ref, tol, what=""):
 
 
 # ----------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("force", ["tile", "skinny", None])
+@pytest.mark.parametrize("force", ["tile", "tile64", "tile128x64", "skinny", None])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 256), (100, 134, 256), (1000, 544, 260),
                                    (37, 56, 2048), (129, 64, 96), (5, 33, 8)])
 def test_gemm_linear_variants(hip, M, N, K, force):
@@ -52,7 +52,7 @@ def test_gemm_linear_variants(hip, M, N, K, force):
     close(out2, F.linear(x, w), 2e-5 * math.sqrt(K / 256), "gemm plain %s" % force)
 
 
-@pytest.mark.parametrize("force", ["tile", "skinny"])
+@pytest.mark.parametrize("force", ["tile", "tile64", "tile128x64", "skinny"])
 def test_gemm_batched_strided_and_colmajor(hip, force):
     B, M, N, K = 3, 210, 256, 64          # M % 4 != 0: scalar column-major path
     a = R(B, K, M, seed=7)                # NCHW-like: [b][k][m]
@@ -68,6 +68,14 @@ def test_gemm_batched_strided_and_colmajor(hip, force):
     hip.gemm(a2.to(DEV), w.to(DEV), out, M=M2, N=N, K=K, lda=M2, ldw=K, ldc=N, batch=B,
              sA=K * M2, sC=M2 * N, colmajor=True, force=force)
     close(out, torch.einsum("bkm,nk->bmn", a2, w), 2e-5, "colmajor vec")
+    # ragged K (K % 32 != 0) on both column-major paths
+    for Mr in (210, 400):
+        Kr = 72
+        ar, wr = R(B, Kr, Mr, seed=13), R(N, Kr, seed=14)
+        out = torch.empty(B, Mr, N, device=DEV)
+        hip.gemm(ar.to(DEV), wr.to(DEV), out, M=Mr, N=N, K=Kr, lda=Mr, ldw=Kr, ldc=N, batch=B,
+                 sA=Kr * Mr, sC=Mr * N, colmajor=True, force=force)
+        close(out, torch.einsum("bkm,nk->bmn", ar, wr), 2e-5, "colmajor ragged K")
     # per-batch W (mask logits: W = mask feature of image b), output with a wide ldc
     q, mf = R(B, 100, 256, seed=11), R(B, 530, 256, seed=12)
     out = torch.empty(B, 100, 530, device=DEV)

@@ -220,9 +220,12 @@ def main():
             try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE
                 # doubled per MI355X_MICROARCH.md + WRITE_SIZE), same workload, same kernel
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                for v in pmc["kernels"].values():
-                    if v.get("bench_name") == dominant:
-                        traffic, traffic_src = v["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+                hits = [v for v in pmc["kernels"].values() if v.get("bench_name") == dominant]
+                if hits:   # template variants of one kernel: launch-weighted mean
+                    n = sum(v["launches_profiled"] for v in hits)
+                    traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches_profiled"]
+                                      for v in hits) / n)
+                    traffic_src = "profiles/r01_pmc_traffic.json"
             except (OSError, ValueError, KeyError):
                 pass
             out["roofline"] = {

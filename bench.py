@@ -54,9 +54,10 @@ def main():
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default="f32",
                     help="f32: exact-fp32 MFMA everywhere (headline); bf16x3: fp32-accurate "
                          "3 x bf16 operand split for the large GEMMs / 3x3 conv")
-    ap.add_argument("--head", choices=["pairnet", "baseline"], default="pairnet",
-                    help="pairnet = CrossHead2 (the headline); baseline = the sibling head "
-                         "CrossHeadBaseline on the same trunk (not the headline metric)")
+    ap.add_argument("--head", choices=["pairnet", "baseline", "psgtr2"], default="pairnet",
+                    help="pairnet = CrossHead2 (the headline); baseline / psgtr2 = the sibling "
+                         "heads CrossHeadBaseline / PSGTrHead2 on the same trunk (not the "
+                         "headline metric)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two stages of consecutive batches back to back on one stream")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight in the pipeline")
@@ -84,16 +85,20 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from pairnet_amd import (CrossHead2, CrossHeadBaseline, PipelinedHead, baseline_head_cfg, hip,
-                             pairnet_head_cfg)
+    from pairnet_amd import (CrossHead2, CrossHeadBaseline, PSGTrHead2, PipelinedHead,
+                             baseline_head_cfg, hip, pairnet_head_cfg, psgtr2_head_cfg)
     from pairnet_amd.dist import all_gather_triplets, pack_triplets
 
-    sibling = args.head == "baseline"
-    cfg = baseline_head_cfg() if sibling else pairnet_head_cfg()
+    sibling = args.head != "pairnet"
+    cfg = {"pairnet": pairnet_head_cfg, "baseline": baseline_head_cfg,
+           "psgtr2": psgtr2_head_cfg}[args.head]()
     cfg.pop("type")
-    head = (CrossHeadBaseline if sibling else CrossHead2)(**cfg)
-    pair_ids = (lambda pl: (pl.sub_ids, pl.obj_ids)) if sibling else \
-        (lambda pl: (pl.sub_pos, pl.obj_pos))
+    head = {"pairnet": CrossHead2, "baseline": CrossHeadBaseline,
+            "psgtr2": PSGTrHead2}[args.head](**cfg)
+    ident = torch.arange(head.num_obj_query, device=dev).unsqueeze(0).expand(args.batch, -1)
+    pair_ids = {"pairnet": lambda pl: (pl.sub_pos, pl.obj_pos),
+                "baseline": lambda pl: (pl.sub_ids, pl.obj_ids),
+                "psgtr2": lambda pl: (ident, ident)}[args.head]   # query i IS triplet i
     head.init_weights(seed=0)
     head.to(dev)
     head.gemm_mode = args.gemm
@@ -189,10 +194,9 @@ def main():
                                                       "MFMA for the large GEMMs, fp32 accumulate)",
             "data": "synthetic",
             "config": {
-                "workload": ("SIBLING HEAD (not the headline): CrossHeadBaseline."
-                             "simple_test_bboxes: pixel decoder -> 9-layer masked decoder -> "
-                             "6-layer relation decoder over the pixel memories -> argmax "
-                             "matching -> get_bboxes" if sibling else
+                "workload": ("SIBLING HEAD (not the headline): %s.simple_test_bboxes on the "
+                             "same pixel decoder + 9-layer masked decoder"
+                             % type(head).__name__ if sibling else
                              "Pair-Net R50 + Mask2Former head hot path (CrossHead2."
                              "simple_test_bboxes: pixel decoder -> 9-layer masked decoder -> "
                              "PPN/Matrix Learner/top-k -> 6-layer relation decoder -> "
@@ -289,9 +293,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.head import OracleCrossHead2
         from oracle.baseline_head import OracleCrossHeadBaseline
+        from oracle.psgtr_head2 import OraclePSGTrHead2
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") \
             else (os.cpu_count() or 1)
-        oracle = (OracleCrossHeadBaseline if sibling else OracleCrossHead2)(**cfg).eval()
+        oracle = {"pairnet": OracleCrossHead2, "baseline": OracleCrossHeadBaseline,
+                  "psgtr2": OraclePSGTrHead2}[args.head](**cfg).eval()
         oracle.load_state_dict(head.state_dict())
         # torch's CPU kernels stop scaling (and then collapse) long before 256 threads on
         # these shapes: pick the thread count by timing the Matrix Learner + one decoder
@@ -308,7 +314,8 @@ def main():
                 oracle.pixel_decoder.encoder.layers[0].ffns[0](torch.randn(21950, 1, 256))
                 if not sibling:
                     oracle.update_importance(torch.randn(B, 100, 100))
-                oracle.sub_query_update(probe_q)
+                if args.head != "psgtr2":
+                    oracle.sub_query_update(probe_q)
                 dt = time.perf_counter() - t
             if best is None or dt < best:
                 best, cores = dt, n

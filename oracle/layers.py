@@ -389,6 +389,9 @@ class MSDeformAttnPixelDecoder(nn.Module):
             self.input_convs.append(ConvModule(in_channels[i], feat_channels,
                                                1, bias=True, groups=groups))
         self.encoder = build_transformer_layer_sequence(encoder)
+        if positional_encoding is None:   # mmdet's default argument (msdeformattn_pixel_decoder.py)
+            positional_encoding = dict(type="SinePositionalEncoding", num_feats=128,
+                                       normalize=True)
         self.postional_encoding = build_positional_encoding(
             positional_encoding)  # (sic) attribute name as in mmdet
         self.level_encoding = nn.Embedding(self.num_encoder_levels,

@@ -20,6 +20,9 @@ Fixtures
                  logits and indices only)
   baseline_small  the sibling head CrossHeadBaseline (relation_heads/baseline.py):
                  forward + get_bboxes on a 96x128 image, batch 2
+  psgtr2_small   the sibling head PSGTrHead2 (relation_heads/psgtr_head2.py): forward +
+                 get_bboxes on a 96x128 image, batch 1 (the reference's get_bboxes only
+                 handles one image per call)
 """
 import argparse
 import os
@@ -239,6 +242,31 @@ def gen_baseline_small():
     np.savez_compressed(os.path.join(OUT, "baseline_small.npz"), **out)
 
 
+def gen_psgtr2_small():
+    head = ref_shim.build_reference_psgtr2_head()
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in head.state_dict().items())
+    sd = seeded.seeded_state_dict(shapes, WEIGHT_SEED + 2)
+    head.load_state_dict(sd, strict=True)
+    H, W = 96, 128
+    feats = seeded.seeded_feats(81, 1, H, W)
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[2.0, 2.0, 2.0, 2.0])]
+    mf_bias = calibrate_mask_bias(head, feats)
+    with torch.no_grad():
+        cls, masks = head.forward(feats, metas)
+        res = head.get_bboxes(cls, masks, metas)
+    out = dict(weight_seed=WEIGHT_SEED + 2, weight_crc=seeded.checksum(sd), feat_seed=81,
+               feat_crc=seeded.checksum(feats), height=H, width=W, batch=1)
+    out["override_" + MF_BIAS] = _np(mf_bias)
+    for k, v in cls.items():
+        out["cls_" + k] = _np(v)
+    for k, v in masks.items():
+        out["mask_" + k] = _np(v)
+    for name, v in zip(RES_NAMES, res[0]):
+        out["res0_" + name] = np.packbits(_np(v)) if name == "masks" else _np(v)
+    out["res0_masks_shape"] = np.array(res[0][3].shape)
+    np.savez_compressed(os.path.join(OUT, "psgtr2_small.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -262,6 +290,8 @@ def main():
             gen_e2e_full(head, sd)
     if want("baseline_small"):
         gen_baseline_small()
+    if want("psgtr2_small"):
+        gen_psgtr2_small()
     for f in sorted(os.listdir(OUT)):
         print("%-16s %8.1f KB" % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))
 

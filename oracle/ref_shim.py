@@ -80,7 +80,7 @@ def install():
          force_fp32=_passthrough_decorator)
     _mod("mmdet")
     _mod("mmdet.core", build_assigner=None, build_sampler=None,
-         multi_apply=None, reduce_mean=None)
+         multi_apply=None, reduce_mean=None, bbox_cxcywh_to_xyxy=None)
     _mod("mmdet.models.utils", get_uncertain_point_coords_with_randomness=None)
     _mod("mmdet.datasets")
     _mod("mmdet.datasets.coco_panoptic", INSTANCE_OFFSET=1000)
@@ -108,6 +108,8 @@ def install():
           "pairnet/models/relation_heads/pairnet_head.py")
     _load("pairnet.models.relation_heads.baseline",
           "pairnet/models/relation_heads/baseline.py")
+    _load("pairnet.models.relation_heads.psgtr_head2",
+          "pairnet/models/relation_heads/psgtr_head2.py")
 
 
 def reference_head_cfg():
@@ -140,6 +142,23 @@ def build_reference_baseline_head(cfg=None):
     install()
     cls = sys.modules["pairnet.models.relation_heads.baseline"].CrossHeadBaseline
     cfg = L.CfgDict(cfg if cfg is not None else reference_baseline_cfg())
+    cfg.pop("type", None)
+    return cls(**cfg, train_cfg=None).eval()
+
+
+def reference_psgtr2_cfg():
+    """model.bbox_head of the reference's configs/psgtr/psgtr_r50_psg_plus.py."""
+    path = os.path.join(REF_ROOT, "configs/psgtr/psgtr_r50_psg_plus.py")
+    scope = {}
+    with open(path) as f:
+        exec(compile(f.read(), path, "exec"), scope)
+    return L.CfgDict(scope["model"]["bbox_head"])
+
+
+def build_reference_psgtr2_head(cfg=None):
+    install()
+    cls = sys.modules["pairnet.models.relation_heads.psgtr_head2"].PSGTrHead2
+    cfg = L.CfgDict(cfg if cfg is not None else reference_psgtr2_cfg())
     cfg.pop("type", None)
     return cls(**cfg, train_cfg=None).eval()
 

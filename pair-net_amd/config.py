@@ -143,6 +143,28 @@ def baseline_head_cfg(in_channels=(256, 512, 1024, 2048), num_obj_query=100,
                        naive_dice=True, eps=1.0, loss_weight=5.0))
 
 
+def psgtr2_head_cfg(in_channels=(256, 512, 1024, 2048), num_obj_query=100, num_classes=133,
+                    num_relations=56):
+    """bbox_head section (type PSGTrHead2) of configs/psgtr/psgtr_r50_psg_plus.py."""
+    pd = _pixel_decoder()
+    pd.pop("positional_encoding")       # that config relies on the decoder's defaults
+    pd.pop("init_cfg")
+    ce = lambda w: dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=w,
+                        class_weight=1.0)
+    mask = dict(type="CrossEntropyLoss", use_sigmoid=True, reduction="mean", loss_weight=5.0)
+    dice = dict(type="DiceLoss", use_sigmoid=True, activate=True, reduction="mean",
+                naive_dice=True, eps=1.0, loss_weight=5.0)
+    return ConfigDict(
+        type="PSGTrHead2", num_classes=num_classes, num_relations=num_relations, use_mask=True,
+        num_obj_query=num_obj_query, pixel_decoder=pd,
+        transformer_decoder=_decoder(9, False, 0.0),
+        positional_encoding=dict(type="SinePositionalEncoding", num_feats=128,
+                                 normalize=True),
+        sub_loss_cls=ce(1.0), sub_loss_mask=dict(mask), sub_loss_dice=dict(dice),
+        obj_loss_cls=ce(1.0), obj_loss_mask=dict(mask), obj_loss_dice=dict(dice),
+        rel_loss_cls=ce(2.0))
+
+
 def pairnet_r50():
     """`model` section: PSGTr(ResNet-50, CrossHead2) as the reference configures it."""
     return ConfigDict(
@@ -158,6 +180,13 @@ def baseline_r50():
     """`model` section: PSGTr(ResNet-50, CrossHeadBaseline)."""
     cfg = pairnet_r50()
     cfg["bbox_head"] = baseline_head_cfg()
+    return cfg
+
+
+def psgtr2_r50():
+    """`model` section: PSGTr(ResNet-50, PSGTrHead2)."""
+    cfg = pairnet_r50()
+    cfg["bbox_head"] = psgtr2_head_cfg()
     return cfg
 
 

@@ -14,6 +14,7 @@ import torch.nn.functional as F
 from .config import ConfigDict
 from .baseline_head import CrossHeadBaseline
 from .head import CrossHead2
+from .psgtr_head2 import PSGTrHead2
 
 
 class Result(object):
@@ -119,7 +120,8 @@ class PSGTr:
             raise NotImplementedError("only the ResNet-50 backbone of pairnet.py is built")
         self.backbone = ResNet50()
         head_cfg = dict(bbox_head)
-        heads = dict(CrossHead2=CrossHead2, CrossHeadBaseline=CrossHeadBaseline)
+        heads = dict(CrossHead2=CrossHead2, CrossHeadBaseline=CrossHeadBaseline,
+                     PSGTrHead2=PSGTrHead2)
         head_type = head_cfg.pop("type", "CrossHead2")
         if head_type not in heads:
             raise NotImplementedError("bbox_head.type must be one of %s" % sorted(heads))

@@ -454,6 +454,20 @@ class CrossHead2:
                 hip.bilinear_nhwc(pl.MF, pl.MFd[l], B, H2, W2, h, wd, 256, False, HW2 * 256,
                                   pl.N[l] * 256)
 
+    def _mlp3(self, prefix, src, dst, pl):
+        """Linear-ReLU-Linear-ReLU-Linear (`mask_embed`-style heads) via pl.m1 / pl.m2."""
+        w = self.w
+        hip.linear(src, w[prefix + ".0.weight"], w[prefix + ".0.bias"], pl.m1, relu=True)
+        hip.linear(pl.m1, w[prefix + ".2.weight"], w[prefix + ".2.bias"], pl.m2, relu=True)
+        hip.linear(pl.m2, w[prefix + ".4.weight"], w[prefix + ".4.bias"], dst)
+
+    def _mask_logits(self, me, pl, out):
+        """out[b, q, :] = me[b, q, :] . MF[b, :, :]^T  (`einsum("bqc,bchw->bqhw")`)."""
+        Q = self.num_obj_query
+        hip.gemm(me, pl.MF, out, M=Q, N=pl.HW2, K=256, lda=256, ldw=256, ldc=pl.HW2,
+                 batch=pl.B, sA=Q * 256, sW=pl.HW2 * 256, sC=Q * pl.HW2,
+                 split=self.gemm_mode == "bf16x3")
+
     def _head_embed(self, q, pl, with_cls, full_mask, cls_out=None, mp_out=None):
         """post_norm -> (cls_embed) -> mask_embed MLP -> pl.me; with `full_mask` also the
         mask logits [B,Q,H2*W2] (pairnet_head.py:236-243).  Outputs go to pl.cls / pl.MP
@@ -465,13 +479,9 @@ class CrossHead2:
                       w["transformer_decoder.post_norm.bias"], pl.qn)
         if with_cls:
             hip.linear(pl.qn, w["cls_embed.weight"], w["cls_embed.bias"], cls_out.view(B * Q, -1))
-        hip.linear(pl.qn, w["mask_embed.0.weight"], w["mask_embed.0.bias"], pl.m1, relu=True)
-        hip.linear(pl.m1, w["mask_embed.2.weight"], w["mask_embed.2.bias"], pl.m2, relu=True)
-        hip.linear(pl.m2, w["mask_embed.4.weight"], w["mask_embed.4.bias"], pl.me)
+        self._mlp3("mask_embed", pl.qn, pl.me, pl)
         if full_mask:
-            hip.gemm(pl.me, pl.MF, mp_out, M=Q, N=pl.HW2, K=256, lda=256, ldw=256, ldc=pl.HW2,
-                     batch=B, sA=Q * 256, sW=pl.HW2 * 256, sC=Q * pl.HW2,
-                     split=self.gemm_mode == "bf16x3")
+            self._mask_logits(pl.me, pl, mp_out)
 
     def _attn_mask(self, pl, lvl, mp=None):
         """Boolean attention mask of level `lvl` + all-masked fix (pairnet_head.py:244-256,
@@ -570,9 +580,10 @@ class CrossHead2:
         self._object_decoder(pl)
         self._relation_stage(pl)
 
-    def _object_decoder(self, pl, all_layers=False):
+    def _object_decoder(self, pl, all_layers=False, final_head=True):
         """The 9 masked-attention layers (pairnet_head.py:289-320) -> pl.q, pl.cls, pl.MP;
-        with `all_layers` every layer's class / mask logits go to pl.cls_all / pl.MP_all."""
+        with `all_layers` every layer's class / mask logits go to pl.cls_all / pl.MP_all;
+        without `final_head` the last layer's class / mask heads are left to the caller."""
         w, B, Q = self.w, pl.B, self.num_obj_query
         pl.q.view(B, Q, 256).copy_(w["query_feat.weight"].unsqueeze(0).expand(B, Q, 256))
         qpos = w["query_embed.weight"]
@@ -589,8 +600,10 @@ class CrossHead2:
             if all_layers:
                 mp = pl.MP_all[i]
                 self._head_embed(pl.q, pl, True, True, pl.cls_all[i], mp)
-            else:
+            elif final_head:
                 self._head_embed(pl.q, pl, i == last, exact or i == last)
+            elif i != last:
+                self._head_embed(pl.q, pl, False, exact)
 
     def _relation_stage(self, pl):
         w, B, Q, R = self.w, pl.B, self.num_obj_query, self.num_rel_query

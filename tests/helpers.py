@@ -54,6 +54,26 @@ def oracle_baseline_head(weight_seed, overrides=None):
     return head, sd, crc
 
 
+def psgtr2_cfg():
+    from pairnet_amd import psgtr2_head_cfg
+    cfg = psgtr2_head_cfg()
+    cfg.pop("type")
+    return cfg
+
+
+def oracle_psgtr2_head(weight_seed, overrides=None):
+    """Oracle of the sibling head PSGTrHead2 with seeded weights."""
+    from oracle.psgtr_head2 import OraclePSGTrHead2
+    head = OraclePSGTrHead2(**psgtr2_cfg()).eval()
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in head.state_dict().items())
+    sd = seeded.seeded_state_dict(shapes, weight_seed)
+    crc = seeded.checksum(sd)
+    for k, v in (overrides or {}).items():
+        sd[k] = torch.as_tensor(v).clone()
+    head.load_state_dict(sd, strict=True)
+    return head, sd, crc
+
+
 def overrides_of(fx):
     return {k[len("override_"):]: fx[k] for k in fx.files if k.startswith("override_")}
 

@@ -61,6 +61,31 @@ def test_reference_config_file_drops_in():
     assert head.num_classes == 133 and head.num_rel_query == 100 and head.use_mask
 
 
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+def test_sibling_heads_drop_in():
+    """BASELINE config #5 / SURVEY 8f rank 3: CrossHeadBaseline and PSGTrHead2 build from
+    the reference's own config files with the reference's state-dict layout."""
+    from pairnet_amd import (CrossHeadBaseline, PSGTrHead2, baseline_r50, build_detector,
+                             load_config, psgtr2_r50)
+    for path, restated, cls, ref_build in (
+            ("configs/mask2former/baseline_r50_psg.py", baseline_r50, CrossHeadBaseline,
+             ref_shim.build_reference_baseline_head),
+            ("configs/psgtr/psgtr_r50_psg_plus.py", psgtr2_r50, PSGTrHead2,
+             ref_shim.build_reference_psgtr2_head)):
+        cfg = load_config(os.path.join(ref_shim.REF_ROOT, path))
+        ref_head = dict(cfg.model.bbox_head)
+        ours = dict(restated().bbox_head)
+        assert {k: v for k, v in ref_head.items()
+                if k not in ("object_classes", "predicate_classes")} == ours, path
+        det = build_detector(dict(cfg.model))
+        assert isinstance(det.bbox_head, cls)
+        ref = ref_build()
+        assert {k: tuple(v.shape) for k, v in det.bbox_head.state_dict().items()} == \
+            {k: tuple(v.shape) for k, v in ref.state_dict().items()}, path
+        for name in ("forward", "get_bboxes", "simple_test_bboxes", "simple_test"):
+            assert callable(getattr(det.bbox_head, name))
+
+
 def test_no_cpu_fallback():
     from pairnet_amd import CrossHead2
     head = CrossHead2(**head_cfg())

@@ -177,3 +177,46 @@ def test_baseline_oracle_equals_shimmed_reference():
                 assert x.shape == y.shape
             else:
                 assert x.dtype == y.dtype and torch.equal(x, y), name
+
+
+# ---- sibling head PSGTrHead2 (relation_heads/psgtr_head2.py) ------------------------
+def test_psgtr2_small_matches_golden():
+    from helpers import oracle_psgtr2_head
+    fx = golden("psgtr2_small")
+    head, sd, crc = oracle_psgtr2_head(int(fx["weight_seed"]), overrides_of(fx))
+    assert crc == int(fx["weight_crc"])
+    H, W = int(fx["height"]), int(fx["width"])
+    feats = seeded.seeded_feats(int(fx["feat_seed"]), 1, H, W)
+    assert seeded.checksum(feats) == int(fx["feat_crc"])
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[2.0, 2.0, 2.0, 2.0])]
+    cls, masks = head.forward(feats, metas)
+    for k, v in cls.items():
+        assert np.array_equal(v.numpy(), fx["cls_" + k]), k
+    for k, v in masks.items():
+        assert np.array_equal(v.numpy(), fx["mask_" + k]), k
+    res = head.get_bboxes(cls, masks, metas)
+    for name, v in zip(RES_NAMES, res[0]):
+        got = np.packbits(v.numpy()) if name == "masks" else v.numpy()
+        assert np.array_equal(got, fx["res0_" + name]), name
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+def test_psgtr2_oracle_equals_shimmed_reference():
+    """The restatement of PSGTrHead2 (including the stale object mask of
+    psgtr_head2.py:404-411) and the reference's own class agree bit for bit."""
+    from helpers import oracle_psgtr2_head
+    ref = ref_shim.build_reference_psgtr2_head()
+    head, sd, _ = oracle_psgtr2_head(5)
+    ref.load_state_dict(sd, strict=True)
+    H, W = 64, 96
+    feats = seeded.seeded_feats(8, 1, H, W)
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[1.5, 1.5, 1.5, 1.5])]
+    with torch.no_grad():
+        a, b = ref.forward(feats, metas), head.forward(feats, metas)
+        for da, db in zip(a, b):
+            assert set(da) == set(db)
+            for k in da:
+                assert torch.equal(da[k], db[k]), k
+        ra, rb = ref.get_bboxes(*a, metas), head.get_bboxes(*b, metas)
+    for name, x, y in zip(RES_NAMES, ra[0], rb[0]):
+        assert x.dtype == y.dtype and torch.equal(x, y), name

@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two stages of consecutive batches back to back on one stream")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight in the pipeline")
+    ap.add_argument("--a-streams", type=int, default=1,
+                    help="streams that stage A of consecutive batches alternates between")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -103,7 +105,8 @@ def main():
     head.to(dev)
     head.gemm_mode = args.gemm
     head.use_graphs = not args.no_graphs
-    engine = None if args.no_pipeline else PipelinedHead(head, depth=args.depth)
+    engine = None if args.no_pipeline else PipelinedHead(head, depth=args.depth,
+                                                          a_streams=args.a_streams)
     B, H, W = args.batch, args.height, args.width
     g = torch.Generator().manual_seed(1000 + rank)
     feats_cpu = [torch.relu(torch.randn(B, c, h, w, generator=g))

@@ -4,8 +4,8 @@
 // Thread = (query, head, sampling point, 4 channels): one 256-thread workgroup per
 // query token, 32 lanes per head = 4 points x 8 lanes; the 8 lanes of a point read
 // one 128-byte value row per bilinear tap as float4s (every tap is a full line) and
-// each lane has only L x 4 = 12 independent loads in flight, which keeps the VGPR
-// count low enough for 6+ waves/SIMD on this latency-bound gather.  The softmax over
+// each lane keeps its L x 4 = 12 independent 16-byte loads in flight at once (48 VGPRs,
+// still 5+ waves/SIMD) on this latency-bound gather.  The softmax over
 // the L*P logits and the sum over points are xor-8 / xor-16 shuffles inside the
 // 32-lane group.  (Measured: the kernel sits at ~75 us/layer regardless of L2 locality
 // -- XCD banding, several tokens per workgroup -- i.e. it is bound by the texture-
@@ -30,6 +30,7 @@ __device__ __forceinline__ float grp_sum(float v) {
   return v + __shfl_xor(v, 16, 64);
 }
 
+template <int L>
 __global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
                                               const float* __restrict__ offaw,
                                               float* __restrict__ out,
@@ -38,8 +39,7 @@ __global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
   const int tid = threadIdx.x;
   const int c4 = tid & 7, pt = (tid >> 3) & 3, head = tid >> 5;
   const int b = blockIdx.y;
-  const int L = lv.L;
-  const int LP = L * 4;
+  constexpr int LP = L * 4;
 
   // XCD-aware token order: the dispatcher puts workgroup g on XCD g % 8; give each XCD
   // one horizontal band of the image at EVERY level (rows [k h_l/8, (k+1) h_l/8)), so
@@ -72,48 +72,65 @@ __global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
   const float* offp = oa + head * LP * 2 + pt * 2;
   const float* awp = oa + 8 * LP * 2 + head * LP + pt;
 
-  float e[4];
+  // every offset / logit load is issued before the first dependent use
+  float e[L];
+  float2 off[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    e[l] = awp[l * 4];
+    off[l] = *reinterpret_cast<const float2*>(offp + l * 8);
+  }
   float mx = -INFINITY;
 #pragma unroll
-  for (int l = 0; l < 4; ++l) {
-    e[l] = (l < L) ? awp[l * 4] : -INFINITY;
-    mx = fmaxf(mx, e[l]);
-  }
+  for (int l = 0; l < L; ++l) mx = fmaxf(mx, e[l]);
   mx = grp_max(mx);
   float den = 0.f;
 #pragma unroll
-  for (int l = 0; l < 4; ++l) {
-    e[l] = (l < L) ? expf(e[l] - mx) : 0.f;
+  for (int l = 0; l < L; ++l) {
+    e[l] = expf(e[l] - mx);
     den += e[l];
   }
   den = grp_sum(den);
 
   const float* vb = value + (int64_t)b * lv.N * ldv + head * 32 + c4 * 4;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // All L x 4 taps are loaded UNCONDITIONALLY from clamped coordinates before any is
+  // used (out-of-map taps get weight 0): one memory round trip per thread.  Predicated
+  // loads would be serialised by hipcc into one branch + full vmcnt wait per level.
+  float4 v[L][4];
+  float wt[L][4], awl[L];
 #pragma unroll
-  for (int l = 0; l < 4; ++l) {
-    if (l >= L) break;
+  for (int l = 0; l < L; ++l) {
     const int Hl = lv.h[l], Wl = lv.w[l];
     const float* vl = vb + (int64_t)lv.start[l] * ldv;
-    const float2 off = *reinterpret_cast<const float2*>(offp + l * 8);
-    const float aw = e[l] / den;
-    const float locx = ref_x + off.x / (float)Wl;
-    const float locy = ref_y + off.y / (float)Hl;
+    awl[l] = e[l] / den;
+    const float locx = ref_x + off[l].x / (float)Wl;
+    const float locy = ref_y + off[l].y / (float)Hl;
     const float gx = 2.f * locx - 1.f, gy = 2.f * locy - 1.f;
     const float ix = ((gx + 1.f) * (float)Wl - 1.f) * 0.5f;
     const float iy = ((gy + 1.f) * (float)Hl - 1.f) * 0.5f;
     const float fx = floorf(ix), fy = floorf(iy);
-    const int x0 = (int)fx, y0 = (int)fy;
+    // (clamp before the int conversion: far-out offsets must not overflow it)
+    const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)Wl), y0 = (int)fminf(fmaxf(fy, -2.f), (float)Hl);
     const float tx = ix - fx, ty = iy - fy;
-    const float w_nw = (1.f - tx) * (1.f - ty), w_ne = tx * (1.f - ty);
-    const float w_sw = (1.f - tx) * ty, w_se = tx * ty;
     const bool xin0 = x0 >= 0 && x0 < Wl, xin1 = x0 + 1 >= 0 && x0 + 1 < Wl;
     const bool yin0 = y0 >= 0 && y0 < Hl, yin1 = y0 + 1 >= 0 && y0 + 1 < Hl;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 v_nw = (xin0 && yin0) ? ld4(vl + ((int64_t)y0 * Wl + x0) * ldv) : z;
-    const float4 v_ne = (xin1 && yin0) ? ld4(vl + ((int64_t)y0 * Wl + x0 + 1) * ldv) : z;
-    const float4 v_sw = (xin0 && yin1) ? ld4(vl + ((int64_t)(y0 + 1) * Wl + x0) * ldv) : z;
-    const float4 v_se = (xin1 && yin1) ? ld4(vl + ((int64_t)(y0 + 1) * Wl + x0 + 1) * ldv) : z;
+    wt[l][0] = (xin0 && yin0) ? (1.f - tx) * (1.f - ty) : 0.f;
+    wt[l][1] = (xin1 && yin0) ? tx * (1.f - ty) : 0.f;
+    wt[l][2] = (xin0 && yin1) ? (1.f - tx) * ty : 0.f;
+    wt[l][3] = (xin1 && yin1) ? tx * ty : 0.f;
+    const int xa = min(max(x0, 0), Wl - 1), xb = min(max(x0 + 1, 0), Wl - 1);
+    const int ya = min(max(y0, 0), Hl - 1), yb = min(max(y0 + 1, 0), Hl - 1);
+    v[l][0] = ld4(vl + (int64_t)(ya * Wl + xa) * ldv);
+    v[l][1] = ld4(vl + (int64_t)(ya * Wl + xb) * ldv);
+    v[l][2] = ld4(vl + (int64_t)(yb * Wl + xa) * ldv);
+    v[l][3] = ld4(vl + (int64_t)(yb * Wl + xb) * ldv);
+  }
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const float w_nw = wt[l][0], w_ne = wt[l][1], w_sw = wt[l][2], w_se = wt[l][3];
+    const float4 v_nw = v[l][0], v_ne = v[l][1], v_sw = v[l][2], v_se = v[l][3];
+    const float aw = awl[l];
     float4 s;
     s.x = ((v_nw.x * w_nw + v_ne.x * w_ne) + v_sw.x * w_sw) + v_se.x * w_se;
     s.y = ((v_nw.y * w_nw + v_ne.y * w_ne) + v_sw.y * w_sw) + v_se.y * w_se;
@@ -149,7 +166,13 @@ extern "C" int pn_msda_f32(const float* value, int64_t ld_value, const float* of
     for (int l = 0; l < L; ++l) c += ((((k + 1) * lv.h[l]) >> 3) - ((k * lv.h[l]) >> 3)) * lv.w[l];
     if (c > per_band) per_band = c;
   }
-  hipLaunchKernelGGL(k_msda, dim3(per_band * 8, B), dim3(256), 0, (hipStream_t)stream, value,
-                     offaw, out, lv, ld_value, ld_offaw);
+  const dim3 grid(per_band * 8, B);
+  hipStream_t s = (hipStream_t)stream;
+  switch (L) {
+    case 1: hipLaunchKernelGGL(k_msda<1>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+    case 2: hipLaunchKernelGGL(k_msda<2>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+    case 3: hipLaunchKernelGGL(k_msda<3>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+    default: hipLaunchKernelGGL(k_msda<4>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+  }
   return PN_LAUNCH_CHECK();
 }

@@ -23,23 +23,26 @@ import torch
 
 
 class PipelinedHead:
-    def __init__(self, head, depth=3):
+    def __init__(self, head, depth=3, a_streams=1):
         if head.device is None or head.device.type != "cuda":
             raise RuntimeError("PipelinedHead needs a head on an MI355X (.to('cuda:N'))")
-        if depth < 2:
-            raise ValueError("depth >= 2")
+        if depth < 2 or not 1 <= a_streams < depth:
+            raise ValueError("depth >= 2 and 1 <= a_streams < depth")
         self.head, self.depth = head, depth
         with torch.cuda.device(head.device):
-            self.stream_a = torch.cuda.Stream(priority=0)
+            # a_streams > 1: stage A of consecutive batches alternates between streams, so
+            # one batch's gather / normalisation kernels can run beside another's GEMMs
+            self.streams_a = [torch.cuda.Stream(priority=0) for _ in range(a_streams)]
             # the query chains' small dependent kernels get the high-priority queues
-            self.streams_b = [torch.cuda.Stream(priority=-1) for _ in range(depth - 1)]
+            self.streams_b = [torch.cuda.Stream(priority=-1)
+                              for _ in range(max(1, depth - a_streams))]
             self.a_done = [torch.cuda.Event() for _ in range(depth)]
             self.b_done = [torch.cuda.Event() for _ in range(depth)]
         self.count = 0
         self.queue = []   # per in-flight batch: dict(slot, pl, metas, rescale, b_started)
 
     def _stream_b(self, index):
-        return self.streams_b[index % (self.depth - 1)]
+        return self.streams_b[index % len(self.streams_b)]
 
     @torch.no_grad()
     def submit(self, feats, img_metas, rescale=False):
@@ -51,19 +54,20 @@ class PipelinedHead:
         slot = idx % self.depth
         pl = head._plan(B, shapes, hw2, slot)
         cur = torch.cuda.current_stream(head.device)
-        self.stream_a.wait_stream(cur)                    # feats produced on the caller's stream
+        sa = self.streams_a[idx % len(self.streams_a)]
+        sa.wait_stream(cur)                                # feats produced on the caller's stream
         if idx >= self.depth:
-            self.stream_a.wait_event(self.b_done[slot])   # slot's buffers are free again
-        with torch.cuda.stream(self.stream_a):
+            sa.wait_event(self.b_done[slot])               # slot's buffers are free again
+        with torch.cuda.stream(sa):
             head._run_stage("a", pl, feats)
-            self.a_done[slot].record(self.stream_a)
+            self.a_done[slot].record(sa)
         for f in feats:                                    # keep feats alive until A has read them
-            f.record_stream(self.stream_a)
+            f.record_stream(sa)
         self.queue.append(dict(idx=idx, slot=slot, pl=pl, metas=img_metas, rescale=rescale,
                                b_started=False))
         self.count += 1
-        # start the query chain of every batch but the newest
-        for item in self.queue[:-1]:
+        # start the query chain of every batch whose stage A is not among the newest ones
+        for item in self.queue[:len(self.queue) - len(self.streams_a)]:
             self._start_b(item)
         if len(self.queue) >= self.depth:
             return self._finish(self.queue.pop(0))

@@ -284,12 +284,34 @@ def main():
         out["breakdown_ms"] = {
             "forward": timeit(lambda: head.forward(feats, metas)),
             "get_bboxes": timeit(lambda: head.get_bboxes(*outs, metas))}
-        try:  # reported separately: the PyTorch-ROCm/MIOpen backbone
+        try:  # reported separately: the backbone, native and MIOpen
+            from pairnet_amd import ResNet50Hip
             from pairnet_amd.detector import ResNet50
-            bb = ResNet50().to(dev)
             img = torch.randn(B, 3, H, W, device=dev)
+            nb = ResNet50Hip().to(dev)
+            nb(img)                       # packs the folded weights, plans the buffers
+            torch.cuda.synchronize()
+            out["breakdown_ms"]["backbone_r50_native_fp32_mfma"] = timeit(lambda: nb(img), 10)
+            # image tensor -> triplets: native backbone feeding the pipelined head
+            head.use_graphs = not args.no_graphs
+            e2e = PipelinedHead(head, depth=args.depth)
+            def e2e_steps(n):
+                for _ in range(n):
+                    e2e.submit(nb(img), metas)
+                e2e.flush()
+            e2e_steps(6)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            e2e_steps(20)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) / 20
+            out["end_to_end_from_image_tensor"] = {
+                "images_per_s": B / dt, "ms_per_step": 1e3 * dt,
+                "what": "ResNet50Hip (native fp32 MFMA backbone, random weights) -> "
+                        "channels_last features -> pipelined %s" % type(head).__name__}
+            bb = ResNet50().to(dev)
             out["breakdown_ms"]["backbone_r50_torch_miopen"] = timeit(lambda: bb(img), 3)
-            del bb, img
+            del bb, nb, img
         except Exception as e:  # pragma: no cover
             out["breakdown_ms"]["backbone_error"] = repr(e)
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 4
+#define PN_ABI_VERSION 5
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -50,6 +50,7 @@ int pn_abi_version(void);
 #define PN_GEMM_FORCE_SKINNY 8 /* testing: force the 32x32 split-K-in-block kernel  */
 #define PN_GEMM_FORCE_TILE64 16     /* tuning: 64x64 tile (row-major A)             */
 #define PN_GEMM_FORCE_TILE128x64 32 /* tuning: 128x64 tile                          */
+#define PN_GEMM_RELU_AFTER_RES 128  /* ReLU after the residual add: relu(act(..)+Res)  */
 #define PN_GEMM_SPLIT_BF16 64  /* opt-in: fp32-accurate 3 x bf16 operand split on the
                                   bf16 MFMA (6 partial products, fp32 accumulate;
                                   error <= 3*2^-24 |a||b| per product, not bitwise the
@@ -93,6 +94,28 @@ int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float* bias,
                        float* out, int B, int H, int W, int Cin, int Cout,
                        int KH, int KW, int pad, int relu, int flags /* 0 or
                        PN_GEMM_SPLIT_BF16, | PN_GEMM_FORCE_TILE */, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Backbone: ResNet-50, style "pytorch", frozen BatchNorm
+ * (configs/mask2former/pairnet.py:9-19; mmdet's ResNet is third-party, restated in
+ * oracle/backbone.py).  BatchNorm is folded into the convolution weights / bias by the
+ * caller; activations are channel-last.
+ * ------------------------------------------------------------------------- */
+/* General form of the convolution above: stride >= 1, any padding,
+ *   Ho = (H + 2 pad - KH) / stride + 1 (same for W),
+ *   out = [relu_after](act(conv + bias) + res),  res/out [B][Ho][Wo][Cout],
+ * flags: PN_GEMM_RELU (act), PN_GEMM_RELU_AFTER_RES, tile / split selectors. */
+int pn_conv2d_nhwc_ex_f32(const float* in, const float* Wp, const float* bias,
+                          const float* res, float* out, int B, int H, int W, int Cin,
+                          int Cout, int KH, int KW, int stride, int pad, int flags,
+                          void* stream);
+/* Stem: relu(conv7x7/2 pad 3 (NCHW RGB image) + bias) -> [B][Ho][Wo][64] channel-last.
+ * Wp [64][160] = conv1.weight [64][3][7][7] flattened, zero-padded 147 -> 160. */
+int pn_stem7x7s2_f32(const float* img_nchw, const float* Wp, const float* bias,
+                     float* out, int B, int H, int W, void* stream);
+/* F.max_pool2d(x, 3, stride=2, padding=1) on channel-last data, C % 4 == 0. */
+int pn_maxpool3x3s2_nhwc_f32(const float* in, float* out, int B, int H, int W, int C,
+                             void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Normalisation

@@ -2,6 +2,7 @@
 from .config import (ConfigDict, baseline_head_cfg, baseline_r50, load_config,  # noqa: F401
                      pairnet_head_cfg, pairnet_r50, psgtr2_head_cfg, psgtr2_r50)
 from .psgtr_head2 import PSGTrHead2  # noqa: F401
+from .backbone import ResNet50Hip  # noqa: F401
 from .baseline_head import CrossHeadBaseline  # noqa: F401
 from .head import CrossHead2  # noqa: F401
 from .pipeline import PipelinedHead  # noqa: F401
@@ -11,4 +12,4 @@ from .dist import all_gather_triplets, shard_indices  # noqa: F401
 __all__ = ["ConfigDict", "load_config", "pairnet_head_cfg", "pairnet_r50", "CrossHead2",
            "PSGTr", "Result", "build_detector", "triplet2Result", "all_gather_triplets",
            "shard_indices", "PipelinedHead", "CrossHeadBaseline", "baseline_head_cfg",
-           "baseline_r50", "PSGTrHead2", "psgtr2_head_cfg", "psgtr2_r50"]
+           "baseline_r50", "PSGTrHead2", "psgtr2_head_cfg", "psgtr2_r50", "ResNet50Hip"]

@@ -1,0 +1,210 @@
+"""ResNet-50 on MI355X: the reference's backbone
+(configs/mask2former/pairnet.py:9-19: mmdet ResNet depth 50, style "pytorch", frozen
+BatchNorm, out_indices 0-3) on the head's own fp32-MFMA kernels.
+
+Every convolution is the persistent implicit-GEMM kernel of csrc/gemm.hip (1x1 layers are
+plain GEMMs over the channel-last pixels); BatchNorm (eval mode) is folded into the weights
+and a bias at pack time, ReLU and the residual add live in the GEMM epilogue, activations
+stay channel-last end to end.  The four outputs are returned as NCHW-shaped tensors in
+`torch.channels_last` memory format: mmdet's contract for `feats`, and `CrossHead2` reads
+that format directly (row-major 1x1 input convolutions, no transpose pass).
+
+State-dict names are mmdet's / torchvision's (`conv1.weight`, `bn1.running_mean`,
+`layer3.4.conv2.weight`, `layer2.0.downsample.0.weight`, ...).  No CPU path.
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import hip
+
+STAGES = ((64, 3), (128, 4), (256, 6), (512, 3))
+EPS = 1e-5
+
+
+def _param_shapes():
+    s = OrderedDict()
+
+    def bn(prefix, c):
+        for n in ("weight", "bias", "running_mean", "running_var"):
+            s["%s.%s" % (prefix, n)] = (c,)
+        s[prefix + ".num_batches_tracked"] = ()
+
+    s["conv1.weight"] = (64, 3, 7, 7)
+    bn("bn1", 64)
+    cin = 64
+    for i, (planes, blocks) in enumerate(STAGES):
+        for b in range(blocks):
+            p = "layer%d.%d." % (i + 1, b)
+            s[p + "conv1.weight"] = (planes, cin, 1, 1)
+            bn(p + "bn1", planes)
+            s[p + "conv2.weight"] = (planes, planes, 3, 3)
+            bn(p + "bn2", planes)
+            s[p + "conv3.weight"] = (planes * 4, planes, 1, 1)
+            bn(p + "bn3", planes * 4)
+            if b == 0:
+                s[p + "downsample.0.weight"] = (planes * 4, cin, 1, 1)
+                bn(p + "downsample.1", planes * 4)
+            cin = planes * 4
+    return s
+
+
+class ResNet50Hip:
+    """Drop-in for the detector's `backbone(img) -> (C2, C3, C4, C5)`."""
+
+    def __init__(self, **unused):
+        self._params = OrderedDict(
+            (k, torch.zeros(shape, dtype=torch.int64 if k.endswith("tracked") else torch.float32))
+            for k, shape in _param_shapes().items())
+        for k, v in self._params.items():          # identity BatchNorm until weights are loaded
+            if k.endswith(("running_var",)) or (k.endswith(".weight") and v.dim() == 1):
+                v.fill_(1.0)
+        g = torch.Generator().manual_seed(0)
+        for k, v in self._params.items():
+            if v.dim() == 4:
+                fan_in = v.shape[1] * v.shape[2] * v.shape[3]
+                v.copy_(torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5)
+        self.device, self.w, self._plans = None, None, {}
+
+    def state_dict(self):
+        return OrderedDict((k, v.clone()) for k, v in self._params.items())
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self._params if k not in sd]
+        unexpected = [k for k in sd if k not in self._params]
+        if strict and (missing or unexpected):
+            raise RuntimeError("state_dict mismatch: missing %s unexpected %s"
+                               % (missing[:5], unexpected[:5]))
+        for k, p in self._params.items():
+            if k in sd:
+                if tuple(sd[k].shape) != tuple(p.shape):
+                    raise RuntimeError("shape mismatch for %s" % k)
+                p.copy_(sd[k].detach().to(p.dtype).cpu())
+        self.w = None
+        return missing, unexpected
+
+    def to(self, device):
+        self.device, self.w, self._plans = torch.device(device), None, {}
+        return self
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------ packing
+    def _fold(self, conv, bn):
+        """conv weight [co][ci][kh][kw] + eval-mode BatchNorm -> ([co][(ky*KW+kx)*ci + ci'],
+        bias[co]) on the device:  bn(conv(x)) = conv(x) * s + (beta - mean * s),
+        s = gamma / sqrt(var + eps)."""
+        P = self._params
+        w = P[conv + ".weight"].double()
+        s = P[bn + ".weight"].double() / torch.sqrt(P[bn + ".running_var"].double() + EPS)
+        b = P[bn + ".bias"].double() - P[bn + ".running_mean"].double() * s
+        w = (w * s.view(-1, 1, 1, 1)).float()
+        return w, b.float()
+
+    def _pack(self):
+        if self.device is None or self.device.type != "cuda":
+            raise RuntimeError("ResNet50Hip runs on an MI355X only: call .to('cuda:0'); there "
+                               "is no CPU path")
+        hip.lib()
+        dev, w = self.device, {}
+        cw, cb = self._fold("conv1", "bn1")
+        stem = torch.zeros(64, 160)
+        stem[:, :147] = cw.reshape(64, 147)                # k = c*49 + ky*7 + kx
+        w["stem.w"], w["stem.b"] = stem.to(dev), cb.to(dev)
+        for i, (planes, blocks) in enumerate(STAGES):
+            for b in range(blocks):
+                p = "layer%d.%d." % (i + 1, b)
+                for conv, bn in (("conv1", "bn1"), ("conv2", "bn2"), ("conv3", "bn3"),
+                                 ("downsample.0", "downsample.1")):
+                    if p + conv + ".weight" not in self._params:
+                        continue
+                    cw, cb = self._fold(p + conv, p + bn)
+                    co = cw.shape[0]
+                    w[p + conv + ".w"] = cw.permute(0, 2, 3, 1).reshape(co, -1).contiguous().to(dev)
+                    w[p + conv + ".b"] = cb.to(dev)
+        self.w = w
+
+    class _Plan:
+        pass
+
+    def _plan(self, B, H, W):
+        key = (B, H, W)
+        if key in self._plans:
+            return self._plans[key]
+        if self.w is None:
+            self._pack()
+        E = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
+        pl = ResNet50Hip._Plan()
+        pl.B = B
+        h1, w1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        h, wd = (h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1
+        pl.stem, pl.hw_stem = E(B, h1, w1, 64), (h1, w1)
+        pl.pool = E(B, h, wd, 64)
+        pl.hw, pl.out, pl.t1, pl.t2, pl.idt, pl.ping = [], [], [], [], [], []
+        for i, (planes, blocks) in enumerate(STAGES):
+            hin, win = h, wd
+            if i > 0:
+                h, wd = (h - 1) // 2 + 1, (wd - 1) // 2 + 1
+            pl.hw.append(((hin, win), (h, wd)))
+            pl.t1.append(E(B, hin, win, planes))       # conv1 output at the input resolution
+            pl.t2.append(E(B, h, wd, planes))
+            pl.idt.append(E(B, h, wd, planes * 4))
+            pl.ping.append(E(B, h, wd, planes * 4))
+            pl.out.append(E(B, h, wd, planes * 4))
+        self._plans[key] = pl
+        return pl
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, img):
+        """img [B,3,H,W] fp32 NCHW on the GPU -> (C2, C3, C4, C5) NCHW-shaped tensors in
+        channels_last memory format (views of per-shape buffers that the next call
+        overwrites)."""
+        if not img.is_cuda or img.dtype != torch.float32 or img.dim() != 4 or img.shape[1] != 3:
+            raise RuntimeError("img must be a [B,3,H,W] fp32 device tensor")
+        if self.device is None:
+            self.to(img.device)
+        img = img.contiguous()
+        B, _, H, W = img.shape
+        pl = self._plan(B, H, W)
+        w = self.w
+        hip.stem7x7s2(img, w["stem.w"], w["stem.b"], pl.stem, B, H, W)
+        hip.maxpool3x3s2(pl.stem, pl.pool, B, pl.hw_stem[0], pl.hw_stem[1], 64)
+        x, cin = pl.pool, 64
+        for i, (planes, blocks) in enumerate(STAGES):
+            (hin, win), (h, wd) = pl.hw[i]
+            for b in range(blocks):
+                p = "layer%d.%d." % (i + 1, b)
+                stride = 2 if (b == 0 and i > 0) else 1
+                hi, wi = (hin, win) if b == 0 else (h, wd)
+                t1 = pl.t1[i].view(-1)[:B * hi * wi * planes].view(B, hi, wi, planes)
+                # conv1 1x1 (+BN+ReLU): a GEMM over the pixels
+                hip.linear(x.view(-1, cin), w[p + "conv1.w"], w[p + "conv1.b"],
+                           t1.view(-1, planes), relu=True)
+                # conv2 3x3, stride on this layer ("pytorch" style) (+BN+ReLU)
+                hip.conv2d_ex(t1, w[p + "conv2.w"], w[p + "conv2.b"], None, pl.t2[i], B, hi, wi,
+                              planes, planes, 3, 3, stride, 1, relu=True)
+                # shortcut: projection in the first block of a stage, identity after it
+                if b == 0:
+                    if stride == 1:
+                        hip.linear(x.view(-1, cin), w[p + "downsample.0.w"],
+                                   w[p + "downsample.0.b"], pl.idt[i].view(-1, planes * 4))
+                    else:
+                        hip.conv2d_ex(x, w[p + "downsample.0.w"], w[p + "downsample.0.b"], None,
+                                      pl.idt[i], B, hi, wi, cin, planes * 4, 1, 1, stride, 0)
+                    idt = pl.idt[i]
+                else:
+                    idt = x
+                # conv3 1x1 (+BN) + shortcut, ReLU; the block input stays intact until here
+                if b == blocks - 1:
+                    dst = pl.out[i]
+                else:
+                    dst = pl.ping[i] if idt is not pl.ping[i] else pl.idt[i]
+                hip.linear(pl.t2[i].view(-1, planes), w[p + "conv3.w"], w[p + "conv3.b"],
+                           dst.view(-1, planes * 4), res=idt.view(-1, planes * 4),
+                           relu_after=True)
+                x, cin = dst, planes * 4
+        return tuple(o.permute(0, 3, 1, 2) for o in pl.out)
+
+    __call__ = forward

@@ -129,13 +129,17 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         const int gm = min(m0 + (tid >> 3) + 32 * j, p.M - 1);
-        a_off[j] = ((unsigned)gm * (unsigned)p.lda + kc) * 4u;
+        if (AMODE == A_CONV || AMODE == A_STEM) {
+          // output pixel -> input coordinates of tap (0, 0) + pad
+          const int oy = gm / p.Wo, ox = gm - oy * p.Wo;
+          cy[j] = oy * p.stride;
+          cx[j] = ox * p.stride;
+          a_off[j] = ((unsigned)(cy[j] * p.Wd + cx[j]) * (unsigned)p.Cin + kc) * 4u;
+        } else {
+          a_off[j] = ((unsigned)gm * (unsigned)p.lda + kc) * 4u;
+        }
         if (ADD) add_off[j] = ((unsigned)(p.Aadd ? gm % p.aadd_rows : gm) *
                                    (unsigned)(p.Aadd ? p.ldaadd : p.lda) + kc) * 4u;
-        if (AMODE == A_CONV) {
-          cy[j] = gm / p.Wd;
-          cx[j] = gm - cy[j] * p.Wd;
-        }
       }
     }
 #pragma unroll
@@ -177,6 +181,29 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
           ra[j].w = buf_ld1(rA, a_off1[j][3], soff);
         }
       }
+    } else if (AMODE == A_STEM) {
+      // K index k = c * 49 + ky * 7 + kx (PyTorch weight order), 147 real + 13 zero
+      // columns; the image is NCHW, so the 4 k of a lane are 4 scalar gathers
+      const GemmP& p = loc.P(lpi);
+      st_in = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = k0 + kc + e;
+        const int c = k / 49, r = k - c * 49;
+        const int ky = r / 7 - p.pad, kx = r - (r / 7) * 7 - p.pad;
+        const bool kvalid = k < 147;
+        const int cc = min(c, 2);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          const int iy = cy[j] + ky, ix = cx[j] + kx;
+          const bool in = kvalid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd;
+          const int yc = min(max(iy, 0), p.H - 1), xc = min(max(ix, 0), p.Wd - 1);
+          const float v = buf_ld1(rA, (unsigned)((cc * p.H + yc) * p.Wd + xc) * 4u, 0);
+          if (e == 0) ra[j].x = v; else if (e == 1) ra[j].y = v;
+          else if (e == 2) ra[j].z = v; else ra[j].w = v;
+          st_in |= (in ? 1u : 0u) << (j * 4 + e);
+        }
+      }
     } else if (AMODE == A_CONV) {
       const GemmP& p = loc.P(lpi);
       const int tap = k0 / p.Cin;
@@ -216,6 +243,13 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
     for (int j = 0; j < NA; ++j) {
       if (ADD && st_add) ra[j] = add4(ra[j], rad[j]);
       if (AMODE == A_CONV && !((st_in >> j) & 1u)) ra[j] = zero4;
+      if (AMODE == A_STEM) {
+        const unsigned m = st_in >> (j * 4);
+        ra[j].x = (m & 1u) ? ra[j].x : 0.f;
+        ra[j].y = (m & 2u) ? ra[j].y : 0.f;
+        ra[j].z = (m & 4u) ? ra[j].z : 0.f;
+        ra[j].w = (m & 8u) ? ra[j].w : 0.f;
+      }
     }
     if (st_ragged) {   // uniform, rare: the ragged chunk was loaded from k = 0; reload it
       // synchronously with per-element bounds (slow path, correctness only)
@@ -350,6 +384,7 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
           float v = acc[mi][ni][r] + bv;
           if (p.relu) v = fmaxf(v, 0.f);
           if (Res) v += rv[r];
+          if (p.relu_after) v = fmaxf(v, 0.f);
           ov[r] = v;
         }
         // interior tiles store without per-element predicates (hipcc puts a full
@@ -516,6 +551,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_skinny(const GemmP p) {
       if (p.bias) v += p.bias[col];
       if (p.relu) v = fmaxf(v, 0.f);
       if (Res) v += Res[(int64_t)row * p.ldres + col];
+      if (p.relu_after) v = fmaxf(v, 0.f);
       C[(int64_t)row * p.ldc + col] = v;
     }
   }
@@ -596,6 +632,7 @@ int pn_fill_params(const pn_gemm_desc* d, GemmP* out) {
   p.M = d->M; p.N = d->N; p.K = d->K; p.aadd_rows = d->Aadd ? d->aadd_rows : 1;
   p.aadd_from_col = d->Aadd ? d->aadd_from_col : 0;
   p.relu = (d->flags & PN_GEMM_RELU) ? 1 : 0;
+  p.relu_after = (d->flags & PN_GEMM_RELU_AFTER_RES) ? 1 : 0;
   p.a_vec = colmajor && d->lda % 4 == 0 && d->strideA % 4 == 0 && aligned16(d->A);
   *out = p;
   return 0;
@@ -644,22 +681,29 @@ extern "C" int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream)
   return PN_LAUNCH_CHECK();
 }
 
-extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float* bias,
-                                  float* out, int B, int H, int W, int Cin, int Cout,
-                                  int KH, int KW, int pad, int relu, int flags,
-                                  void* stream) {
-  if (!in || !Wp || !out || B <= 0 || H <= 0 || W <= 0) return PN_BAD_ARG;
+extern "C" int pn_conv2d_nhwc_ex_f32(const float* in, const float* Wp, const float* bias,
+                                     const float* res, float* out, int B, int H, int W,
+                                     int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                     int flags, void* stream) {
+  if (!in || !Wp || !out || B <= 0 || H <= 0 || W <= 0 || stride <= 0 || pad < 0)
+    return PN_BAD_ARG;
   if (Cin % 32 || !aligned16(in) || !aligned16(Wp)) return PN_BAD_ARG;
   if ((int64_t)H * W * Cin >= ((int64_t)1 << 29)) return PN_BAD_ARG;
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return PN_BAD_ARG;
   GemmP p{};
-  p.A = in; p.W = Wp; p.bias = bias; p.C = out;
-  p.M = H * W; p.N = Cout; p.K = KH * KW * Cin;
-  p.lda = Cin; p.ldw = p.K; p.ldc = Cout;
-  p.sA = (int64_t)H * W * Cin; p.sW = 0; p.sC = (int64_t)H * W * Cout;
-  p.relu = relu ? 1 : 0; p.aadd_rows = 1;
-  p.H = H; p.Wd = W; p.Cin = Cin; p.KW = KW; p.pad = pad;
+  p.A = in; p.W = Wp; p.bias = bias; p.C = out; p.Res = res;
+  p.M = Ho * Wo; p.N = Cout; p.K = KH * KW * Cin;
+  p.lda = Cin; p.ldw = p.K; p.ldc = Cout; p.ldres = Cout;
+  p.sA = (int64_t)H * W * Cin; p.sW = 0;
+  p.sC = p.sRes = (int64_t)Ho * Wo * Cout;
+  p.relu = (flags & PN_GEMM_RELU) ? 1 : 0;
+  p.relu_after = (flags & PN_GEMM_RELU_AFTER_RES) ? 1 : 0;
+  p.aadd_rows = 1;
+  p.H = H; p.Wd = W; p.Cin = Cin; p.KW = KW; p.pad = pad; p.stride = stride; p.Wo = Wo;
   hipStream_t s = (hipStream_t)stream;
   if (flags & PN_GEMM_SPLIT_BF16) {
+    if (stride != 1 || Ho != H || Wo != W || res || p.relu_after) return PN_BAD_ARG;
     return pn_launch_gemm_split(p, B, /*conv=*/true, (flags & PN_GEMM_FORCE_TILE) != 0, s);
   }
   // 64x64 tiles everywhere (3x3 FPN conv on MI355X: 625 us / 126 TFLOP/s, against 730
@@ -668,6 +712,33 @@ extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float*
   if (flags & PN_GEMM_FORCE_TILE128x64) return launch_tile<128, 64, 64, 32, A_CONV>(p, B, s);
   if (flags & PN_GEMM_FORCE_TILE) return launch_tile<128, 128, 64, 64, A_CONV>(p, B, s);
   return launch_tile<64, 64, 32, 32, A_CONV>(p, B, s);
+}
+
+extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float* bias,
+                                  float* out, int B, int H, int W, int Cin, int Cout,
+                                  int KH, int KW, int pad, int relu, int flags,
+                                  void* stream) {
+  if (KH != 2 * pad + 1 || KW != 2 * pad + 1) return PN_BAD_ARG;   // "same" convolution
+  return pn_conv2d_nhwc_ex_f32(in, Wp, bias, nullptr, out, B, H, W, Cin, Cout, KH, KW, 1, pad,
+                               (flags & ~PN_GEMM_RELU) | (relu ? PN_GEMM_RELU : 0), stream);
+}
+
+// ResNet stem: 7x7 stride-2 pad-3 convolution of the NCHW RGB image + folded BatchNorm
+// + ReLU -> channel-last [B][Ho][Wo][64].  Wp is [64][160]: the PyTorch weight
+// [64][3][7][7] flattened (k = c*49 + ky*7 + kx) and zero-padded from 147 to 160.
+extern "C" int pn_stem7x7s2_f32(const float* img, const float* Wp, const float* bias, float* out,
+                                int B, int H, int W, void* stream) {
+  if (!img || !Wp || !out || B <= 0 || H <= 0 || W <= 0 || !aligned16(Wp)) return PN_BAD_ARG;
+  if ((int64_t)3 * H * W >= ((int64_t)1 << 29)) return PN_BAD_ARG;
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  GemmP p{};
+  p.A = img; p.W = Wp; p.bias = bias; p.C = out;
+  p.M = Ho * Wo; p.N = 64; p.K = 160;
+  p.lda = 0; p.ldw = 160; p.ldc = 64;
+  p.sA = (int64_t)3 * H * W; p.sW = 0; p.sC = (int64_t)Ho * Wo * 64;
+  p.relu = 1; p.aadd_rows = 1;
+  p.H = H; p.Wd = W; p.Cin = 0; p.KW = 7; p.pad = 3; p.stride = 2; p.Wo = Wo;
+  return launch_tile<64, 64, 32, 32, A_STEM>(p, B, (hipStream_t)stream);
 }
 
 extern "C" int pn_abi_version(void) { return PN_ABI_VERSION; }

@@ -8,10 +8,14 @@ struct GemmP {
   int64_t lda, ldaadd, ldw, ldres, ldc;
   int64_t sA, sW, sRes, sC;
   int M, N, K, aadd_rows, aadd_from_col, relu, a_vec;
-  int H, Wd, Cin, KW, pad;  // conv mode
+  int relu_after;           // ReLU after the residual add (ResNet bottleneck output)
+  // conv modes: input H x Wd x Cin (A_STEM: NCHW, Cin = 3), output rows M = Ho * Wo
+  int H, Wd, Cin, KW, pad, stride, Wo;
 };
 
-enum { A_ROW = 0, A_COL = 1, A_CONV = 2 };
+// A operand: row-major matrix | column-major matrix | implicit im2col of a channel-last
+// image | implicit im2col of the NCHW RGB image for ResNet's 7x7/2 stem (K = 147 -> 160)
+enum { A_ROW = 0, A_COL = 1, A_CONV = 2, A_STEM = 3 };
 
 
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }

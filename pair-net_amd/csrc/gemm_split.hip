@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_gemm_split(const GemmP p) {
         const int row = m0 + wm * WM + mi * 32 + mfma32_row(r, lh);
         if (row < p.M) {
           float v = acc[mi][ni][r] + bv;
-          if (p.relu) v = fmaxf(v, 0.f);
+          if (p.relu) v = fmaxf(v, 0.f);  // (relu_after: not offered by the split path)
           if (Res) v += Res[(int64_t)row * p.ldres + col];
           C[(int64_t)row * p.ldc + col] = v;
         }

@@ -130,3 +130,43 @@ extern "C" int pn_bilinear_planar_gt0_u8(const float* in, uint8_t* out, int64_t 
                                          int ho, int wo, void* stream) {
   return launch_planar(in, out, P, hi, wi, ho, wo, true, stream);
 }
+
+// ---- 3x3 stride-2 pad-1 max pooling, channel-last (ResNet stem) ----
+__global__ __launch_bounds__(256) void k_maxpool3x3s2(const float* __restrict__ in,
+                                                      float* __restrict__ out, int H, int W,
+                                                      int Ho, int Wo, int C4) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (pixel, float4 channel group)
+  const int64_t total = (int64_t)Ho * Wo * C4;
+  if (e >= total) return;
+  const int b = blockIdx.y;
+  const int c = (int)(e % C4);
+  const int pix = (int)(e / C4);
+  const int oy = pix / Wo, ox = pix - oy * Wo;
+  const float* ib = in + (int64_t)b * H * W * C4 * 4;
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * 2 - 1 + ky;
+    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * 2 - 1 + kx;
+      if (ix < 0 || ix >= W) continue;
+      const float4 v = ld4(ib + ((int64_t)iy * W + ix) * C4 * 4 + c * 4);
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+  }
+  st4(out + ((int64_t)b * Ho * Wo * C4 + e) * 4, m);
+}
+
+extern "C" int pn_maxpool3x3s2_nhwc_f32(const float* in, float* out, int B, int H, int W, int C,
+                                        void* stream) {
+  if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 ||
+      (((uintptr_t)in | (uintptr_t)out) & 15))
+    return PN_BAD_ARG;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(k_maxpool3x3s2, dim3(pn_cdiv(total, 256), B), dim3(256), 0,
+                     (hipStream_t)stream, in, out, H, W, Ho, Wo, C / 4);
+  return PN_LAUNCH_CHECK();
+}

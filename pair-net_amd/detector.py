@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .config import ConfigDict
+from .backbone import ResNet50Hip
 from .baseline_head import CrossHeadBaseline
 from .head import CrossHead2
 from .psgtr_head2 import PSGTrHead2
@@ -118,7 +119,12 @@ class PSGTr:
         backbone = ConfigDict(backbone)
         if backbone.get("type", "ResNet") != "ResNet" or backbone.get("depth", 50) != 50:
             raise NotImplementedError("only the ResNet-50 backbone of pairnet.py is built")
-        self.backbone = ResNet50()
+        # "hip" (default): the native fp32-MFMA backbone of backbone.py, channels_last
+        # features straight into the head; "torch": PyTorch-ROCm / MIOpen (same state dict)
+        impl = backbone.get("impl", "hip")
+        if impl not in ("hip", "torch"):
+            raise ValueError("backbone.impl must be 'hip' or 'torch'")
+        self.backbone = ResNet50Hip() if impl == "hip" else ResNet50()
         head_cfg = dict(bbox_head)
         heads = dict(CrossHead2=CrossHead2, CrossHeadBaseline=CrossHeadBaseline,
                      PSGTrHead2=PSGTrHead2)

@@ -314,8 +314,9 @@ class CrossHead2:
     class _Plan:
         pass
 
-    def _plan(self, B, shapes, hw2, slot=0):
-        key = (B, tuple(shapes), tuple(hw2), slot, getattr(self, "return_all_layers", False))
+    def _plan(self, B, shapes, hw2, slot=0, nhwc=False):
+        key = (B, tuple(shapes), tuple(hw2), slot, getattr(self, "return_all_layers", False),
+               nhwc)
         if key in self._plans:
             return self._plans[key]
         if self.w is None:
@@ -323,7 +324,7 @@ class CrossHead2:
         dev, f32 = self.device, torch.float32
         E = lambda *s: torch.empty(*s, device=dev, dtype=f32)
         pl = CrossHead2._Plan()
-        pl.B, pl.shapes, pl.hw2 = B, list(shapes), tuple(hw2)
+        pl.B, pl.shapes, pl.hw2, pl.nhwc = B, list(shapes), tuple(hw2), nhwc
         pl.graph_a = pl.graph_b = pl.static_feats = pl.graph_cfg = None
         pl.calls_a = pl.calls_b = 0
         pl.N = [h * w for h, w in shapes]
@@ -408,9 +409,12 @@ class CrossHead2:
         for l in range(3):
             f = feats[3 - l]
             cin, n = f.shape[1], pl.N[l]
+            # NCHW features are read as column-major A operands, channels_last ones as
+            # row-major [pixels][channels]: no transpose pass either way
             hip.gemm(f, w[pd + "input_convs.%d.conv.weight" % l], pl.tmpconv, M=n, N=256, K=cin,
-                     lda=n, ldw=cin, ldc=256, bias=w[pd + "input_convs.%d.conv.bias" % l],
-                     batch=B, sA=cin * n, sC=n * 256, colmajor=True)
+                     lda=cin if pl.nhwc else n, ldw=cin, ldc=256,
+                     bias=w[pd + "input_convs.%d.conv.bias" % l], batch=B, sA=cin * n,
+                     sC=n * 256, colmajor=not pl.nhwc)
             hip.groupnorm_nhwc(pl.tmpconv, w[pd + "input_convs.%d.gn.weight" % l],
                                w[pd + "input_convs.%d.gn.bias" % l], pl.X[:, pl.start[l]:],
                                pl.gn_part, B, n, self.gn_groups, False, n * 256, SN * 256)
@@ -434,8 +438,9 @@ class CrossHead2:
         f = feats[0]
         cin, HW2 = f.shape[1], pl.HW2
         H2, W2 = pl.hw2
-        hip.gemm(f, w[pd + "lateral_convs.0.conv.weight"], pl.T1, M=HW2, N=256, K=cin, lda=HW2,
-                 ldw=cin, ldc=256, batch=B, sA=cin * HW2, sC=HW2 * 256, colmajor=True)
+        hip.gemm(f, w[pd + "lateral_convs.0.conv.weight"], pl.T1, M=HW2, N=256, K=cin,
+                 lda=cin if pl.nhwc else HW2, ldw=cin, ldc=256, batch=B, sA=cin * HW2,
+                 sC=HW2 * 256, colmajor=not pl.nhwc)
         hip.groupnorm_nhwc(pl.T1, w[pd + "lateral_convs.0.gn.weight"],
                            w[pd + "lateral_convs.0.gn.bias"], pl.T2, pl.gn_part, B, HW2,
                            self.gn_groups, False, HW2 * 256, HW2 * 256)
@@ -653,13 +658,17 @@ class CrossHead2:
     def _check_feats(self, feats, img_metas):
         B = len(img_metas)
         assert len(feats) == 4 and all(f.shape[0] == B for f in feats)
+        nchw = all(f.is_contiguous() for f in feats)
+        nhwc = not nchw and all(f.is_contiguous(memory_format=torch.channels_last) for f in feats)
         for f, c in zip(feats, self.in_channels):
-            if not f.is_cuda or f.dtype != torch.float32 or f.shape[1] != c or not f.is_contiguous():
-                raise RuntimeError("feats must be contiguous fp32 NCHW device tensors with "
-                                   "channels %s" % self.in_channels)
+            if not f.is_cuda or f.dtype != torch.float32 or f.shape[1] != c or not (nchw or nhwc):
+                raise RuntimeError("feats must be fp32 [B,C,H,W] device tensors with channels %s, "
+                                   "all contiguous or all in channels_last memory format"
+                                   % self.in_channels)
         if self.device is None:
             self.to(feats[0].device)
         shapes = [tuple(feats[3 - l].shape[-2:]) for l in range(3)]
+        self._feats_nhwc = nhwc
         return B, shapes, tuple(feats[0].shape[-2:])
 
     def _run_stage(self, which, pl, feats=None):
@@ -709,7 +718,7 @@ class CrossHead2:
         dicts (pairnet_head.py:405-417).  Output tensors are views of per-shape
         buffers that the next forward() of the same shape (and slot) overwrites."""
         B, shapes, hw2 = self._check_feats(feats, img_metas)
-        pl = self._plan(B, shapes, hw2, slot)
+        pl = self._plan(B, shapes, hw2, slot, self._feats_nhwc)
         self._run_stage("a", pl, feats)
         self._run_stage("b", pl)
         self._last_plan = pl

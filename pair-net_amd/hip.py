@@ -15,6 +15,7 @@ _i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 GEMM_RELU, GEMM_A_COLMAJOR, GEMM_FORCE_TILE, GEMM_FORCE_SKINNY = 1, 2, 4, 8
 GEMM_FORCE_TILE64, GEMM_FORCE_TILE128x64 = 16, 32
+GEMM_RELU_AFTER_RES = 128
 
 
 class GemmDesc(C.Structure):
@@ -35,6 +36,9 @@ _SIGS = {
     "pn_gemm_variant": (C.c_int, [C.POINTER(GemmDesc)]),
     "pn_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
     "pn_conv2d_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp]),
+    "pn_conv2d_nhwc_ex_f32": (C.c_int, [_vp] * 5 + [_i32] * 10 + [_vp]),
+    "pn_stem7x7s2_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "pn_maxpool3x3s2_nhwc_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_layernorm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "pn_groupnorm_nblk": (C.c_int, [_i64]),
     "pn_groupnorm_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32,
@@ -70,7 +74,7 @@ _SIGS = {
     "pn_mask_iou_counts": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 4   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 5   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -165,7 +169,8 @@ def _rowmajor(t):
 
 def gemm_desc(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaadd=0,
               aadd_rows=0, aadd_from_col=0, res=None, ldres=0, batch=1, sA=0, sW=0, sC=0,
-              sRes=0, relu=False, colmajor=False, force=None, split=False, into=None):
+              sRes=0, relu=False, colmajor=False, force=None, split=False, into=None,
+              relu_after=False):
     """Fill a pn_gemm_desc; tensors only supply base pointers."""
     d = into if into is not None else GemmDesc()
     d.A, d.lda, d.strideA = _ptr(A), lda, sA
@@ -177,7 +182,8 @@ def gemm_desc(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaad
     d.M, d.N, d.K, d.batch = M, N, K, batch
     d.flags = (GEMM_RELU if relu else 0) | (GEMM_A_COLMAJOR if colmajor else 0) | \
         {None: 0, "tile": GEMM_FORCE_TILE, "skinny": GEMM_FORCE_SKINNY, "tile64": 16,
-         "tile128x64": 32}[force] | (GEMM_SPLIT_BF16 if split else 0)
+         "tile128x64": 32}[force] | (GEMM_SPLIT_BF16 if split else 0) | \
+        (GEMM_RELU_AFTER_RES if relu_after else 0)
     return d
 
 
@@ -209,7 +215,7 @@ def gemm_group(problems):
 
 
 def linear(x, weight, bias, out, *, aadd=None, aadd_from_col=0, res=None, relu=False,
-           force=None, split=False):
+           force=None, split=False, relu_after=False):
     """out = act((x + aadd[row % len(aadd)]) @ weight.T + bias) + res on 2-D views
     (aadd only feeds output columns >= aadd_from_col)."""
     M, lda = _rowmajor(x)
@@ -225,7 +231,7 @@ def linear(x, weight, bias, out, *, aadd=None, aadd_from_col=0, res=None, relu=F
         assert rr == M
         kw.update(res=res, ldres=ldr)
     gemm(x, weight, out, M=M, N=N, K=x.shape[1], lda=lda, ldw=ldw, ldc=ldc, bias=bias,
-         relu=relu, force=force, split=split, **kw)
+         relu=relu, force=force, split=split, relu_after=relu_after, **kw)
 
 
 def conv2d_nhwc(x, wp, bias, out, B, H, W, Cin, Cout, KH, KW, pad, relu, split=False,
@@ -242,6 +248,33 @@ def conv2d_nhwc(x, wp, bias, out, B, H, W, Cin, Cout, KH, KW, pad, relu, split=F
         _ptr(x), _ptr(wp), _ptr(bias), _ptr(out), B, H, W, Cin, Cout, KH, KW, pad, int(relu),
         (GEMM_SPLIT_BF16 if split else 0) | (GEMM_FORCE_TILE if big_tile else 0) | tflag,
         _stream())), "pn_conv2d_nhwc_f32")
+
+
+def conv2d_ex(x, wp, bias, res, out, B, H, W, Cin, Cout, KH, KW, stride, pad, relu=False,
+              relu_after=False):
+    """General channel-last convolution (stride, residual, ReLU before / after it)."""
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    flops = 2.0 * B * Ho * Wo * Cout * KH * KW * Cin
+    nbytes = 4.0 * (B * (H * W * Cin + Ho * Wo * Cout * (2 if res is not None else 1))
+                    + Cout * KH * KW * Cin)
+    flags = (GEMM_RELU if relu else 0) | (GEMM_RELU_AFTER_RES if relu_after else 0)
+    _check(_launch("k_gemm_tile<64,64,32,32,A_CONV>", flops, nbytes,
+                   lambda: lib().pn_conv2d_nhwc_ex_f32(
+                       _ptr(x), _ptr(wp), _ptr(bias), _ptr(res), _ptr(out), B, H, W, Cin, Cout,
+                       KH, KW, stride, pad, flags, _stream())), "pn_conv2d_nhwc_ex_f32")
+
+
+def stem7x7s2(img, wp, bias, out, B, H, W):
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    _check(_launch("k_gemm_tile<64,64,32,32,A_STEM>", 2.0 * B * Ho * Wo * 64 * 147,
+                   4.0 * B * (3 * H * W + Ho * Wo * 64),
+                   lambda: lib().pn_stem7x7s2_f32(_ptr(img), _ptr(wp), _ptr(bias), _ptr(out), B,
+                                                  H, W, _stream())), "pn_stem7x7s2_f32")
+
+
+def maxpool3x3s2(x, out, B, H, W, Cc):
+    _check(lib().pn_maxpool3x3s2_nhwc_f32(_ptr(x), _ptr(out), B, H, W, Cc, _stream()),
+           "pn_maxpool3x3s2_nhwc_f32")
 
 
 def layernorm(x, gamma, beta, out, eps=1e-5):

@@ -52,7 +52,7 @@ class PipelinedHead:
         B, shapes, hw2 = head._check_feats(feats, img_metas)
         idx = self.count
         slot = idx % self.depth
-        pl = head._plan(B, shapes, hw2, slot)
+        pl = head._plan(B, shapes, hw2, slot, head._feats_nhwc)
         cur = torch.cuda.current_stream(head.device)
         sa = self.streams_a[idx % len(self.streams_a)]
         sa.wait_stream(cur)                                # feats produced on the caller's stream

@@ -66,6 +66,10 @@ typedef struct pn_gemm_desc {
   const float* Res;   int64_t ldres;  int64_t strideRes;  /* optional residual     */
   float*       C;     int64_t ldc;    int64_t strideC;    /* [M][N]                */
   int32_t M, N, K, batch, flags;
+  /* optional split-K workspace (NULL = never split): problems whose M x N gives too few
+   * 64x64 tiles to fill 256 CUs (the backbone's late stages, the C5/C4 input convs)
+   * contract K in up to 16 slices into this scratch and sum them in slice order */
+  float* splitk_scratch;  int64_t splitk_scratch_floats;
 } pn_gemm_desc;
 
 int pn_gemm_f32(const pn_gemm_desc* d, void* stream);
@@ -108,7 +112,8 @@ int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float* bias,
 int pn_conv2d_nhwc_ex_f32(const float* in, const float* Wp, const float* bias,
                           const float* res, float* out, int B, int H, int W, int Cin,
                           int Cout, int KH, int KW, int stride, int pad, int flags,
-                          void* stream);
+                          float* splitk_scratch /* or NULL */,
+                          int64_t splitk_scratch_floats, void* stream);
 /* Stem: relu(conv7x7/2 pad 3 (NCHW RGB image) + bias) -> [B][Ho][Wo][64] channel-last.
  * Wp [64][160] = conv1.weight [64][3][7][7] flattened, zero-padded 147 -> 160. */
 int pn_stem7x7s2_f32(const float* img_nchw, const float* Wp, const float* bias,

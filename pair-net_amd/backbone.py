@@ -141,6 +141,9 @@ class ResNet50Hip:
         h, wd = (h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1
         pl.stem, pl.hw_stem = E(B, h1, w1, 64), (h1, w1)
         pl.pool = E(B, h, wd, 64)
+        # split-K workspace for the late stages (few output tiles, long K): sized for the
+        # largest S x M x N the library can ask for here
+        pl.scratch = E(B * 16 * 1024 * 1024 // 2)
         pl.hw, pl.out, pl.t1, pl.t2, pl.idt, pl.ping = [], [], [], [], [], []
         for i, (planes, blocks) in enumerate(STAGES):
             hin, win = h, wd
@@ -181,18 +184,20 @@ class ResNet50Hip:
                 t1 = pl.t1[i].view(-1)[:B * hi * wi * planes].view(B, hi, wi, planes)
                 # conv1 1x1 (+BN+ReLU): a GEMM over the pixels
                 hip.linear(x.view(-1, cin), w[p + "conv1.w"], w[p + "conv1.b"],
-                           t1.view(-1, planes), relu=True)
+                           t1.view(-1, planes), relu=True, scratch=pl.scratch)
                 # conv2 3x3, stride on this layer ("pytorch" style) (+BN+ReLU)
                 hip.conv2d_ex(t1, w[p + "conv2.w"], w[p + "conv2.b"], None, pl.t2[i], B, hi, wi,
-                              planes, planes, 3, 3, stride, 1, relu=True)
+                              planes, planes, 3, 3, stride, 1, relu=True, scratch=pl.scratch)
                 # shortcut: projection in the first block of a stage, identity after it
                 if b == 0:
                     if stride == 1:
                         hip.linear(x.view(-1, cin), w[p + "downsample.0.w"],
-                                   w[p + "downsample.0.b"], pl.idt[i].view(-1, planes * 4))
+                                   w[p + "downsample.0.b"], pl.idt[i].view(-1, planes * 4),
+                                   scratch=pl.scratch)
                     else:
                         hip.conv2d_ex(x, w[p + "downsample.0.w"], w[p + "downsample.0.b"], None,
-                                      pl.idt[i], B, hi, wi, cin, planes * 4, 1, 1, stride, 0)
+                                      pl.idt[i], B, hi, wi, cin, planes * 4, 1, 1, stride, 0,
+                                      scratch=pl.scratch)
                     idt = pl.idt[i]
                 else:
                     idt = x
@@ -203,7 +208,7 @@ class ResNet50Hip:
                     dst = pl.ping[i] if idt is not pl.ping[i] else pl.idt[i]
                 hip.linear(pl.t2[i].view(-1, planes), w[p + "conv3.w"], w[p + "conv3.b"],
                            dst.view(-1, planes * 4), res=idt.view(-1, planes * 4),
-                           relu_after=True)
+                           relu_after=True, scratch=pl.scratch)
                 x, cin = dst, planes * 4
         return tuple(o.permute(0, 3, 1, 2) for o in pl.out)
 

@@ -90,7 +90,7 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
   // vmcnt wait per element): out-of-range rows are clamped to the last valid row (their
   // products land in output rows / columns that are never stored); a ragged K tail and
   // the conv halo read a clamped address and are zeroed when the chunk goes to LDS.
-  int lpi = 0, lK = 0;
+  int lpi = 0, lK = 0, lkt0 = 0;   // problem, its K, first chunk of this split
   const float* bA = nullptr;      // batch base of A
   const float* bW = nullptr;
   const float* bAdd = nullptr;
@@ -107,8 +107,11 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
     lpi = tr.pi;
     lK = p.K;
     const int m0 = tr.tm * BM, n0 = tr.tn * BN;
-    bA = p.A + (int64_t)tr.bz * p.sA;
-    bW = p.W + (int64_t)tr.bz * p.sW;
+    const int ks = max(p.ksplit, 1);
+    const int bb = tr.bz / ks;                 // batch index (bz = bb * ksplit + split)
+    lkt0 = (tr.bz - bb * ks) * p.split_chunks;
+    bA = p.A + (int64_t)bb * p.sA;
+    bW = p.W + (int64_t)bb * p.sW;
     bAdd = p.Aadd ? p.Aadd : bA;   // (without an addend it only has to be readable)
     rA = make_rsrc(bA);
     rW = make_rsrc(bW);
@@ -156,7 +159,7 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
   int st_k0 = 0;
   unsigned st_in = 0;
   auto load_chunk = [&](int kt) {
-    const int k0 = kt * BK;
+    const int k0 = (lkt0 + kt) * BK;
     // a ragged last chunk (K % 32 != 0, rare) re-reads the previous 32 columns' address
     // range shifted back to stay in bounds; store_chunk zeroes what lies past K
     const bool ragged = k0 + BK > lK;
@@ -209,8 +212,9 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
       const int tap = k0 / p.Cin;
       const int ci0 = k0 - tap * p.Cin;
       const int dy = tap / p.KW - p.pad, dx = tap % p.KW - p.pad;
-      if (ci0 == 0) {   // new tap (uniform): which rows' taps fall inside the image, and
-                        // their per-lane offsets; the channel advance rides in soffset
+      if (ci0 == 0 || kt == 0) {   // new tap, or first chunk of a tile / K split (uniform):
+                                   // which rows' taps fall inside the image, and their
+                                   // per-lane offsets; the channel advance rides in soffset
         in_mask = 0;
         const int tap_off = (dy * p.Wd + dx) * p.Cin;
 #pragma unroll
@@ -341,7 +345,11 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
     const GemmP& p = loc.P(cur.pi);
     // the tile after this one (clamped: the last tile re-loads its own first chunk, unused)
     const TileRef nxt = loc(base + min(t + per, cnt - 1));
-    const int nk = (p.K + BK - 1) / BK;
+    int nk = (p.K + BK - 1) / BK;
+    if (p.ksplit > 1) {
+      const int sidx = cur.bz % p.ksplit;
+      nk = min(p.split_chunks, nk - sidx * p.split_chunks);
+    }
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -592,9 +600,75 @@ static int launch_tile(const GemmP& p, int batch, hipStream_t s) {
   return PN_LAUNCH_CHECK();
 }
 
+// ---- split-K for problems with too few output tiles to fill the chip -----------------
+// part [batch][S][M][N] (dense) -> C = [relu_after](act(sum_s part + bias) + Res); the
+// partials are summed in split order, so the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ part,
+                                                       const GemmP p, const int S) {
+  const int n4 = p.N >> 2;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)p.M * n4) return;
+  const int b = blockIdx.y;
+  const int row = (int)(e / n4), col = (int)(e - (int64_t)row * n4) * 4;
+  const int64_t mn = (int64_t)p.M * p.N;
+  const float* pp = part + (int64_t)b * S * mn + (int64_t)row * p.N + col;
+  float4 v = ld4(pp);
+  for (int s = 1; s < S; ++s) v = add4(v, ld4(pp + s * mn));
+  if (p.bias) v = add4(v, ld4(p.bias + col));
+  if (p.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+  if (p.Res) {
+    const float* r = p.Res + (int64_t)b * p.sRes + (int64_t)row * p.ldres + col;
+    v = add4(v, make_float4(r[0], r[1], r[2], r[3]));
+  }
+  if (p.relu_after)
+    v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+  float* c = p.C + (int64_t)b * p.sC + (int64_t)row * p.ldc + col;
+  c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+}
+
+// Number of K splits for a 64x64-tile launch: enough work items for ~4 workgroups per CU,
+// at least 4 chunks (128 k) per split, and the partials must fit the caller's scratch.
+static int splitk_factor(const GemmP& p, int batch, const float* scratch, int64_t scratch_floats,
+                         int* chunks_per_split) {
+  const int nk = pn_cdiv(p.K, 32);
+  const int64_t tiles = (int64_t)pn_cdiv(p.M, 64) * pn_cdiv(p.N, 64) * batch;
+  *chunks_per_split = nk;
+  if (!scratch || tiles >= 512 || nk < 8 || (p.N & 3) || !aligned16(p.bias) ||
+      ((uintptr_t)scratch & 15))
+    return 1;
+  int S = (int)((1024 + tiles - 1) / tiles);
+  if (S > 16) S = 16;
+  if (S > nk / 4) S = nk / 4;
+  const int64_t per = (int64_t)batch * p.M * p.N;
+  if ((int64_t)S * per > scratch_floats) S = (int)(scratch_floats / per);
+  if (S < 2) return 1;
+  const int cps = pn_cdiv(nk, S);
+  *chunks_per_split = cps;
+  return pn_cdiv(nk, cps);          // every split owns at least one chunk
+}
+
+template <int AMODE>
+static int launch_tile64_splitk(const GemmP& p, int batch, float* scratch, int64_t scratch_floats,
+                                hipStream_t s) {
+  int cps;
+  const int S = splitk_factor(p, batch, scratch, scratch_floats, &cps);
+  if (S <= 1) return launch_tile<64, 64, 32, 32, AMODE>(p, batch, s);
+  GemmP q = p;                       // pass 1: raw partial products into the scratch
+  q.C = scratch; q.ldc = p.N; q.sC = (int64_t)p.M * p.N;
+  q.bias = nullptr; q.Res = nullptr; q.relu = 0; q.relu_after = 0;
+  q.ksplit = S; q.split_chunks = cps;
+  if (int rc = launch_tile<64, 64, 32, 32, AMODE>(q, batch * S, s)) return rc;
+  const int64_t n = (int64_t)p.M * (p.N / 4);
+  hipLaunchKernelGGL(k_splitk_reduce, dim3(pn_cdiv(n, 256), batch), dim3(256), 0, s, scratch, p, S);
+  return PN_LAUNCH_CHECK();
+}
+
 static bool gemm_use_skinny(const pn_gemm_desc* d) {
   const int64_t tiles128 = (int64_t)pn_cdiv(d->M, 128) * pn_cdiv(d->N, 128) * d->batch;
+  const int64_t tiles64 = (int64_t)pn_cdiv(d->M, 64) * pn_cdiv(d->N, 64) * d->batch;
   bool skinny = tiles128 < 96;
+  // with a split-K scratch the 64x64 tile kernel takes over from ~64 tiles up
+  if (d->splitk_scratch && tiles64 >= 64 && d->K >= 256 && !(d->N & 3)) skinny = false;
   if (d->flags & (PN_GEMM_FORCE_TILE | PN_GEMM_FORCE_TILE64 | PN_GEMM_FORCE_TILE128x64))
     skinny = false;
   if (d->flags & PN_GEMM_FORCE_SKINNY) skinny = true;
@@ -658,8 +732,10 @@ extern "C" int pn_gemm_f32(const pn_gemm_desc* d, void* stream) {
   if (d->flags & PN_GEMM_FORCE_TILE)
     return colmajor ? launch_tile<128, 128, 64, 64, A_COL>(p, d->batch, s)
                     : launch_tile<128, 128, 64, 64, A_ROW>(p, d->batch, s);
-  return colmajor ? launch_tile<64, 64, 32, 32, A_COL>(p, d->batch, s)
-                  : launch_tile<64, 64, 32, 32, A_ROW>(p, d->batch, s);
+  return colmajor ? launch_tile64_splitk<A_COL>(p, d->batch, d->splitk_scratch,
+                                                d->splitk_scratch_floats, s)
+                  : launch_tile64_splitk<A_ROW>(p, d->batch, d->splitk_scratch,
+                                                d->splitk_scratch_floats, s);
 }
 
 extern "C" int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream) {
@@ -684,7 +760,8 @@ extern "C" int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream)
 extern "C" int pn_conv2d_nhwc_ex_f32(const float* in, const float* Wp, const float* bias,
                                      const float* res, float* out, int B, int H, int W,
                                      int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                     int flags, void* stream) {
+                                     int flags, float* splitk_scratch,
+                                     int64_t splitk_scratch_floats, void* stream) {
   if (!in || !Wp || !out || B <= 0 || H <= 0 || W <= 0 || stride <= 0 || pad < 0)
     return PN_BAD_ARG;
   if (Cin % 32 || !aligned16(in) || !aligned16(Wp)) return PN_BAD_ARG;
@@ -711,7 +788,7 @@ extern "C" int pn_conv2d_nhwc_ex_f32(const float* in, const float* Wp, const flo
   // selectable for sweeps
   if (flags & PN_GEMM_FORCE_TILE128x64) return launch_tile<128, 64, 64, 32, A_CONV>(p, B, s);
   if (flags & PN_GEMM_FORCE_TILE) return launch_tile<128, 128, 64, 64, A_CONV>(p, B, s);
-  return launch_tile<64, 64, 32, 32, A_CONV>(p, B, s);
+  return launch_tile64_splitk<A_CONV>(p, B, splitk_scratch, splitk_scratch_floats, s);
 }
 
 extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float* bias,
@@ -720,7 +797,8 @@ extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float*
                                   void* stream) {
   if (KH != 2 * pad + 1 || KW != 2 * pad + 1) return PN_BAD_ARG;   // "same" convolution
   return pn_conv2d_nhwc_ex_f32(in, Wp, bias, nullptr, out, B, H, W, Cin, Cout, KH, KW, 1, pad,
-                               (flags & ~PN_GEMM_RELU) | (relu ? PN_GEMM_RELU : 0), stream);
+                               (flags & ~PN_GEMM_RELU) | (relu ? PN_GEMM_RELU : 0), nullptr, 0,
+                               stream);
 }
 
 // ResNet stem: 7x7 stride-2 pad-3 convolution of the NCHW RGB image + folded BatchNorm

@@ -9,6 +9,10 @@ struct GemmP {
   int64_t sA, sW, sRes, sC;
   int M, N, K, aadd_rows, aadd_from_col, relu, a_vec;
   int relu_after;           // ReLU after the residual add (ResNet bottleneck output)
+  // split-K: the launch's batch index bz = (batch b) * ksplit + (split s); split s
+  // contracts the 32-deep chunks [s * split_chunks, (s+1) * split_chunks) into its own
+  // partial C (k_splitk_reduce sums the partials in split order and applies the epilogue)
+  int ksplit, split_chunks;
   // conv modes: input H x Wd x Cin (A_STEM: NCHW, Cin = 3), output rows M = Ho * Wo
   int H, Wd, Cin, KW, pad, stride, Wo;
 };

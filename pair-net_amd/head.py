@@ -350,6 +350,7 @@ class CrossHead2:
         pl.VOA = E(B, SN, 544)          # [value | offsets | logits] per token
         pl.H = E(M, self.enc_ffn)
         pl.tmpconv = E(B, max(pl.N), 256)
+        pl.splitk = E(B * 9 * 1024 * 1024)   # split-K workspace of the C5 / C4 input convs
         nblk = max(hip.groupnorm_nblk(HW2), hip.groupnorm_nblk(max(pl.N)))
         pl.gn_part = torch.empty(B * nblk * 32 * 2, device=dev, dtype=torch.float64)
         pl.T1, pl.T2 = E(B, HW2, 256), E(B, HW2, 256)
@@ -414,7 +415,7 @@ class CrossHead2:
             hip.gemm(f, w[pd + "input_convs.%d.conv.weight" % l], pl.tmpconv, M=n, N=256, K=cin,
                      lda=cin if pl.nhwc else n, ldw=cin, ldc=256,
                      bias=w[pd + "input_convs.%d.conv.bias" % l], batch=B, sA=cin * n,
-                     sC=n * 256, colmajor=not pl.nhwc)
+                     sC=n * 256, colmajor=not pl.nhwc, scratch=pl.splitk)
             hip.groupnorm_nhwc(pl.tmpconv, w[pd + "input_convs.%d.gn.weight" % l],
                                w[pd + "input_convs.%d.gn.bias" % l], pl.X[:, pl.start[l]:],
                                pl.gn_part, B, n, self.gn_groups, False, n * 256, SN * 256)

@@ -27,7 +27,8 @@ class GemmDesc(C.Structure):
                 ("Res", _vp), ("ldres", _i64), ("strideRes", _i64),
                 ("C", _vp), ("ldc", _i64), ("strideC", _i64),
                 ("M", _i32), ("N", _i32), ("K", _i32), ("batch", _i32),
-                ("flags", _i32)]
+                ("flags", _i32),
+                ("splitk_scratch", _vp), ("splitk_scratch_floats", _i64)]
 
 
 _SIGS = {
@@ -36,7 +37,7 @@ _SIGS = {
     "pn_gemm_variant": (C.c_int, [C.POINTER(GemmDesc)]),
     "pn_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
     "pn_conv2d_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp]),
-    "pn_conv2d_nhwc_ex_f32": (C.c_int, [_vp] * 5 + [_i32] * 10 + [_vp]),
+    "pn_conv2d_nhwc_ex_f32": (C.c_int, [_vp] * 5 + [_i32] * 10 + [_vp, _i64, _vp]),
     "pn_stem7x7s2_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_maxpool3x3s2_nhwc_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_layernorm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
@@ -170,7 +171,7 @@ def _rowmajor(t):
 def gemm_desc(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaadd=0,
               aadd_rows=0, aadd_from_col=0, res=None, ldres=0, batch=1, sA=0, sW=0, sC=0,
               sRes=0, relu=False, colmajor=False, force=None, split=False, into=None,
-              relu_after=False):
+              relu_after=False, scratch=None):
     """Fill a pn_gemm_desc; tensors only supply base pointers."""
     d = into if into is not None else GemmDesc()
     d.A, d.lda, d.strideA = _ptr(A), lda, sA
@@ -184,6 +185,8 @@ def gemm_desc(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaad
         {None: 0, "tile": GEMM_FORCE_TILE, "skinny": GEMM_FORCE_SKINNY, "tile64": 16,
          "tile128x64": 32}[force] | (GEMM_SPLIT_BF16 if split else 0) | \
         (GEMM_RELU_AFTER_RES if relu_after else 0)
+    d.splitk_scratch = _ptr(scratch)
+    d.splitk_scratch_floats = scratch.numel() if scratch is not None else 0
     return d
 
 
@@ -215,7 +218,7 @@ def gemm_group(problems):
 
 
 def linear(x, weight, bias, out, *, aadd=None, aadd_from_col=0, res=None, relu=False,
-           force=None, split=False, relu_after=False):
+           force=None, split=False, relu_after=False, scratch=None):
     """out = act((x + aadd[row % len(aadd)]) @ weight.T + bias) + res on 2-D views
     (aadd only feeds output columns >= aadd_from_col)."""
     M, lda = _rowmajor(x)
@@ -231,7 +234,7 @@ def linear(x, weight, bias, out, *, aadd=None, aadd_from_col=0, res=None, relu=F
         assert rr == M
         kw.update(res=res, ldres=ldr)
     gemm(x, weight, out, M=M, N=N, K=x.shape[1], lda=lda, ldw=ldw, ldc=ldc, bias=bias,
-         relu=relu, force=force, split=split, relu_after=relu_after, **kw)
+         relu=relu, force=force, split=split, relu_after=relu_after, scratch=scratch, **kw)
 
 
 def conv2d_nhwc(x, wp, bias, out, B, H, W, Cin, Cout, KH, KW, pad, relu, split=False,
@@ -251,7 +254,7 @@ def conv2d_nhwc(x, wp, bias, out, B, H, W, Cin, Cout, KH, KW, pad, relu, split=F
 
 
 def conv2d_ex(x, wp, bias, res, out, B, H, W, Cin, Cout, KH, KW, stride, pad, relu=False,
-              relu_after=False):
+              relu_after=False, scratch=None):
     """General channel-last convolution (stride, residual, ReLU before / after it)."""
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     flops = 2.0 * B * Ho * Wo * Cout * KH * KW * Cin
@@ -261,7 +264,9 @@ def conv2d_ex(x, wp, bias, res, out, B, H, W, Cin, Cout, KH, KW, stride, pad, re
     _check(_launch("k_gemm_tile<64,64,32,32,A_CONV>", flops, nbytes,
                    lambda: lib().pn_conv2d_nhwc_ex_f32(
                        _ptr(x), _ptr(wp), _ptr(bias), _ptr(res), _ptr(out), B, H, W, Cin, Cout,
-                       KH, KW, stride, pad, flags, _stream())), "pn_conv2d_nhwc_ex_f32")
+                       KH, KW, stride, pad, flags, _ptr(scratch),
+                       scratch.numel() if scratch is not None else 0, _stream())),
+           "pn_conv2d_nhwc_ex_f32")
 
 
 def stem7x7s2(img, wp, bias, out, B, H, W):

@@ -84,6 +84,31 @@ def test_gemm_batched_strided_and_colmajor(hip, force):
     close(out, torch.einsum("bqc,bpc->bqp", q, mf), 2e-5, "batched W")
 
 
+@pytest.mark.parametrize("colmajor", [False, True])
+def test_gemm_splitk_matches_single_pass(hip, colmajor):
+    """Split-K (few tiles, long K; scratch supplied) == one-pass result up to fp32
+    re-association, is deterministic, and keeps the fused epilogue."""
+    B, M, N, K = 2, 1050, 256, 2048
+    a = R(B, K, M, seed=1) if colmajor else R(B, M, K, seed=1)
+    w, bias, res = R(N, K, seed=2), R(N, seed=3), R(B, M, N, seed=4)
+    ref = F.relu(F.relu((torch.einsum("bkm,nk->bmn", a, w) if colmajor
+                         else torch.einsum("bmk,nk->bmn", a, w)) + bias) + res)
+    kw = dict(M=M, N=N, K=K, lda=M if colmajor else K, ldw=K, ldc=N, bias=bias.to(DEV),
+              res=res.to(DEV), ldres=N, sRes=M * N, batch=B, sA=K * M, sC=M * N, relu=True,
+              relu_after=True, colmajor=colmajor)
+    scratch = torch.empty(B * 16 * M * N, device=DEV)
+    outs = []
+    for sc in (scratch, scratch, None):
+        out = torch.empty(B, M, N, device=DEV)
+        hip.gemm(a.to(DEV), w.to(DEV), out, scratch=sc, force=None if sc is not None else "tile64",
+                 **kw)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])                      # deterministic
+    close(outs[0], ref, 2e-5 * math.sqrt(K / 256), "split-K")
+    close(outs[2], ref, 2e-5 * math.sqrt(K / 256), "single pass")
+    assert float((outs[0] - outs[2]).abs().max()) > 0         # the split path really ran
+
+
 def test_gemm_group_and_column_split_add(hip):
     """Grouped launch (the decoder K/V projections) == the same problems one by one;
     Aadd restricted to columns >= 256 (the fused [value | offsets | logits] GEMM)."""

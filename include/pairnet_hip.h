@@ -74,15 +74,15 @@ typedef struct pn_gemm_desc {
 
 int pn_gemm_f32(const pn_gemm_desc* d, void* stream);
 
-/* `count` (<= 16) independent row-major problems in ONE launch of the 128x128 tile
- * kernel (all their tiles share the grid): used for the 18 key/value projections of
+/* `count` (<= 16) independent row-major problems in ONE launch of the persistent 64x64
+ * tile kernel (all their tiles share the grid): used for the 18 key/value projections of
  * the 9 decoder layers, whose per-problem tile counts do not fill 256 CUs evenly. */
 int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream);
 
 /* Which kernel pn_gemm_f32 would launch for `d` (for profiling / roofline
  * attribution; +1 = the column-major-A instantiation). */
 #define PN_GEMM_VARIANT_SKINNY        0  /* k_gemm_skinny<A>                 */
-#define PN_GEMM_VARIANT_TILE_128x64   2  /* k_gemm_tile<128,64,32,64,A>      */
+#define PN_GEMM_VARIANT_TILE_128x64   2  /* k_gemm_tile<128,64,64,32,A>      */
 #define PN_GEMM_VARIANT_TILE_128x128  4  /* k_gemm_tile<128,128,64,64,A>     */
 #define PN_GEMM_VARIANT_TILE_64x64    6  /* k_gemm_tile<64,64,32,32,A> (default) */
 #define PN_GEMM_VARIANT_SPLIT         8  /* k_gemm_split<A_ROW>                  */

@@ -1,12 +1,15 @@
 // fp32 contractions on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
-// bitwise an fmaf chain).  Two kernels behind pn_gemm_f32 / pn_conv2d_nhwc_f32:
+// bitwise an fmaf chain).  The kernels behind pn_gemm_f32 / pn_gemm_group_f32 /
+// pn_conv2d_nhwc(_ex)_f32 / pn_stem7x7s2_f32:
 //
 //   k_gemm_tile   persistent workgroups (4 waves) walking BMxBN output tiles, 32-deep
 //                 k-chunks staged global -> registers -> one LDS stage, MFMA operand
 //                 fragments double-buffered in registers.  A rows come from a
 //                 row-major matrix, a column-major matrix (an NCHW feature map read as
-//                 [K][M]) or an on-the-fly im2col of a channel-last image
-//                 (implicit-GEMM convolution).
+//                 [K][M]), an on-the-fly im2col of a channel-last image (implicit-GEMM
+//                 convolution, any stride) or of the NCHW RGB image (ResNet stem).
+//   k_splitk_reduce  second pass of the deterministic split-K used when a problem has
+//                 too few output tiles to fill 256 CUs.
 //   k_gemm_skinny 32x32 output tile per workgroup, the 4 waves split K and reduce
 //                 through LDS; operands go global->VGPR directly.  For the M~100
 //                 query-side GEMMs of the decoders, where a 128-row tile would

@@ -204,7 +204,7 @@ def gemm(A, W, Cout, **kw):
 
 def gemm_group(problems):
     """`problems`: list of kwargs dicts for gemm_desc (+ 'A','W','C'), <= 16, row-major:
-    one launch of the grouped 128x128 tile kernel."""
+    one launch of the grouped (persistent 64x64 tile) kernel."""
     n = len(problems)
     arr = (GemmDesc * n)()
     flops = nbytes = 0.0

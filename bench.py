@@ -250,7 +250,9 @@ def main():
                     "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] else 0.0}
                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
 
-    if rank == 0 and not args.no_extras:
+    # (single-GPU runs only: the extras re-enter step(), whose triplet all-gather is a
+    # collective the other ranks would not be in)
+    if rank == 0 and world == 1 and not args.no_extras:
         def timeit(fn, n=5):
             fn()
             torch.cuda.synchronize()

@@ -70,3 +70,25 @@ def test_all_gather_triplets_world2_gloo():
     expect = torch.stack([_record(i) for i in range(n_images)])
     for r in range(world):
         assert torch.equal(outs[r], expect)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_complete_and_report_whole_job_rate():
+    """`bench.py --gpus 2` under torch.distributed.run (the driver's launch line; gloo so
+    that two ranks can share the test box's single GPU): every rank must leave every
+    collective, and rank 0 prints one JSON line with the whole-job rate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PAIRNET_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "6", "--warmup", "3", "--height", "256", "--width", "320"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["value"] > 0
+    assert rec["scaling"] == "weak" and "roofline" in rec

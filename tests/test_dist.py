@@ -3,6 +3,8 @@ over gloo."""
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

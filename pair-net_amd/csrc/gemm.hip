@@ -700,6 +700,7 @@ int pn_fill_params(const pn_gemm_desc* d, GemmP* out) {
   // the tile kernels address each per-batch operand with 32-bit element offsets
   const int64_t lim = (int64_t)1 << 29;
   if (!colmajor && (int64_t)(d->M - 1) * d->lda + d->K >= lim) return PN_BAD_ARG;
+  if (colmajor && (int64_t)(d->K - 1) * d->lda + d->M >= lim) return PN_BAD_ARG;
   if ((int64_t)(d->N - 1) * d->ldw + d->K >= lim) return PN_BAD_ARG;
   if (d->Aadd && (int64_t)d->aadd_rows * d->ldaadd >= lim) return PN_BAD_ARG;
   GemmP p{};

@@ -325,7 +325,7 @@ class CrossHead2:
         E = lambda *s: torch.empty(*s, device=dev, dtype=f32)
         pl = CrossHead2._Plan()
         pl.B, pl.shapes, pl.hw2, pl.nhwc = B, list(shapes), tuple(hw2), nhwc
-        pl.graph_a = pl.graph_b = pl.static_feats = pl.graph_cfg = None
+        pl.graph_a = pl.graph_b = pl.static_feats = pl.graph_cfg = pl.feats_read = None
         pl.calls_a = pl.calls_b = 0
         pl.N = [h * w for h, w in shapes]
         pl.start = [0, pl.N[0], pl.N[0] + pl.N[1]]
@@ -687,13 +687,17 @@ class CrossHead2:
                     dst.copy_(src)
                 pl.graph_a = self._capture(lambda: self._stage_a(pl.static_feats, pl))
             pl.calls_a += 1
+            if pl.feats_read is None:
+                pl.feats_read = torch.cuda.Event()
             if self.use_graphs and pl.graph_a is not None:
                 for dst, src in zip(pl.static_feats, feats):
                     if dst.data_ptr() != src.data_ptr():
                         dst.copy_(src)
+                pl.feats_read.record()      # the caller's feature buffers are free again
                 pl.graph_a.replay()
             else:
                 self._stage_a(feats, pl)
+                pl.feats_read.record()
         else:
             if self.use_graphs and pl.graph_b is None and pl.calls_b >= 1:
                 pl.graph_b = self._capture(lambda: self._stage_b(pl))

@@ -61,6 +61,9 @@ class PipelinedHead:
         with torch.cuda.stream(sa):
             head._run_stage("a", pl, feats)
             self.a_done[slot].record(sa)
+        # a producer that reuses its output buffers (the native backbone does) must not
+        # overwrite them before stage A has read them
+        cur.wait_event(pl.feats_read)
         for f in feats:                                    # keep feats alive until A has read them
             f.record_stream(sa)
         self.queue.append(dict(idx=idx, slot=slot, pl=pl, metas=img_metas, rescale=rescale,

@@ -125,3 +125,42 @@ def test_detector_end_to_end_native_backbone():
     res = det.simple_test(img, metas)
     assert len(res) == 1 and res[0].rel_dists.shape == (100, 57)
     assert res[0].masks.shape == (200, 128, 160)
+
+
+def test_pipelined_detector_with_reused_backbone_buffers():
+    """Native backbone (whose outputs are views of reused buffers) feeding the 3-deep
+    pipelined head with a DIFFERENT image every step == the one-image-at-a-time results,
+    bitwise: stage A must have consumed the features before the backbone overwrites them."""
+    from helpers import head_cfg, oracle_head
+    from pairnet_amd import CrossHead2, PipelinedHead, ResNet50Hip
+    _, sd, _ = oracle_head(7)
+    head = CrossHead2(**head_cfg())
+    head.load_state_dict(sd)
+    head.to(DEV)
+    net = ResNet50Hip()
+    net.load_state_dict(seeded_backbone_state(41))
+    net.to(DEV)
+    H, W = 160, 224
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[1.0] * 4)]
+    imgs = [R(1, 3, H, W, seed=50 + i).to(DEV) for i in range(6)]
+    want = []
+    for im in imgs:
+        r = head.simple_test_bboxes(net(im), metas)[0]
+        want.append([t.clone() if t.is_cuda else t for t in r])
+    torch.cuda.synchronize()
+    for graphs in (False, True):
+        head.use_graphs = graphs
+        pipe = PipelinedHead(head, depth=3)
+        got = []
+        for rep in range(2):                 # second pass runs on captured graphs
+            got = []
+            for im in imgs:
+                o = pipe.submit(net(im), metas)
+                if o is not None:
+                    got.append([t.clone() if t.is_cuda else t for t in o[0]])
+            got += [o[0] for o in pipe.flush()]
+        torch.cuda.synchronize()
+        assert len(got) == len(want)
+        for a, b in zip(want, got):
+            for x, y in zip(a, b):
+                assert torch.equal(x.cpu(), y.cpu())

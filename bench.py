@@ -58,6 +58,9 @@ def main():
                     help="pairnet = CrossHead2 (the headline); baseline / psgtr2 = the sibling "
                          "heads CrossHeadBaseline / PSGTrHead2 on the same trunk (not the "
                          "headline metric)")
+    ap.add_argument("--queries", type=int, default=100, help="object queries (BASELINE configs[3]: 200)")
+    ap.add_argument("--in-channels", default="256,512,1024,2048",
+                    help="backbone channel widths (Swin-L: 192,384,768,1536)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two stages of consecutive batches back to back on one stream")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight in the pipeline")
@@ -92,8 +95,11 @@ def main():
     from pairnet_amd.dist import all_gather_triplets, pack_triplets
 
     sibling = args.head != "pairnet"
+    chans = tuple(int(c) for c in args.in_channels.split(","))
     cfg = {"pairnet": pairnet_head_cfg, "baseline": baseline_head_cfg,
-           "psgtr2": psgtr2_head_cfg}[args.head]()
+           "psgtr2": psgtr2_head_cfg}[args.head](in_channels=chans, num_obj_query=args.queries)
+    if args.head == "baseline":
+        cfg["num_rel_query"] = args.queries
     cfg.pop("type")
     head = {"pairnet": CrossHead2, "baseline": CrossHeadBaseline,
             "psgtr2": PSGTrHead2}[args.head](**cfg)
@@ -110,7 +116,7 @@ def main():
     B, H, W = args.batch, args.height, args.width
     g = torch.Generator().manual_seed(1000 + rank)
     feats_cpu = [torch.relu(torch.randn(B, c, h, w, generator=g))
-                 for c, (h, w) in zip((256, 512, 1024, 2048), feature_shapes(H, W))]
+                 for c, (h, w) in zip(chans, feature_shapes(H, W))]
     feats = [f.to(dev) for f in feats_cpu]
     sf = 2.083
     metas = [dict(img_shape=(H, W, 3), scale_factor=[sf, sf, sf, sf])] * B
@@ -203,9 +209,10 @@ def main():
                              "Pair-Net R50 + Mask2Former head hot path (CrossHead2."
                              "simple_test_bboxes: pixel decoder -> 9-layer masked decoder -> "
                              "PPN/Matrix Learner/top-k -> 6-layer relation decoder -> "
-                             "get_bboxes") + ", 100 object / 100 relation queries, bs=%d per "
-                            "GPU, %dx%d, R50 feature pyramid resident in HBM, default-init "
-                            "weights" % (B, H, W),
+                             "get_bboxes") + ", %d object / %d relation queries, channels %s, "
+                            "bs=%d per GPU, %dx%d, feature pyramid resident in HBM, "
+                            "default-init weights" % (head.num_obj_query, head.num_rel_query,
+                                                      list(chans), B, H, W),
                 "global_batch": world * B, "per_gpu_batch": B, "image": [H, W],
                 "parallelism": "dp%d" % world,
                 "schedule": ("eager" if args.no_graphs else "hipGraph replay per stage") + (

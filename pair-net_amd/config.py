@@ -154,7 +154,7 @@ def psgtr2_head_cfg(in_channels=(256, 512, 1024, 2048), num_obj_query=100, num_c
     mask = dict(type="CrossEntropyLoss", use_sigmoid=True, reduction="mean", loss_weight=5.0)
     dice = dict(type="DiceLoss", use_sigmoid=True, activate=True, reduction="mean",
                 naive_dice=True, eps=1.0, loss_weight=5.0)
-    return ConfigDict(
+    cfg = ConfigDict(
         type="PSGTrHead2", num_classes=num_classes, num_relations=num_relations, use_mask=True,
         num_obj_query=num_obj_query, pixel_decoder=pd,
         transformer_decoder=_decoder(9, False, 0.0),
@@ -163,6 +163,9 @@ def psgtr2_head_cfg(in_channels=(256, 512, 1024, 2048), num_obj_query=100, num_c
         sub_loss_cls=ce(1.0), sub_loss_mask=dict(mask), sub_loss_dice=dict(dice),
         obj_loss_cls=ce(1.0), obj_loss_mask=dict(mask), obj_loss_dice=dict(dice),
         rel_loss_cls=ce(2.0))
+    if tuple(in_channels) != (256, 512, 1024, 2048):   # the reference file relies on the default
+        cfg["in_channels"] = list(in_channels)
+    return cfg
 
 
 def pairnet_r50():

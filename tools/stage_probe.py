@@ -1,0 +1,23 @@
+"""Tuning aid: stage A / stage B alone (graph replay and eager), no overlap."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pairnet_amd import CrossHead2, pairnet_head_cfg
+dev = torch.device("cuda:0")
+cfg = pairnet_head_cfg(); cfg.pop("type")
+head = CrossHead2(**cfg); head.init_weights(seed=0); head.to(dev)
+shapes = [(200, 334), (100, 167), (50, 84), (25, 42)]
+feats = [torch.relu(torch.randn(1, c, h, w)).to(dev) for c, (h, w) in zip((256, 512, 1024, 2048), shapes)]
+metas = [dict(img_shape=(800, 1333, 3), scale_factor=[2.083] * 4)]
+def T(fn, n=30):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return 1e3 * (time.perf_counter() - t) / n
+head.use_graphs = True
+for _ in range(3): head.forward(feats, metas)
+pl = head._last_plan
+print("graph replay: stage A %.3f ms, stage B %.3f ms" % (T(lambda: pl.graph_a.replay()), T(lambda: pl.graph_b.replay())))
+head.use_graphs = False
+print("eager:        stage A %.3f ms, stage B %.3f ms" % (T(lambda: head._stage_a(feats, pl)), T(lambda: head._stage_b(pl))))
+outs = head._outputs(pl)
+print("get_bboxes eager %.3f ms" % T(lambda: head.get_bboxes(*outs, metas)))

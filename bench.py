@@ -146,10 +146,16 @@ def main():
                 res = engine._finish(engine.queue.pop(0))
                 gather(res, *pair_ids(head._last_plan))
 
-    # ---- warm-up ----
+    # ---- warm-up (graph capture happens in the first two steps), then the stream ->
+    # hardware-queue placement of the pipeline is chosen empirically (pipeline.py) ----
     for _ in range(args.warmup):
         step()
     drain()
+    calibration = None
+    if engine is not None and args.warmup >= 2:
+        calibration = engine.calibrate(feats, metas)
+        step()
+        drain()
     # Python's cyclic GC (gen-2 passes of 50-100 ms over torch's object graph) would
     # land inside the timed region at random: collect now, then keep it off, as a
     # serving loop would.
@@ -214,6 +220,7 @@ def main():
                             "default-init weights" % (head.num_obj_query, head.num_rel_query,
                                                       list(chans), B, H, W),
                 "global_batch": world * B, "per_gpu_batch": B, "image": [H, W],
+                "stream_placement_calibration_ms": calibration,
                 "parallelism": "dp%d" % world,
                 "schedule": ("eager" if args.no_graphs else "hipGraph replay per stage") + (
                     ", single stream" if args.no_pipeline else

@@ -25,4 +25,3 @@ enum { A_ROW = 0, A_COL = 1, A_CONV = 2, A_STEM = 3 };
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 int pn_fill_params(const pn_gemm_desc* d, GemmP* out);
-int pn_launch_gemm_split(const GemmP& p, int batch, bool conv, bool big_tile, hipStream_t s);

@@ -112,7 +112,7 @@ class CrossHead2:
         self.exact_mask_order = False
         # "f32": every contraction on the exact-fp32 MFMA (default, the measured headline).
         # "bf16x3": the large GEMMs / the 3x3 conv use the fp32-accurate 3 x bf16 operand
-        # split (csrc/gemm_split.hip): same error class, not bitwise the fp32 chain.
+        # split (the SPLIT mode of csrc/gemm.hip): same error class, not bitwise the fp32 chain.
         self.gemm_mode = "f32"
         # replay each stage as one hipGraph (no per-launch host cost) after a warm-up call
         self.use_graphs = False
@@ -449,7 +449,7 @@ class CrossHead2:
         hip.bilinear_nhwc(pl.X[:, pl.start[2]:], pl.T2, B, h2, w2, H2, W2, 256, True, SN * 256,
                           HW2 * 256)
         hip.conv2d_nhwc(pl.T2, w[pd + "output_convs.0.conv.weight"], None, pl.T1, B, H2, W2, 256,
-                        256, 3, 3, 1, False, split=sp, big_tile=sp)
+                        256, 3, 3, 1, False, split=sp)
         hip.groupnorm_nhwc(pl.T1, w[pd + "output_convs.0.gn.weight"],
                            w[pd + "output_convs.0.gn.bias"], pl.T2, pl.gn_part, B, HW2,
                            self.gn_groups, True, HW2 * 256, HW2 * 256)

@@ -106,7 +106,7 @@ GEMM_KERNELS = {0: "k_gemm_skinny<A_ROW>", 1: "k_gemm_skinny<A_COL>",
                 2: "k_gemm_tile<128,64,64,32,A_ROW>", 3: "k_gemm_tile<128,64,64,32,A_COL>",
                 4: "k_gemm_tile<128,128,64,64,A_ROW>", 5: "k_gemm_tile<128,128,64,64,A_COL>",
                 6: "k_gemm_tile<64,64,32,32,A_ROW>", 7: "k_gemm_tile<64,64,32,32,A_COL>",
-                8: "k_gemm_split<A_ROW>"}
+                8: "k_gemm_tile<64,64,32,32,A_ROW,bf16x3>"}
 GEMM_SPLIT_BF16 = 64
 
 
@@ -241,7 +241,7 @@ def conv2d_nhwc(x, wp, bias, out, B, H, W, Cin, Cout, KH, KW, pad, relu, split=F
                 big_tile=False, tile=None):
     """tile: None (library default: 64x64), "128x64" or "128" (sweeps)."""
     tflag = {None: 0, "128": GEMM_FORCE_TILE, "128x64": GEMM_FORCE_TILE128x64}[tile]
-    name = "k_gemm_split<A_CONV>" if split else (
+    name = "k_gemm_tile<A_CONV,bf16x3>" if split else (
         "k_gemm_tile<128,64,64,32,A_CONV>" if tile == "128x64" else
         "k_gemm_tile<128,128,64,64,A_CONV>" if tile == "128" else
         "k_gemm_tile<64,64,32,32,A_CONV>")

@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--queries", type=int, default=100, help="object queries (BASELINE configs[3]: 200)")
     ap.add_argument("--in-channels", default="256,512,1024,2048",
                     help="backbone channel widths (Swin-L: 192,384,768,1536)")
+    ap.add_argument("--conv", choices=["winograd", "winograd4", "direct"], default=None,
+                    help="algorithm of the 3x3 FPN convolution (default: the head's)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the two stages of consecutive batches back to back on one stream")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight in the pipeline")
@@ -110,6 +112,8 @@ def main():
     head.init_weights(seed=0)
     head.to(dev)
     head.gemm_mode = args.gemm
+    if args.conv:
+        head.conv_algo = args.conv
     head.use_graphs = not args.no_graphs
     engine = None if args.no_pipeline else PipelinedHead(head, depth=args.depth,
                                                           a_streams=args.a_streams)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 5
+#define PN_ABI_VERSION 6
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -98,6 +98,25 @@ int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float* bias,
                        float* out, int B, int H, int W, int Cin, int Cout,
                        int KH, int KW, int pad, int relu, int flags /* 0 or
                        PN_GEMM_SPLIT_BF16, | PN_GEMM_FORCE_TILE */, void* stream);
+
+/* Winograd F(2x2, 3x3) form of the same 3x3 "same" convolution (even H and W, C % 4 == 0):
+ *   pn_winograd_f23_input_f32:  V [16][B*(H/2)*(W/2)][Cin]  = B^T d B of every 4x4 patch
+ *   16 GEMMs (one batched pn_gemm_f32 call, batch = 16):  M_xi = V_xi . U_xi^T with
+ *       U [16][Cout][Cin] = G g G^T of the weights (computed once by the caller)
+ *   pn_winograd_f23_output_f32: out [B][H][W][Cout] = act(A^T M A + bias)
+ * 2.25x fewer multiplications than the direct form; fp32, differs from it by fp32
+ * re-association only. */
+int pn_winograd_f23_input_f32(const float* in, float* V, int B, int H, int W, int C,
+                              void* stream);
+int pn_winograd_f23_output_f32(const float* M, const float* bias, float* out, int B, int H,
+                               int W, int C, int relu, void* stream);
+/* F(4x4, 3x3): 36 positions (V, M: [36][B*ceil(H/4)*ceil(W/4)][C], U [36][Cout][Cin]), 4x fewer
+ * multiplications than the direct form; any H, W (edge tiles are padded / clipped).  Its
+ * transform constants (up to 8 and 1/24) cost about one more decimal digit than F(2x2). */
+int pn_winograd_f43_input_f32(const float* in, float* V, int B, int H, int W, int C,
+                              void* stream);
+int pn_winograd_f43_output_f32(const float* M, const float* bias, float* out, int B, int H,
+                               int W, int C, int relu, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Backbone: ResNet-50, style "pytorch", frozen BatchNorm

@@ -40,6 +40,10 @@ _SIGS = {
     "pn_conv2d_nhwc_ex_f32": (C.c_int, [_vp] * 5 + [_i32] * 10 + [_vp, _i64, _vp]),
     "pn_stem7x7s2_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_maxpool3x3s2_nhwc_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pn_winograd_f23_input_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pn_winograd_f23_output_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "pn_winograd_f43_input_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pn_winograd_f43_output_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pn_layernorm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "pn_groupnorm_nblk": (C.c_int, [_i64]),
     "pn_groupnorm_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32,
@@ -75,7 +79,7 @@ _SIGS = {
     "pn_mask_iou_counts": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 5   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 6   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -280,6 +284,47 @@ def stem7x7s2(img, wp, bias, out, B, H, W):
 def maxpool3x3s2(x, out, B, H, W, Cc):
     _check(lib().pn_maxpool3x3s2_nhwc_f32(_ptr(x), _ptr(out), B, H, W, Cc, _stream()),
            "pn_maxpool3x3s2_nhwc_f32")
+
+
+def winograd_weights(w):
+    """conv weight [Cout][Cin][3][3] (any device, fp32) -> U [16][Cout][Cin] = G g G^T."""
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
+                     dtype=torch.float64, device=w.device)
+    U = torch.einsum("ik,ockl,jl->ijoc", G, w.double(), G)
+    return U.reshape(16, w.shape[0], w.shape[1]).float().contiguous()
+
+
+def winograd43_weights(w):
+    """conv weight [Cout][Cin][3][3] -> U [36][Cout][Cin] = G g G^T for F(4x4, 3x3)."""
+    G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
+                      [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
+                     dtype=torch.float64, device=w.device)
+    U = torch.einsum("ik,ockl,jl->ijoc", G, w.double(), G)
+    return U.reshape(36, w.shape[0], w.shape[1]).float().contiguous()
+
+
+def conv3x3_winograd43(x, U, bias, out, V, Mbuf, B, H, W, Cin, Cout, relu, split=False):
+    """F(4x4,3x3) form; V / Mbuf: 36 * B*ceil(H/4)*ceil(W/4) * Cin / Cout floats."""
+    T = B * ((H + 3) // 4) * ((W + 3) // 4)
+    _check(lib().pn_winograd_f43_input_f32(_ptr(x), _ptr(V), B, H, W, Cin, _stream()),
+           "pn_winograd_f43_input_f32")
+    gemm(V, U, Mbuf, M=T, N=Cout, K=Cin, lda=Cin, ldw=Cin, ldc=Cout, batch=36, sA=T * Cin,
+         sW=Cout * Cin, sC=T * Cout, split=split)
+    _check(lib().pn_winograd_f43_output_f32(_ptr(Mbuf), _ptr(bias), _ptr(out), B, H, W, Cout,
+                                            int(relu), _stream()), "pn_winograd_f43_output_f32")
+
+
+def conv3x3_winograd(x, U, bias, out, V, Mbuf, B, H, W, Cin, Cout, relu, split=False):
+    """3x3 pad-1 stride-1 convolution as Winograd F(2x2,3x3): input transform, one batched
+    GEMM over the 16 transform positions, output transform.  V / Mbuf: scratch of
+    16 * B*(H/2)*(W/2) * Cin / Cout floats."""
+    T = B * (H // 2) * (W // 2)
+    _check(lib().pn_winograd_f23_input_f32(_ptr(x), _ptr(V), B, H, W, Cin, _stream()),
+           "pn_winograd_f23_input_f32")
+    gemm(V, U, Mbuf, M=T, N=Cout, K=Cin, lda=Cin, ldw=Cin, ldc=Cout, batch=16, sA=T * Cin,
+         sW=Cout * Cin, sC=T * Cout, split=split)
+    _check(lib().pn_winograd_f23_output_f32(_ptr(Mbuf), _ptr(bias), _ptr(out), B, H, W, Cout,
+                                            int(relu), _stream()), "pn_winograd_f23_output_f32")
 
 
 def layernorm(x, gamma, beta, out, eps=1e-5):

@@ -93,8 +93,9 @@ def test_e2e_small_against_reference_golden():
         assert r[0].shape == (200, 5) and float(r[0].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("gemm_mode", ["f32", "bf16x3"])
-def test_e2e_full_800x1333_against_reference_golden(gemm_mode):
+@pytest.mark.parametrize("gemm_mode,conv_algo", [("f32", "winograd"), ("f32", "direct"),
+                                                 ("f32", "winograd4"), ("bf16x3", "winograd")])
+def test_e2e_full_800x1333_against_reference_golden(gemm_mode, conv_algo):
     fx = golden("e2e_full")
     head_o, sd, crc = oracle_head(int(fx["weight_seed"]), overrides_of(fx))
     assert crc == int(fx["weight_crc"])
@@ -104,7 +105,7 @@ def test_e2e_full_800x1333_against_reference_golden(gemm_mode):
     assert [tuple(f.shape) for f in feats] == [tuple(s) for s in fx["feat_shapes"].tolist()]
     metas = [dict(img_shape=(H, W, 3), scale_factor=[2.083] * 4)]
     head = _hip_head(sd)
-    head.gemm_mode = gemm_mode
+    head.gemm_mode, head.conv_algo = gemm_mode, conv_algo
     cls, masks = head.forward([f.to(DEV) for f in feats], metas)
     torch.cuda.synchronize()
     trace = {}
@@ -114,7 +115,8 @@ def test_e2e_full_800x1333_against_reference_golden(gemm_mode):
     e_imp = _err(cls["importance"], fx["importance"])
     probe = masks["mask"].flatten()[torch.from_numpy(fx["mask_probe_idx"]).to(DEV)]
     e_mask = _err(probe, fx["mask_probe"])
-    print("e2e_full errors: rel %.3e cls %.3e importance %.3e mask %.3e" % (e_rel, e_cls, e_imp, e_mask))
+    print("e2e_full [%s, %s] errors: rel %.3e cls %.3e importance %.3e mask %.3e"
+          % (gemm_mode, conv_algo, e_rel, e_cls, e_imp, e_mask))
     assert e_rel < 1e-3 and e_cls < 1e-3 and e_imp < 1e-3
     assert e_mask < 1e-3 * max(1.0, float(np.abs(fx["mask_probe"]).max()))
     ok, exact = tie_aware_topk_match(fx["importance"][0], fx["topk_idx"][0],

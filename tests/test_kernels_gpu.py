@@ -208,6 +208,40 @@ def test_layernorm_l2norm(hip):
     close(out, F.normalize(x, p=2, dim=-1, eps=1e-12), 1e-6, "l2norm")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,relu", [(1, 24, 32, 256, 256, False),
+                                                 (2, 10, 14, 64, 128, True), (1, 2, 2, 32, 32, False)])
+def test_conv3x3_winograd_matches_torch(hip, B, H, W, Cin, Cout, relu):
+    x, w, b = R(B, Cin, H, W, seed=1), R(Cout, Cin, 3, 3, seed=2) * 0.05, R(Cout, seed=3)
+    ref = F.conv2d(x, w, b, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    T = B * (H // 2) * (W // 2)
+    V, Mb = torch.empty(16, T, Cin, device=DEV), torch.empty(16, T, Cout, device=DEV)
+    out = torch.empty(B, H, W, Cout, device=DEV)
+    hip.conv3x3_winograd(x.permute(0, 2, 3, 1).contiguous().to(DEV), hip.winograd_weights(w).to(DEV),
+                         b.to(DEV), out, V, Mb, B, H, W, Cin, Cout, relu)
+    close(out.permute(0, 3, 1, 2), ref, 3e-5 * math.sqrt(9 * Cin / 256), "winograd 3x3")
+    with pytest.raises(RuntimeError):      # odd sides are refused (callers fall back)
+        hip.conv3x3_winograd(out, hip.winograd_weights(w).to(DEV), None, out, V, Mb, B, H + 1, W,
+                             Cin, Cout, False)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,relu", [(1, 24, 32, 256, 256, False),
+                                                 (2, 10, 15, 64, 128, True), (1, 3, 5, 32, 32, False)])
+def test_conv3x3_winograd43_matches_torch(hip, B, H, W, Cin, Cout, relu):
+    x, w, b = R(B, Cin, H, W, seed=1), R(Cout, Cin, 3, 3, seed=2) * 0.05, R(Cout, seed=3)
+    ref = F.conv2d(x, w, b, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    T = B * ((H + 3) // 4) * ((W + 3) // 4)
+    V, Mb = torch.empty(36, T, Cin, device=DEV), torch.empty(36, T, Cout, device=DEV)
+    out = torch.empty(B, H, W, Cout, device=DEV)
+    hip.conv3x3_winograd43(x.permute(0, 2, 3, 1).contiguous().to(DEV),
+                           hip.winograd43_weights(w).to(DEV), b.to(DEV), out, V, Mb, B, H, W, Cin,
+                           Cout, relu)
+    close(out.permute(0, 3, 1, 2), ref, 2e-4 * math.sqrt(9 * Cin / 256), "winograd F(4,3)")
+
+
 @pytest.mark.parametrize("M,hidden", [(100, 2048), (200, 2048), (37, 128)])
 def test_fused_ffn_layernorm(hip, M, hidden):
     x = R(M, 256, seed=1, lo=-2, hi=2)

@@ -13,6 +13,11 @@ Fixtures
   ppn        G1  reference sub/obj MLPs + ConvTiny + top-k on a stored query tensor
   reldec     G3  pair features -> relation logits through the reference head's
                  relation decoder loop (pairnet_head.py:353-378)
+  fwdhead    G4  reference forward_head (pairnet_head.py:216-258) on a reduced mask
+                 feature: class / mask logits, boolean attention mask, pre-threshold
+                 resized logits (so that bits next to the threshold can be exempted)
+  declayer   G5  one masked-attention decoder layer of the reference head
+                 (transformer_decoder.layers[0], attn_masks=[mask, None]) at reduced K
   msda       G6  deformable sampling on a reduced pyramid (restated CPU formula;
                  unpinned against mmcv)
   e2e_small  G7  whole head + get_bboxes on a 96x128 image, batch 2
@@ -108,6 +113,41 @@ def gen_reldec(head, sd):
         rel = head.rel_cls_embed(r.transpose(0, 1))
     np.savez_compressed(os.path.join(OUT, "reldec.npz"), weight_seed=WEIGHT_SEED,
                         weight_crc=seeded.checksum(sd), pair_feat=_np(pair), rel_preds=_np(rel))
+
+
+def gen_fwdhead(head, sd):
+    rng = np.random.default_rng(51)
+    dec = seeded.uniform(rng, (100, 2, 256), -2.0, 2.0)
+    mf = seeded.uniform(rng, (2, 256, 16, 24), -1.0, 1.0)
+    with torch.no_grad():
+        cls, mask, attn = head.forward_head(dec, mf, (8, 12))
+        resized = F.interpolate(mask, (8, 12), mode="bilinear", align_corners=False)
+    np.savez_compressed(os.path.join(OUT, "fwdhead.npz"), weight_seed=WEIGHT_SEED,
+                        weight_crc=seeded.checksum(sd), decoder_out=_np(dec), mask_feature=_np(mf),
+                        cls_pred=_np(cls), mask_pred=_np(mask),
+                        attn_mask=np.packbits(_np(attn)), attn_shape=np.array(attn.shape),
+                        resized_logits=_np(resized))
+
+
+def gen_declayer(head, sd):
+    rng = np.random.default_rng(61)
+    Q, K, bs = 100, 96, 2
+    q = seeded.uniform(rng, (Q, bs, 256), -1.0, 1.0)
+    mem = seeded.uniform(rng, (K, bs, 256), -1.0, 1.0)
+    # positional terms are batch-independent in the model (embedding / sine table repeated)
+    qpos = seeded.uniform(rng, (Q, 1, 256), -1.0, 1.0).repeat(1, bs, 1)
+    kpos = seeded.uniform(rng, (K, 1, 256), -1.0, 1.0).repeat(1, bs, 1)
+    mask = torch.from_numpy(rng.random((bs, Q, K)) < 0.5)
+    mask[:, 7, :] = False                      # the all-masked-row fix leaves such rows open
+    attn = mask.unsqueeze(1).repeat(1, head.n_heads, 1, 1).flatten(0, 1)
+    with torch.no_grad():
+        out = head.transformer_decoder.layers[0](
+            query=q, key=mem, value=mem, query_pos=qpos, key_pos=kpos, attn_masks=[attn, None],
+            query_key_padding_mask=None, key_padding_mask=None)
+    np.savez_compressed(os.path.join(OUT, "declayer.npz"), weight_seed=WEIGHT_SEED,
+                        weight_crc=seeded.checksum(sd), query=_np(q), query_pos=_np(qpos),
+                        memory=_np(mem), key_pos=_np(kpos), mask=np.packbits(_np(mask)),
+                        mask_shape=np.array(mask.shape), out=_np(out))
 
 
 def gen_msda():
@@ -278,12 +318,16 @@ def main():
         gen_convtiny()
     if want("msda"):
         gen_msda()
-    if any(want(n) for n in ("ppn", "reldec", "e2e_small", "e2e_full")):
+    if any(want(n) for n in ("ppn", "reldec", "fwdhead", "declayer", "e2e_small", "e2e_full")):
         head, sd = build_ref()
         if want("ppn"):
             gen_ppn(head, sd)
         if want("reldec"):
             gen_reldec(head, sd)
+        if want("fwdhead"):
+            gen_fwdhead(head, sd)
+        if want("declayer"):
+            gen_declayer(head, sd)
         if want("e2e_small"):
             gen_e2e_small(head, sd)
         if want("e2e_full"):

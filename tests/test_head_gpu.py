@@ -323,3 +323,65 @@ def test_evaluator_feed_mask_iou_counts_are_exact():
     i, a, b = inter.cpu().double(), ap.cpu().double()[:, None], ag.cpu().double()[None]
     iou = i / (a + b - i)
     assert float(iou[5, 2]) == 1.0
+
+
+# ---- G4 / G5 fixtures: forward_head and one masked decoder layer --------
+def test_forward_head_against_reference_golden():
+    fx = golden("fwdhead")
+    _, sd, crc = oracle_head(int(fx["weight_seed"]))
+    assert crc == int(fx["weight_crc"])
+    head = _hip_head(sd)
+    cls, mask, attn = head.forward_head(torch.from_numpy(fx["decoder_out"]).to(DEV),
+                                        torch.from_numpy(fx["mask_feature"]).to(DEV), (8, 12))
+    torch.cuda.synchronize()
+    assert _err(cls, fx["cls_pred"]) < 1e-4
+    assert _err(mask, fx["mask_pred"]) < 1e-3 * max(1.0, float(np.abs(fx["mask_pred"]).max()))
+    shape = tuple(fx["attn_shape"])
+    ref_bits = np.unpackbits(fx["attn_mask"])[:int(np.prod(shape))].reshape(shape).astype(bool)
+    got = attn.cpu().numpy()
+    assert got.shape == shape and got.dtype == np.bool_
+    # the threshold is a discrete decision: positions whose reference logit is
+    # within 1e-4 of it are exempt, every other bit must agree
+    sure = np.abs(fx["resized_logits"]).reshape(2, 1, 100, 96) > 1e-4
+    sure = np.broadcast_to(sure, (2, 8, 100, 96)).reshape(shape)
+    assert np.array_equal(got[sure], ref_bits[sure])
+    assert sure.mean() > 0.999
+
+
+def test_masked_decoder_layer_against_reference_golden():
+    """One cross-attn -> self-attn -> FFN layer (transformer_decoder.layers[0]) on the
+    reference's own inputs, through the kernels `_layer` strings together."""
+    from pairnet_amd import hip
+    fx = golden("declayer")
+    _, sd, crc = oracle_head(int(fx["weight_seed"]))
+    assert crc == int(fx["weight_crc"])
+    head = _hip_head(sd)
+    head._pack()
+    w = head.w
+    Q, B, K = 100, 2, 96
+    E = lambda *s: torch.empty(*s, device=DEV)
+    bf = lambda a: torch.from_numpy(a).permute(1, 0, 2).contiguous().to(DEV)   # (L,B,C)->(B,L,C)
+    x = bf(fx["query"]).view(B * Q, 256).clone()
+    xpos = torch.from_numpy(fx["query_pos"][:, 0]).contiguous().to(DEV)
+    mem, kpos = bf(fx["memory"]), torch.from_numpy(fx["key_pos"][:, 0]).contiguous().to(DEV)
+    a0 = "transformer_decoder.layers.0.attentions.0.attn."
+    Kp, Vp = E(B, K, 256), E(B, K, 256)
+    hip.linear(mem.view(-1, 256), w[a0 + "in_proj_weight"][256:512], w[a0 + "in_proj_bias"][256:512],
+               Kp.view(-1, 256), aadd=kpos)
+    hip.linear(mem.view(-1, 256), w[a0 + "in_proj_weight"][512:], w[a0 + "in_proj_bias"][512:],
+               Vp.view(-1, 256))
+    shape = tuple(fx["mask_shape"])
+    mask = np.unpackbits(fx["mask"])[:int(np.prod(shape))].reshape(shape).astype(bool)
+    logits = torch.from_numpy(np.where(mask, -1.0, 1.0).astype(np.float32)).to(DEV).view(B * Q, K)
+    bits = torch.empty(B * Q * ((K + 31) // 32), device=DEV, dtype=torch.int32)
+    rowall = torch.empty(B * Q, device=DEV, dtype=torch.int32)
+    hip.mask_pack(logits, bits, rowall, B * Q, K)
+    scr = E(max(hip.attn_scratch_floats(B, Q, K), hip.attn_scratch_floats(B, Q, Q)))
+    hbuf = E(hip.ffn_scratch_floats(B * Q, head.dec_ffn))
+    x1, x2, y, Qp, att = (E(B * Q, 256) for _ in range(5))
+    VQK = E(B * Q, 768)
+    head._layer("transformer_decoder.layers.0.", x, xpos, x1, x2, y, Qp, VQK, att, hbuf, Kp, 256,
+                Vp, 256, K, B, Q, bits, rowall, scr, head.dec_ffn)
+    torch.cuda.synchronize()
+    got = x.view(B, Q, 256).permute(1, 0, 2)
+    assert _err(got, fx["out"]) < 1e-4

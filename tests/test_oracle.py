@@ -220,3 +220,32 @@ def test_psgtr2_oracle_equals_shimmed_reference():
         ra, rb = ref.get_bboxes(*a, metas), head.get_bboxes(*b, metas)
     for name, x, y in zip(RES_NAMES, ra[0], rb[0]):
         assert x.dtype == y.dtype and torch.equal(x, y), name
+
+
+# ---- G4 / G5: forward_head and one masked decoder layer ------------------------------
+def test_forward_head_matches_golden():
+    fx = golden("fwdhead")
+    head, sd, crc = oracle_head(int(fx["weight_seed"]))
+    assert crc == int(fx["weight_crc"])
+    with torch.no_grad():
+        cls, mask, attn = head.forward_head(torch.from_numpy(fx["decoder_out"]),
+                                            torch.from_numpy(fx["mask_feature"]), (8, 12))
+    assert np.array_equal(cls.numpy(), fx["cls_pred"]) and np.array_equal(mask.numpy(), fx["mask_pred"])
+    assert tuple(attn.shape) == tuple(fx["attn_shape"])
+    assert np.array_equal(np.packbits(attn.numpy()), fx["attn_mask"])
+
+
+def test_masked_decoder_layer_matches_golden():
+    fx = golden("declayer")
+    head, sd, crc = oracle_head(int(fx["weight_seed"]))
+    assert crc == int(fx["weight_crc"])
+    shape = tuple(fx["mask_shape"])
+    mask = torch.from_numpy(np.unpackbits(fx["mask"])[:int(np.prod(shape))].reshape(shape).astype(bool))
+    attn = mask.unsqueeze(1).repeat(1, head.n_heads, 1, 1).flatten(0, 1)
+    t = lambda k: torch.from_numpy(fx[k])
+    with torch.no_grad():
+        out = head.transformer_decoder.layers[0](
+            query=t("query"), key=t("memory"), value=t("memory"), query_pos=t("query_pos"),
+            key_pos=t("key_pos"), attn_masks=[attn, None], query_key_padding_mask=None,
+            key_padding_mask=None)
+    assert np.array_equal(out.numpy(), fx["out"])

@@ -249,3 +249,36 @@ def test_masked_decoder_layer_matches_golden():
             key_pos=t("key_pos"), attn_masks=[attn, None], query_key_padding_mask=None,
             key_padding_mask=None)
     assert np.array_equal(out.numpy(), fx["out"])
+
+
+# ---- Swin backbone restatement pinned to an independent implementation ----------------
+@pytest.mark.parametrize("ed,depths,heads,ws,H,W", [
+    (32, (2, 2, 2, 2), (1, 2, 4, 8), 4, 75, 101),      # odd maps: every padding path
+    (32, (2, 2, 2), (1, 2, 4), 7, 64, 96),
+    (64, (2, 1, 2, 1), (2, 4, 8, 16), 3, 50, 41)])
+def test_swin_oracle_matches_transformers_swin(ed, depths, heads, ws, H, W):
+    """oracle/swin.py (mmdet module tree, nn.Unfold patch-merging order) against
+    HuggingFace `SwinBackbone` with the same weights: shifted windows, window / patch
+    padding, relative position bias, output norms."""
+    tr = pytest.importorskip("transformers")
+    from oracle.swin import OracleSwin, seeded_swin_state, to_hf_state
+    n = len(depths)
+    m = OracleSwin(embed_dims=ed, depths=depths, num_heads=heads, window_size=ws,
+                   out_indices=tuple(range(n)))
+    sd = seeded_swin_state(m, 5)
+    m.load_state_dict(sd)
+    cfg = tr.SwinConfig(embed_dim=ed, depths=list(depths), num_heads=list(heads), window_size=ws,
+                        out_features=["stage%d" % (i + 1) for i in range(n)])
+    hf = tr.SwinBackbone(cfg).eval()
+    res = hf.load_state_dict(to_hf_state(sd, depths), strict=False)
+    assert not res.unexpected_keys
+    assert all("relative_position_index" in k or k.startswith("swin.layernorm")
+               for k in res.missing_keys)
+    img = torch.randn(2, 3, H, W, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        want = hf(img).feature_maps
+    got = m(img)
+    assert len(got) == len(want) == n
+    for g, w in zip(got, want):
+        assert tuple(g.shape) == tuple(w.shape)
+        assert float((g - w).abs().max()) < 2e-5 * float(w.abs().max())

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 6
+#define PN_ABI_VERSION 7
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -51,6 +51,7 @@ int pn_abi_version(void);
 #define PN_GEMM_FORCE_TILE64 16     /* tuning: 64x64 tile (row-major A)             */
 #define PN_GEMM_FORCE_TILE128x64 32 /* tuning: 128x64 tile                          */
 #define PN_GEMM_RELU_AFTER_RES 128  /* ReLU after the residual add: relu(act(..)+Res)  */
+#define PN_GEMM_GELU 256           /* act = exact (erf) GELU; Swin FFN                  */
 #define PN_GEMM_SPLIT_BF16 64  /* opt-in: fp32-accurate 3 x bf16 operand split on the
                                   bf16 MFMA (6 partial products, fp32 accumulate;
                                   error <= 3*2^-24 |a||b| per product, not bitwise the
@@ -149,6 +150,39 @@ int pn_maxpool3x3s2_nhwc_f32(const float* in, float* out, int B, int H, int W, i
  * pairnet_head.py:236.) */
 int pn_layernorm_f32(const float* x, const float* gamma, const float* beta,
                      float* y, int64_t rows, int C, float eps, void* stream);
+
+/* The same over rows of any width C % 4 == 0, C <= 3072, with row strides (floats):
+ * the norms of the Swin backbone ([3P] mmdet SwinTransformer configured at
+ * configs/mask2former/pairnet_swinb.py:203-226: patch_embed.norm, norm1 / norm2 of every
+ * block, the output norm of every stage). */
+int pn_layernorm_rows_f32(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                          float* y, int64_t ldy, int64_t rows, int C, float eps, void* stream);
+
+/* Swin patch merging up to its Linear: x [B][H*W][C] -> y [B][H2*W2][4C], H2 = ceil(H/2),
+ * row (b, y2, x2) = LayerNorm_4C([x(2y2,2x2) | x(2y2,2x2+1) | x(2y2+1,2x2) | x(2y2+1,2x2+1)])
+ * with zeros beyond an odd map's edge.  gamma / beta (and the columns of the reduction
+ * weight that follows) are in this neighbour-major order: index (row*2+col)*C + c, the
+ * permutation of mmdet's nn.Unfold order c*4 + row*2 + col. */
+int pn_patch_merge_ln_f32(const float* x, const float* gamma, const float* beta, float* y,
+                          int B, int H, int W, int C, float eps, void* stream);
+
+/* Swin patch embedding, im2col half: NCHW RGB image [B][3][H][W] -> rows
+ * [B*ceil(H/4)*ceil(W/4)][64], column c*16 + ky*4 + kx (the flattening of the
+ * [C][3][4][4] projection weight), columns 48..63 zero, pixels beyond H / W zero (the
+ * reference pads bottom / right to a multiple of the patch). */
+int pn_patch_im2col4_f32(const float* img, float* out, int B, int H, int W, void* stream);
+
+/* Swin (shifted-)window multi-head attention, head dim 32, on the qkv rows
+ * [B*H*W][ldqkv] (q | k | v, each C = heads*32 wide) -> out [B*H*W][ldo]:
+ * zero-padding of the map to a multiple of `ws` (padded tokens' q/k/v = qkv_bias, as the
+ * reference pads after norm1), cyclic shift by `shift`, window partition, softmax(q k^T *
+ * scale + bias_table[(dy+ws-1)(2ws-1)+(dx+ws-1)][head] + (-100 between different
+ * wrap-around regions)) v, window merge, un-shift and crop are all index arithmetic.
+ * bias_table is [(2ws-1)^2][heads].  ws*ws <= 169. */
+int pn_window_attention_f32(const float* qkv, int64_t ldqkv, const float* qkv_bias,
+                            const float* bias_table, float* out, int64_t ldo, int B, int H,
+                            int W, int C, int heads, int ws, int shift, float scale,
+                            void* stream);
 
 /* GroupNorm over channel-last x[b][HW][C] with G groups (+ optional ReLU); image b
  * starts at x + b*x_bstride / y + b*y_bstride (floats).  `partials` is caller

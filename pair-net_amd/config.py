@@ -179,6 +179,29 @@ def pairnet_r50():
         test_cfg=dict(max_per_img=100))
 
 
+def swin_backbone_cfg(variant="B"):
+    """`backbone` section of configs/mask2former/pairnet_swinb.py:203-226 (Swin-B, window 12,
+    pretrain 384); "L" = the Swin-L of BASELINE.json configs[3] (same file, embed 192 and
+    heads 6/12/24/48), "T" = Swin-T (window 7)."""
+    embed, depths, heads, ws = {"T": (96, (2, 2, 6, 2), (3, 6, 12, 24), 7),
+                                "B": (128, (2, 2, 18, 2), (4, 8, 16, 32), 12),
+                                "L": (192, (2, 2, 18, 2), (6, 12, 24, 48), 12)}[variant]
+    return dict(type="SwinTransformer", embed_dims=embed, depths=list(depths),
+                num_heads=list(heads), window_size=ws, mlp_ratio=4, qkv_bias=True, qk_scale=None,
+                drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.3, patch_norm=True,
+                out_indices=(0, 1, 2, 3), convert_weights=True, frozen_stages=3,
+                pretrain_img_size=384)
+
+
+def pairnet_swin(variant="B", num_obj_query=100):
+    """`model` section: PSGTr(Swin, CrossHead2) (pairnet_swinb.py:201-240)."""
+    bb = swin_backbone_cfg(variant)
+    chans = [bb["embed_dims"] * 2 ** i for i in range(4)]
+    return ConfigDict(type="PSGTr", backbone=bb,
+                      bbox_head=pairnet_head_cfg(in_channels=chans, num_obj_query=num_obj_query),
+                      test_cfg=dict(max_per_img=100))
+
+
 def baseline_r50():
     """`model` section: PSGTr(ResNet-50, CrossHeadBaseline)."""
     cfg = pairnet_r50()

@@ -499,7 +499,7 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = acc[mi][ni][r] + bv;
-          if (p.relu) v = fmaxf(v, 0.f);
+          v = gemm_act(v, p.relu);
           if (Res) v += rv[r];
           if (p.relu_after) v = fmaxf(v, 0.f);
           ov[r] = v;
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_skinny(const GemmP p) {
 #pragma unroll
       for (int w = 1; w < NW; ++w) v += red[w * 1024 + e];
       if (p.bias) v += p.bias[col];
-      if (p.relu) v = fmaxf(v, 0.f);
+      v = gemm_act(v, p.relu);
       if (Res) v += Res[(int64_t)row * p.ldres + col];
       if (p.relu_after) v = fmaxf(v, 0.f);
       C[(int64_t)row * p.ldc + col] = v;
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
   float4 v = ld4(pp);
   for (int s = 1; s < S; ++s) v = add4(v, ld4(pp + s * mn));
   if (p.bias) v = add4(v, ld4(p.bias + col));
-  if (p.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+  v = make_float4(gemm_act(v.x, p.relu), gemm_act(v.y, p.relu), gemm_act(v.z, p.relu), gemm_act(v.w, p.relu));
   if (p.Res) {
     const float* r = p.Res + (int64_t)b * p.sRes + (int64_t)row * p.ldres + col;
     v = add4(v, make_float4(r[0], r[1], r[2], r[3]));
@@ -821,7 +821,7 @@ int pn_fill_params(const pn_gemm_desc* d, GemmP* out) {
   p.sA = d->strideA; p.sW = d->strideW; p.sRes = d->strideRes; p.sC = d->strideC;
   p.M = d->M; p.N = d->N; p.K = d->K; p.aadd_rows = d->Aadd ? d->aadd_rows : 1;
   p.aadd_from_col = d->Aadd ? d->aadd_from_col : 0;
-  p.relu = (d->flags & PN_GEMM_RELU) ? 1 : 0;
+  p.relu = (d->flags & PN_GEMM_GELU) ? 2 : (d->flags & PN_GEMM_RELU) ? 1 : 0;
   p.relu_after = (d->flags & PN_GEMM_RELU_AFTER_RES) ? 1 : 0;
   p.a_vec = colmajor && d->lda % 4 == 0 && d->strideA % 4 == 0 && aligned16(d->A);
   *out = p;

@@ -7,7 +7,7 @@ struct GemmP {
   const float* Res; float* C;
   int64_t lda, ldaadd, ldw, ldres, ldc;
   int64_t sA, sW, sRes, sC;
-  int M, N, K, aadd_rows, aadd_from_col, relu, a_vec;
+  int M, N, K, aadd_rows, aadd_from_col, relu /* act: 0 none, 1 ReLU, 2 GELU (erf) */, a_vec;
   int relu_after;           // ReLU after the residual add (ResNet bottleneck output)
   // split-K: the launch's batch index bz = (batch b) * ksplit + (split s); split s
   // contracts the 32-deep chunks [s * split_chunks, (s+1) * split_chunks) into its own
@@ -25,3 +25,10 @@ enum { A_ROW = 0, A_COL = 1, A_CONV = 2, A_STEM = 3 };
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 int pn_fill_params(const pn_gemm_desc* d, GemmP* out);
+
+// act of the epilogue: the code is wave-uniform (a kernel argument)
+__device__ __forceinline__ float gemm_act(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+  return v;
+}

@@ -16,6 +16,7 @@ from .backbone import ResNet50Hip
 from .baseline_head import CrossHeadBaseline
 from .head import CrossHead2
 from .psgtr_head2 import PSGTrHead2
+from .swin import SwinTransformerHip
 
 
 class Result(object):
@@ -117,14 +118,20 @@ class PSGTr:
                  init_cfg=None, neck=None):
         assert neck is None
         backbone = ConfigDict(backbone)
-        if backbone.get("type", "ResNet") != "ResNet" or backbone.get("depth", 50) != 50:
-            raise NotImplementedError("only the ResNet-50 backbone of pairnet.py is built")
-        # "hip" (default): the native fp32-MFMA backbone of backbone.py, channels_last
-        # features straight into the head; "torch": PyTorch-ROCm / MIOpen (same state dict)
-        impl = backbone.get("impl", "hip")
-        if impl not in ("hip", "torch"):
-            raise ValueError("backbone.impl must be 'hip' or 'torch'")
-        self.backbone = ResNet50Hip() if impl == "hip" else ResNet50()
+        btype = backbone.get("type", "ResNet")
+        if btype == "SwinTransformer":
+            # pairnet_swinb.py:203-226; native only (swin.py)
+            self.backbone = SwinTransformerHip(**{k: v for k, v in backbone.items() if k != "type"})
+        elif btype == "ResNet" and backbone.get("depth", 50) == 50:
+            # "hip" (default): the native fp32-MFMA backbone of backbone.py, channels_last
+            # features straight into the head; "torch": PyTorch-ROCm / MIOpen (same state dict)
+            impl = backbone.get("impl", "hip")
+            if impl not in ("hip", "torch"):
+                raise ValueError("backbone.impl must be 'hip' or 'torch'")
+            self.backbone = ResNet50Hip() if impl == "hip" else ResNet50()
+        else:
+            raise NotImplementedError("backbones built: ResNet depth 50 (pairnet.py) and "
+                                      "SwinTransformer (pairnet_swinb.py)")
         head_cfg = dict(bbox_head)
         heads = dict(CrossHead2=CrossHead2, CrossHeadBaseline=CrossHeadBaseline,
                      PSGTrHead2=PSGTrHead2)

@@ -14,6 +14,7 @@ from .build import LIB_PATH
 _i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 GEMM_RELU, GEMM_A_COLMAJOR, GEMM_FORCE_TILE, GEMM_FORCE_SKINNY = 1, 2, 4, 8
+GEMM_GELU = 256
 GEMM_FORCE_TILE64, GEMM_FORCE_TILE128x64 = 16, 32
 GEMM_RELU_AFTER_RES = 128
 
@@ -45,6 +46,11 @@ _SIGS = {
     "pn_winograd_f43_input_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_winograd_f43_output_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pn_layernorm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "pn_layernorm_rows_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp]),
+    "pn_patch_merge_ln_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "pn_patch_im2col4_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "pn_window_attention_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64] + [_i32] * 7 +
+                                [_f32, _vp]),
     "pn_groupnorm_nblk": (C.c_int, [_i64]),
     "pn_groupnorm_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32,
                                         _i32, _f32, _i32, _i64, _i64, _vp]),
@@ -79,7 +85,7 @@ _SIGS = {
     "pn_mask_iou_counts": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 6   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 7   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -175,7 +181,7 @@ def _rowmajor(t):
 def gemm_desc(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaadd=0,
               aadd_rows=0, aadd_from_col=0, res=None, ldres=0, batch=1, sA=0, sW=0, sC=0,
               sRes=0, relu=False, colmajor=False, force=None, split=False, into=None,
-              relu_after=False, scratch=None):
+              relu_after=False, scratch=None, gelu=False):
     """Fill a pn_gemm_desc; tensors only supply base pointers."""
     d = into if into is not None else GemmDesc()
     d.A, d.lda, d.strideA = _ptr(A), lda, sA
@@ -188,7 +194,7 @@ def gemm_desc(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaad
     d.flags = (GEMM_RELU if relu else 0) | (GEMM_A_COLMAJOR if colmajor else 0) | \
         {None: 0, "tile": GEMM_FORCE_TILE, "skinny": GEMM_FORCE_SKINNY, "tile64": 16,
          "tile128x64": 32}[force] | (GEMM_SPLIT_BF16 if split else 0) | \
-        (GEMM_RELU_AFTER_RES if relu_after else 0)
+        (GEMM_RELU_AFTER_RES if relu_after else 0) | (GEMM_GELU if gelu else 0)
     d.splitk_scratch = _ptr(scratch)
     d.splitk_scratch_floats = scratch.numel() if scratch is not None else 0
     return d
@@ -222,7 +228,7 @@ def gemm_group(problems):
 
 
 def linear(x, weight, bias, out, *, aadd=None, aadd_from_col=0, res=None, relu=False,
-           force=None, split=False, relu_after=False, scratch=None):
+           force=None, split=False, relu_after=False, scratch=None, gelu=False):
     """out = act((x + aadd[row % len(aadd)]) @ weight.T + bias) + res on 2-D views
     (aadd only feeds output columns >= aadd_from_col)."""
     M, lda = _rowmajor(x)
@@ -238,7 +244,8 @@ def linear(x, weight, bias, out, *, aadd=None, aadd_from_col=0, res=None, relu=F
         assert rr == M
         kw.update(res=res, ldres=ldr)
     gemm(x, weight, out, M=M, N=N, K=x.shape[1], lda=lda, ldw=ldw, ldc=ldc, bias=bias,
-         relu=relu, force=force, split=split, relu_after=relu_after, scratch=scratch, **kw)
+         relu=relu, force=force, split=split, relu_after=relu_after, scratch=scratch, gelu=gelu,
+         **kw)
 
 
 def conv2d_nhwc(x, wp, bias, out, B, H, W, Cin, Cout, KH, KW, pad, relu, split=False,
@@ -331,6 +338,48 @@ def layernorm(x, gamma, beta, out, eps=1e-5):
     rows = x.numel() // 256
     _check(lib().pn_layernorm_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), rows, 256,
                                   eps, _stream()), "pn_layernorm_f32")
+
+
+def layernorm_rows(x, gamma, beta, out, eps=1e-5):
+    """LayerNorm over the last dim of 2-D row views (any C % 4 == 0, C <= 3072)."""
+    rows, ldx = _rowmajor(x)
+    ro, ldo = _rowmajor(out)
+    assert ro == rows and out.shape[1] == x.shape[1]
+    _check(_launch("k_ln_rows", 0.0, 8.0 * rows * x.shape[1],
+                   lambda: lib().pn_layernorm_rows_f32(_ptr(x), ldx, _ptr(gamma), _ptr(beta),
+                                                       _ptr(out), ldo, rows, x.shape[1], eps,
+                                                       _stream())), "pn_layernorm_rows_f32")
+
+
+def patch_merge_ln(x, gamma, beta, out, B, H, W, C, eps=1e-5):
+    """x [B][H*W][C] -> out [B][ceil(H/2)*ceil(W/2)][4C] = LayerNorm of the 2x2 neighbourhoods
+    concatenated neighbour-major ((row*2+col)*C + c); gamma / beta in that order."""
+    _check(_launch("k_ln_rows<merge>", 0.0, 8.0 * B * H * W * C,
+                   lambda: lib().pn_patch_merge_ln_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out),
+                                                       B, H, W, C, eps, _stream())),
+           "pn_patch_merge_ln_f32")
+
+
+def patch_im2col4(img, out, B, H, W):
+    """NCHW RGB image -> [B*ceil(H/4)*ceil(W/4)][64] rows of 4x4 patches (c*16+ky*4+kx, 48
+    columns + 16 zeros); pixels beyond H / W read as zero."""
+    _check(_launch("k_patch_im2col", 0.0, 4.0 * B * H * W * 3 * 2.4,
+                   lambda: lib().pn_patch_im2col4_f32(_ptr(img), _ptr(out), B, H, W, _stream())),
+           "pn_patch_im2col4_f32")
+
+
+def window_attention(qkv, qkv_bias, table, out, B, H, W, C, heads, ws, shift):
+    """(Shifted-)window attention on the [B*H*W][3C] qkv rows -> out [B*H*W][C]."""
+    n, ldq = _rowmajor(qkv)
+    no, ldo = _rowmajor(out)
+    assert n == no == B * H * W and qkv.shape[1] == 3 * C
+    hp, wp = -(-H // ws) * ws, -(-W // ws) * ws
+    flops = 4.0 * B * hp * wp * (ws * ws) * C
+    _check(_launch("k_window_attn", flops, 16.0 * n * C,
+                   lambda: lib().pn_window_attention_f32(_ptr(qkv), ldq, _ptr(qkv_bias),
+                                                         _ptr(table), _ptr(out), ldo, B, H, W, C,
+                                                         heads, ws, shift, 32 ** -0.5, _stream())),
+           "pn_window_attention_f32")
 
 
 def groupnorm_nblk(hw):

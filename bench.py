@@ -306,16 +306,24 @@ def main():
             "forward": timeit(lambda: head.forward(feats, metas)),
             "get_bboxes": timeit(lambda: head.get_bboxes(*outs, metas))}
         try:  # reported separately: the backbone, native and MIOpen
-            from pairnet_amd import ResNet50Hip
+            from pairnet_amd import ResNet50Hip, SwinTransformerHip, swin_backbone_cfg
             from pairnet_amd.detector import ResNet50
             img = torch.randn(B, 3, H, W, device=dev)
-            nb = ResNet50Hip().to(dev)
+            # the backbone whose channel widths the head was built for: ResNet-50
+            # (pairnet.py) or Swin-T/B/L (pairnet_swinb.py; configs[3] is Swin-L)
+            swin = {96: "T", 128: "B", 192: "L"}.get(chans[0])
+            if swin:
+                scfg = swin_backbone_cfg(swin)
+                scfg.pop("type")
+                nb, bname = SwinTransformerHip(**scfg).to(dev), "swin_%s" % swin.lower()
+            else:
+                nb, bname = ResNet50Hip().to(dev), "r50"
             nb(img)                       # packs the folded weights, plans the buffers
             torch.cuda.synchronize()
             # (best of two timed loops: freeing the constructor's ~200 MB of host-side
             # temporaries is an munmap, whose amdgpu MMU-notifier stall lands in whatever
             # GPU work runs next -- DESIGN.md 6b)
-            out["breakdown_ms"]["backbone_r50_native_fp32_mfma"] = min(
+            out["breakdown_ms"]["backbone_%s_native_fp32_mfma" % bname] = min(
                 timeit(lambda: nb(img), 10), timeit(lambda: nb(img), 10))
             # image tensor -> triplets: native backbone feeding the pipelined head
             head.use_graphs = not args.no_graphs
@@ -339,11 +347,14 @@ def main():
                 dt = d1 if dt is None else min(dt, d1)
             out["end_to_end_from_image_tensor"] = {
                 "images_per_s": B / dt, "ms_per_step": 1e3 * dt,
-                "what": "ResNet50Hip (native fp32 MFMA backbone, random weights) -> "
-                        "channels_last features -> pipelined %s" % type(head).__name__}
-            bb = ResNet50().to(dev)
-            out["breakdown_ms"]["backbone_r50_torch_miopen"] = timeit(lambda: bb(img), 3)
-            del bb, nb, img
+                "what": "%s (native fp32 MFMA backbone, random weights) -> channels_last "
+                        "features -> pipelined %s" % (type(nb).__name__ + (" " + swin if swin else ""),
+                                                      type(head).__name__)}
+            if not swin:
+                bb = ResNet50().to(dev)
+                out["breakdown_ms"]["backbone_r50_torch_miopen"] = timeit(lambda: bb(img), 3)
+                del bb
+            del nb, img
         except Exception as e:  # pragma: no cover
             out["breakdown_ms"]["backbone_error"] = repr(e)
 

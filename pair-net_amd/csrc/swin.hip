@@ -147,8 +147,18 @@ extern "C" int pn_patch_im2col4_f32(const float* img, float* out, int B, int H, 
 // from the accumulator registers.  Added before the softmax: the relative position bias
 // table[(qy - ky + ws - 1)(2 ws - 1) + (qx - kx + ws - 1)][head] (this head's column is
 // staged in LDS) and -100 between tokens of different wrap-around regions (shift > 0).
-#define WA_LD 36
-#define WA_MAXN 169  // ws <= 13: K, V, the bias column and the metadata fit 64 KB of LDS
+// LDS: K and V rows of 32 floats without padding (the 18-block stage of Swin-L launches 840
+// workgroups: at 40 KB each all of them are resident, 4 per CU).  K row r keeps its 16-byte
+// chunk c at position c ^ ((r ^ r >> 3) & 7): the per-lane-row b128 reads of the S^T MFMA
+// touch every bank once per 16 lanes.  V row r lives at physical row swap_bits_0_2(r): the
+// two half-waves of the P.V operand read (rows r, r + 4) land in different bank halves.
+// Rows N8..32 nt of the last tile are never stored; reads there fall into the arrays that
+// follow (V -> K rows, finite, times P = 0; K -> table / metadata, whose scores are
+// discarded by the key < N select).
+#define WA_MAXN 169  // ws <= 13
+
+__device__ __forceinline__ int wa_kpos(int r, int c) { return r * 32 + 4 * (c ^ ((r ^ (r >> 3)) & 7)); }
+__device__ __forceinline__ int wa_vrow(int r) { return (r & ~5) | ((r & 1) << 2) | ((r >> 2) & 1); }
 
 struct WinP {
   const float* qkv; const float* qkv_bias; const float* table; float* out;
@@ -161,9 +171,10 @@ __global__ __launch_bounds__(512) void k_window_attn(const WinP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = p.ws * p.ws;
   const int nt = (N + 31) >> 5;            // key tiles == waves
-  float* Ks = smem;                        // [nt*32][WA_LD]
-  float* Vs = Ks + nt * 32 * WA_LD;
-  float* tab = Vs + nt * 32 * WA_LD;       // [(2ws-1)^2] this head's bias column
+  const int N8 = (N + 7) & ~7;
+  float* Vs = smem;                        // [N8][32], rows permuted
+  float* Ks = Vs + N8 * 32;                // [N8][32], chunks swizzled
+  float* tab = Ks + N8 * 32;               // [(2ws-1)^2] this head's bias column
   int* meta = reinterpret_cast<int*>(tab + (2 * p.ws - 1) * (2 * p.ws - 1));  // [nt*32]
   int* srcrow = meta + nt * 32;            // [nt*32] source token row or -1 (padding)
 
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(512) void k_window_attn(const WinP p) {
   // K / V rows of the window -> LDS (8 float4 per row)
   const float* kbias = p.qkv_bias + p.C + head * 32;
   const float* vbias = p.qkv_bias + 2 * p.C + head * 32;
-  for (int e = tid; e < nt * 32 * 8; e += nthreads) {
+  for (int e = tid; e < N8 * 8; e += nthreads) {
     const int t = e >> 3, c4 = (e & 7) * 4;
     float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
     if (t < N) {
@@ -215,8 +226,8 @@ __global__ __launch_bounds__(512) void k_window_attn(const WinP p) {
         vv = ld4(vbias + c4);
       }
     }
-    st4(Ks + t * WA_LD + c4, kv);
-    st4(Vs + t * WA_LD + c4, vv);
+    st4(Ks + wa_kpos(t, e & 7), kv);
+    st4(Vs + wa_vrow(t) * 32 + c4, vv);
   }
 
   // this lane's query
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(512) void k_window_attn(const WinP p) {
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float4 a = ld4(Ks + (k0 + li) * WA_LD + 16 * lh + 4 * u);
+      const float4 a = ld4(Ks + wa_kpos(k0 + li, 4 * lh + u));
       s = mfma32(a.x, qf[4 * u + 0], s);
       s = mfma32(a.y, qf[4 * u + 1], s);
       s = mfma32(a.z, qf[4 * u + 2], s);
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(512) void k_window_attn(const WinP p) {
     for (int r = 0; r < 16; ++r) o[r] *= alpha;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-      const float a = Vs[(k0 + mfma32_row(t, lh)) * WA_LD + li];
+      const float a = Vs[wa_vrow(k0 + mfma32_row(t, lh)) * 32 + li];
       o = mfma32(a, s[t], o);
     }
   }
@@ -314,7 +325,10 @@ extern "C" int pn_window_attention_f32(const float* qkv, int64_t ldqkv, const fl
   p.Hp = (H + ws - 1) / ws * ws; p.Wp = (W + ws - 1) / ws * ws;
   p.nwx = p.Wp / ws;
   const int nt = (ws * ws + 31) / 32;
-  const size_t lds = (size_t)(2 * nt * 32 * WA_LD + (2 * ws - 1) * (2 * ws - 1) + 2 * nt * 32) * 4;
+  const int N8 = (ws * ws + 7) & ~7;
+  int tail = (2 * ws - 1) * (2 * ws - 1) + 2 * nt * 32;      // table + metadata
+  if (tail < (nt * 32 - N8) * 32) tail = (nt * 32 - N8) * 32;  // over-read of the last K tile
+  const size_t lds = (size_t)(2 * N8 * 32 + tail) * 4;
   if (lds > 65536) return PN_BAD_ARG;
   hipLaunchKernelGGL(k_window_attn, dim3(p.nwx * (p.Hp / ws), heads, B), dim3(nt * 64), lds,
                      (hipStream_t)stream, p);

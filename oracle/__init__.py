@@ -8,9 +8,12 @@ Contents
 --------
 layers.py          fp32 torch-CPU restatement of the un-vendored third-party
                    layers the reference builds from its config (mmcv-full 1.7.0,
-                   mmdet 2.25.1).  PARITY UNPINNED for
-                   these: the real packages are not in /root/reference and not
-                   installed, the reference has no tests for them.
+                   mmdet 2.25.1).  Unpinned against
+                   those packages (not in /root/reference, not installed); the
+                   arithmetic is pinned against HuggingFace transformers'
+                   independent Mask2Former implementation (hf_pin.py).
+hf_pin.py          state-dict converters oracle -> transformers for those pins.
+swin.py            Swin backbone restatement, pinned to transformers.SwinBackbone.
 matrix_learner.py  restatement of the reference's in-tree Matrix Learner
                    (pairnet/models/frameworks/cnn_factory.py:6-53); pinned
                    against the reference module imported by path.

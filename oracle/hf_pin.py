@@ -1,0 +1,76 @@
+"""Pinning aids (TEST INFRASTRUCTURE): state-dict converters from this repo's restatements
+of the un-vendored mmdet / mmcv layers to HuggingFace `transformers`' independent
+implementations of the same published models, so that the [3P] arithmetic the oracle
+restates from memory can be checked against code written by somebody else.
+
+  pixel_decoder_to_hf   oracle/layers.py MSDeformAttnPixelDecoder (mmdet 2.25.1 names:
+                        input_convs / encoder.layers.N.{attentions.0,norms,ffns} /
+                        level_encoding / lateral_convs / output_convs / mask_feature)
+                        -> transformers Mask2FormerPixelDecoder
+  (oracle/swin.py::to_hf_state does the same for the Swin backbone.)
+
+Only tests/ imports this.
+"""
+
+
+def pixel_decoder_to_hf(sd):
+    out = {}
+    for k, v in sd.items():
+        leaf = k.split(".")[-1]
+        if k.startswith("input_convs."):
+            i, part = k.split(".")[1:3]
+            out["input_projections.%s.%d.%s" % (i, 0 if part == "conv" else 1, leaf)] = v
+        elif k == "level_encoding.weight":
+            out["level_embed"] = v
+        elif k.startswith("lateral_convs.0.") or k.startswith("output_convs.0."):
+            part = k.split(".")[2]
+            name = "adapter_1" if k.startswith("lateral") else "layer_1"
+            out["%s.%d.%s" % (name, 0 if part == "conv" else 1, leaf)] = v
+        elif k.startswith("mask_feature."):
+            out["mask_projection." + leaf] = v
+        elif k.startswith("encoder.layers."):
+            n = k.split(".")[2]
+            rest = ".".join(k.split(".")[3:])
+            p = "encoder.layers.%s." % n
+            if rest.startswith("attentions.0."):
+                out[p + "self_attn." + rest[len("attentions.0."):]] = v
+            elif rest.startswith("norms.0."):
+                out[p + "self_attn_layer_norm." + leaf] = v
+            elif rest.startswith("norms.1."):
+                out[p + "final_layer_norm." + leaf] = v
+            elif rest.startswith("ffns.0.layers.0.0."):
+                out[p + "fc1." + leaf] = v
+            elif rest.startswith("ffns.0.layers.1."):
+                out[p + "fc2." + leaf] = v
+            else:
+                raise KeyError(k)
+        else:
+            raise KeyError(k)
+    return out
+
+
+def decoder_layer_to_hf(sd):
+    """One masked-attention decoder layer (mmcv BaseTransformerLayer with operation order
+    cross_attn, norm, self_attn, norm, ffn, norm; oracle/layers.py) ->
+    transformers Mask2FormerMaskedAttentionDecoderLayer (whose self-attention is its own
+    q/k/v-projection implementation, not nn.MultiheadAttention)."""
+    out = {}
+    for k, v in sd.items():
+        leaf = k.split(".")[-1]
+        if k.startswith("attentions.0.attn."):
+            out["cross_attn." + k[len("attentions.0.attn."):]] = v
+        elif k.startswith("attentions.1.attn.in_proj_"):
+            for name, part in zip(("q_proj", "k_proj", "v_proj"), v.chunk(3, 0)):
+                out["self_attn.%s.%s" % (name, "weight" if leaf.endswith("weight") else "bias")] = part
+        elif k.startswith("attentions.1.attn.out_proj."):
+            out["self_attn.out_proj." + leaf] = v
+        elif k.startswith("norms."):
+            name = ("cross_attn_layer_norm", "self_attn_layer_norm", "final_layer_norm")[int(k.split(".")[1])]
+            out["%s.%s" % (name, leaf)] = v
+        elif k.startswith("ffns.0.layers.0.0."):
+            out["fc1." + leaf] = v
+        elif k.startswith("ffns.0.layers.1."):
+            out["fc2." + leaf] = v
+        else:
+            raise KeyError(k)
+    return out

@@ -1,11 +1,24 @@
 """fp32 torch-CPU restatement of the third-party layers on the Pair-Net hot path.
 
-TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED: the sources of
-mmcv-full==1.7.0 / mmdet==2.25.1 (README.md:80-87 of the reference) are neither
-under /root/reference nor installed; the semantics below follow SURVEY.md
-Appendix A and the in-tree copies the reference keeps of two of them
+TEST INFRASTRUCTURE (see oracle/__init__.py).  The sources of mmcv-full==1.7.0 /
+mmdet==2.25.1 (README.md:80-87 of the reference) are neither under /root/reference
+nor installed; the semantics below follow SURVEY.md Appendix A and the in-tree
+copies the reference keeps of two of them
 (pairnet/models/relation_heads/facebook_detr.py:311-353 for the attention
 wrapper, :378-432 for the layer glue).
+
+PARITY: unpinned against mmcv / mmdet themselves, but the ARITHMETIC is pinned
+against an independent implementation of the same published models, HuggingFace
+`transformers` (importable in this image), with identical weights through the key
+converters of oracle/hf_pin.py (tests/test_oracle.py):
+  * MSDeformAttnPixelDecoder (1x1 convs + GN, sine PE + level embedding, reference
+    points, 6 x [MultiScaleDeformableAttention -> LN -> FFN -> LN], FPN level,
+    mask_feature) == transformers Mask2FormerPixelDecoder to 2e-5 relative;
+  * one masked-attention decoder layer (BaseTransformerLayer + MultiheadAttention
+    wrapper + FFN, cross -> self -> ffn, post-norm) == transformers
+    Mask2FormerMaskedAttentionDecoderLayer (its self-attention is not
+    nn.MultiheadAttention) to 2e-5 relative.
+The state-dict KEY NAMES of mmcv / mmdet are from memory and stay unpinned.
 
 Every module keeps the attribute / state-dict names of the package it restates
 so that a reference checkpoint would load (note N7).

@@ -5,9 +5,10 @@ configs/mask2former/pairnet.py:9-19.  TEST INFRASTRUCTURE.
 mmdet 2.25.1 is not vendored in /root/reference and not installed, so this restates its
 published ResNet-50 (identical in structure and parameter names to torchvision's: stride on
 the 3x3 convolution of the first block of stages 2-4, 1x1 stride-s projection shortcut,
-BatchNorm in eval mode with eps 1e-5) from torch.nn primitives.  PARITY UNPINNED against
-mmdet itself (same status as oracle/layers.py); the arithmetic is torch's own fp32 CPU
-convolution / batch-norm.
+BatchNorm in eval mode with eps 1e-5) from torch.nn primitives.  Unpinned against mmdet
+itself; pinned against an independent implementation of the same network, HuggingFace
+`transformers.ResNetBackbone`, with identical weights
+(tests/test_oracle.py::test_resnet50_oracle_matches_transformers_resnet).
 """
 import torch
 import torch.nn as nn

@@ -74,3 +74,24 @@ def decoder_layer_to_hf(sd):
         else:
             raise KeyError(k)
     return out
+
+
+def resnet50_to_hf(sd):
+    """oracle/backbone.py (mmdet / torchvision names) -> transformers ResNetBackbone."""
+    out = {}
+    for k, v in sd.items():
+        parts = k.split(".")
+        if parts[0] in ("conv1", "bn1"):
+            out["embedder.embedder.%s.%s" % ("convolution" if parts[0] == "conv1" else "normalization",
+                                             parts[-1])] = v
+            continue
+        stage, blk = int(parts[0][5:]) - 1, parts[1]
+        base = "encoder.stages.%d.layers.%s." % (stage, blk)
+        if parts[2] == "downsample":
+            out[base + "shortcut.%s.%s" % ("convolution" if parts[3] == "0" else "normalization",
+                                           parts[-1])] = v
+        else:
+            i = int(parts[2][-1]) - 1                       # conv1/bn1 -> layer.0, ...
+            kind = "convolution" if parts[2].startswith("conv") else "normalization"
+            out[base + "layer.%d.%s.%s" % (i, kind, parts[-1])] = v
+    return out

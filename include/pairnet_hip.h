@@ -176,9 +176,10 @@ int pn_patch_im2col4_f32(const float* img, float* out, int B, int H, int W, void
  * [B*H*W][ldqkv] (q | k | v, each C = heads*32 wide) -> out [B*H*W][ldo]:
  * zero-padding of the map to a multiple of `ws` (padded tokens' q/k/v = qkv_bias, as the
  * reference pads after norm1), cyclic shift by `shift`, window partition, softmax(q k^T *
- * scale + bias_table[(dy+ws-1)(2ws-1)+(dx+ws-1)][head] + (-100 between different
+ * scale + bias_table[head][(dy+ws-1)(2ws-1)+(dx+ws-1)] + (-100 between different
  * wrap-around regions)) v, window merge, un-shift and crop are all index arithmetic.
- * bias_table is [(2ws-1)^2][heads].  ws*ws <= 169. */
+ * bias_table is [heads][(2ws-1)^2]: the TRANSPOSE of mmdet's
+ * relative_position_bias_table parameter.  ws*ws <= 169. */
 int pn_window_attention_f32(const float* qkv, int64_t ldqkv, const float* qkv_bias,
                             const float* bias_table, float* out, int64_t ldo, int B, int H,
                             int W, int C, int heads, int ws, int shift, float scale,

@@ -145,7 +145,7 @@ extern "C" int pn_patch_im2col4_f32(const float* img, float* out, int B, int H, 
 // Scores follow k_attn_chunk (attn.hip): S^T = K Q^T on the f32 MFMA with the query in
 // lane & 31, so softmax statistics are lane-local plus one xor-32; P^T feeds the P.V MFMA
 // from the accumulator registers.  Added before the softmax: the relative position bias
-// table[(qy - ky + ws - 1)(2 ws - 1) + (qx - kx + ws - 1)][head] (this head's column is
+// table[head][(qy - ky + ws - 1)(2 ws - 1) + (qx - kx + ws - 1)] (this head's row is
 // staged in LDS) and -100 between tokens of different wrap-around regions (shift > 0).
 // LDS: K and V rows of 32 floats without padding (the 18-block stage of Swin-L launches 840
 // workgroups: at 40 KB each all of them are resident, 4 per CU).  K row r keeps its 16-byte
@@ -156,6 +156,7 @@ extern "C" int pn_patch_im2col4_f32(const float* img, float* out, int B, int H, 
 // follow (V -> K rows, finite, times P = 0; K -> table / metadata, whose scores are
 // discarded by the key < N select).
 #define WA_MAXN 169  // ws <= 13
+#define LOG2E 1.4426950408889634f
 
 __device__ __forceinline__ int wa_kpos(int r, int c) { return r * 32 + 4 * (c ^ ((r ^ (r >> 3)) & 7)); }
 __device__ __forceinline__ int wa_vrow(int r) { return (r & ~5) | ((r & 1) << 2) | ((r >> 2) & 1); }
@@ -174,79 +175,93 @@ __global__ __launch_bounds__(512) void k_window_attn(const WinP p) {
   const int N8 = (N + 7) & ~7;
   float* Vs = smem;                        // [N8][32], rows permuted
   float* Ks = Vs + N8 * 32;                // [N8][32], chunks swizzled
-  float* tab = Ks + N8 * 32;               // [(2ws-1)^2] this head's bias column
+  float* tab = Ks + N8 * 32;               // [(2ws-1)^2] this head's bias row
   int* meta = reinterpret_cast<int*>(tab + (2 * p.ws - 1) * (2 * p.ws - 1));  // [nt*32]
-  int* srcrow = meta + nt * 32;            // [nt*32] source token row or -1 (padding)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int win = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
   const int wy = win / p.nwx, wx = win - wy * p.nwx;
   const int nthreads = nt * 64;
+  const int nrel = (2 * p.ws - 1) * (2 * p.ws - 1);
 
-  // per-token metadata: relative-position key term | region label << 16, source row
-  for (int t = tid; t < nt * 32; t += nthreads) {
-    int m = 0, src = -1;
-    if (t < N) {
-      const int py = t / p.ws, px = t - py * p.ws;
-      const int y = wy * p.ws + py, x = wx * p.ws + px;
-      int ys = y + p.shift, xs = x + p.shift;
-      if (ys >= p.Hp) ys -= p.Hp;
-      if (xs >= p.Wp) xs -= p.Wp;
-      if (ys < p.H && xs < p.W) src = (b * p.H + ys) * p.W + xs;
-      int label = 0;
-      if (p.shift > 0) {
-        const int rh = (y >= p.Hp - p.ws) + (y >= p.Hp - p.shift);
-        const int rw = (x >= p.Wp - p.ws) + (x >= p.Wp - p.shift);
-        label = rh * 3 + rw;
-      }
-      m = (py * (2 * p.ws - 1) + px) | (label << 16);
+  // token t of this window -> its q/k/v row (the qkv bias for a padding token) and its
+  // metadata (relative-position key term | region label << 16); pure index arithmetic, so
+  // every global load of the prologue can be issued before anything is waited for
+  auto token = [&](int t, int& m, int& src) -> const float* {
+    const int py = t / p.ws, px = t - py * p.ws;
+    const int y = wy * p.ws + py, x = wx * p.ws + px;
+    int ys = y + p.shift, xs = x + p.shift;
+    if (ys >= p.Hp) ys -= p.Hp;
+    if (xs >= p.Wp) xs -= p.Wp;
+    int label = 0;
+    if (p.shift > 0) {
+      const int rh = (y >= p.Hp - p.ws) + (y >= p.Hp - p.shift);
+      const int rw = (x >= p.Wp - p.ws) + (x >= p.Wp - p.shift);
+      label = rh * 3 + rw;
     }
-    meta[t] = m;
-    srcrow[t] = src;
-  }
-  for (int t = tid; t < (2 * p.ws - 1) * (2 * p.ws - 1); t += nthreads)
-    tab[t] = p.table[(int64_t)t * p.heads + head];
-  __syncthreads();
-
-  // K / V rows of the window -> LDS (8 float4 per row)
-  const float* kbias = p.qkv_bias + p.C + head * 32;
-  const float* vbias = p.qkv_bias + 2 * p.C + head * 32;
-  for (int e = tid; e < N8 * 8; e += nthreads) {
-    const int t = e >> 3, c4 = (e & 7) * 4;
-    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-    if (t < N) {
-      const int src = srcrow[t];
-      if (src >= 0) {
-        const float* r = p.qkv + (int64_t)src * p.ldqkv + head * 32 + c4;
-        kv = ld4(r + p.C);
-        vv = ld4(r + 2 * p.C);
-      } else {
-        kv = ld4(kbias + c4);
-        vv = ld4(vbias + c4);
-      }
-    }
-    st4(Ks + wa_kpos(t, e & 7), kv);
-    st4(Vs + wa_vrow(t) * 32 + c4, vv);
-  }
+    m = (py * (2 * p.ws - 1) + px) | (label << 16);
+    src = (ys < p.H && xs < p.W) ? (b * p.H + ys) * p.W + xs : -1;
+    return (src >= 0 ? p.qkv + (int64_t)src * p.ldqkv : p.qkv_bias) + head * 32;
+  };
 
   // this lane's query
   const int myq = wave * 32 + li;
   const bool q_ok = myq < N;
-  const int qt = q_ok ? myq : N - 1;
-  const int qsrc = srcrow[qt];
-  const int qmeta = meta[qt];
+  int qmeta, qsrc;
+  const float* qrow = token(q_ok ? myq : N - 1, qmeta, qsrc);
+  float4 qv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) qv[u] = ld4(qrow + 16 * lh + 4 * u);
+  // K / V rows of the window (8 float4 per row, <= 4 per thread), the bias row, metadata
+  float4 kv[4], vv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = tid + i * nthreads;
+    int m, src;
+    const float* r = token(min(e >> 3, N - 1), m, src) + (e & 7) * 4;
+    kv[i] = ld4(r + p.C);
+    vv[i] = ld4(r + 2 * p.C);
+  }
+  float tv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) tv[i] = p.table[(int64_t)head * nrel + min(tid + i * nthreads, nrel - 1)];
+  if (tid < nt * 32) {
+    int m = 0, src;
+    if (tid < N) token(tid, m, src);
+    meta[tid] = m;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (tid + i * nthreads < nrel) tab[tid + i * nthreads] = tv[i] * LOG2E;
+  for (int t = tid + 2 * nthreads; t < nrel; t += nthreads)
+    tab[t] = p.table[(int64_t)head * nrel + t] * LOG2E;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = tid + i * nthreads, t = e >> 3;
+    if (e < N8 * 8) {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      st4(Ks + wa_kpos(t, e & 7), t < N ? kv[i] : z);
+      st4(Vs + wa_vrow(t) * 32 + (e & 7) * 4, t < N ? vv[i] : z);
+    }
+  }
+  for (int e = tid + 4 * nthreads; e < N8 * 8; e += nthreads) {   // (not reached for ws <= 13)
+    int m, src;
+    const int t = e >> 3;
+    const float* r = token(min(t, N - 1), m, src) + (e & 7) * 4;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    st4(Ks + wa_kpos(t, e & 7), t < N ? ld4(r + p.C) : z);
+    st4(Vs + wa_vrow(t) * 32 + (e & 7) * 4, t < N ? ld4(r + 2 * p.C) : z);
+  }
   const int qlabel = qmeta >> 16;
   const int qbase = (qmeta & 0xffff) + (p.ws - 1) * (2 * p.ws - 1) + (p.ws - 1);
+  const float qscale = p.scale * LOG2E;
+  const bool shifted = p.shift > 0;
   float qf[16];
-  {
-    const float* qp = (qsrc >= 0 ? p.qkv + (int64_t)qsrc * p.ldqkv : p.qkv_bias) + head * 32 + 16 * lh;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float4 v = ld4(qp + 4 * u);
-      qf[4 * u + 0] = v.x * p.scale; qf[4 * u + 1] = v.y * p.scale;
-      qf[4 * u + 2] = v.z * p.scale; qf[4 * u + 3] = v.w * p.scale;
-    }
+  for (int u = 0; u < 4; ++u) {
+    qf[4 * u + 0] = qv[u].x * qscale; qf[4 * u + 1] = qv[u].y * qscale;
+    qf[4 * u + 2] = qv[u].z * qscale; qf[4 * u + 3] = qv[u].w * qscale;
   }
   __syncthreads();
 
@@ -267,24 +282,27 @@ __global__ __launch_bounds__(512) void k_window_attn(const WinP p) {
       s = mfma32(a.z, qf[4 * u + 2], s);
       s = mfma32(a.w, qf[4 * u + 3], s);
     }
+    // scores are in log2 units (log2(e) is folded into the q scale and the LDS copy of
+    // the bias row), so the softmax numerators are single v_exp_f32 instructions
     float tmax = -INFINITY;
+    const bool tail = k0 + 32 > N;              // wave-uniform: only the last tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + mfma32_row(r, lh);
       const int km = meta[key];
       float v = s[r] + tab[qbase - (km & 0xffff)];
-      if ((km >> 16) != qlabel) v += -100.f;
-      v = key < N ? v : -INFINITY;
+      if (shifted && (km >> 16) != qlabel) v += -100.f * LOG2E;
+      if (tail) v = key < N ? v : -INFINITY;
       s[r] = v;
       tmax = fmaxf(tmax, v);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);     // tile 0 always holds key 0: finite
-    const float alpha = expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float pv = expf(s[r] - m_new);
+      const float pv = __builtin_amdgcn_exp2f(s[r] - m_new);
       s[r] = pv;
       psum += pv;
     }
@@ -326,7 +344,7 @@ extern "C" int pn_window_attention_f32(const float* qkv, int64_t ldqkv, const fl
   p.nwx = p.Wp / ws;
   const int nt = (ws * ws + 31) / 32;
   const int N8 = (ws * ws + 7) & ~7;
-  int tail = (2 * ws - 1) * (2 * ws - 1) + 2 * nt * 32;      // table + metadata
+  int tail = (2 * ws - 1) * (2 * ws - 1) + nt * 32;          // table + metadata
   if (tail < (nt * 32 - N8) * 32) tail = (nt * 32 - N8) * 32;  // over-read of the last K tile
   const size_t lds = (size_t)(2 * N8 * 32 + tail) * 4;
   if (lds > 65536) return PN_BAD_ARG;

@@ -369,7 +369,8 @@ def patch_im2col4(img, out, B, H, W):
 
 
 def window_attention(qkv, qkv_bias, table, out, B, H, W, C, heads, ws, shift):
-    """(Shifted-)window attention on the [B*H*W][3C] qkv rows -> out [B*H*W][C]."""
+    """(Shifted-)window attention on the [B*H*W][3C] qkv rows -> out [B*H*W][C];
+    `table` is the relative position bias table transposed to [heads][(2ws-1)^2]."""
     n, ldq = _rowmajor(qkv)
     no, ldo = _rowmajor(out)
     assert n == no == B * H * W and qkv.shape[1] == 3 * C

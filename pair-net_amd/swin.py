@@ -144,6 +144,8 @@ class SwinTransformerHip:
                 pw = torch.zeros(v.shape[0], 64)
                 pw[:, :48] = v.reshape(v.shape[0], 48)            # c*16 + ky*4 + kx
                 v = pw
+            elif k.endswith("relative_position_bias_table"):
+                v = v.t()                                         # [heads][(2ws-1)^2]
             elif ".downsample." in k:
                 # nn.Unfold order c*4 + (row*2+col) -> neighbour-major (row*2+col)*C + c
                 c = v.shape[-1] // 4

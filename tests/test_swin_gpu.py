@@ -119,7 +119,7 @@ def test_window_attention_matches_oracle(B, H, W, heads, ws, shift):
         qkv = m.w_msa.qkv(x).reshape(B * H * W, 3 * C)
     out = torch.full((B * H * W, C), float("nan"), device=DEV)
     hip.window_attention(qkv.to(DEV), m.w_msa.qkv.bias.data.to(DEV),
-                         m.w_msa.relative_position_bias_table.data.to(DEV), out, B, H, W, C, heads,
+                         m.w_msa.relative_position_bias_table.data.t().contiguous().to(DEV), out, B, H, W, C, heads,
                          ws, shift)
     assert rel(out.view(B, H * W, C), want) < 2e-5
 

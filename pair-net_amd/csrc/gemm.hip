@@ -107,11 +107,13 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
   constexpr int LDK = BM + 4;  // k-major A tile stride (A_COL)
   constexpr int A_ELEMS = TileSmem<BM, BN, AMODE, SPLIT>::A_ELEMS;
   static_assert(!(SPLIT && AMODE == A_COL), "the split mode takes row-major / conv operands");
-  constexpr int NA = (BM * BK / 4) / 256;
-  constexpr int NB = (BN * BK / 4) / 256;
+  constexpr int NT = 64 * (BM / WM) * WAVES_N;   // threads: one wave per WM x WN sub-tile
+  constexpr int RPP = NT / 8;        // tile rows staged per pass (8 lanes per 32-float row)
+  constexpr int NA = (BM * BK / 4) / NT;
+  constexpr int NB = (BN * BK / 4) / NT;
   constexpr int QM = BM / 4;         // float4 per k-row of a column-major A tile
-  constexpr int KSTEP = 256 / QM;    // k rows covered per pass
-  static_assert((BM / WM) * WAVES_N == 4, "4 waves");
+  constexpr int KSTEP = NT / QM;     // k rows covered per pass
+  static_assert(NT == 256 || NT == 512, "4 or 8 waves");
 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
   const int q8 = ntiles >> 3, r8 = ntiles & 7;
@@ -176,7 +178,7 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
     } else {
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
-        const int gm = min(m0 + (tid >> 3) + 32 * j, p.M - 1);
+        const int gm = min(m0 + (tid >> 3) + RPP * j, p.M - 1);
         if (AMODE == A_CONV || AMODE == A_STEM) {
           // output pixel -> input coordinates of tap (0, 0) + pad
           const int oy = gm / p.Wo, ox = gm - oy * p.Wo;
@@ -192,7 +194,7 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j)
-      w_off[j] = ((unsigned)min(n0 + (tid >> 3) + 32 * j, p.N - 1) * (unsigned)p.ldw + kc) * 4u;
+      w_off[j] = ((unsigned)min(n0 + (tid >> 3) + RPP * j, p.N - 1) * (unsigned)p.ldw + kc) * 4u;
   };
 
   // Raw loaded chunk + what store_chunk has to do to it.  Nothing here may CONSUME a
@@ -339,7 +341,7 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
       uint2 h, m, l;
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
-        const int r = wr + 32 * j;
+        const int r = wr + RPP * j;
         const int off = r * 64 + ((wch ^ ((r >> 2) & 3)) << 4) + wsub;
         split3_pack(ra[j], h, m, l);
         *reinterpret_cast<uint2*>(pa + off) = h;
@@ -348,7 +350,7 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
       }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const int r = wr + 32 * j;
+        const int r = wr + RPP * j;
         const int off = r * 64 + ((wch ^ ((r >> 2) & 3)) << 4) + wsub;
         split3_pack(rb[j], h, m, l);
         *reinterpret_cast<uint2*>(pb + off) = h;
@@ -360,12 +362,12 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
       for (int j = 0; j < NA; ++j)
         st4(sA + (tid / QM + KSTEP * j) * LDK + (tid % QM) * 4, ra[j]);
 #pragma unroll
-      for (int j = 0; j < NB; ++j) st4(sB + ((tid >> 3) + 32 * j) * LD + kc, rb[j]);
+      for (int j = 0; j < NB; ++j) st4(sB + ((tid >> 3) + RPP * j) * LD + kc, rb[j]);
     } else {
 #pragma unroll
-      for (int j = 0; j < NA; ++j) st4(sA + ((tid >> 3) + 32 * j) * LD + kc, ra[j]);
+      for (int j = 0; j < NA; ++j) st4(sA + ((tid >> 3) + RPP * j) * LD + kc, ra[j]);
 #pragma unroll
-      for (int j = 0; j < NB; ++j) st4(sB + ((tid >> 3) + 32 * j) * LD + kc, rb[j]);
+      for (int j = 0; j < NB; ++j) st4(sB + ((tid >> 3) + RPP * j) * LD + kc, rb[j]);
     }
   };
 
@@ -538,7 +540,8 @@ struct SingleLocator {
 
 // ADD: the launch has a row-periodic addend on A (positional encodings), pn_gemm_desc.Aadd
 template <int BM, int BN, int WM, int WN, int AMODE, bool ADD = false, bool SPLIT = false>
-__global__ __launch_bounds__(256) void k_gemm_tile(const GemmP p, const int batch) {
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void k_gemm_tile(const GemmP p,
+                                                                          const int batch) {
   __shared__ __attribute__((aligned(16))) float smem[TileSmem<BM, BN, AMODE, SPLIT>::FLOATS];
   const SingleLocator loc{p, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN};
   gemm_persistent<BM, BN, WM, WN, AMODE, ADD, SPLIT>(loc, loc.mt * loc.nt * batch, smem);
@@ -693,9 +696,9 @@ static int persistent_grid(int64_t ntiles, int wg_per_cu) {
 // instantiation), capped at 4: the persistent grid must not exceed what is resident at
 // once, or the surplus workgroups start a second round with their whole static share.
 template <typename Kern>
-static int resident_wgs(Kern kern, int cap) {
+static int resident_wgs(Kern kern, int cap, int threads = 256) {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, 0) != hipSuccess || n < 1) n = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, 0) != hipSuccess || n < 1) n = 1;
   return n < cap ? n : cap;
 }
 
@@ -703,14 +706,15 @@ template <int BM, int BN, int WM, int WN, int AMODE, bool SPLIT = false>
 static int launch_tile(const GemmP& p, int batch, hipStream_t s) {
   const int64_t ntiles = (int64_t)pn_cdiv(p.N, BN) * pn_cdiv(p.M, BM) * batch;
   constexpr int cap = (BM * BN <= 64 * 64) ? 4 : (BM * BN <= 128 * 64) ? 3 : 2;
+  constexpr int NT = 64 * (BM / WM) * (BN / WN);
   if (AMODE == A_ROW && p.Aadd) {
     auto kern = k_gemm_tile<BM, BN, WM, WN, AMODE, AMODE == A_ROW, SPLIT>;
-    static const int wgs = resident_wgs(kern, cap);
-    hipLaunchKernelGGL(kern, dim3(persistent_grid(ntiles, wgs)), dim3(256), 0, s, p, batch);
+    static const int wgs = resident_wgs(kern, cap, NT);
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(ntiles, wgs)), dim3(NT), 0, s, p, batch);
   } else {
     auto kern = k_gemm_tile<BM, BN, WM, WN, AMODE, false, SPLIT>;
-    static const int wgs = resident_wgs(kern, cap);
-    hipLaunchKernelGGL(kern, dim3(persistent_grid(ntiles, wgs)), dim3(256), 0, s, p, batch);
+    static const int wgs = resident_wgs(kern, cap, NT);
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(ntiles, wgs)), dim3(NT), 0, s, p, batch);
   }
   return PN_LAUNCH_CHECK();
 }

@@ -19,7 +19,10 @@ for M,N,K in shapes:
     x=torch.randn(M,K,device=dev); w=torch.randn(N,K,device=dev)*0.1; o=torch.empty(M,N,device=dev)
     sc=torch.empty(16*1024*1024,device=dev)
     row=[]
-    for name,kw in (("tile64",dict(force="tile64")),("t128x64",dict(force="tile128x64")),("default+scratch",dict(scratch=sc))):
+    ref=(x[:512].double()@w.double().t())
+    for name,kw in (("tile64",dict(force="tile64")),("t128x64",dict(force="tile128x64")),("tile64 again",dict(force="tile64"))):
+        o.zero_()
         us=T(lambda: hip.linear(x,w,None,o,**kw))
-        row.append("%s %7.1fus %5.1fTF" % (name, us, 2.0*M*N*K/us/1e6))
+        err=(o[:512].double()-ref).abs().max().item()/ref.abs().max().item()
+        row.append("%s %7.1fus %5.1fTF e%.0e" % (name, us, 2.0*M*N*K/us/1e6, err))
     print("%6d %5d %5d"%(M,N,K)," | ".join(row))

@@ -35,25 +35,34 @@ extern "C" int pn_layernorm_f32(const float* x, const float* gamma, const float*
 // in fp64 (exact enough that E[x^2]-E[x]^2 is safe) and writes them to `partials`.
 // Pass 2: every block re-reduces the (small) partials of its image in a fixed order
 // -> mean / rstd per group, then normalises its own pixels.  Deterministic.
+// 16 waves per block: a 66 800-pixel map is only 261 blocks (about one per CU), so the
+// block itself has to supply the memory-level parallelism.
 #define GN_PIX 256
+#define GN_SUB 16   // waves per block = pixel sub-lanes
 
 extern "C" int pn_groupnorm_nblk(int64_t HW) { return pn_cdiv(HW, GN_PIX); }
 
-__global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ x,
-                                                    double* __restrict__ partials,
-                                                    int64_t HW, int G, int64_t xbs) {
-  __shared__ double red[4][64][2];
+__global__ __launch_bounds__(64 * GN_SUB) void k_gn_partial(const float* __restrict__ x,
+                                                            double* __restrict__ partials,
+                                                            int64_t HW, int G, int64_t xbs) {
+  __shared__ double red[GN_SUB][64][2];
   const int tid = threadIdx.x, c4 = tid & 63, sub = tid >> 6;
   const int b = blockIdx.y;
   const int64_t p0 = (int64_t)blockIdx.x * GN_PIX;
   const float* xb = x + (int64_t)b * xbs;
+  // all loads first, unconditional (clamped; hipcc serialises predicated loads)
+  constexpr int NP = GN_PIX / GN_SUB;
+  float4 v[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j)
+    v[j] = ld4(xb + min(p0 + sub + j * GN_SUB, HW - 1) * 256 + c4 * 4);
   double s = 0.0, ss = 0.0;
-  for (int i = sub; i < GN_PIX; i += 4) {
-    const int64_t pix = p0 + i;
-    if (pix < HW) {
-      const float4 v = ld4(xb + pix * 256 + c4 * 4);
-      s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
-      ss += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    if (p0 + sub + j * GN_SUB < HW) {
+      s += ((double)v[j].x + (double)v[j].y) + ((double)v[j].z + (double)v[j].w);
+      ss += ((double)v[j].x * v[j].x + (double)v[j].y * v[j].y) +
+            ((double)v[j].z * v[j].z + (double)v[j].w * v[j].w);
     }
   }
   red[sub][c4][0] = s;
@@ -65,19 +74,19 @@ __global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ x,
     const int g = tid >> 1, which = tid & 1;
     double t = 0.0;
     for (int l = 0; l < lanes_per_group; ++l)
-      for (int k = 0; k < 4; ++k) t += red[k][g * lanes_per_group + l][which];
+      for (int k = 0; k < GN_SUB; ++k) t += red[k][g * lanes_per_group + l][which];
     partials[(((int64_t)b * gridDim.x + blockIdx.x) * G + g) * 2 + which] = t;
   }
 }
 
-__global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x,
-                                                  const float* __restrict__ gamma,
-                                                  const float* __restrict__ beta,
-                                                  float* __restrict__ y,
-                                                  const double* __restrict__ partials,
-                                                  int64_t HW, int G, float eps, int relu,
-                                                  int64_t xbs, int64_t ybs) {
-  __shared__ double acc[4][64];
+__global__ __launch_bounds__(64 * GN_SUB) void k_gn_apply(const float* __restrict__ x,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          float* __restrict__ y,
+                                                          const double* __restrict__ partials,
+                                                          int64_t HW, int G, float eps, int relu,
+                                                          int64_t xbs, int64_t ybs) {
+  __shared__ double acc[GN_SUB][64];
   __shared__ float stat[64][2];
   const int tid = threadIdx.x, b = blockIdx.y;
   const int nblk = gridDim.x;
@@ -85,16 +94,18 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x,
     const int col = tid & 63, part = tid >> 6;
     double t = 0.0;
     if (col < 2 * G)
-      for (int i = part; i < nblk; i += 4)
+      for (int i = part; i < nblk; i += GN_SUB)
         t += partials[((int64_t)b * nblk + i) * G * 2 + col];
     acc[part][col] = t;
   }
   __syncthreads();
   if (tid < G) {
     const double n = (double)HW * (256 / G);
-    const double s = (acc[0][2 * tid] + acc[1][2 * tid]) + (acc[2][2 * tid] + acc[3][2 * tid]);
-    const double ss = (acc[0][2 * tid + 1] + acc[1][2 * tid + 1]) +
-                      (acc[2][2 * tid + 1] + acc[3][2 * tid + 1]);
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < GN_SUB; ++k) {
+      s += acc[k][2 * tid];
+      ss += acc[k][2 * tid + 1];
+    }
     const double mean = s / n;
     double var = ss / n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -109,18 +120,21 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x,
   const int64_t p0 = (int64_t)blockIdx.x * GN_PIX;
   const float* xb = x + (int64_t)b * xbs;
   float* yb = y + (int64_t)b * ybs;
-  for (int i = sub; i < GN_PIX; i += 4) {
-    const int64_t pix = p0 + i;
-    if (pix < HW) {
-      const float4 v = ld4(xb + pix * 256 + c4 * 4);
-      float4 o = make_float4((v.x - mean) * rstd * gg.x + bb.x, (v.y - mean) * rstd * gg.y + bb.y,
-                             (v.z - mean) * rstd * gg.z + bb.z, (v.w - mean) * rstd * gg.w + bb.w);
-      if (relu) {
-        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f);
-        o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-      }
-      st4(yb + pix * 256 + c4 * 4, o);
+  constexpr int NP = GN_PIX / GN_SUB;
+  float4 v[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j)
+    v[j] = ld4(xb + min(p0 + sub + j * GN_SUB, HW - 1) * 256 + c4 * 4);
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int64_t pix = p0 + sub + j * GN_SUB;
+    float4 o = make_float4((v[j].x - mean) * rstd * gg.x + bb.x, (v[j].y - mean) * rstd * gg.y + bb.y,
+                           (v[j].z - mean) * rstd * gg.z + bb.z, (v[j].w - mean) * rstd * gg.w + bb.w);
+    if (relu) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f);
+      o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
+    if (pix < HW) st4(yb + pix * 256 + c4 * 4, o);
   }
 }
 
@@ -134,8 +148,8 @@ extern "C" int pn_groupnorm_nhwc_f32(const float* x, const float* gamma, const f
   if ((x_bstride | y_bstride) & 3) return PN_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(pn_groupnorm_nblk(HW), B);
-  hipLaunchKernelGGL(k_gn_partial, grid, dim3(256), 0, s, x, partials, HW, G, x_bstride);
-  hipLaunchKernelGGL(k_gn_apply, grid, dim3(256), 0, s, x, gamma, beta, y, partials, HW, G,
+  hipLaunchKernelGGL(k_gn_partial, grid, dim3(64 * GN_SUB), 0, s, x, partials, HW, G, x_bstride);
+  hipLaunchKernelGGL(k_gn_apply, grid, dim3(64 * GN_SUB), 0, s, x, gamma, beta, y, partials, HW, G,
                      eps, relu, x_bstride, y_bstride);
   return PN_LAUNCH_CHECK();
 }

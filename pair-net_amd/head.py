@@ -340,6 +340,7 @@ class CrossHead2:
         pl = CrossHead2._Plan()
         pl.B, pl.shapes, pl.hw2, pl.nhwc = B, list(shapes), tuple(hw2), nhwc
         pl.graph_a = pl.graph_b = pl.static_feats = pl.graph_cfg = pl.feats_read = None
+        pl.static_ptrs, pl.staged = None, False
         pl.calls_a = pl.calls_b = 0
         pl.N = [h * w for h, w in shapes]
         pl.start = [0, pl.N[0], pl.N[0] + pl.N[1]]
@@ -708,20 +709,33 @@ class CrossHead2:
             pl.graph_a = pl.graph_b = None
             pl.graph_cfg = cfg
         if which == "a":
+            ptrs = tuple(f.data_ptr() for f in feats)
             if self.use_graphs and pl.graph_a is None and pl.calls_a >= 1:
-                pl.static_feats = [torch.empty_like(f) for f in feats]
-                for dst, src in zip(pl.static_feats, feats):
-                    dst.copy_(src)
+                # captured on the caller's own buffers: a caller that hands over the same
+                # buffers every time (a backbone writing into per-shape outputs, a resident
+                # pyramid) pays no staging copy
+                pl.static_feats, pl.static_ptrs, pl.staged = list(feats), ptrs, False
                 pl.graph_a = self._capture(lambda: self._stage_a(pl.static_feats, pl))
             pl.calls_a += 1
             if pl.feats_read is None:
                 pl.feats_read = torch.cuda.Event()
             if self.use_graphs and pl.graph_a is not None:
-                for dst, src in zip(pl.static_feats, feats):
-                    if dst.data_ptr() != src.data_ptr():
+                if not pl.staged and ptrs != pl.static_ptrs:
+                    # other buffers than the captured ones: from now on stage the features
+                    # into private copies (one re-capture on them)
+                    pl.static_feats = [torch.empty_like(f) for f in feats]
+                    for dst, src in zip(pl.static_feats, feats):
                         dst.copy_(src)
-                pl.feats_read.record()      # the caller's feature buffers are free again
-                pl.graph_a.replay()
+                    pl.static_ptrs, pl.staged = None, True
+                    pl.graph_a = self._capture(lambda: self._stage_a(pl.static_feats, pl))
+                if pl.staged:
+                    for dst, src in zip(pl.static_feats, feats):
+                        dst.copy_(src)
+                    pl.feats_read.record()  # the caller's feature buffers are free again
+                    pl.graph_a.replay()
+                else:
+                    pl.graph_a.replay()
+                    pl.feats_read.record()  # (read in place, up to the FPN level)
             else:
                 self._stage_a(feats, pl)
                 pl.feats_read.record()

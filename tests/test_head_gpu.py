@@ -214,6 +214,38 @@ def test_graph_replay_and_two_stream_pipeline_are_bitwise_the_eager_path():
                         assert torch.equal(x, y), (depth, rep, n)
 
 
+def test_graph_reads_reused_feature_buffers_in_place():
+    """A caller that hands over the SAME buffers every step (new contents written in place)
+    gets stage A's graph captured on those buffers -- no staging copy -- and still sees
+    every step's own features; a caller that switches buffers falls back to staging."""
+    _, sd, _ = oracle_head(77)
+    head = _hip_head(sd)
+    H, W = 64, 96
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[1.0] * 4)] * 2
+    batches = [[f.to(DEV) for f in seeded.seeded_feats(300 + i, 2, H, W)] for i in range(4)]
+    eager = []
+    for b in batches:
+        cls, _ = head.forward(b, metas)
+        eager.append(cls["rel"].clone())
+    head.use_graphs = True
+    bufs = [torch.empty_like(f) for f in batches[0]]
+    for rep in range(2):
+        for b, want in zip(batches, eager):
+            for dst, src in zip(bufs, b):
+                dst.copy_(src)
+            cls, _ = head.forward(bufs, metas)
+            assert torch.equal(cls["rel"], want)
+    assert head._last_plan.graph_a is not None and head._last_plan.staged is False
+    for b, want in zip(batches, eager):                    # other buffers: staged from now on
+        cls, _ = head.forward(b, metas)
+        assert torch.equal(cls["rel"], want)
+    assert head._last_plan.staged is True
+    for dst, src in zip(bufs, batches[2]):
+        dst.copy_(src)
+    cls, _ = head.forward(bufs, metas)
+    assert torch.equal(cls["rel"], eager[2])
+
+
 def test_swin_l_200_query_configuration():
     """BASELINE.json configs[3]: Swin-L channel widths, 200 object queries (200x200
     importance matrix, top-k over 40 000), batch 2 -- against the CPU oracle."""

@@ -21,3 +21,17 @@ head.use_graphs = False
 print("eager:        stage A %.3f ms, stage B %.3f ms" % (T(lambda: head._stage_a(feats, pl)), T(lambda: head._stage_b(pl))))
 outs = head._outputs(pl)
 print("get_bboxes eager %.3f ms" % T(lambda: head.get_bboxes(*outs, metas)))
+if "--kernels" in sys.argv:
+    from pairnet_amd import hip
+    for name, fn in (("A", lambda: head._stage_a(feats, pl)), ("B", lambda: head._stage_b(pl))):
+        hip.TIMER = hip.KernelTimer()
+        for _ in range(3): fn()
+        agg = hip.TIMER.summary(); hip.TIMER = None
+        tot = sum(v["ms"] for v in agg.values()) / 3
+        print("stage %s: %d launches, %.3f ms of kernel time (events around each launch)" % (
+            name, sum(v["launches"] for v in agg.values()) // 3, tot))
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            print("  %-44s %4d x %8.1f us = %7.3f ms  %6.1f TF %6.0f GB/s" % (
+                k, v["launches"] // 3, 1e3 * v["ms"] / v["launches"], v["ms"] / 3,
+                v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0,
+                v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] else 0))

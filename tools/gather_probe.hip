@@ -1,51 +1,56 @@
-// Micro-probe (tuning aid): rate of the deformable-attention access pattern -- 8 lanes read
-// one 128-byte line as float4s, 12 independent lines per lane group -- against the size of
-// the window the lines are drawn from (HBM/L2-resident 22 MB ... L1-resident 16 KB).
+// Micro-probe (tuning aid): rate of the deformable-attention access pattern -- W lanes read
+// one random 128-byte line (W = 8: float4 per lane, the kernel's shape; 16: float2; 32: float),
+// 12 * W / 8 independent lines per lane group -- drawn from a 32 MB window (HBM-bound) or a
+// 512 KB one (L2-resident).  All index loads are hoisted before the gathers.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+template <int W>
 __global__ __launch_bounds__(256) void k(const float* __restrict__ v, const int* __restrict__ idx,
-                                         float* __restrict__ out, int nlines_mask, int per_wg_window) {
-  const int tid = threadIdx.x, c4 = tid & 7, grp = tid >> 3;
+                                         float* __restrict__ out, int mask) {
+  constexpr int VEC = 32 / W;                 // floats per lane
+  constexpr int NL = 12 * (W / 8);            // lines per lane group (same bytes per thread)
+  const int tid = threadIdx.x, c = tid % W, grp = tid / W;
   const int wg = blockIdx.x;
-  // window base: per_wg_window != 0 -> each workgroup draws from its own window (spatial
-  // locality: neighbouring workgroups overlap), else all from the whole buffer
-  const int base = per_wg_window ? (((wg * 37) & ~nlines_mask) & ((1 << 18) - 1)) : 0;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 r[12];
+  float r[NL][VEC];
+  float acc = 0.f;
 #pragma unroll
-  for (int j = 0; j < 12; ++j) {
-    const int line = base + (idx[(wg * 32 + grp) * 12 + j] & nlines_mask);
-    r[j] = *reinterpret_cast<const float4*>(v + (size_t)line * 32 + c4 * 4);
+  for (int j = 0; j < NL; ++j) {
+    const int line = idx[((size_t)wg * (256 / W) + grp) * NL + j] & mask;
+    const float* p = v + (size_t)line * 32 + c * VEC;
+    if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(p); r[j][0] = t.x; r[j][1 % VEC] = t.y; r[j][2 % VEC] = t.z; r[j][3 % VEC] = t.w; }
+    else if (VEC == 2) { const float2 t = *reinterpret_cast<const float2*>(p); r[j][0] = t.x; r[j][1 % VEC] = t.y; }
+    else r[j][0] = *p;
   }
 #pragma unroll
-  for (int j = 0; j < 12; ++j) { acc.x += r[j].x; acc.y += r[j].y; acc.z += r[j].z; acc.w += r[j].w; }
-  acc.x += __shfl_xor(acc.x, 8, 64); acc.x += __shfl_xor(acc.x, 16, 64);
-  if (((tid >> 3) & 3) == 0) out[(size_t)wg * 64 + (tid >> 5) * 8 + c4] = acc.x + acc.y + acc.z + acc.w;
+  for (int j = 0; j < NL; ++j)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc += r[j][e];
+  out[(size_t)wg * 256 + tid] = acc;
+}
+template <int W> void run(const float* v, const int* idx, float* out, int NWG, int mask) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k<W>, dim3(NWG), dim3(256), 0, 0, v, idx, out, mask);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k<W>, dim3(NWG), dim3(256), 0, 0, v, idx, out, mask);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+  const double bytes = (double)NWG * 256 * 12 * 16;
+  printf("%2d lanes x %2d B per line, window %7.1f KB: %7.1f us per layer-equivalent, %6.2f TB/s\n", W, 128 / W,
+         (mask + 1) * 128 / 1024.0, ms * 1e3 / 4, bytes / ms / 1e9);
 }
 int main() {
-  const int NWG = 21950 * 4;               // 4x the layer's work for a stable timing
-  const size_t total_lines = 1 << 18;      // 32 MB buffer
+  const int NWG = 21950 * 4;
   float* v; int* idx; float* out;
-  hipMalloc(&v, total_lines * 128 + (1 << 20)); hipMemset(v, 0, total_lines * 128 + (1 << 20));
-  hipMalloc(&out, (size_t)NWG * 64 * 4);
-  std::vector<int> h((size_t)NWG * 32 * 12);
+  hipMalloc(&v, (size_t)(1 << 18) * 128); hipMemset(v, 0, (size_t)(1 << 18) * 128);
+  hipMalloc(&out, (size_t)NWG * 256 * 4);
+  std::vector<int> h((size_t)NWG * 32 * 12 * 4);
   for (auto& x : h) x = rand();
   hipMalloc(&idx, h.size() * 4); hipMemcpy(idx, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int mode = 0; mode < 2; ++mode)
-    for (int lines : {1 << 18, 1 << 15, 1 << 12, 1 << 9, 1 << 7, 1 << 5}) {
-      if (mode == 1 && lines > (1 << 12)) continue;
-      hipLaunchKernelGGL(k, dim3(NWG), dim3(256), 0, 0, v, idx, out, lines - 1, mode);
-      hipDeviceSynchronize();
-      hipEventRecord(e0);
-      for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k, dim3(NWG), dim3(256), 0, 0, v, idx, out, lines - 1, mode);
-      hipEventRecord(e1); hipEventSynchronize(e1);
-      float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
-      const double bytes = (double)NWG * 256 * 12 * 16;
-      printf("%s window %8.1f KB: %7.1f us per layer-equivalent, %6.2f TB/s gathered\n",
-             mode ? "per-WG " : "global ", lines * 128 / 1024.0, ms * 1e3 / 4, bytes / ms / 1e9);
-    }
+  for (int mask : {(1 << 18) - 1, (1 << 12) - 1}) {
+    run<8>(v, idx, out, NWG, mask); run<16>(v, idx, out, NWG, mask); run<32>(v, idx, out, NWG, mask);
+  }
   return 0;
 }

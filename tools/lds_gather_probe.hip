@@ -1,7 +1,7 @@
 // Micro-probe (tuning aid): the deformable-attention gather served from LDS instead of L1:
 // a workgroup stages a window of 128-byte rows with coalesced loads, then every 8-lane group
 // reads random rows of it as float4s (ds_read_b128).  Compare with tools/gather_probe.hip
-// (~12 TB/s for the same pattern straight from global memory).
+// (26 TB/s L2-resident, 7.8 TB/s from HBM for the same pattern straight from global memory).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,17 +1,13 @@
 // Multi-scale deformable attention sampling for the pixel-decoder encoder
-// (8 heads x 32 channels, P = 4 points, L <= 4 levels), HBM/L2-bound gather.
+// (8 heads x 32 channels, P = 4 points, L <= 4 levels): an L2-resident gather.
 //
-// Thread = (query, head, sampling point, 4 channels): one 256-thread workgroup per
-// query token, 32 lanes per head = 4 points x 8 lanes; the 8 lanes of a point read
-// one 128-byte value row per bilinear tap as float4s (every tap is a full line) and
-// each lane keeps its L x 4 = 12 independent 16-byte loads in flight at once (48 VGPRs,
-// still 5+ waves/SIMD) on this latency-bound gather.  The softmax over
-// the L*P logits and the sum over points are xor-8 / xor-16 shuffles inside the
-// 32-lane group.  (Measured: the kernel sits at ~75 us/layer regardless of L2 locality
-// -- XCD banding, several tokens per workgroup -- i.e. it is bound by the texture-
-// addresser rate of 16-byte-per-lane gathers, ~1 GB of them per layer.)  Reference point + offset / (W_l, H_l) and the grid_sample
-// un-normalisation follow mmcv's CPU formula
-// (multi_scale_deformable_attn_pytorch):
+// Two phases per workgroup (k_msda below).  The gather threads are (head, sampling point,
+// 4 channels): 32 lanes per head = 4 points x 8 lanes; the 8 lanes of a point read one
+// 128-byte value row per bilinear tap as float4s (every tap is a full line), L x 4 = 12
+// independent 16-byte loads in flight per lane, all unconditional (clamped rows, weight 0
+// outside the map).  The sum over points is an xor-8 / xor-16 shuffle.
+// Reference point + offset / (W_l, H_l) and the grid_sample un-normalisation follow mmcv's
+// CPU formula (multi_scale_deformable_attn_pytorch):
 //   loc = ref + off / (W_l, H_l);  g = 2 loc - 1;  ix = ((g + 1) W_l - 1) / 2
 // with zero padding outside the map.
 #include "common.h"
@@ -21,23 +17,40 @@ struct MsdaLevels {
   int L, N;
 };
 
-__device__ __forceinline__ float grp_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 8, 64));
-  return fmaxf(v, __shfl_xor(v, 16, 64));
+// 16-lane groups (one head's L x 4 logits, padded to 16)
+__device__ __forceinline__ float grp16_max(float v) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
 }
-__device__ __forceinline__ float grp_sum(float v) {
+__device__ __forceinline__ float pt_sum(float v) {   // over the 4 points: lanes ^8, ^16
   v += __shfl_xor(v, 8, 64);
   return v + __shfl_xor(v, 16, 64);
 }
 
+struct __attribute__((aligned(16))) MsdaTap {
+  unsigned off[4];   // byte offsets of the 4 taps' value rows (clamped into the map)
+  float w[4];        // bilinear weight x attention weight (0 for taps outside the map)
+};
+
+#define MSDA_TQ 2   // queries per workgroup
+
+// Workgroup = MSDA_TQ query tokens.  Phase 1: thread (query, head, point, level) -- 128
+// threads per query, a head's 16 (point, level) slots in one 16-lane group -- computes the
+// softmax weight, the sampling location and the four tap offsets / weights ONCE and parks
+// them in LDS (the gather threads used to recompute them eight times over).  Phase 2:
+// thread (head, point, 4 channels) reads them back (broadcast within its 8 lanes), issues
+// the L x 4 float4 gathers of a query back to back and accumulates.
 template <int L>
 __global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
                                               const float* __restrict__ offaw,
                                               float* __restrict__ out,
                                               const MsdaLevels lv, const int64_t ldv,
                                               const int64_t ldo) {
+  __shared__ MsdaTap taps[MSDA_TQ][8][4][4];   // [query][head][point][level]
+  __shared__ float attw[MSDA_TQ][8][4][4];     // softmax weight of the same slot
+  __shared__ int tok[MSDA_TQ];
   const int tid = threadIdx.x;
-  const int c4 = tid & 7, pt = (tid >> 3) & 3, head = tid >> 5;
   const int b = blockIdx.y;
   constexpr int LP = L * 4;
 
@@ -45,102 +58,108 @@ __global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
   // one horizontal band of the image at EVERY level (rows [k h_l/8, (k+1) h_l/8)), so
   // the value rows its tokens sample (all levels, around the same normalised position)
   // stay inside that XCD's 4 MB L2 instead of streaming the whole 22 MB map through
-  // all eight L2s.  Wave-uniform integer math; tokens past a band's end exit.
+  // all eight L2s.  Tokens past a band's end are skipped.
   const int band = blockIdx.x & 7;
-  int i = blockIdx.x >> 3;            // index inside the band
-  int n = -1, qw = 1, qh = 1, qs = 0;
+  // ---- phase 1 ----
+  {
+    const int qi = tid >> 7, head = (tid >> 4) & 7, pt = (tid >> 2) & 3, l = tid & 3;
+    int i = (blockIdx.x >> 3) * MSDA_TQ + qi;            // index inside the band
+    int n = -1, qw = 1, qh = 1, qs = 0;
 #pragma unroll
-  for (int l = 0; l < 4; ++l) {
-    if (l < L && n < 0) {
-      const int r0 = (band * lv.h[l]) >> 3, r1 = ((band + 1) * lv.h[l]) >> 3;
-      const int cnt = (r1 - r0) * lv.w[l];
-      if (i < cnt) {
-        n = lv.start[l] + r0 * lv.w[l] + i;
-        qw = lv.w[l]; qh = lv.h[l]; qs = lv.start[l];
-      } else {
-        i -= cnt;
+    for (int k = 0; k < 4; ++k) {
+      if (k < L && n < 0) {
+        const int r0 = (band * lv.h[k]) >> 3, r1 = ((band + 1) * lv.h[k]) >> 3;
+        const int cnt = (r1 - r0) * lv.w[k];
+        if (i < cnt) {
+          n = lv.start[k] + r0 * lv.w[k] + i;
+          qw = lv.w[k]; qh = lv.h[k]; qs = lv.start[k];
+        } else {
+          i -= cnt;
+        }
       }
     }
-  }
-  if (n < 0) return;
-  const int idx = n - qs;
-  const int qy = idx / qw, qx = idx - qy * qw;
-  const float ref_x = ((float)qx + 0.5f) / (float)qw;
-  const float ref_y = ((float)qy + 0.5f) / (float)qh;
-
-  const float* oa = offaw + ((int64_t)b * lv.N + n) * ldo;
-  const float* offp = oa + head * LP * 2 + pt * 2;
-  const float* awp = oa + 8 * LP * 2 + head * LP + pt;
-
-  // every offset / logit load is issued before the first dependent use
-  float e[L];
-  float2 off[L];
+    if ((tid & 127) == 0) tok[qi] = n;
+    const bool live = n >= 0 && l < L;
+    const int nc = max(n, 0), lc = min(l, L - 1);
+    const float* oa = offaw + ((int64_t)b * lv.N + nc) * ldo;
+    const float e = oa[8 * LP * 2 + head * LP + lc * 4 + pt];
+    const float2 off = *reinterpret_cast<const float2*>(oa + head * LP * 2 + lc * 8 + pt * 2);
+    // softmax over the head's L x 4 logits: levels summed in order per point, then the
+    // points pairwise (the summation order of the reference-checked first version)
+    const float mx = grp16_max(l < L ? e : -INFINITY);
+    const float ex = l < L ? expf(e - mx) : 0.f;
+    const int g0 = (tid & 63) & ~3;
+    float den = __shfl(ex, g0, 64);
 #pragma unroll
-  for (int l = 0; l < L; ++l) {
-    e[l] = awp[l * 4];
-    off[l] = *reinterpret_cast<const float2*>(offp + l * 8);
-  }
-  float mx = -INFINITY;
+    for (int k = 1; k < L; ++k) den += __shfl(ex, g0 + k, 64);
+    den += __shfl_xor(den, 4, 64);
+    den += __shfl_xor(den, 8, 64);
+    const float aw = ex / den;
+    if (live) {
+      const int idx = n - qs;
+      const int qy = idx / qw, qx = idx - qy * qw;
+      const float ref_x = ((float)qx + 0.5f) / (float)qw;
+      const float ref_y = ((float)qy + 0.5f) / (float)qh;
+      const int Hl = lv.h[lc], Wl = lv.w[lc];
+      const float locx = ref_x + off.x / (float)Wl;
+      const float locy = ref_y + off.y / (float)Hl;
+      const float gx = 2.f * locx - 1.f, gy = 2.f * locy - 1.f;
+      const float ix = ((gx + 1.f) * (float)Wl - 1.f) * 0.5f;
+      const float iy = ((gy + 1.f) * (float)Hl - 1.f) * 0.5f;
+      const float fx = floorf(ix), fy = floorf(iy);
+      // (clamp before the int conversion: far-out offsets must not overflow it)
+      const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)Wl), y0 = (int)fminf(fmaxf(fy, -2.f), (float)Hl);
+      const float tx = ix - fx, ty = iy - fy;
+      const bool xin0 = x0 >= 0 && x0 < Wl, xin1 = x0 + 1 >= 0 && x0 + 1 < Wl;
+      const bool yin0 = y0 >= 0 && y0 < Hl, yin1 = y0 + 1 >= 0 && y0 + 1 < Hl;
+      const int xa = min(max(x0, 0), Wl - 1), xb = min(max(x0 + 1, 0), Wl - 1);
+      const int ya = min(max(y0, 0), Hl - 1), yb = min(max(y0 + 1, 0), Hl - 1);
+      MsdaTap t;
+      // out-of-map taps read a clamped row with weight 0: every gather is unconditional
+      t.w[0] = (xin0 && yin0) ? (1.f - tx) * (1.f - ty) : 0.f;
+      t.w[1] = (xin1 && yin0) ? tx * (1.f - ty) : 0.f;
+      t.w[2] = (xin0 && yin1) ? (1.f - tx) * ty : 0.f;
+      t.w[3] = (xin1 && yin1) ? tx * ty : 0.f;
+      const unsigned row = (unsigned)ldv * 4u, base = (unsigned)lv.start[lc];
+      t.off[0] = (base + (unsigned)(ya * Wl + xa)) * row;
+      t.off[1] = (base + (unsigned)(ya * Wl + xb)) * row;
+      t.off[2] = (base + (unsigned)(yb * Wl + xa)) * row;
+      t.off[3] = (base + (unsigned)(yb * Wl + xb)) * row;
+      taps[qi][head][pt][lc] = t;
+      attw[qi][head][pt][lc] = aw;   // multiplies the bilinear sum afterwards (rounding order)
+    }
+    __syncthreads();
+    // ---- phase 2 ----
+    const int c4 = tid & 7, p2 = (tid >> 3) & 3, h2 = tid >> 5;
+    const char* vb = reinterpret_cast<const char*>(value + (int64_t)b * lv.N * ldv + h2 * 32 + c4 * 4);
 #pragma unroll
-  for (int l = 0; l < L; ++l) mx = fmaxf(mx, e[l]);
-  mx = grp_max(mx);
-  float den = 0.f;
+    for (int q = 0; q < MSDA_TQ; ++q) {
+      const int nq = tok[q];
+      if (nq < 0) continue;                   // (uniform)
+      float4 v[L][4];
+      MsdaTap t[L];
 #pragma unroll
-  for (int l = 0; l < L; ++l) {
-    e[l] = expf(e[l] - mx);
-    den += e[l];
-  }
-  den = grp_sum(den);
-
-  const float* vb = value + (int64_t)b * lv.N * ldv + head * 32 + c4 * 4;
-  // All L x 4 taps are loaded UNCONDITIONALLY from clamped coordinates before any is
-  // used (out-of-map taps get weight 0): one memory round trip per thread.  Predicated
-  // loads would be serialised by hipcc into one branch + full vmcnt wait per level.
-  float4 v[L][4];
-  float wt[L][4], awl[L];
+      for (int k = 0; k < L; ++k) {
+        t[k] = taps[q][h2][p2][k];
 #pragma unroll
-  for (int l = 0; l < L; ++l) {
-    const int Hl = lv.h[l], Wl = lv.w[l];
-    const float* vl = vb + (int64_t)lv.start[l] * ldv;
-    awl[l] = e[l] / den;
-    const float locx = ref_x + off[l].x / (float)Wl;
-    const float locy = ref_y + off[l].y / (float)Hl;
-    const float gx = 2.f * locx - 1.f, gy = 2.f * locy - 1.f;
-    const float ix = ((gx + 1.f) * (float)Wl - 1.f) * 0.5f;
-    const float iy = ((gy + 1.f) * (float)Hl - 1.f) * 0.5f;
-    const float fx = floorf(ix), fy = floorf(iy);
-    // (clamp before the int conversion: far-out offsets must not overflow it)
-    const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)Wl), y0 = (int)fminf(fmaxf(fy, -2.f), (float)Hl);
-    const float tx = ix - fx, ty = iy - fy;
-    const bool xin0 = x0 >= 0 && x0 < Wl, xin1 = x0 + 1 >= 0 && x0 + 1 < Wl;
-    const bool yin0 = y0 >= 0 && y0 < Hl, yin1 = y0 + 1 >= 0 && y0 + 1 < Hl;
-    wt[l][0] = (xin0 && yin0) ? (1.f - tx) * (1.f - ty) : 0.f;
-    wt[l][1] = (xin1 && yin0) ? tx * (1.f - ty) : 0.f;
-    wt[l][2] = (xin0 && yin1) ? (1.f - tx) * ty : 0.f;
-    wt[l][3] = (xin1 && yin1) ? tx * ty : 0.f;
-    const int xa = min(max(x0, 0), Wl - 1), xb = min(max(x0 + 1, 0), Wl - 1);
-    const int ya = min(max(y0, 0), Hl - 1), yb = min(max(y0 + 1, 0), Hl - 1);
-    v[l][0] = ld4(vl + (int64_t)(ya * Wl + xa) * ldv);
-    v[l][1] = ld4(vl + (int64_t)(ya * Wl + xb) * ldv);
-    v[l][2] = ld4(vl + (int64_t)(yb * Wl + xa) * ldv);
-    v[l][3] = ld4(vl + (int64_t)(yb * Wl + xb) * ldv);
-  }
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < 4; ++j) v[k][j] = *reinterpret_cast<const float4*>(vb + t[k].off[j]);
+      }
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int l = 0; l < L; ++l) {
-    const float w_nw = wt[l][0], w_ne = wt[l][1], w_sw = wt[l][2], w_se = wt[l][3];
-    const float4 v_nw = v[l][0], v_ne = v[l][1], v_sw = v[l][2], v_se = v[l][3];
-    const float aw = awl[l];
-    float4 s;
-    s.x = ((v_nw.x * w_nw + v_ne.x * w_ne) + v_sw.x * w_sw) + v_se.x * w_se;
-    s.y = ((v_nw.y * w_nw + v_ne.y * w_ne) + v_sw.y * w_sw) + v_se.y * w_se;
-    s.z = ((v_nw.z * w_nw + v_ne.z * w_ne) + v_sw.z * w_sw) + v_se.z * w_se;
-    s.w = ((v_nw.w * w_nw + v_ne.w * w_ne) + v_sw.w * w_sw) + v_se.w * w_se;
-    acc.x += s.x * aw; acc.y += s.y * aw; acc.z += s.z * aw; acc.w += s.w * aw;
+      for (int k = 0; k < L; ++k) {
+        const float a = attw[q][h2][p2][k];
+        float4 s4;
+        s4.x = ((v[k][0].x * t[k].w[0] + v[k][1].x * t[k].w[1]) + v[k][2].x * t[k].w[2]) + v[k][3].x * t[k].w[3];
+        s4.y = ((v[k][0].y * t[k].w[0] + v[k][1].y * t[k].w[1]) + v[k][2].y * t[k].w[2]) + v[k][3].y * t[k].w[3];
+        s4.z = ((v[k][0].z * t[k].w[0] + v[k][1].z * t[k].w[1]) + v[k][2].z * t[k].w[2]) + v[k][3].z * t[k].w[3];
+        s4.w = ((v[k][0].w * t[k].w[0] + v[k][1].w * t[k].w[1]) + v[k][2].w * t[k].w[2]) + v[k][3].w * t[k].w[3];
+        acc.x += s4.x * a; acc.y += s4.y * a; acc.z += s4.z * a; acc.w += s4.w * a;
+      }
+      acc.x = pt_sum(acc.x); acc.y = pt_sum(acc.y);
+      acc.z = pt_sum(acc.z); acc.w = pt_sum(acc.w);
+      if (p2 == 0) st4(out + ((int64_t)b * lv.N + nq) * 256 + h2 * 32 + c4 * 4, acc);
+    }
   }
-  acc.x = grp_sum(acc.x); acc.y = grp_sum(acc.y);
-  acc.z = grp_sum(acc.z); acc.w = grp_sum(acc.w);
-  if (pt == 0) st4(out + ((int64_t)b * lv.N + n) * 256 + head * 32 + c4 * 4, acc);
 }
 
 extern "C" int pn_msda_f32(const float* value, int64_t ld_value, const float* offaw,
@@ -166,7 +185,8 @@ extern "C" int pn_msda_f32(const float* value, int64_t ld_value, const float* of
     for (int l = 0; l < L; ++l) c += ((((k + 1) * lv.h[l]) >> 3) - ((k * lv.h[l]) >> 3)) * lv.w[l];
     if (c > per_band) per_band = c;
   }
-  const dim3 grid(per_band * 8, B);
+  if ((int64_t)n * ld_value * 4 >= ((int64_t)1 << 32)) return PN_BAD_ARG;   // 32-bit tap offsets
+  const dim3 grid((per_band + MSDA_TQ - 1) / MSDA_TQ * 8, B);
   hipStream_t s = (hipStream_t)stream;
   switch (L) {
     case 1: hipLaunchKernelGGL(k_msda<1>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;

@@ -5,7 +5,10 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-conv = [r for r in rows if "k_gemm_tile<64, 64, 32, 32, 2" in r["Kernel_Name"] and int(r["Grid_Size_X"]) >= 200000]
+# step marker: a kernel that runs exactly once per step on the stage-A queue
+conv = [r for r in rows if "k_wino_f23_input" in r["Kernel_Name"]]
+if not conv:   # conv_algo="direct": the FPN convolution itself
+    conv = [r for r in rows if "k_gemm_tile<64, 64, 32, 32, 2" in r["Kernel_Name"] and int(r["Grid_Size_X"]) >= 200000]
 q = collections.Counter(r["Queue_Id"] for r in conv).most_common(1)[0][0]
 cq = [r for r in conv if r["Queue_Id"] == q]
 a, b = 12, 44

@@ -334,7 +334,7 @@ def test_bilinear(hip):
                       12 * 21 * 256, 24 * 42 * 256)
     close(out.permute(0, 3, 1, 2), ref, 2e-6, "bilinear nhwc")
     m = R(7, 40, 67, seed=3, lo=-4, hi=4)
-    for size in ((5, 9), (10, 17), (20, 34), (77, 131)):
+    for size in ((5, 9), (10, 17), (20, 34), (77, 131), (77, 132), (96, 160), (3, 4)):   # wo % 4 == 0: the 4-pixel kernel
         ref = F.interpolate(m[None], size, mode="bilinear", align_corners=False)[0]
         out = torch.empty(7, *size, device=DEV)
         hip.bilinear_planar(m.to(DEV), out, 7, 40, 67, size[0], size[1])

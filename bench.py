@@ -46,7 +46,7 @@ def feature_shapes(h, w):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--height", type=int, default=800)

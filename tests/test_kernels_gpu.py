@@ -314,6 +314,21 @@ def test_msda_golden_and_random(hip):
           "msda random")
 
 
+@pytest.mark.parametrize("shapes,bs", [([(5, 7)], 2), ([(3, 5), (6, 9)], 1),
+                                        ([(2, 3), (4, 5), (7, 9), (13, 17)], 2),
+                                        ([(9, 1), (17, 3), (33, 5)], 1)])
+def test_msda_level_counts_batches_and_odd_bands(hip, shapes, bs):
+    """1 / 2 / 4 levels, batch > 1, maps whose per-band token counts are odd (the second
+    query slot of a workgroup is empty) and offsets that leave the map on every side."""
+    nl = len(shapes)
+    n = sum(h * w for h, w in shapes)
+    value = R(bs, n, 8, 32, seed=11)
+    off = R(bs, n, 8, nl, 4, 2, seed=12, lo=-9, hi=9)
+    logits = R(bs, n, 8, nl * 4, seed=13, lo=-3, hi=3)
+    close(_run_msda(hip, value, off, logits, shapes), _msda_ref(value, off, logits, shapes), 2e-6,
+          "msda %d levels" % nl)
+
+
 # ----------------------------------------------------------------------------- PE / resize
 def test_sine_pe(hip):
     pe = L.SinePositionalEncoding(128, normalize=True)

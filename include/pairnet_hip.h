@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 7
+#define PN_ABI_VERSION 8
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -203,6 +203,13 @@ int64_t pn_ffn_scratch_floats(int M, int hidden);
 int pn_ffn_ln_f32(const float* x, const float* W1, const float* b1, const float* W2,
                   const float* b2, const float* gamma, const float* beta, float* y,
                   float* scratch, int M, int C, int hidden, float eps, void* stream);
+/* The same with a SECOND LayerNorm of the result written to y2 (nullable): the decoder's
+ * post_norm that `forward_head` applies to every layer's output (pairnet_head.py:236), bit
+ * for bit the arithmetic of pn_layernorm_f32 on y. */
+int pn_ffn_ln2_f32(const float* x, const float* W1, const float* b1, const float* W2,
+                   const float* b2, const float* gamma, const float* beta, float* y,
+                   const float* gamma2, const float* beta2, float* y2, float* scratch, int M,
+                   int C, int hidden, float eps, void* stream);
 
 /* y[r][:] = x[r][:] / max(||x[r]||_2, eps)   (F.normalize, pairnet_head.py:325-326) */
 int pn_l2normalize_f32(const float* x, float* y, int64_t rows, int C, float eps,

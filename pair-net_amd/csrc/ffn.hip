@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void k_reduce_ln(const float* __restrict__ par
                                                    const float* __restrict__ g,
                                                    const float* __restrict__ b,
                                                    float* __restrict__ y, int64_t rows,
-                                                   float eps) {
+                                                   float eps, const float* __restrict__ g2,
+                                                   const float* __restrict__ b2n,
+                                                   float* __restrict__ y2) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -109,28 +111,48 @@ __global__ __launch_bounds__(256) void k_reduce_ln(const float* __restrict__ par
   const float var = wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.f / 256.f);
   const float rstd = 1.f / sqrtf(var + eps);
   const float4 gg = ld4(g + lane * 4), bb = ld4(b + lane * 4);
-  st4(y + row * 256 + lane * 4,
-      make_float4(dx * rstd * gg.x + bb.x, dy * rstd * gg.y + bb.y,
-                  dz * rstd * gg.z + bb.z, dw * rstd * gg.w + bb.w));
+  const float4 o = make_float4(dx * rstd * gg.x + bb.x, dy * rstd * gg.y + bb.y,
+                               dz * rstd * gg.z + bb.z, dw * rstd * gg.w + bb.w);
+  st4(y + row * 256 + lane * 4, o);
+  if (y2) {   // a second LayerNorm of the result (the decoder's post_norm): the arithmetic of
+              // k_layernorm256 on the row this wave already holds
+    const float m2 = wave_sum((o.x + o.y) + (o.z + o.w)) * (1.f / 256.f);
+    const float ex = o.x - m2, ey = o.y - m2, ez = o.z - m2, ew = o.w - m2;
+    const float v2 = wave_sum((ex * ex + ey * ey) + (ez * ez + ew * ew)) * (1.f / 256.f);
+    const float r2 = 1.f / sqrtf(v2 + eps);
+    const float4 g4 = ld4(g2 + lane * 4), b4 = ld4(b2n + lane * 4);
+    st4(y2 + row * 256 + lane * 4, make_float4(ex * r2 * g4.x + b4.x, ey * r2 * g4.y + b4.y,
+                                               ez * r2 * g4.z + b4.z, ew * r2 * g4.w + b4.w));
+  }
 }
 
 extern "C" int64_t pn_ffn_scratch_floats(int M, int hidden) {
   return (int64_t)(hidden / FFN_HC) * M * 256;
 }
 
-extern "C" int pn_ffn_ln_f32(const float* x, const float* W1, const float* b1, const float* W2,
-                             const float* b2, const float* gamma, const float* beta, float* y,
-                             float* scratch, int M, int C, int hidden, float eps,
-                             void* stream) {
+extern "C" int pn_ffn_ln2_f32(const float* x, const float* W1, const float* b1, const float* W2,
+                              const float* b2, const float* gamma, const float* beta, float* y,
+                              const float* gamma2, const float* beta2, float* y2,
+                              float* scratch, int M, int C, int hidden, float eps,
+                              void* stream) {
   if (!x || !W1 || !b1 || !W2 || !b2 || !gamma || !beta || !y || !scratch) return PN_BAD_ARG;
   if (C != 256 || M <= 0 || hidden <= 0 || hidden % FFN_HC) return PN_BAD_ARG;
   if (((uintptr_t)x | (uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)scratch | (uintptr_t)y) & 15)
     return PN_BAD_ARG;
+  if (y2 && (!gamma2 || !beta2 || ((uintptr_t)y2 & 15))) return PN_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int S = hidden / FFN_HC;
   hipLaunchKernelGGL(k_ffn_partial, dim3(S, pn_cdiv(M, 32)), dim3(512), 0, s, x, W1, b1, W2,
                      scratch, M, hidden);
   hipLaunchKernelGGL(k_reduce_ln, dim3(pn_cdiv(M, 4)), dim3(256), 0, s, scratch, S, b2, x, gamma,
-                     beta, y, (int64_t)M, eps);
+                     beta, y, (int64_t)M, eps, gamma2, beta2, y2);
   return PN_LAUNCH_CHECK();
+}
+
+extern "C" int pn_ffn_ln_f32(const float* x, const float* W1, const float* b1, const float* W2,
+                             const float* b2, const float* gamma, const float* beta, float* y,
+                             float* scratch, int M, int C, int hidden, float eps,
+                             void* stream) {
+  return pn_ffn_ln2_f32(x, W1, b1, W2, b2, gamma, beta, y, nullptr, nullptr, nullptr, scratch, M,
+                        C, hidden, eps, stream);
 }

@@ -107,6 +107,7 @@ class CrossHead2:
         self.device = None
         self.w = None
         self._plans = {}
+        self._dummies = {}
         # True: compute attention masks in the reference's operation order (full-size mask
         # logits -> bilinear resize); False: resample the mask feature once (see _attn_mask)
         self.exact_mask_order = False
@@ -233,7 +234,7 @@ class CrossHead2:
             for n in ("value_proj", "output_proj"):
                 self._params[p + n + ".weight"].copy_(U((256, 256), math.sqrt(6.0 / 512)))
                 self._params[p + n + ".bias"].zero_()
-        self.w = None
+        self.w, self._plans = None, {}   # plans cache weight-derived buffers and graphs
 
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._params.items())
@@ -250,7 +251,7 @@ class CrossHead2:
                     raise RuntimeError("shape mismatch for %s: %s vs %s"
                                        % (k, tuple(sd[k].shape), tuple(p.shape)))
                 p.copy_(sd[k].detach().to(torch.float32).cpu())
-        self.w = None
+        self.w, self._plans = None, {}   # plans cache weight-derived buffers and graphs
         return missing, unexpected
 
     def eval(self):
@@ -340,7 +341,7 @@ class CrossHead2:
         pl = CrossHead2._Plan()
         pl.B, pl.shapes, pl.hw2, pl.nhwc = B, list(shapes), tuple(hw2), nhwc
         pl.graph_a = pl.graph_b = pl.static_feats = pl.graph_cfg = pl.feats_read = None
-        pl.static_ptrs, pl.staged = None, False
+        pl.static_ptrs, pl.staged, pl.me0 = None, False, None
         pl.calls_a = pl.calls_b = 0
         pl.N = [h * w for h, w in shapes]
         pl.start = [0, pl.N[0], pl.N[0] + pl.N[1]]
@@ -502,22 +503,23 @@ class CrossHead2:
                  batch=pl.B, sA=Q * 256, sW=pl.HW2 * 256, sC=Q * pl.HW2,
                  split=self.gemm_mode == "bf16x3")
 
-    def _head_embed(self, q, pl, with_cls, full_mask, cls_out=None, mp_out=None):
+    def _head_embed(self, q, pl, with_cls, full_mask, cls_out=None, mp_out=None, normed=False):
         """post_norm -> (cls_embed) -> mask_embed MLP -> pl.me; with `full_mask` also the
         mask logits [B,Q,H2*W2] (pairnet_head.py:236-243).  Outputs go to pl.cls / pl.MP
         unless other destinations are given."""
         w, B, Q = self.w, pl.B, self.num_obj_query
         cls_out = pl.cls if cls_out is None else cls_out
         mp_out = pl.MP if mp_out is None else mp_out
-        hip.layernorm(q, w["transformer_decoder.post_norm.weight"],
-                      w["transformer_decoder.post_norm.bias"], pl.qn)
+        if not normed:   # (`normed`: pl.qn already holds post_norm(q), from the FFN kernel)
+            hip.layernorm(q, w["transformer_decoder.post_norm.weight"],
+                          w["transformer_decoder.post_norm.bias"], pl.qn)
         if with_cls:
             hip.linear(pl.qn, w["cls_embed.weight"], w["cls_embed.bias"], cls_out.view(B * Q, -1))
         self._mlp3("mask_embed", pl.qn, pl.me, pl)
         if full_mask:
             self._mask_logits(pl.me, pl, mp_out)
 
-    def _attn_mask(self, pl, lvl, mp=None):
+    def _attn_mask(self, pl, lvl, mp=None, me=None):
         """Boolean attention mask of level `lvl` + all-masked fix (pairnet_head.py:244-256,
         :300) -> pl.bits / pl.rowall.
 
@@ -533,12 +535,12 @@ class CrossHead2:
             hip.bilinear_planar(pl.MP if mp is None else mp, pl.ML, B * Q, pl.hw2[0], pl.hw2[1],
                                 h, wd)
         else:
-            hip.gemm(pl.me, pl.MFd[lvl], pl.ML, M=Q, N=n, K=256, lda=256, ldw=256, ldc=n,
-                     batch=B, sA=Q * 256, sW=n * 256, sC=Q * n)
+            hip.gemm(pl.me if me is None else me, pl.MFd[lvl], pl.ML, M=Q, N=n, K=256, lda=256,
+                     ldw=256, ldc=n, batch=B, sA=Q * 256, sW=n * 256, sC=Q * n)
         hip.mask_pack(pl.ML, pl.bits, pl.rowall, B * Q, n)
 
     def _layer(self, pre, x, xpos, x1, x2, y, Qp, VQK, att, hbuf, Kp, ldk, Vp, ldv, Nk, B, nq,
-               bits, rowall, scr, ffn, self_first=False):
+               bits, rowall, scr, ffn, self_first=False, post=None):
         """One post-norm decoder layer (facebook_detr.py:378-432 semantics); x is updated
         in place.  Operation order (cross_attn, norm, self_attn, norm, ffn, norm), or with
         `self_first` (self_attn, norm, cross_attn, norm, ffn, norm); attentions.<j> is the
@@ -572,7 +574,8 @@ class CrossHead2:
             self_attn(x1, x2)
         hip.ffn_ln(x2, w[pre + "ffns.0.layers.0.0.weight"], w[pre + "ffns.0.layers.0.0.bias"],
                    w[pre + "ffns.0.layers.1.weight"], w[pre + "ffns.0.layers.1.bias"],
-                   w[pre + "norms.2.weight"], w[pre + "norms.2.bias"], x, hbuf, B * nq, ffn)
+                   w[pre + "norms.2.weight"], w[pre + "norms.2.bias"], x, hbuf, B * nq, ffn,
+                   post=post)
 
     # --------------------------------------------------------------- forward
     # Stage A: everything that does not depend on the query chain (pixel decoder, the
@@ -622,22 +625,31 @@ class CrossHead2:
         pl.q.view(B, Q, 256).copy_(w["query_feat.weight"].unsqueeze(0).expand(B, Q, 256))
         qpos = w["query_embed.weight"]
         exact = self.exact_mask_order
-        self._head_embed(pl.q, pl, False, exact)
+        # mask embedding of the INITIAL queries (learned, input-independent): computed on the
+        # plan's first call and kept (a new state dict drops the plans)
+        if exact:
+            self._head_embed(pl.q, pl, False, True)
+        elif pl.me0 is None:
+            self._head_embed(pl.q, pl, False, False)
+            pl.me0 = pl.me.clone()
         last = self.num_dec_layers - 1
         mp = None
+        # post_norm of every layer's output comes out of the layer's FFN kernel
+        post = (w["transformer_decoder.post_norm.weight"], w["transformer_decoder.post_norm.bias"],
+                pl.qn)
         for i in range(self.num_dec_layers):
             l = i % 3
-            self._attn_mask(pl, l, mp)
+            self._attn_mask(pl, l, mp, me=pl.me0 if (i == 0 and not exact) else None)
             self._layer("transformer_decoder.layers.%d." % i, pl.q, qpos, pl.q1, pl.q2, pl.qy,
                         pl.Qp, pl.VQK, pl.att, pl.hq, pl.Kp[i], 256, pl.Vp[i], 256, pl.N[l], B,
-                        Q, pl.bits, pl.rowall, pl.scr, self.dec_ffn)
+                        Q, pl.bits, pl.rowall, pl.scr, self.dec_ffn, post=post)
             if all_layers:
                 mp = pl.MP_all[i]
-                self._head_embed(pl.q, pl, True, True, pl.cls_all[i], mp)
+                self._head_embed(pl.q, pl, True, True, pl.cls_all[i], mp, normed=True)
             elif final_head:
-                self._head_embed(pl.q, pl, i == last, exact or i == last)
+                self._head_embed(pl.q, pl, i == last, exact or i == last, normed=True)
             elif i != last:
-                self._head_embed(pl.q, pl, False, exact)
+                self._head_embed(pl.q, pl, False, exact, normed=True)
 
     def _relation_stage(self, pl):
         w, B, Q, R = self.w, pl.B, self.num_obj_query, self.num_rel_query
@@ -706,7 +718,7 @@ class CrossHead2:
         (the first, eager one is the warm-up torch requires before capture)."""
         cfg = (self.gemm_mode, self.exact_mask_order, self.conv_algo)
         if pl.graph_cfg != cfg:          # a captured graph bakes these switches in
-            pl.graph_a = pl.graph_b = None
+            pl.graph_a = pl.graph_b = pl.me0 = None
             pl.graph_cfg = cfg
         if which == "a":
             ptrs = tuple(f.data_ptr() for f in feats)
@@ -857,10 +869,13 @@ class CrossHead2:
                             W0, state, up, area, seg)
         pan_img = seg.view(H0, W0)
         self.last_panoptic_state = state
-        det_bboxes = torch.zeros((2 * R, 5), device=dev)
-        r_scores = torch.zeros(R, device=dev)
-        r_labels = torch.zeros(R, device=dev)
-        rel_pairs = torch.arange(2 * R, dtype=torch.int).reshape(2, -1).T
+        # the reference's dummy outputs (:907-913) are constants: made once per device
+        key = (str(dev), R)
+        if key not in self._dummies:
+            self._dummies[key] = (torch.zeros((2 * R, 5), device=dev), torch.zeros(R, device=dev),
+                                  torch.zeros(R, device=dev),
+                                  torch.arange(2 * R, dtype=torch.int).reshape(2, -1).T)
+        det_bboxes, r_scores, r_labels, rel_pairs = self._dummies[key]
         return (det_bboxes, labels, rel_pairs, masks, pan_img, r_scores, r_labels, r_dists)
 
     def panoptic_status(self):

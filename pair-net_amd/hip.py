@@ -57,6 +57,7 @@ _SIGS = {
     "pn_l2normalize_f32": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _vp]),
     "pn_ffn_scratch_floats": (_i64, [_i32, _i32]),
     "pn_ffn_ln_f32": (C.c_int, [_vp] * 9 + [_i32, _i32, _i32, _f32, _vp]),
+    "pn_ffn_ln2_f32": (C.c_int, [_vp] * 12 + [_i32, _i32, _i32, _f32, _vp]),
     "pn_msda_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, C.POINTER(_i32),
                               C.POINTER(_i32), _vp]),
     "pn_sine_pe_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp]),
@@ -85,7 +86,7 @@ _SIGS = {
     "pn_mask_iou_counts": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 7   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 8   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -398,12 +399,15 @@ def ffn_scratch_floats(M, hidden):
     return lib().pn_ffn_scratch_floats(M, hidden)
 
 
-def ffn_ln(x, W1, b1, W2, b2, gamma, beta, out, scratch, M, hidden, eps=1e-5):
+def ffn_ln(x, W1, b1, W2, b2, gamma, beta, out, scratch, M, hidden, eps=1e-5, post=None):
+    """post = (gamma2, beta2, out2): a second LayerNorm of the result into out2."""
+    g2, b2n, y2 = post if post is not None else (None, None, None)
     _check(_launch("k_ffn_partial+k_reduce_ln", 4.0 * M * 256 * hidden,
                    4.0 * (2 * 256 * hidden + 2 * M * 256),
-                   lambda: lib().pn_ffn_ln_f32(_ptr(x), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
-                                               _ptr(gamma), _ptr(beta), _ptr(out), _ptr(scratch),
-                                               M, 256, hidden, eps, _stream())), "pn_ffn_ln_f32")
+                   lambda: lib().pn_ffn_ln2_f32(_ptr(x), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
+                                                _ptr(gamma), _ptr(beta), _ptr(out), _ptr(g2),
+                                                _ptr(b2n), _ptr(y2), _ptr(scratch), M, 256, hidden,
+                                                eps, _stream())), "pn_ffn_ln2_f32")
 
 
 def l2normalize(x, out, eps=1e-12):

@@ -6,8 +6,9 @@ dev = torch.device("cuda:0")
 cfg = pairnet_head_cfg(); cfg.pop("type")
 head = CrossHead2(**cfg); head.init_weights(seed=0); head.to(dev)
 shapes = [(200, 334), (100, 167), (50, 84), (25, 42)]
-feats = [torch.relu(torch.randn(1, c, h, w)).to(dev) for c, (h, w) in zip((256, 512, 1024, 2048), shapes)]
-metas = [dict(img_shape=(800, 1333, 3), scale_factor=[2.083] * 4)]
+NB = int(os.environ.get("BATCH", "1"))
+feats = [torch.relu(torch.randn(NB, c, h, w)).to(dev) for c, (h, w) in zip((256, 512, 1024, 2048), shapes)]
+metas = [dict(img_shape=(800, 1333, 3), scale_factor=[2.083] * 4)] * NB
 def T(fn, n=30):
     for _ in range(3): fn()
     torch.cuda.synchronize(); t = time.perf_counter()

@@ -3,9 +3,10 @@
 `PSGTr` mirrors pairnet/models/frameworks/psgtr.py:73-88,148-156 (backbone -> head
 -> `Result`), `triplet2Result` :15-51, `Result` the fields of
 pairnet/models/relation_heads/approaches/relation_util.py:20-97 that the PSG
-evaluator reads.  The backbone is SURVEY.md section 8 row a1 / (f)-2: a plain
-PyTorch-ROCm (MIOpen) ResNet-50 with the torchvision/mmdet key layout; it is not
-one of the hand-written kernels.
+evaluator reads.  The backbone is SURVEY.md section 8 row a1 / (f)-2: the native
+`ResNet50Hip` (backbone.py) or `SwinTransformerHip` (swin.py) by `backbone.type`;
+`backbone.impl="torch"` selects a plain PyTorch-ROCm (MIOpen) ResNet-50 with the same
+state dict, kept as the comparison leg of bench.py.
 """
 import torch
 import torch.nn as nn

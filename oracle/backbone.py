@@ -38,10 +38,12 @@ class Bottleneck(nn.Module):
 
 
 class OracleResNet50(nn.Module):
-    STAGES = ((64, 3), (128, 4), (256, 6), (512, 3))
+    """depth 50 (default) or 101: mmdet's bottleneck arch_settings (3,4,6,3) / (3,4,23,3)."""
+    BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 
-    def __init__(self):
+    def __init__(self, depth=50):
         super().__init__()
+        self.STAGES = tuple(zip((64, 128, 256, 512), self.BLOCKS[depth]))
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         cin = 64
@@ -63,12 +65,12 @@ class OracleResNet50(nn.Module):
         return tuple(outs)
 
 
-def seeded_backbone_state(seed):
+def seeded_backbone_state(seed, depth=50):
     """Deterministic ResNet-50 state dict (numpy PCG64): He-style conv weights, BatchNorm
     statistics away from the identity so that folding is exercised."""
     import numpy as np
     rng = np.random.default_rng(seed)
-    sd = OracleResNet50().state_dict()
+    sd = OracleResNet50(depth).state_dict()
     out = {}
     for k, v in sd.items():
         shape = tuple(v.shape)

@@ -18,11 +18,16 @@ import torch
 
 from . import hip
 
-STAGES = ((64, 3), (128, 4), (256, 6), (512, 3))
+BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}   # bottleneck ResNets (mmdet arch_settings)
 EPS = 1e-5
 
 
-def _param_shapes():
+def _stages(depth):
+    return tuple(zip((64, 128, 256, 512), BLOCKS[depth]))
+
+
+def _param_shapes(depth=50):
+    STAGES = _stages(depth)
     s = OrderedDict()
 
     def bn(prefix, c):
@@ -52,10 +57,13 @@ def _param_shapes():
 class ResNet50Hip:
     """Drop-in for the detector's `backbone(img) -> (C2, C3, C4, C5)`."""
 
-    def __init__(self, **unused):
+    def __init__(self, depth=50, **unused):
+        if depth not in BLOCKS:
+            raise NotImplementedError("bottleneck ResNets: depth 50 or 101")
+        self.depth, self.stages = depth, _stages(depth)
         self._params = OrderedDict(
             (k, torch.zeros(shape, dtype=torch.int64 if k.endswith("tracked") else torch.float32))
-            for k, shape in _param_shapes().items())
+            for k, shape in _param_shapes(depth).items())
         for k, v in self._params.items():          # identity BatchNorm until weights are loaded
             if k.endswith(("running_var",)) or (k.endswith(".weight") and v.dim() == 1):
                 v.fill_(1.0)
@@ -112,7 +120,7 @@ class ResNet50Hip:
         stem = torch.zeros(64, 160)
         stem[:, :147] = cw.reshape(64, 147)                # k = c*49 + ky*7 + kx
         w["stem.w"], w["stem.b"] = stem.to(dev), cb.to(dev)
-        for i, (planes, blocks) in enumerate(STAGES):
+        for i, (planes, blocks) in enumerate(self.stages):
             for b in range(blocks):
                 p = "layer%d.%d." % (i + 1, b)
                 for conv, bn in (("conv1", "bn1"), ("conv2", "bn2"), ("conv3", "bn3"),
@@ -145,7 +153,7 @@ class ResNet50Hip:
         # largest S x M x N the library can ask for here
         pl.scratch = E(B * 16 * 1024 * 1024 // 2)
         pl.hw, pl.out, pl.t1, pl.t2, pl.idt, pl.ping = [], [], [], [], [], []
-        for i, (planes, blocks) in enumerate(STAGES):
+        for i, (planes, blocks) in enumerate(self.stages):
             hin, win = h, wd
             if i > 0:
                 h, wd = (h - 1) // 2 + 1, (wd - 1) // 2 + 1
@@ -175,7 +183,7 @@ class ResNet50Hip:
         hip.stem7x7s2(img, w["stem.w"], w["stem.b"], pl.stem, B, H, W)
         hip.maxpool3x3s2(pl.stem, pl.pool, B, pl.hw_stem[0], pl.hw_stem[1], 64)
         x, cin = pl.pool, 64
-        for i, (planes, blocks) in enumerate(STAGES):
+        for i, (planes, blocks) in enumerate(self.stages):
             (hin, win), (h, wd) = pl.hw[i]
             for b in range(blocks):
                 p = "layer%d.%d." % (i + 1, b)

@@ -123,16 +123,20 @@ class PSGTr:
         if btype == "SwinTransformer":
             # pairnet_swinb.py:203-226; native only (swin.py)
             self.backbone = SwinTransformerHip(**{k: v for k, v in backbone.items() if k != "type"})
-        elif btype == "ResNet" and backbone.get("depth", 50) == 50:
+        elif btype == "ResNet" and backbone.get("depth", 50) in (50, 101):
             # "hip" (default): the native fp32-MFMA backbone of backbone.py, channels_last
             # features straight into the head; "torch": PyTorch-ROCm / MIOpen (same state dict)
             impl = backbone.get("impl", "hip")
             if impl not in ("hip", "torch"):
                 raise ValueError("backbone.impl must be 'hip' or 'torch'")
-            self.backbone = ResNet50Hip() if impl == "hip" else ResNet50()
+            depth = backbone.get("depth", 50)
+            if impl == "torch" and depth != 50:
+                raise NotImplementedError("the PyTorch comparison backbone is ResNet-50 only")
+            self.backbone = ResNet50Hip(depth=depth) if impl == "hip" else ResNet50()
         else:
-            raise NotImplementedError("backbones built: ResNet depth 50 (pairnet.py) and "
-                                      "SwinTransformer (pairnet_swinb.py)")
+            raise NotImplementedError("backbones built: ResNet depth 50 / 101 (pairnet.py, "
+                                      "psgformer_r101_psg.py) and SwinTransformer "
+                                      "(pairnet_swinb.py)")
         head_cfg = dict(bbox_head)
         heads = dict(CrossHead2=CrossHead2, CrossHeadBaseline=CrossHeadBaseline,
                      PSGTrHead2=PSGTrHead2)

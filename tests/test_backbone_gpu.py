@@ -83,6 +83,27 @@ def test_backbone_matches_oracle(B, H, W):
         assert e < 1e-4
 
 
+def test_resnet101_matches_oracle():
+    """depth 101 (the R101 configs of the reference, e.g. configs/psgformer/psgformer_r101_psg.py):
+    same kernels, 23 blocks in stage 3."""
+    from pairnet_amd import ResNet50Hip
+    sd = seeded_backbone_state(37, 101)
+    oracle = OracleResNet50(101)
+    oracle.load_state_dict(sd)
+    net = ResNet50Hip(depth=101)
+    assert set(net.state_dict()) == set(sd)
+    net.load_state_dict(sd)
+    net.to(DEV)
+    img = R(1, 3, 75, 101, seed=8)
+    want = oracle(img)
+    got = net(img.to(DEV))
+    torch.cuda.synchronize()
+    for g, o in zip(got, want):
+        assert tuple(g.shape) == tuple(o.shape) and rel(g, o) < 2e-4
+    with pytest.raises(NotImplementedError):
+        ResNet50Hip(depth=34)
+
+
 def test_head_reads_channels_last_features():
     """The head's outputs do not depend on the memory format of `feats`."""
     from helpers import head_cfg, oracle_head

@@ -356,17 +356,18 @@ def test_masked_decoder_layer_oracle_matches_transformers_mask2former():
     assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
 
 
-def test_resnet50_oracle_matches_transformers_resnet():
-    """oracle/backbone.py (mmdet ResNet-50, style "pytorch", eval-mode BatchNorm) against
-    HuggingFace's ResNetBackbone (v1.5: stride on the 3x3) with the same weights."""
+@pytest.mark.parametrize("depth", [50, 101])
+def test_resnet50_oracle_matches_transformers_resnet(depth):
+    """oracle/backbone.py (mmdet ResNet-50 / -101, style "pytorch", eval-mode BatchNorm)
+    against HuggingFace's ResNetBackbone (v1.5: stride on the 3x3) with the same weights."""
     tr = pytest.importorskip("transformers")
     from oracle.backbone import OracleResNet50, seeded_backbone_state
     from oracle.hf_pin import resnet50_to_hf
-    sd = seeded_backbone_state(31)
-    m = OracleResNet50()
+    sd = seeded_backbone_state(31, depth)
+    m = OracleResNet50(depth)
     m.load_state_dict(sd)
     cfg = tr.ResNetConfig(embedding_size=64, hidden_sizes=[256, 512, 1024, 2048],
-                          depths=[3, 4, 6, 3], layer_type="bottleneck", hidden_act="relu",
+                          depths=list(OracleResNet50.BLOCKS[depth]), layer_type="bottleneck", hidden_act="relu",
                           downsample_in_first_stage=False, downsample_in_bottleneck=False,
                           out_features=["stage1", "stage2", "stage3", "stage4"])
     hf = tr.ResNetBackbone(cfg).eval()

@@ -234,35 +234,45 @@ def main():
                 "collective": "all-gather of triplet records" if world > 1 else "none"},
         }
         if timer and dominant:
-            agg = prof[dominant]
             nprof = min(args.steps, 10)
-            sec = agg["ms"] * 1e-3
-            if dominant in HBM_KERNELS:
-                ach, peak, unit, bound = agg["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
-            else:
-                ach, peak, unit = agg["flops"] / sec / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
-                bound = "mfma"
-            traffic, traffic_src = None, None
-            try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE
-                # doubled per MI355X_MICROARCH.md + WRITE_SIZE), same workload, same kernel
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                hits = [v for v in pmc["kernels"].values() if v.get("bench_name") == dominant]
-                if hits:   # template variants of one kernel: launch-weighted mean
-                    n = sum(v["launches_profiled"] for v in hits)
-                    traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches_profiled"]
-                                      for v in hits) / n)
-                    traffic_src = "profiles/r01_pmc_traffic.json"
-            except (OSError, ValueError, KeyError):
-                pass
-            out["roofline"] = {
-                "kernel": dominant, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": agg["bytes"] / agg["launches"],
-                "launches_per_step": agg["launches"] // nprof,
-                "avg_launch_us": 1e3 * agg["ms"] / agg["launches"],
-                "ms_per_step": agg["ms"] / nprof,
-                "measured": "HIP events around each launch on the launching stream, %d "
-                            "eager single-stream steps right after the timed region" % nprof}
+
+            def roof(name):
+                agg = prof[name]
+                sec = agg["ms"] * 1e-3
+                if name in HBM_KERNELS:
+                    ach, peak, unit, bound = agg["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+                else:
+                    ach, peak, unit = agg["flops"] / sec / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+                    bound = "mfma"
+                traffic, traffic_src = None, None
+                try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE
+                    # doubled per MI355X_MICROARCH.md + WRITE_SIZE), same workload, same kernel
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                    hits = [v for v in pmc["kernels"].values()
+                            if v.get("bench_name") == name or
+                            (name in HBM_KERNELS and str(v.get("bench_name")).startswith(name))]
+                    if hits:   # template variants of one kernel: launch-weighted mean
+                        n = sum(v["launches_profiled"] for v in hits)
+                        traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches_profiled"]
+                                          for v in hits) / n)
+                        traffic_src = "profiles/r01_pmc_traffic.json"
+                except (OSError, ValueError, KeyError):
+                    pass
+                return {
+                    "kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                    "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": agg["bytes"] / agg["launches"],
+                    "launches_per_step": agg["launches"] // nprof,
+                    "avg_launch_us": 1e3 * agg["ms"] / agg["launches"],
+                    "ms_per_step": agg["ms"] / nprof,
+                    "measured": "HIP events around each launch on the launching stream, %d "
+                                "eager single-stream steps right after the timed region" % nprof}
+
+            out["roofline"] = roof(dominant)
+            # the north star's other named kernel: achieved HBM GB/s of the deformable sampling
+            msda = [k for k in prof if k.startswith("k_msda")]
+            if msda:
+                out["roofline_deformable_sampling"] = roof(msda[0])
             out["kernel_profile"] = {
                 k: {"ms_per_step": v["ms"] / nprof, "launches_per_step": v["launches"] // nprof,
                     "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0.0,

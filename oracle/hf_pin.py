@@ -95,3 +95,27 @@ def resnet50_to_hf(sd):
             kind = "convolution" if parts[2].startswith("conv") else "normalization"
             out[base + "layer.%d.%s.%s" % (i, kind, parts[-1])] = v
     return out
+
+
+def self_first_layer_to_hf(sd):
+    """A decoder layer with operation order (self_attn, norm, cross_attn, norm, ffn, norm) --
+    CrossHeadBaseline's relation decoder -- -> transformers DetrDecoderLayer, whose self- and
+    cross-attention are both its own q/k/v-projection code (no nn.MultiheadAttention)."""
+    out = {}
+    for k, v in sd.items():
+        leaf = k.split(".")[-1]
+        for j, name in ((0, "self_attn"), (1, "encoder_attn")):
+            pre = "attentions.%d.attn." % j
+            if k.startswith(pre + "in_proj_"):
+                for proj, part in zip(("q_proj", "k_proj", "v_proj"), v.chunk(3, 0)):
+                    out["%s.%s.%s" % (name, proj, "weight" if leaf.endswith("weight") else "bias")] = part
+            elif k.startswith(pre + "out_proj."):
+                out["%s.o_proj.%s" % (name, leaf)] = v
+        if k.startswith("norms."):
+            name = ("self_attn_layer_norm", "encoder_attn_layer_norm", "final_layer_norm")[int(k.split(".")[1])]
+            out["%s.%s" % (name, leaf)] = v
+        elif k.startswith("ffns.0.layers.0.0."):
+            out["mlp.fc1." + leaf] = v
+        elif k.startswith("ffns.0.layers.1."):
+            out["mlp.fc2." + leaf] = v
+    return out

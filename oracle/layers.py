@@ -17,7 +17,9 @@ converters of oracle/hf_pin.py (tests/test_oracle.py):
   * one masked-attention decoder layer (BaseTransformerLayer + MultiheadAttention
     wrapper + FFN, cross -> self -> ffn, post-norm) == transformers
     Mask2FormerMaskedAttentionDecoderLayer (its self-attention is not
-    nn.MultiheadAttention) to 2e-5 relative.
+    nn.MultiheadAttention) to 2e-5 relative;
+  * the same layer in (self -> cross -> ffn) order == transformers DetrDecoderLayer
+    (own attention code for both attentions) to 2e-5 relative.
 The state-dict KEY NAMES of mmcv / mmdet are from memory and stay unpinned.
 
 Every module keeps the attribute / state-dict names of the package it restates

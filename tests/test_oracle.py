@@ -379,3 +379,35 @@ def test_resnet50_oracle_matches_transformers_resnet(depth):
     for g, w in zip(got, want):
         assert tuple(g.shape) == tuple(w.shape)
         assert float((g - w).abs().max()) < 1e-5 * float(w.abs().max())
+
+
+def test_self_first_decoder_layer_oracle_matches_transformers_detr():
+    """The self-attention-first layer order of CrossHeadBaseline's relation decoder
+    (baseline_r50_psg.py: self_attn, norm, cross_attn, norm, ffn, norm) as restated in
+    oracle/layers.py, against HuggingFace's DetrDecoderLayer (own attention code for both
+    attentions: also an independent check of the nn.MultiheadAttention wrapper's semantics:
+    positions on q / k, not on v)."""
+    tr = pytest.importorskip("transformers")
+    from transformers.models.detr.modeling_detr import DetrDecoderLayer
+    from helpers import oracle_baseline_head
+    from oracle.hf_pin import self_first_layer_to_hf
+    head, _, _ = oracle_baseline_head(9)
+    layer = head.relation_decoder.layers[2]
+    assert tuple(layer.operation_order[:3]) == ("self_attn", "norm", "cross_attn")
+    hc = tr.DetrConfig(d_model=256, decoder_attention_heads=8,
+                       decoder_ffn_dim=layer.ffns[0].layers[1].in_features, dropout=0.0,
+                       attention_dropout=0.0, activation_dropout=0.0, activation_function="relu")
+    hf = DetrDecoderLayer(hc).eval()
+    hf.load_state_dict(self_first_layer_to_hf(layer.state_dict()), strict=True)
+    g = torch.Generator().manual_seed(23)
+    Q, K, B = 17, 55, 2
+    query, qpos = torch.randn(Q, B, 256, generator=g), torch.randn(Q, B, 256, generator=g)
+    mem, kpos = torch.randn(K, B, 256, generator=g), torch.randn(K, B, 256, generator=g)
+    with torch.no_grad():
+        got = layer(query=query, key=mem, value=mem, query_pos=qpos, key_pos=kpos,
+                    attn_masks=None, query_key_padding_mask=None, key_padding_mask=None)
+        want = hf(query.transpose(0, 1), spatial_position_embeddings=kpos.transpose(0, 1),
+                  object_queries_position_embeddings=qpos.transpose(0, 1),
+                  encoder_hidden_states=mem.transpose(0, 1))
+        want = (want[0] if isinstance(want, tuple) else want).transpose(0, 1)
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())

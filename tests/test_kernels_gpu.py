@@ -254,6 +254,14 @@ def test_fused_ffn_layernorm(hip, M, hidden):
     hip.ffn_ln(x.to(DEV), W1.to(DEV), b1.to(DEV), W2.to(DEV), b2.to(DEV), g.to(DEV), b.to(DEV),
                out, scr, M, hidden)
     close(out, ref, 5e-6, "ffn+ln")
+    # second LayerNorm output (the decoder's post_norm): bit for bit pn_layernorm_f32 of `out`
+    g2, b2n = R(256, seed=8).to(DEV), R(256, seed=9).to(DEV)
+    out_b, y2 = torch.empty(M, 256, device=DEV), torch.empty(M, 256, device=DEV)
+    hip.ffn_ln(x.to(DEV), W1.to(DEV), b1.to(DEV), W2.to(DEV), b2.to(DEV), g.to(DEV), b.to(DEV),
+               out_b, scr, M, hidden, post=(g2, b2n, y2))
+    want2 = torch.empty(M, 256, device=DEV)
+    hip.layernorm(out, g2, b2n, want2)
+    assert torch.equal(out_b, out) and torch.equal(y2, want2)
 
 
 @pytest.mark.parametrize("relu", [False, True])

@@ -242,6 +242,227 @@ def gen_e2e_full(head, sd):
     print("e2e_full: reference forward %.1f s on %d threads" % (dt, torch.get_num_threads()))
 
 
+# --------------------------------------------------------------------------- separated
+# "Separated" fixtures (e2e_small_sep, e2e_full_sep, ppn_sep): the same seeded weights
+# plus a few stored edits (oracle/seeded.py "ops") chosen so that the reference's top-k
+# pair list is STABLE -- every gap between consecutive scores among the top k+1 is far
+# above what fp32 re-association can move a score by -- and strict index equality is a
+# meaningful assertion.  With purely random weights it is not, for two measured reasons
+# (DESIGN.md section 3): (1) the nine post-norm decoder layers collapse all queries onto
+# one common vector (diversity 1-3 % of the norm), so the pair scores differ by 1e-5 while
+# a single flipped attention-mask bit (a mask logit within 1e-6 of zero; a few per 800x1333
+# forward, also between the reference's own fp32 and fp64 runs) moves them by 1e-6; (2) a
+# random 3-layer 7x7x64 CNN ends in 3136-term sums whose rounding error is 3e-5 of its
+# output spread, about the typical smallest gap of 100 order statistics.  The edits give
+# the head the properties of a trained one: cross-attention that does not add a common
+# vector to every query (value bias centred on this input, output projection scaled so
+# that queries stay dominated by their own learned embeddings), subject / object
+# embeddings without the common component and of low dimension (wide cosine spread), and
+# a Matrix Learner with an identity path beside its (fully random) weights.  A cheap
+# search over the seed of the two last MLP layers then picks the widest minimum gap.
+XATTN_GAIN = float(os.environ.get("SEP_XATTN", 0.1))
+MIN_MARGIN = 10.0   # min gap / fp32-vs-fp64 score error the generator insists on
+EMB_DIM, SEARCH = int(os.environ.get("SEP_DIM", 16)), int(os.environ.get("SEP_SEARCH", 1000))
+
+
+def _ppn_scores(sd, q, dtype):
+    """pairnet_head.py:322-333 from a state dict (used by the seed search)."""
+    W = lambda n: sd[n].to(dtype)
+    q = q.to(dtype)
+
+    def mlp(p):
+        x = F.relu(F.linear(q, W(p + ".0.weight"), W(p + ".0.bias")))
+        x = F.relu(F.linear(x, W(p + ".2.weight"), W(p + ".2.bias")))
+        x = F.linear(x, W(p + ".4.weight"), W(p + ".4.bias"))
+        return F.normalize(x.transpose(0, 1), p=2, dim=-1, eps=1e-12)
+    x = torch.matmul(mlp("sub_query_update"), mlp("obj_query_update").transpose(1, 2))[:, None]
+    for i in range(3):
+        p = "update_importance.conv_layers.%d.0." % i
+        x = F.conv2d(x, W(p + "weight"), W(p + "bias"), padding=3)
+        if i < 2:
+            x = F.relu(x)
+    return x[:, 0]
+
+
+def _top_noise(imp32, imp64, k):
+    """Largest |fp32 - fp64| score difference among the 2k highest-scoring pairs of each
+    image (the pairs whose order the top-k list depends on)."""
+    a, b = imp32.flatten(-2, -1).double(), imp64.flatten(-2, -1).double()
+    top = a.topk(2 * k, dim=-1)[1]
+    return float((a - b).abs().gather(-1, top).max())
+
+
+def separate(oracle_cls, cfg, sd0, feats, metas, q_override=None, log=print):
+    """Returns (ops, report) for the seeded state dict `sd0` on this input.  With
+    `q_override` (Q,B,256) only the PPN edits are made (the ppn_sep fixture)."""
+    import copy
+    k = cfg["num_rel_query"]
+    ops = {}
+
+    def build(dtype=torch.float32):
+        h = oracle_cls(**cfg).eval()
+        h.load_state_dict(seeded.apply_ops(dict(sd0), ops), strict=True)
+        return h.to(dtype)
+
+    def queries():
+        out = []
+        for dtype in (torch.float32, torch.float64):
+            trace = {}
+            build(dtype).forward([f.to(dtype) for f in feats], metas, trace=trace)
+            out.append(trace["query_feat"])
+        return out
+
+    with torch.no_grad():
+        if q_override is None:
+            h = build()
+            ops["override_" + MF_BIAS] = _np(calibrate_mask_bias(h, feats))
+            _, mems = h.pixel_decoder(feats)
+            hooks = []
+            for i, layer in enumerate(h.transformer_decoder.layers):
+                # cross-attention: values centred over this input's memory, output scaled
+                a = layer.attentions[0].attn
+                m = mems[i % 3].flatten(2).mean(dim=(0, 2)) + h.level_embed.weight[i % 3]
+                a.in_proj_bias[512:] = -(a.in_proj_weight[512:] @ m)
+                a.out_proj.weight *= XATTN_GAIN
+                ops["scale_transformer_decoder.layers.%d.attentions.0.attn.out_proj.weight" % i] \
+                    = np.array([XATTN_GAIN, 0, 256])
+                # self-attention values and the FFN output centred over the queries, on the
+                # fly during one calibration pass (each layer sees the calibrated earlier ones)
+                def centre_v(mod, args):
+                    mod.attn.in_proj_bias[512:] = -(mod.attn.in_proj_weight[512:]
+                                                    @ args[0].mean(dim=(0, 1)))
+                def centre_ffn(mod, args):
+                    mod.layers[1].bias -= mod.layers(args[0]).mean(dim=(0, 1))
+                hooks.append(layer.attentions[1].register_forward_pre_hook(centre_v))
+                hooks.append(layer.ffns[0].register_forward_pre_hook(centre_ffn))
+            h.forward(feats, metas)
+            for hk in hooks:
+                hk.remove()
+            for i, layer in enumerate(h.transformer_decoder.layers):
+                p = "override_transformer_decoder.layers.%d." % i
+                for j in (0, 1):
+                    ops[p + "attentions.%d.attn.in_proj_bias" % j] = \
+                        _np(layer.attentions[j].attn.in_proj_bias)
+                ops[p + "ffns.0.layers.1.bias"] = _np(layer.ffns[0].layers[1].bias)
+            q32, q64 = queries()
+        else:
+            q32, q64 = q_override, q_override.double()
+        log("queries: common component %.2f, diversity %.2f, fp32-vs-fp64 error %.2e"
+            % (q64.mean(0).norm(dim=-1).mean(), (q64 - q64.mean(0, keepdim=True)).norm(dim=-1).mean(),
+               (q32.double() - q64).abs().max()))
+        sd = seeded.apply_ops(dict(sd0), ops)
+        for mlp in ("sub_query_update", "obj_query_update"):
+            pre = F.linear(q32, sd[mlp + ".0.weight"], sd[mlp + ".0.bias"])
+            ops["override_%s.0.bias" % mlp] = _np(sd[mlp + ".0.bias"] - pre.mean(dim=(0, 1)))
+            ops["keeprows_%s.4.weight" % mlp] = np.array(EMB_DIM)
+            ops["keeprows_%s.4.bias" % mlp] = np.array(EMB_DIM)
+        ops["mlearner_skip"] = np.array(1.0)
+        best = None
+        for s in range(SEARCH):
+            ops["reseed_sub_query_update.4.weight"] = np.array(7000 + 2 * s)
+            ops["reseed_obj_query_update.4.weight"] = np.array(7001 + 2 * s)
+            sd = seeded.apply_ops(dict(sd0), ops)
+            i32 = _ppn_scores(sd, q32, torch.float32)
+            gap = float(topk_gaps(i32, k).min())
+            if best is not None and gap < 0.5 * best[1]:
+                continue   # (the fp64 pass is the expensive half)
+            noise = _top_noise(i32, _ppn_scores(sd, q64, torch.float64), k)
+            if best is None or gap / noise > best[1] / best[2]:
+                best = (s, gap, noise)
+        s, gap, noise = best
+        ops["reseed_sub_query_update.4.weight"] = np.array(7000 + 2 * s)
+        ops["reseed_obj_query_update.4.weight"] = np.array(7001 + 2 * s)
+        # exact power-of-two output gain: min gap >= 2e-4 without any new rounding
+        gain = 2.0 ** max(0, int(np.ceil(np.log2(2e-4 / gap))))
+        for n in ("weight", "bias"):
+            ops["scale_update_importance.conv_layers.2.0." + n] = np.array([gain, 0, 1])
+        log("PPN seed %d of %d: min gap %.3e x %g, fp32-vs-fp64 score error %.3e -> margin %.0f"
+            % (s, SEARCH, gap, gain, noise, gap / noise))
+    return ops, dict(min_gap=gap * gain, noise=noise * gain)
+
+
+def _sep_check(head_o64, head, feats, metas, cls, idx, k):
+    """The recorded run against the fp64 evaluation of the same head: how far fp32
+    arithmetic alone moves the scores, and that the top-k list survives it."""
+    t64 = {}
+    c64, _ = head_o64.forward([f.double() for f in feats], metas, trace=t64)
+    noise = _top_noise(cls["importance"], c64["importance"], k)
+    gap = float(topk_gaps(cls["importance"], k).min())
+    assert torch.equal(t64["topk_idx"], idx), "top-k list differs between fp32 and fp64"
+    assert gap >= 1e-4 and gap >= MIN_MARGIN * noise, (gap, noise)
+    return gap, noise
+
+
+def gen_e2e_sep(name, H, W, bs, feat_seed, sf):
+    from .head import OracleCrossHead2
+    cfg = ref_shim.reference_head_cfg()
+    cfg.pop("type", None)
+    head = ref_shim.build_reference_head()
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in head.state_dict().items())
+    sd0 = seeded.seeded_state_dict(shapes, WEIGHT_SEED)
+    feats = seeded.seeded_feats(feat_seed, bs, H, W)
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[sf] * 4)] * bs
+    ops, rep = separate(OracleCrossHead2, dict(cfg), sd0, feats, metas)
+    sd = seeded.apply_ops(dict(sd0), ops)
+    head.load_state_dict(sd, strict=True)
+    cls, masks, idx, dt = _run_e2e(head, feats, metas)
+    o64 = OracleCrossHead2(**cfg).eval()
+    o64.load_state_dict(sd)
+    gap, noise = _sep_check(o64.double(), head, feats, metas, cls, idx, head.num_rel_query)
+    print("%s: min gap %.3e, fp32-vs-fp64 importance error %.3e (margin %.0f)"
+          % (name, gap, noise, gap / noise))
+    with torch.no_grad():
+        res = head.get_bboxes(cls, masks, metas)
+    m = masks["mask"]
+    probe = torch.from_numpy(np.random.default_rng(feat_seed + 1).integers(0, m.numel(), 4096))
+    sub = torch.div(idx, head.num_obj_query, rounding_mode="trunc")
+    out = dict(weight_seed=WEIGHT_SEED, weight_crc=seeded.checksum(sd), feat_seed=feat_seed,
+               feat_crc=seeded.checksum(feats), height=H, width=W, batch=bs, img_scale=sf,
+               rel=_np(cls["rel"]), cls=_np(cls["cls"]), importance=_np(cls["importance"]),
+               sub=_np(cls["sub"]), obj=_np(cls["obj"]),
+               topk_idx=_np(idx), sub_pos=_np(sub), obj_pos=_np(idx - sub * head.num_obj_query),
+               min_gap=gap, fp64_noise=noise,
+               mask_probe_idx=_np(probe), mask_probe=_np(m.flatten()[probe]),
+               mask_neg_frac=float((m < 0).float().mean()), ref_seconds=dt, **ops)
+    for i, r in enumerate(res):
+        out["res%d_labels" % i] = _np(r[1])
+        out["res%d_r_dists" % i] = _np(r[7])
+        out["res%d_pan_img" % i] = _np(r[4]).astype(np.int32)
+        rows = np.arange(0, r[3].shape[0], 1 if H * W < 100000 else 10)   # (fixture size)
+        out["res%d_masks_rows" % i] = rows
+        out["res%d_masks" % i] = np.packbits(_np(r[3])[rows])
+        out["res%d_masks_shape" % i] = np.array((len(rows),) + tuple(r[3].shape[1:]))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
+def gen_ppn_sep():
+    from .head import OracleCrossHead2
+    cfg = ref_shim.reference_head_cfg()
+    cfg.pop("type", None)
+    head = ref_shim.build_reference_head()
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in head.state_dict().items())
+    sd0 = seeded.seeded_state_dict(shapes, WEIGHT_SEED)
+    q = seeded.uniform(np.random.default_rng(23), (100, 2, 256), -2.0, 2.0)
+    ops, rep = separate(OracleCrossHead2, dict(cfg), sd0, None, None, q_override=q)
+    sd = seeded.apply_ops(dict(sd0), ops)
+    head.load_state_dict(sd, strict=True)
+    with torch.no_grad():  # pairnet_head.py:322-340 with the reference's modules
+        s = F.normalize(head.sub_query_update(q).transpose(0, 1), p=2, dim=-1, eps=1e-12)
+        o = F.normalize(head.obj_query_update(q).transpose(0, 1), p=2, dim=-1, eps=1e-12)
+        raw = torch.matmul(s, o.transpose(1, 2))
+        imp = head.update_importance(raw)
+        _, idx = torch.topk(imp.flatten(-2, -1), k=head.num_rel_query)
+        sub = torch.div(idx, head.num_obj_query, rounding_mode="trunc")
+        obj = torch.remainder(idx, head.num_obj_query)
+        i64 = _ppn_scores(sd, q, torch.float64)
+    gap, noise = float(topk_gaps(imp, 100).min()), _top_noise(imp, i64, 100)
+    assert gap >= 1e-4 and gap >= MIN_MARGIN * noise, (gap, noise)
+    np.savez_compressed(os.path.join(OUT, "ppn_sep.npz"), weight_seed=WEIGHT_SEED,
+                        weight_crc=seeded.checksum(sd), query_feat=_np(q),
+                        importance_raw=_np(raw), importance=_np(imp), topk_idx=_np(idx),
+                        sub_pos=_np(sub), obj_pos=_np(obj), min_gap=gap, fp64_noise=noise, **ops)
+
+
 RES_NAMES = ("bboxes", "labels", "rel_pairs", "masks", "pan_img", "r_scores", "r_labels",
              "r_dists")
 
@@ -332,6 +553,12 @@ def main():
             gen_e2e_small(head, sd)
         if want("e2e_full"):
             gen_e2e_full(head, sd)
+    if want("ppn_sep"):
+        gen_ppn_sep()
+    if want("e2e_small_sep"):
+        gen_e2e_sep("e2e_small_sep", 96, 128, 2, 53, 2.0)
+    if want("e2e_full_sep"):
+        gen_e2e_sep("e2e_full_sep", 800, 1333, 1, 63, 2.083)
     if want("baseline_small"):
         gen_baseline_small()
     if want("psgtr2_small"):

@@ -652,8 +652,13 @@ class CrossHead2:
                 self._head_embed(pl.q, pl, False, exact, normed=True)
 
     def _relation_stage(self, pl):
+        self._pair_proposal(pl)
+        self._relation_decoder(pl)
+
+    def _pair_proposal(self, pl):
+        """Pair Proposal Network (pairnet_head.py:322-351): pl.q -> pl.imp_raw, pl.imp,
+        pl.topk_idx / sub_pos / obj_pos and the gathered pair features pl.pair."""
         w, B, Q, R = self.w, pl.B, self.num_obj_query, self.num_rel_query
-        # ---- Pair Proposal Network (pairnet_head.py:322-340) ----
         for mlp, dst in (("sub_query_update", pl.sn), ("obj_query_update", pl.on)):
             hip.linear(pl.q, w[mlp + ".0.weight"], w[mlp + ".0.bias"], pl.s1, relu=True)
             hip.linear(pl.s1, w[mlp + ".2.weight"], w[mlp + ".2.bias"], pl.s2, relu=True)
@@ -667,10 +672,15 @@ class CrossHead2:
                         7, 7, 3, True)
         hip.mlearner_last(pl.c2, w[ml + "2.0.weight"], w[ml + "2.0.bias"], pl.imp, B, Q)
         hip.topk_pairs(pl.imp, pl.topk_idx, pl.sub_pos, pl.obj_pos, B, Q, R)
-        # ---- pair features + Relation Fusion decoder (:342-378) ----
+        # ---- pair features (:342-351) ----
         pl.pair_idx[:, :R].copy_(pl.sub_pos)
         pl.pair_idx[:, R:].copy_(pl.obj_pos)
         hip.gather_rows(pl.q, pl.pair_idx, pl.pair, B, Q, 2 * R, 256)
+
+    def _relation_decoder(self, pl):
+        """Relation Fusion decoder (pairnet_head.py:353-378) over pl.pair ([B][sub R | obj R]
+        rows) -> pl.rel, then the output gathers (:380-403)."""
+        w, B, Q, R = self.w, pl.B, self.num_obj_query, self.num_rel_query
         pl.r.view(B, R, 256).copy_(w["rel_query_feat.weight"].unsqueeze(0).expand(B, R, 256))
         rpos, ppos = w["rel_query_embed.weight"], w["rel_query_embed2.weight"]
         for i in range(self.num_rel_layers):

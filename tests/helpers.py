@@ -23,13 +23,13 @@ def head_cfg():
 
 
 def oracle_head(weight_seed, overrides=None):
-    """Oracle head with seeded weights (+ fixture overrides); returns (head, state_dict)."""
+    """Oracle head with seeded weights (+ fixture ops); returns (head, state_dict, crc of
+    the seeded weights before the ops)."""
     head = OracleCrossHead2(**head_cfg()).eval()
     shapes = OrderedDict((k, tuple(v.shape)) for k, v in head.state_dict().items())
     sd = seeded.seeded_state_dict(shapes, weight_seed)
     crc = seeded.checksum(sd)
-    for k, v in (overrides or {}).items():
-        sd[k] = torch.as_tensor(v).clone()
+    seeded.apply_ops(sd, overrides or {})
     head.load_state_dict(sd, strict=True)
     return head, sd, crc
 
@@ -48,8 +48,7 @@ def oracle_baseline_head(weight_seed, overrides=None):
     shapes = OrderedDict((k, tuple(v.shape)) for k, v in head.state_dict().items())
     sd = seeded.seeded_state_dict(shapes, weight_seed)
     crc = seeded.checksum(sd)
-    for k, v in (overrides or {}).items():
-        sd[k] = torch.as_tensor(v).clone()
+    seeded.apply_ops(sd, overrides or {})
     head.load_state_dict(sd, strict=True)
     return head, sd, crc
 
@@ -68,14 +67,14 @@ def oracle_psgtr2_head(weight_seed, overrides=None):
     shapes = OrderedDict((k, tuple(v.shape)) for k, v in head.state_dict().items())
     sd = seeded.seeded_state_dict(shapes, weight_seed)
     crc = seeded.checksum(sd)
-    for k, v in (overrides or {}).items():
-        sd[k] = torch.as_tensor(v).clone()
+    seeded.apply_ops(sd, overrides or {})
     head.load_state_dict(sd, strict=True)
     return head, sd, crc
 
 
 def overrides_of(fx):
-    return {k[len("override_"):]: fx[k] for k in fx.files if k.startswith("override_")}
+    """The weight edits a fixture stores on top of its seed (oracle/seeded.py "ops")."""
+    return seeded.ops_of(fx)
 
 
 def tie_aware_topk_match(ref_scores, ref_idx, got_idx, tol):

@@ -1,11 +1,15 @@
 """GPU: the whole hot path (CrossHead2.forward / get_bboxes through the C ABI) against
 the golden vectors recorded from the reference and against the CPU oracle.
 
-Tolerances (BASELINE.json north_star): relation logits within 1e-3 (fp32); top-k
-pair indices bit-exact -- proven at kernel level on the reference's own importance
-tensor (test_kernels_gpu.py), and end to end up to near-ties of the reference scores
-(consecutive reference scores closer than TIE_TOL may legitimately swap under a
-different fp32 summation order; the fixtures' min_gap is ~1e-7)."""
+Tolerances (BASELINE.json north_star): relation logits within 1e-3 (fp32); top-k pair
+indices bit-exact.  Strict index equality is asserted end to end on the SEPARATED
+fixtures (e2e_small_sep at 96x128, e2e_full_sep at 800x1333, ppn_sep): seeded weights plus
+stored edits that spread the reference's top scores far wider than fp32 rounding can move
+them (oracle/make_golden.py `separate`; the generator asserts min_gap >= 1e-4 and >= 10 x
+the reference's own fp32-vs-fp64 score difference).  On the older purely-random-weight
+fixtures, whose smallest top-k gap (3e-8 ... 2e-7) is BELOW the reference's own
+fp32-vs-fp64 difference, the list is compared tie-aware with TIE_TOL = 10 x the measured
+score error and a floor on the number of identical positions."""
 import numpy as np
 import pytest
 import torch
@@ -15,7 +19,8 @@ from oracle import seeded
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TIE_TOL = 2e-5
+TIE_TOL_SMALL, TIE_TOL_FULL = 3e-6, 1.5e-5   # 10 x the GPU-vs-reference score error measured
+                                              # on these fixtures (2.7e-7 / 1.5e-6)
 
 
 def _hip_head(sd):
@@ -65,9 +70,9 @@ def test_e2e_small_against_reference_golden():
     pl = head._last_plan
     for b in range(bs):
         ok, exact = tie_aware_topk_match(fx["cls_importance"][b], fx["topk_idx"][b],
-                                         pl.topk_idx[b].cpu().numpy(), TIE_TOL)
+                                         pl.topk_idx[b].cpu().numpy(), TIE_TOL_SMALL)
         print("image %d: %d/100 top-k positions identical" % (b, exact))
-        assert ok
+        assert ok and exact >= 98
     # gathered outputs are consistent with the GPU's own indices
     sub = pl.sub_pos.cpu()
     assert torch.equal(cls["sub"].cpu(),
@@ -120,18 +125,122 @@ def test_e2e_full_800x1333_against_reference_golden(gemm_mode, conv_algo):
     assert e_rel < 1e-3 and e_cls < 1e-3 and e_imp < 1e-3
     assert e_mask < 1e-3 * max(1.0, float(np.abs(fx["mask_probe"]).max()))
     ok, exact = tie_aware_topk_match(fx["importance"][0], fx["topk_idx"][0],
-                                     head._last_plan.topk_idx[0].cpu().numpy(), TIE_TOL)
+                                     head._last_plan.topk_idx[0].cpu().numpy(), TIE_TOL_FULL)
     print("%d/100 top-k positions identical" % exact)
-    assert ok
+    # (the reference's own fp64 evaluation agrees with its fp32 list in no more positions:
+    # a few attention-mask bits flip per 800x1333 forward)
+    assert ok and exact >= 85
     # size-independent properties at the full size
+    first_rel, first_idx = cls["rel"].clone(), head._last_plan.topk_idx.clone()
     again_cls, again_masks = head.forward([f.to(DEV) for f in feats], metas)
-    assert torch.equal(again_cls["rel"], cls["rel"])          # deterministic (views of the
-    neg = float((masks["mask"] < 0).float().mean())          # same buffers: compare values)
+    assert torch.equal(again_cls["rel"], first_rel)           # deterministic run to run
+    assert torch.equal(head._last_plan.topk_idx, first_idx)
+    neg = float((masks["mask"] < 0).float().mean())
     assert abs(neg - float(fx["mask_neg_frac"])) < 1e-3
     res = head.get_bboxes(again_cls, again_masks, metas)
     assert res[0][3].shape == (200, round(H / 2.083), round(W / 2.083))
     assert res[0][7].shape == (100, 57)
     assert float((res[0][7].sum(-1) - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["e2e_small_sep", "e2e_full_sep"])
+def test_e2e_topk_pair_indices_bit_exact_on_separated_fixtures(name):
+    """north_star: "top-k pair indices bit-exact", end to end, at 96x128 (batch 2) and at
+    800x1333: strict equality of topk_idx / sub_pos / obj_pos with the reference's, relation
+    logits compared directly with the reference's (no re-evaluation), get_bboxes labels
+    exact."""
+    fx = golden(name)
+    _, sd, _ = oracle_head(int(fx["weight_seed"]), overrides_of(fx))
+    assert seeded.checksum(sd) == int(fx["weight_crc"])
+    H, W, bs, sf = int(fx["height"]), int(fx["width"]), int(fx["batch"]), float(fx["img_scale"])
+    feats = seeded.seeded_feats(int(fx["feat_seed"]), bs, H, W)
+    assert seeded.checksum(feats) == int(fx["feat_crc"])
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[sf] * 4)] * bs
+    assert float(fx["min_gap"]) >= 1e-4 and float(fx["min_gap"]) >= 10 * float(fx["fp64_noise"])
+    head = _hip_head(sd)
+    cls, masks = head.forward([f.to(DEV) for f in feats], metas)
+    torch.cuda.synchronize()
+    pl = head._last_plan
+    imp = cls["importance"].cpu().numpy().reshape(bs, -1)
+    ref = fx["importance"].reshape(bs, -1)
+    top = np.argsort(-ref, axis=1)[:, :200]
+    e_top = float(np.abs(np.take_along_axis(imp - ref, top, 1)).max())
+    print("%s: min gap %.3e, GPU score error on the top pairs %.3e (margin %.0f; the "
+          "reference's fp32-vs-fp64 error is %.3e)" % (name, float(fx["min_gap"]), e_top,
+                                                       float(fx["min_gap"]) / max(e_top, 1e-12),
+                                                       float(fx["fp64_noise"])))
+    assert np.array_equal(pl.topk_idx.cpu().numpy(), fx["topk_idx"])
+    assert np.array_equal(pl.sub_pos.cpu().numpy(), fx["sub_pos"])
+    assert np.array_equal(pl.obj_pos.cpu().numpy(), fx["obj_pos"])
+    assert e_top < float(fx["min_gap"]) / 4
+    errs = {k: _err(cls[k], fx[k]) for k in ("rel", "cls", "sub", "obj")}
+    errs["importance"] = float(np.abs(imp - ref).max()) / max(1.0, float(np.abs(ref).max()))
+    probe = masks["mask"].flatten()[torch.from_numpy(fx["mask_probe_idx"]).to(DEV)]
+    errs["mask"] = _err(probe, fx["mask_probe"]) / max(1.0, float(np.abs(fx["mask_probe"]).max()))
+    print(name, "errors:", errs)
+    assert all(e < 1e-3 for e in errs.values()), errs
+    res = head.get_bboxes(cls, masks, metas)
+    for i, r in enumerate(res):
+        assert np.array_equal(r[1].cpu().numpy(), fx["res%d_labels" % i])
+        assert _err(r[7], fx["res%d_r_dists" % i]) < 1e-3
+        shape = tuple(fx["res%d_masks_shape" % i])
+        ref_masks = np.unpackbits(fx["res%d_masks" % i])[:int(np.prod(shape))].reshape(shape)
+        got = r[3].cpu().numpy()[fx["res%d_masks_rows" % i]]
+        assert got.shape == shape and r[3].shape[0] == 200
+        assert (got != ref_masks.astype(bool)).mean() < 1e-3
+        assert (r[4].cpu().numpy() != fx["res%d_pan_img" % i]).mean() < 5e-3
+
+
+@pytest.mark.parametrize("name", ["ppn", "ppn_sep"])
+def test_pair_proposal_chain_on_golden_query_features(name):
+    """G1 through the HIP path: the reference's last-layer query features -> sub / obj
+    MLPs, L2 normalisation, Q x Q cosine matrix, Matrix Learner, top-k (pairnet_head.py:
+    322-340) against the reference's recorded importance_raw / importance / indices."""
+    fx = golden(name)
+    _, sd, _ = oracle_head(int(fx["weight_seed"]), overrides_of(fx))
+    head = _hip_head(sd)
+    q = torch.from_numpy(fx["query_feat"])                     # (Q, B, 256) seq-first
+    B = q.shape[1]
+    pl = head._plan(B, [(3, 4), (6, 8), (12, 16)], (24, 32))
+    pl.q.copy_(q.transpose(0, 1).reshape(-1, 256).to(DEV))
+    head._pair_proposal(pl)
+    torch.cuda.synchronize()
+    e_raw = _err(pl.imp_raw, fx["importance_raw"])
+    scale = max(1.0, float(np.abs(fx["importance"]).max()))
+    e_imp = _err(pl.imp, fx["importance"]) / scale
+    gap = float(np.min(fx["min_gap"]))
+    print("%s: importance_raw err %.2e, importance err %.2e (relative to %.2f), min gap %.2e"
+          % (name, e_raw, e_imp, scale, gap))
+    assert e_raw < 1e-5 and e_imp < 1e-5
+    assert np.array_equal(pl.topk_idx.cpu().numpy(), fx["topk_idx"].reshape(B, -1))
+    assert np.array_equal(pl.sub_pos.cpu().numpy(), fx["sub_pos"].reshape(B, -1))
+    assert np.array_equal(pl.obj_pos.cpu().numpy(), fx["obj_pos"].reshape(B, -1))
+    # the gathered pair features are exactly the selected query rows
+    pair = pl.pair.view(B, 200, 256).cpu()
+    want = torch.stack([q[:, b][torch.from_numpy(np.concatenate(
+        [fx["sub_pos"].reshape(B, -1)[b], fx["obj_pos"].reshape(B, -1)[b]]))] for b in range(B)])
+    assert torch.equal(pair, want)
+
+
+def test_relation_decoder_on_golden_pair_features():
+    """G3 through the HIP path: pair features -> six Relation Fusion layers -> relation
+    logits (pairnet_head.py:353-378) against the reference's recorded rel_preds."""
+    fx = golden("reldec")
+    _, sd, _ = oracle_head(int(fx["weight_seed"]))
+    head = _hip_head(sd)
+    pair = torch.from_numpy(fx["pair_feat"])                   # (2R, B, 256) seq-first
+    B = pair.shape[1]
+    pl = head._plan(B, [(3, 4), (6, 8), (12, 16)], (24, 32))
+    pl.pair.copy_(pair.transpose(0, 1).reshape(-1, 256).to(DEV))
+    for t in (pl.cls, pl.MP):
+        t.zero_()
+    pl.sub_pos.zero_()
+    pl.obj_pos.zero_()
+    head._relation_decoder(pl)
+    torch.cuda.synchronize()
+    e = _err(pl.rel, fx["rel_preds"])
+    print("reldec: rel_preds err %.2e" % e)
+    assert e < 1e-4
 
 
 @pytest.mark.parametrize("exact_mask_order,gemm_mode", [(False, "f32"), (True, "f32"),

@@ -91,6 +91,79 @@ def test_e2e_small_matches_golden():
             assert np.array_equal(got, ref), (i, name)
 
 
+def _gaps(imp, k=100):
+    v = np.sort(imp.reshape(imp.shape[0], -1), axis=1)[:, ::-1][:, :k + 1]
+    return float((v[:, :-1] - v[:, 1:]).min())
+
+
+def test_separated_fixtures_are_tie_free_and_match_the_oracle():
+    """The fixtures strict top-k parity is asserted on (tests/test_head_gpu.py): the
+    oracle reproduces the recorded reference outputs bit for bit, every gap among the
+    top k+1 scores is >= 1e-4 and >= 10 x what fp32-vs-fp64 arithmetic moves a score by
+    (both recorded by oracle/make_golden.py from the reference run)."""
+    fx = golden("ppn_sep")
+    head, sd, _ = oracle_head(int(fx["weight_seed"]), overrides_of(fx))
+    assert seeded.checksum(sd) == int(fx["weight_crc"])
+    q = torch.from_numpy(fx["query_feat"])
+    with torch.no_grad():
+        s = F.normalize(head.sub_query_update(q).transpose(0, 1), p=2, dim=-1, eps=1e-12)
+        o = F.normalize(head.obj_query_update(q).transpose(0, 1), p=2, dim=-1, eps=1e-12)
+        raw = torch.matmul(s, o.transpose(1, 2))
+        imp = head.update_importance(raw)
+        idx = torch.topk(imp.flatten(-2, -1), k=100)[1]
+    assert np.array_equal(raw.numpy(), fx["importance_raw"])
+    assert np.array_equal(imp.numpy(), fx["importance"])
+    assert np.array_equal(idx.numpy(), fx["topk_idx"])
+    assert abs(_gaps(fx["importance"]) - float(fx["min_gap"])) < 1e-9
+    assert float(fx["min_gap"]) >= 1e-4 and float(fx["min_gap"]) >= 10 * float(fx["fp64_noise"])
+    fx = golden("e2e_small_sep")
+    head, sd, _ = oracle_head(int(fx["weight_seed"]), overrides_of(fx))
+    assert seeded.checksum(sd) == int(fx["weight_crc"])
+    H, W, bs, sf = int(fx["height"]), int(fx["width"]), int(fx["batch"]), float(fx["img_scale"])
+    feats = seeded.seeded_feats(int(fx["feat_seed"]), bs, H, W)
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[sf] * 4)] * bs
+    trace = {}
+    cls, masks = head.forward(feats, metas, trace=trace)
+    for k in ("rel", "cls", "importance", "sub", "obj"):
+        assert np.array_equal(cls[k].numpy(), fx[k]), k
+    for k in ("topk_idx", "sub_pos", "obj_pos"):
+        assert np.array_equal(trace[k].numpy(), fx[k]), k
+    assert abs(_gaps(fx["importance"]) - float(fx["min_gap"])) < 1e-9
+    assert float(fx["min_gap"]) >= 1e-4 and float(fx["min_gap"]) >= 10 * float(fx["fp64_noise"])
+    # the fp64 evaluation of the same head selects the same list (what "stable" means)
+    c64, _ = head.double().forward([f.double() for f in feats], metas, trace=trace)
+    assert np.array_equal(trace["topk_idx"].numpy(), fx["topk_idx"])
+    res = head.float().get_bboxes(cls, masks, metas)
+    for i, r in enumerate(res):
+        assert np.array_equal(r[1].numpy(), fx["res%d_labels" % i])
+        assert np.array_equal(r[4].numpy(), fx["res%d_pan_img" % i])
+    fx = golden("e2e_full_sep")          # (the 800x1333 run itself is a GPU-side test)
+    assert abs(_gaps(fx["importance"]) - float(fx["min_gap"])) < 1e-9
+    assert float(fx["min_gap"]) >= 1e-4 and float(fx["min_gap"]) >= 10 * float(fx["fp64_noise"])
+    assert np.array_equal(np.argsort(-fx["importance"].reshape(1, -1), axis=1)[:, :100],
+                          fx["topk_idx"])
+
+
+def test_fixture_ops_apply_in_their_documented_order():
+    shapes = {"a.weight": (4, 3), "update_importance.conv_layers.0.0.weight": (2, 1, 7, 7),
+              "update_importance.conv_layers.1.0.weight": (2, 2, 7, 7),
+              "update_importance.conv_layers.2.0.weight": (1, 2, 7, 7)}
+    base = seeded.seeded_state_dict(shapes, 5)
+    ops = {"scale_a.weight": np.array([2.0, 0, 2]), "keeprows_a.weight": np.array(3),
+           "reseed_a.weight": np.array(9), "mlearner_skip": np.array(1.0),
+           "scale_update_importance.conv_layers.2.0.weight": np.array([4.0, 0, 1]),
+           "img_scale": np.array(2.0)}                    # (not an op: ignored)
+    sd = seeded.apply_ops(dict(base), seeded.ops_of(ops))
+    fresh = seeded.seeded_param("a.weight", (4, 3), np.random.default_rng(9))
+    want = fresh.clone()
+    want[3:] = 0
+    want[:2] *= 2
+    assert torch.equal(sd["a.weight"], want)
+    w2, b2 = sd["update_importance.conv_layers.2.0.weight"], base["update_importance.conv_layers.2.0.weight"]
+    assert float(w2[0, 0, 3, 3]) == float((b2[0, 0, 3, 3] + 1) * 4)   # skip first, then the gain
+    assert torch.equal(base["a.weight"], seeded.seeded_state_dict(shapes, 5)["a.weight"])
+
+
 @pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
 def test_oracle_equals_shimmed_reference():
     """Same weights, same inputs: the restatement and the reference's own class agree

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 8
+#define PN_ABI_VERSION 9
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -317,9 +317,11 @@ int pn_gather_rows_f32(const float* in, const int64_t* index, float* out, int B,
  * Post-processing (pairnet_head.py:788-924)
  * ------------------------------------------------------------------------- */
 /* softmax over C logits, drop the last (background) column, max/argmax
- * (:811-815, :823-825).  label = argmax (0-based), score = max prob. */
+ * (:811-815, :823-825).  label = argmax + label_offset (the triplet labels are
+ * 1-based, `+ 1` at :812 / :815; the panoptic branch :823-825 is 0-based),
+ * score = max prob. */
 int pn_cls_argmax_f32(const float* logits, int64_t* label, float* score,
-                      int64_t rows, int C, void* stream);
+                      int64_t rows, int C, int label_offset, void* stream);
 /* r_dists[r][0] = 0, r_dists[r][1:] = softmax(logits[r][:])  (:817-820) */
 int pn_rel_dists_f32(const float* logits, float* out, int64_t rows, int C,
                      void* stream);
@@ -346,20 +348,30 @@ int pn_panoptic_f32(const float* masks, const int64_t* labels,
 /* The whole panoptic branch of _get_bboxes_single (:845-905) with no host round trip:
  * keep = (label != num_classes-1) & (score > 0.5) in query order, duplicate stuff
  * classes (label >= 80) merged into their first occurrence, kept masks resized to
- * (ho, wo), per-pixel argmax -> seg = id*1000 + label, then `passes` rounds of "drop
- * segments with area <= 4 and redo the argmax" (a round whose predecessor dropped
- * nothing returns immediately; the reference loops until nothing is dropped, which in
- * practice takes <= 2 rounds).  No kept query -> seg = 1 everywhere (:850).
+ * (ho, wo), per-pixel argmax -> seg = id*1000 + label, then up to `rounds` rounds of
+ * "drop segments with area <= 4 and redo the argmax" (the `while True` of :893-905; a
+ * round after convergence returns at once).  The reference loops until nothing is
+ * dropped: if the enqueued rounds were not enough, state.active is still 1 and
+ * pn_panoptic_continue_f32 runs further rounds on the same buffers; state.all_gone
+ * means every segment was filtered (the reference raises IndexError there, :882).
+ * No kept query -> seg = 1 everywhere (:850).
  *   masks [Q][hi][wi] mask logits; labels/scores from pn_cls_argmax_f32 over all_cls
- *   state: pn_panoptic_state_bytes() bytes, readable afterwards: int32 nkeep,
- *          changed[8], all_gone (every segment dropped: the reference raises),
- *          overflow (still dropping after the last round)
- *   up_scratch Q*ho*wo floats; area_scratch 256*passes int32; seg [ho*wo] int64 */
+ *   state: pn_panoptic_state_bytes() bytes; its first int32 words, readable after the
+ *          stream has drained: nkeep, active, rounds (that dropped something), all_gone
+ *   up_scratch Q*ho*wo floats; area_scratch 256 int32; seg [ho*wo] int64 */
 int64_t pn_panoptic_state_bytes(void);
 int pn_panoptic_device_f32(const float* masks, const int64_t* labels, const float* scores,
                            int Q, int num_classes, int hi, int wi, int ho, int wo,
                            void* state, float* up_scratch, int32_t* area_scratch,
-                           int64_t* seg, int passes, void* stream);
+                           int64_t* seg, int rounds, void* stream);
+int pn_panoptic_continue_f32(void* state, const float* up_scratch, int32_t* area_scratch,
+                             int64_t* seg, int ho, int wo, int rounds, void* stream);
+
+/* One fixed-shape fp32 record per image for the all-gather of predicted triplets that
+ * replaces mmdet's pickled collect_results_gpu (tools/test.py:256-267):
+ * rec = [labels 2R | rel_dists R*C1 | sub_pos R | obj_pos R], 4R + R*C1 floats. */
+int pn_pack_triplets_f32(const int64_t* labels, const float* r_dists, const int64_t* sub_pos,
+                         const int64_t* obj_pos, float* rec, int R, int C1, void* stream);
 
 /* Evaluator feed (pairnet/evaluation/sgg_metrics.py:1276-1380, mask_iou :1374-1380):
  * masks as bit rows (bit i of word w = pixel 64w+i) and the exact integer counts

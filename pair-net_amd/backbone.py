@@ -73,6 +73,8 @@ class ResNet50Hip:
                 fan_in = v.shape[1] * v.shape[2] * v.shape[3]
                 v.copy_(torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5)
         self.device, self.w, self._plans = None, None, {}
+        # replay the forward pass as one hipGraph after an eager warm-up call
+        self.use_graphs = False
 
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._params.items())
@@ -88,7 +90,7 @@ class ResNet50Hip:
                 if tuple(sd[k].shape) != tuple(p.shape):
                     raise RuntimeError("shape mismatch for %s" % k)
                 p.copy_(sd[k].detach().to(p.dtype).cpu())
-        self.w = None
+        self.w, self._plans = None, {}     # plans hold graphs captured on the old weights
         return missing, unexpected
 
     def to(self, device):
@@ -145,6 +147,8 @@ class ResNet50Hip:
         E = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
         pl = ResNet50Hip._Plan()
         pl.B = B
+        pl.graph = pl.static_img = pl.outs = None
+        pl.calls, pl.staged = 0, False
         h1, w1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         h, wd = (h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1
         pl.stem, pl.hw_stem = E(B, h1, w1, 64), (h1, w1)
@@ -179,6 +183,36 @@ class ResNet50Hip:
         img = img.contiguous()
         B, _, H, W = img.shape
         pl = self._plan(B, H, W)
+        if not self.use_graphs:
+            return self._run(img, pl)
+        # hipGraph replay of the ~55 launches: captured on the caller's image buffer when it
+        # comes back with the same one (a resident input, a preprocessing stage writing
+        # into a fixed buffer), otherwise on a private copy that each call is staged into
+        if pl.graph is None:
+            if pl.calls == 0:
+                pl.calls = 1
+                return self._run(img, pl)          # eager warm-up
+            pl.static_img, pl.staged = img, False
+            pl.graph, pl.outs = self._capture(lambda: self._run(pl.static_img, pl))
+        if not pl.staged and img.data_ptr() != pl.static_img.data_ptr():
+            pl.static_img, pl.staged = torch.empty_like(img), True
+            pl.graph, pl.outs = self._capture(lambda: self._run(pl.static_img, pl))
+        if pl.staged:
+            pl.static_img.copy_(img)
+        pl.graph.replay()
+        return pl.outs
+
+    @staticmethod
+    def _capture(fn):
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        box = {}
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            box["out"] = fn()
+        return g, box["out"]
+
+    def _run(self, img, pl):
+        B, _, H, W = img.shape
         w = self.w
         hip.stem7x7s2(img, w["stem.w"], w["stem.b"], pl.stem, B, H, W)
         hip.maxpool3x3s2(pl.stem, pl.pool, B, pl.hw_stem[0], pl.hw_stem[1], 64)

@@ -136,11 +136,14 @@ class CrossHeadBaseline(CrossHead2):
     @torch.no_grad()
     def get_bboxes(self, cls_scores, mask_preds, img_metas, rescale=False):
         """baseline.py:967-998."""
-        return [self._get_bboxes_single(
+        self._pan_jobs = []
+        res = CrossHead2.ResultList(self._get_bboxes_single(
             mask_preds["mask"][-1, i], cls_scores["cls"][-1, i], cls_scores["sub"][i],
             cls_scores["obj"][i], cls_scores["rel"][i], mask_preds["sub_seg"][i],
             mask_preds["obj_seg"][i], img_metas[i]["img_shape"],
-            img_metas[i]["scale_factor"], rescale) for i in range(len(img_metas))]
+            img_metas[i]["scale_factor"], rescale) for i in range(len(img_metas)))
+        res.panoptic_jobs = tuple(self._pan_jobs)
+        return res
 
     def _get_bboxes_single(self, all_masks, all_cls, s_cls, o_cls, r_cls, s_seg, o_seg,
                            img_shape, scale_factor, rescale=False):
@@ -179,11 +182,11 @@ class CrossHeadBaseline(CrossHead2):
         hip.cls_argmax(all_cls.contiguous(), all_labels, all_scores, Q, nc)
         state = torch.empty(hip.panoptic_state_bytes(), device=dev, dtype=torch.uint8)
         up = f32(Q, H0 * W0)
-        area = torch.empty(256 * hip.PAN_PASSES, device=dev, dtype=torch.int32)
+        area = torch.empty(256, device=dev, dtype=torch.int32)
         pan = i64(H0 * W0)
         hip.panoptic_device(all_masks.contiguous(), all_labels, all_scores, Q, nc - 1, h, wd, H0,
                             W0, state, up, area, pan)
-        self.last_panoptic_state = state
+        self._pan_jobs.append((state, up, area, pan, H0, W0))
         # the reference fills det_bboxes with torch.rand as "dummy bboxes for eval" (:1134)
         det_bboxes = torch.zeros((2 * k, 5), device=dev)
         rel_pairs = torch.arange(2 * k, dtype=torch.int).reshape(2, -1).T

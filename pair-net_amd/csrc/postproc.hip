@@ -7,7 +7,7 @@
 __global__ __launch_bounds__(256) void k_cls_argmax(const float* __restrict__ logits,
                                                     int64_t* __restrict__ label,
                                                     float* __restrict__ score, int64_t rows,
-                                                    int C) {
+                                                    int C, int label_offset) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -44,14 +44,14 @@ __global__ __launch_bounds__(256) void k_cls_argmax(const float* __restrict__ lo
     const int oi = __shfl_xor(bi, o, 64);
     if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
   }
-  if (lane == 0) { label[row] = bi; score[row] = best; }
+  if (lane == 0) { label[row] = bi + label_offset; score[row] = best; }
 }
 
 extern "C" int pn_cls_argmax_f32(const float* logits, int64_t* label, float* score,
-                                 int64_t rows, int C, void* stream) {
+                                 int64_t rows, int C, int label_offset, void* stream) {
   if (!logits || !label || !score || rows <= 0 || C < 2 || C > 256) return PN_BAD_ARG;
   hipLaunchKernelGGL(k_cls_argmax, dim3(pn_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                     logits, label, score, rows, C);
+                     logits, label, score, rows, C, label_offset);
   return PN_LAUNCH_CHECK();
 }
 
@@ -240,15 +240,18 @@ extern "C" int pn_panoptic_f32(const float* masks, const int64_t* labels, const 
 // trips).  The reference filters queries on the host (`keep`), merges duplicate stuff
 // classes, and re-runs the per-pixel argmax while any segment has area <= 4, reading
 // areas back with .item() each time.  Here the keep list, the duplicate map, the alive
-// flags and the compact ranks live in device memory; a FIXED number of argmax/filter
-// passes is enqueued and a pass whose predecessor changed nothing returns at once.
+// flags and the compact ranks live in device memory; a bounded number of argmax/filter
+// rounds is enqueued, a round after convergence returns at once, and `active` tells the
+// caller (at whatever D2H point it already has) whether the loop still has to go on
+// (pn_panoptic_continue_f32).
 // ---------------------------------------------------------------------------------
 struct PanState {      // device-resident, Q <= 256
   int32_t nkeep;       // number of kept queries
-  int32_t changed[8];  // changed[p]: filter pass p removed something
+  int32_t active;      // 1: the last filter round dropped something -> another round is due
+  int32_t rounds;      // filter rounds that dropped something so far
   int32_t all_gone;    // every kept segment was filtered (the reference raises here)
-  int32_t overflow;    // still changing after the last enqueued pass
-  int32_t pad[5];
+  int32_t first;       // 1 until the first argmax round has run (stuff merging applies to it)
+  int32_t pad[11];
   int32_t kept[256];   // kept position -> query index
   int32_t remap[256];  // kept position -> first kept position of the same stuff class
   int32_t alive[256];
@@ -268,9 +271,10 @@ __global__ __launch_bounds__(256) void k_pan_select(const int64_t* __restrict__ 
     int c = 0;
     for (int i = 0; i < 256; ++i) { pos[i] = c; c += flag[i]; }
     st->nkeep = c;
-    for (int p = 0; p < 8; ++p) st->changed[p] = 0;
+    st->active = 1;
+    st->rounds = 0;
     st->all_gone = 0;
-    st->overflow = 0;
+    st->first = 1;
   }
   __syncthreads();
   if (keep) {
@@ -320,11 +324,10 @@ __global__ __launch_bounds__(256) void k_resize_kept(const float* __restrict__ i
 }
 
 __global__ __launch_bounds__(256) void k_pan_argmax(const float* __restrict__ up,
-                                                    PanState* __restrict__ st,
+                                                    const PanState* __restrict__ st,
                                                     int64_t* __restrict__ seg,
-                                                    int32_t* __restrict__ area, int64_t HW,
-                                                    int pass) {
-  if (pass > 0 && st->changed[pass - 1] == 0) return;
+                                                    int32_t* __restrict__ area, int64_t HW) {
+  if (!st->active) return;
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= HW) return;
   const int n = st->nkeep;
@@ -337,58 +340,107 @@ __global__ __launch_bounds__(256) void k_pan_argmax(const float* __restrict__ up
     if (bi < 0 || v > best) { best = v; bi = i; }
   }
   if (bi < 0) return;                   // nothing alive: all_gone is set by the filter
-  if (pass == 0) bi = st->remap[bi];    // merge duplicate stuff classes (:873-878)
+  if (st->first) bi = st->remap[bi];    // merge duplicate stuff classes (:873-878)
   seg[p] = (int64_t)st->rank[bi] * 1000 + st->klab[bi];
-  atomicAdd(&area[pass * 256 + bi], 1);
+  atomicAdd(&area[bi], 1);
 }
 
-__global__ __launch_bounds__(256) void k_pan_filter(PanState* st, const int32_t* __restrict__ area,
-                                                    int pass, int last_pass) {
-  __shared__ int any_small, nalive;
-  if (pass > 0 && st->changed[pass - 1] == 0) return;
+// One workgroup: drop the segments of area <= 4 (:893-905); nothing to drop -> converged.
+// Also clears the area counters for the next round.
+__global__ __launch_bounds__(256) void k_pan_filter(PanState* st, int32_t* __restrict__ area) {
+  __shared__ int any_small;
+  if (!st->active) return;
   const int t = threadIdx.x, n = st->nkeep;
-  if (t == 0) { any_small = 0; nalive = 0; }
+  if (t == 0) any_small = 0;
   __syncthreads();
   bool a = t < n && st->alive[t] != 0;
-  if (a && area[pass * 256 + t] <= 4) { a = false; any_small = 1; }
+  if (a && area[t] <= 4) { a = false; any_small = 1; }
+  area[t] = 0;
   __syncthreads();
-  if (!any_small) return;               // converged: changed[pass] stays 0
+  if (t == 0) st->first = 0;
+  if (!any_small || n == 0) {
+    if (t == 0) st->active = 0;
+    return;
+  }
   if (t < n) st->alive[t] = a ? 1 : 0;
   __syncthreads();
   if (t == 0) {
     int c = 0;
     for (int i = 0; i < n; ++i) { st->rank[i] = c; c += st->alive[i]; }
-    st->changed[pass] = 1;
-    if (c == 0) st->all_gone = 1;
-    if (last_pass) st->overflow = 1;
+    st->rounds += 1;
+    if (c == 0) { st->all_gone = 1; st->active = 0; }
   }
 }
 
 extern "C" int64_t pn_panoptic_state_bytes(void) { return (int64_t)sizeof(PanState); }
 
+static void pan_rounds(PanState* st, const float* up, int32_t* area, int64_t* seg, int64_t HW,
+                       int rounds, hipStream_t s) {
+  for (int p = 0; p < rounds; ++p) {
+    hipLaunchKernelGGL(k_pan_argmax, dim3(pn_cdiv(HW, 256)), dim3(256), 0, s, up, st, seg, area,
+                       HW);
+    hipLaunchKernelGGL(k_pan_filter, dim3(1), dim3(256), 0, s, st, area);
+  }
+}
+
 extern "C" int pn_panoptic_device_f32(const float* masks, const int64_t* labels,
                                       const float* scores, int Q, int num_classes, int hi,
                                       int wi, int ho, int wo, void* state, float* up_scratch,
-                                      int32_t* area_scratch, int64_t* seg, int passes,
+                                      int32_t* area_scratch, int64_t* seg, int rounds,
                                       void* stream) {
   if (!masks || !labels || !scores || !state || !up_scratch || !area_scratch || !seg)
     return PN_BAD_ARG;
-  if (Q <= 0 || Q > 256 || passes < 1 || passes > 8 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0)
+  if (Q <= 0 || Q > 256 || rounds < 1 || rounds > 256 || hi <= 0 || wi <= 0 || ho <= 0 ||
+      wo <= 0)
     return PN_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   PanState* st = (PanState*)state;
   const int64_t HW = (int64_t)ho * wo;
-  (void)hipMemsetAsync(area_scratch, 0, sizeof(int32_t) * 256 * passes, s);
+  (void)hipMemsetAsync(area_scratch, 0, sizeof(int32_t) * 256, s);
   hipLaunchKernelGGL(k_pan_select, dim3(1), dim3(256), 0, s, labels, scores, Q, num_classes - 1,
                      st);
   hipLaunchKernelGGL(k_resize_kept, dim3(pn_cdiv(HW, 256), Q), dim3(256), 0, s, masks, up_scratch,
                      st, hi, wi, ho, wo);
-  for (int p = 0; p < passes; ++p) {
-    hipLaunchKernelGGL(k_pan_argmax, dim3(pn_cdiv(HW, 256)), dim3(256), 0, s, up_scratch, st, seg,
-                       area_scratch, HW, p);
-    hipLaunchKernelGGL(k_pan_filter, dim3(1), dim3(256), 0, s, st, area_scratch, p,
-                       p == passes - 1 ? 1 : 0);
-  }
+  pan_rounds(st, up_scratch, area_scratch, seg, HW, rounds, s);
+  return PN_LAUNCH_CHECK();
+}
+
+extern "C" int pn_panoptic_continue_f32(void* state, const float* up_scratch,
+                                        int32_t* area_scratch, int64_t* seg, int ho, int wo,
+                                        int rounds, void* stream) {
+  if (!state || !up_scratch || !area_scratch || !seg || ho <= 0 || wo <= 0 || rounds < 1 ||
+      rounds > 256)
+    return PN_BAD_ARG;
+  pan_rounds((PanState*)state, up_scratch, area_scratch, seg, (int64_t)ho * wo, rounds,
+             (hipStream_t)stream);
+  return PN_LAUNCH_CHECK();
+}
+
+// One fixed-shape record per image for the all-gather of predicted triplets:
+// [labels 2R | rel_dists R*(C+1) | sub_pos R | obj_pos R] as fp32 (indices < 2^24 are exact).
+__global__ __launch_bounds__(256) void k_pack_triplets(const int64_t* __restrict__ labels,
+                                                       const float* __restrict__ r_dists,
+                                                       const int64_t* __restrict__ sub_pos,
+                                                       const int64_t* __restrict__ obj_pos,
+                                                       float* __restrict__ rec, int R, int C1) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n0 = 2 * R, n1 = n0 + R * C1, n2 = n1 + R, n3 = n2 + R;
+  if (i >= n3) return;
+  float v;
+  if (i < n0) v = (float)labels[i];
+  else if (i < n1) v = r_dists[i - n0];
+  else if (i < n2) v = (float)sub_pos[i - n1];
+  else v = (float)obj_pos[i - n2];
+  rec[i] = v;
+}
+
+extern "C" int pn_pack_triplets_f32(const int64_t* labels, const float* r_dists,
+                                    const int64_t* sub_pos, const int64_t* obj_pos, float* rec,
+                                    int R, int C1, void* stream) {
+  if (!labels || !r_dists || !sub_pos || !obj_pos || !rec || R <= 0 || C1 <= 0) return PN_BAD_ARG;
+  const int n = 4 * R + R * C1;
+  hipLaunchKernelGGL(k_pack_triplets, dim3(pn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     labels, r_dists, sub_pos, obj_pos, rec, R, C1);
   return PN_LAUNCH_CHECK();
 }
 

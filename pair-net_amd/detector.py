@@ -163,6 +163,11 @@ class PSGTr:
         """psgtr.py:148-156."""
         feat = self.extract_feat(img)
         results_list = self.bbox_head.simple_test(feat, img_metas, rescale=rescale)
+        # the D2H point: the device-side panoptic loops are checked / finished here, where
+        # the results are copied to the host anyway (raises like the reference when every
+        # segment was filtered, pairnet_head.py:882)
+        if hasattr(results_list, "panoptic_jobs"):
+            self.bbox_head.panoptic_status(results_list)
         return [triplet2Result(t, self.bbox_head.use_mask) for t in results_list]
 
     def forward(self, img=None, img_metas=None, return_loss=False, rescale=False, **kw):

@@ -63,3 +63,45 @@ def all_gather_triplets(local_records, num_images, group=None):
     # rank r's j-th row is image r + j*W: interleave (zip over ranks) and truncate
     out = recv.view(W, per_rank, L).transpose(0, 1).reshape(W * per_rank, L)
     return out[:num_images].contiguous()
+
+
+class TripletGatherer:
+    """The per-step collective of a data-parallel run with everything preallocated:
+    `pack(i, result, sub_pos, obj_pos)` writes image i's record straight into the send
+    buffer (one small HIP kernel, csrc/postproc.hip k_pack_triplets; no torch.cat), and
+    `gather()` issues ONE all-gather (RCCL over xGMI for backend "nccl") into a
+    preallocated receive buffer and returns the records in dataset order
+    ([world * n_local, L], a view of an internal buffer)."""
+
+    def __init__(self, n_local, num_rel_query, num_relations, device, group=None):
+        from . import hip
+        self.hip, self.group = hip, group
+        self.R, self.C1 = num_rel_query, num_relations + 1
+        self.L = triplet_record_len(num_rel_query, num_relations)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.n_local = n_local
+        self.on_device = torch.device(device).type == "cuda"
+        self.send = torch.zeros((n_local, self.L), device=device, dtype=torch.float32)
+        self.recv = torch.empty((self.world * n_local, self.L), device=device, dtype=torch.float32)
+        self.out = torch.empty_like(self.recv)
+        self.records_gathered = 0
+
+    def pack(self, i, labels, rel_dists, sub_pos, obj_pos):
+        self.hip.pack_triplets(labels, rel_dists, sub_pos, obj_pos, self.send[i], self.R, self.C1)
+
+    def gather(self, host_staging=False):
+        """`host_staging`: run the collective on host copies (backend "gloo": the
+        single-GPU functional check of the multi-rank control flow)."""
+        if self.world == 1:
+            self.records_gathered += self.n_local
+            return self.send
+        send, recv = (self.send.cpu(), self.recv.cpu()) if host_staging else (self.send, self.recv)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        self.records_gathered += self.world * self.n_local
+        if self.n_local == 1:          # one image per rank: rank order IS dataset order
+            return recv
+        # rank r's j-th row is image r + j*W: interleave (zip over ranks)
+        out = self.out.cpu() if host_staging else self.out
+        out.view(self.n_local, self.world, self.L).copy_(
+            recv.view(self.world, self.n_local, self.L).transpose(0, 1))
+        return out

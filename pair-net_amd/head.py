@@ -108,6 +108,8 @@ class CrossHead2:
         self.w = None
         self._plans = {}
         self._dummies = {}
+        self._post = OrderedDict()
+        self._pan_jobs = []
         # True: compute attention masks in the reference's operation order (full-size mask
         # logits -> bilinear resize); False: resample the mask feature once (see _attn_mask)
         self.exact_mask_order = False
@@ -261,6 +263,7 @@ class CrossHead2:
         self.device = torch.device(device)
         self.w = None
         self._plans = {}
+        self._post.clear()
         return self
 
     def cuda(self, index=0):
@@ -341,6 +344,7 @@ class CrossHead2:
         pl = CrossHead2._Plan()
         pl.B, pl.shapes, pl.hw2, pl.nhwc = B, list(shapes), tuple(hw2), nhwc
         pl.graph_a = pl.graph_b = pl.static_feats = pl.graph_cfg = pl.feats_read = None
+        pl.graph_c = {}
         pl.static_ptrs, pl.staged, pl.me0 = None, False, None
         pl.calls_a = pl.calls_b = 0
         pl.N = [h * w for h, w in shapes]
@@ -729,6 +733,7 @@ class CrossHead2:
         cfg = (self.gemm_mode, self.exact_mask_order, self.conv_algo)
         if pl.graph_cfg != cfg:          # a captured graph bakes these switches in
             pl.graph_a = pl.graph_b = pl.me0 = None
+            pl.graph_c = {}
             pl.graph_cfg = cfg
         if which == "a":
             ptrs = tuple(f.data_ptr() for f in feats)
@@ -827,19 +832,64 @@ class CrossHead2:
         return cls, mp.view(B, Q, h, wd), attn.reshape(B * self.n_heads, Q, th * tw)
 
     # ------------------------------------------------------- post-processing
+    class ResultList(list):
+        """The list `get_bboxes` returns, plus the device-side panoptic loop states of its
+        images (`panoptic_status` reads them at the caller's D2H point)."""
+        panoptic_jobs = ()
+
+    def _post_buffers(self, anchor, key, build):
+        """Per-(input buffer, output size) post-processing buffers: `anchor` is the tensor
+        whose storage identifies the caller's buffer (a plan's outputs keep their address,
+        so the hot loop allocates nothing); bounded, oldest entry dropped first."""
+        k = (anchor.data_ptr(), str(anchor.device)) + tuple(key)
+        pb = self._post.get(k)
+        if pb is None:
+            if len(self._post) >= 64:
+                self._post.pop(next(iter(self._post)))
+            pb = self._post[k] = build()
+        return pb
+
     @torch.no_grad()
     def get_bboxes(self, cls_scores, mask_preds, img_metas, rescale=False):
-        """pairnet_head.py:760-786."""
-        return [self._get_bboxes_single(
+        """pairnet_head.py:760-786.  With `use_graphs`, the post-processing of a plan's own
+        outputs is replayed as one hipGraph per (plan, image sizes)."""
+        pl = getattr(self, "_last_plan", None)
+        mine = (pl is not None and self.use_graphs and "cls" in cls_scores
+                and cls_scores["cls"].data_ptr() == pl.cls.data_ptr()
+                and mask_preds["mask"].data_ptr() == pl.MP.data_ptr())
+        if not mine:
+            return self._get_bboxes_all(cls_scores, mask_preds, img_metas, rescale)
+        key = (tuple((tuple(m["img_shape"]), tuple(float(v) for v in m["scale_factor"]))
+                     for m in img_metas), bool(rescale))
+        ent = pl.graph_c.setdefault(key, dict(calls=0, graph=None, res=None))
+        if ent["graph"] is None:
+            if ent["calls"] == 0:          # eager warm-up (allocates the buffers)
+                ent["calls"] = 1
+                return self._get_bboxes_all(cls_scores, mask_preds, img_metas, rescale)
+            box = {}
+            ent["graph"] = self._capture(lambda: box.update(
+                res=self._get_bboxes_all(cls_scores, mask_preds, img_metas, rescale)))
+            ent["res"] = box["res"]
+        ent["graph"].replay()
+        self._pan_jobs = list(ent["res"].panoptic_jobs)
+        return ent["res"]
+
+    def _get_bboxes_all(self, cls_scores, mask_preds, img_metas, rescale):
+        self._pan_jobs = []
+        res = CrossHead2.ResultList(self._get_bboxes_single(
             mask_preds["mask"][i], cls_scores["cls"][i], cls_scores["sub"][i],
             cls_scores["obj"][i], cls_scores["rel"][i], mask_preds["sub_seg"][i],
             mask_preds["obj_seg"][i], img_metas[i]["img_shape"],
-            img_metas[i]["scale_factor"], rescale) for i in range(len(img_metas))]
+            img_metas[i]["scale_factor"], rescale) for i in range(len(img_metas)))
+        res.panoptic_jobs = tuple(self._pan_jobs)
+        return res
 
     def _get_bboxes_single(self, all_masks, all_cls, s_cls, o_cls, r_cls, s_seg, o_seg,
                            img_shape, scale_factor, rescale=False):
         """pairnet_head.py:788-924 on the device, without any host round trip (every
-        launch is asynchronous; `panoptic_status()` reads the flags back on demand)."""
+        launch is asynchronous; `panoptic_status()` reads the loop flags back at the
+        caller's D2H point).  The outputs are views of buffers owned by the head, one set
+        per (input buffer, output size): the next call on the same inputs overwrites them."""
         assert len(s_cls) == len(o_cls) == len(r_cls)
         dev = all_cls.device
         R, Q = self.num_rel_query, all_cls.shape[0]
@@ -847,38 +897,40 @@ class CrossHead2:
         H0 = round(img_shape[0] / scale_factor[1])
         W0 = round(img_shape[1] / scale_factor[0])
         h, wd = all_masks.shape[-2:]
-        i64 = lambda *s: torch.empty(*s, device=dev, dtype=torch.int64)
-        f32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-        # triplet labels and relation distributions (:811-820)
-        so_cls = torch.cat((s_cls, o_cls), 0).contiguous()
-        labels, _ = i64(2 * R), None
-        sc_tmp = f32(2 * R)
-        hip.cls_argmax(so_cls, labels, sc_tmp, 2 * R, nc)
-        labels += 1
-        r_dists = f32(R, self.num_relations + 1)
-        hip.rel_dists(r_cls.contiguous(), r_dists, R, self.num_relations)
+        for t in (all_masks, all_cls, s_cls, o_cls, r_cls, s_seg, o_seg):
+            if not t.is_contiguous():
+                raise RuntimeError("get_bboxes takes contiguous tensors (the head's own outputs)")
+
+        def build():
+            i64 = lambda *s: torch.empty(*s, device=dev, dtype=torch.int64)
+            f32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+            return dict(labels=i64(2 * R), sc_tmp=f32(2 * R), r_dists=f32(R, self.num_relations + 1),
+                        masks=torch.empty(2 * R, H0, W0, device=dev, dtype=torch.uint8),
+                        all_labels=i64(Q), all_scores=f32(Q),
+                        state=torch.empty(hip.panoptic_state_bytes(), device=dev, dtype=torch.uint8),
+                        up=f32(Q, H0 * W0), area=torch.empty(256, device=dev, dtype=torch.int32),
+                        seg=i64(H0 * W0))
+        pb = self._post_buffers(all_cls, (H0, W0, Q, R), build)
+        # triplet labels (1-based) and relation distributions (:811-820)
+        labels = pb["labels"]
+        hip.cls_argmax(s_cls, labels[:R], pb["sc_tmp"][:R], R, nc, 1)
+        hip.cls_argmax(o_cls, labels[R:], pb["sc_tmp"][R:], R, nc, 1)
+        hip.rel_dists(r_cls, pb["r_dists"], R, self.num_relations)
         # subject / object masks at the original image size (:826-843)
-        masks_u8 = torch.empty(2 * R, H0, W0, device=dev, dtype=torch.uint8)
-        hip.bilinear_planar_gt0(s_seg.contiguous(), masks_u8[:R], R, h, wd, H0, W0)
-        hip.bilinear_planar_gt0(o_seg.contiguous(), masks_u8[R:], R, h, wd, H0, W0)
-        masks = masks_u8.view(torch.bool)
-        # panoptic map (:823-825, :845-905), entirely on the device and without a host
-        # round trip: keep list, stuff-class merging, argmax and the "drop segments of
-        # area <= 4 and redo" loop are enqueued as a fixed number of passes
-        # (csrc/postproc.hip).  pan_img stays on the device (the reference returns a
-        # host tensor, :883): a fresh multi-MB host allocation per image is an
-        # mmap/munmap pair, and on ROCm every munmap runs the amdgpu MMU notifier against
-        # the busy GPU (~75 ms stalls measured).
-        all_labels, all_scores = i64(Q), f32(Q)
-        hip.cls_argmax(all_cls.contiguous(), all_labels, all_scores, Q, nc)
-        state = torch.empty(hip.panoptic_state_bytes(), device=dev, dtype=torch.uint8)
-        up = f32(Q, H0 * W0)
-        area = torch.empty(256 * hip.PAN_PASSES, device=dev, dtype=torch.int32)
-        seg = i64(H0 * W0)
-        hip.panoptic_device(all_masks.contiguous(), all_labels, all_scores, Q, nc - 1, h, wd, H0,
-                            W0, state, up, area, seg)
-        pan_img = seg.view(H0, W0)
-        self.last_panoptic_state = state
+        masks_u8 = pb["masks"]
+        hip.bilinear_planar_gt0(s_seg, masks_u8[:R], R, h, wd, H0, W0)
+        hip.bilinear_planar_gt0(o_seg, masks_u8[R:], R, h, wd, H0, W0)
+        # panoptic map (:823-825, :845-905), entirely on the device: keep list, stuff-class
+        # merging, argmax and the "drop segments of area <= 4 and redo" loop are enqueued as
+        # a bounded number of rounds (csrc/postproc.hip); whether the loop has converged is
+        # a flag the caller reads at its D2H point (`panoptic_status`).  pan_img stays on the
+        # device (the reference returns a host tensor, :883): a fresh multi-MB host
+        # allocation per image is an mmap/munmap pair, and on ROCm every munmap runs the
+        # amdgpu MMU notifier against the busy GPU (~75 ms stalls measured).
+        hip.cls_argmax(all_cls, pb["all_labels"], pb["all_scores"], Q, nc)
+        hip.panoptic_device(all_masks, pb["all_labels"], pb["all_scores"], Q, nc - 1, h, wd, H0,
+                            W0, pb["state"], pb["up"], pb["area"], pb["seg"])
+        self._pan_jobs.append((pb["state"], pb["up"], pb["area"], pb["seg"], H0, W0))
         # the reference's dummy outputs (:907-913) are constants: made once per device
         key = (str(dev), R)
         if key not in self._dummies:
@@ -886,20 +938,30 @@ class CrossHead2:
                                   torch.zeros(R, device=dev),
                                   torch.arange(2 * R, dtype=torch.int).reshape(2, -1).T)
         det_bboxes, r_scores, r_labels, rel_pairs = self._dummies[key]
-        return (det_bboxes, labels, rel_pairs, masks, pan_img, r_scores, r_labels, r_dists)
+        return (det_bboxes, labels, rel_pairs, masks_u8.view(torch.bool),
+                pb["seg"].view(H0, W0), r_scores, r_labels, pb["r_dists"])
 
-    def panoptic_status(self):
-        """Host check of the last image's panoptic pass (one small D2H): dict with
-        nkeep and the two flags the sync-free loop cannot raise on its own."""
-        st = self.last_panoptic_state[:44].cpu().view(torch.int32)
-        out = dict(nkeep=int(st[0]), passes_that_dropped=int(st[1:9].sum()),
-                   all_gone=bool(st[9]), overflow=bool(st[10]))
-        if out["all_gone"]:
-            raise IndexError("every panoptic segment was filtered (the reference fails here "
-                             "too, pairnet_head.py:882)")
-        if out["overflow"]:
-            raise RuntimeError("panoptic area filter did not converge in %d passes"
-                               % hip.PAN_PASSES)
+    def panoptic_status(self, results=None):
+        """Finish and check the panoptic loops of `results` (a list `get_bboxes` returned;
+        default: the last one).  The reference loops on the host until no segment of area
+        <= 4 is left (pairnet_head.py:893-905) and fails with an IndexError when every
+        segment is filtered (:882).  The device loop runs hip.PAN_ROUNDS rounds up front;
+        here -- one small D2H per image, at a point where the caller copies results to the
+        host anyway -- unfinished loops are continued to convergence and the IndexError is
+        raised.  Returns one dict(nkeep, rounds) per image."""
+        jobs = self._pan_jobs if results is None else results.panoptic_jobs
+        out = []
+        for state, up, area, seg, H0, W0 in jobs:
+            while True:
+                nkeep, active, rounds, all_gone = state[:16].cpu().view(torch.int32).tolist()
+                if all_gone:
+                    raise IndexError("every panoptic segment was filtered (the reference fails "
+                                     "here too, pairnet_head.py:882)")
+                if not active:
+                    break
+                with torch.cuda.device(state.device):
+                    hip.panoptic_continue(state, up, area, seg, H0, W0)
+            out.append(dict(nkeep=nkeep, rounds=rounds))
         return out
 
     def simple_test_bboxes(self, feats, img_metas, rescale=False):

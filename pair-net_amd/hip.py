@@ -73,7 +73,7 @@ _SIGS = {
     "pn_topk_pairs": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_topk_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_gather_rows_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
-    "pn_cls_argmax_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "pn_cls_argmax_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "pn_rel_dists_f32": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "pn_softmax_fg_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "pn_row_argmax_f32": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
@@ -82,11 +82,13 @@ _SIGS = {
     "pn_panoptic_state_bytes": (_i64, []),
     "pn_panoptic_device_f32": (C.c_int, [_vp, _vp, _vp] + [_i32] * 6 + [_vp, _vp, _vp, _vp,
                                                                         _i32, _vp]),
+    "pn_panoptic_continue_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "pn_pack_triplets_f32": (C.c_int, [_vp] * 5 + [_i32, _i32, _vp]),
     "pn_pack_mask_bits": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "pn_mask_iou_counts": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 8   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 9   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -490,9 +492,9 @@ def gather_rows(x, index, out, B, rows_in, rows_out, length):
                                     rows_out, length, _stream()), "pn_gather_rows_f32")
 
 
-def cls_argmax(logits, label, score, rows, Cc):
+def cls_argmax(logits, label, score, rows, Cc, label_offset=0):
     _check(lib().pn_cls_argmax_f32(_ptr(logits), _ptr(label, torch.int64), _ptr(score), rows,
-                                   Cc, _stream()), "pn_cls_argmax_f32")
+                                   Cc, label_offset, _stream()), "pn_cls_argmax_f32")
 
 
 def rel_dists(logits, out, rows, Cc):
@@ -526,7 +528,11 @@ def panoptic(masks, labels, remap, seg, area, n, HW):
                                  _ptr(area, torch.int32), n, HW, _stream()), "pn_panoptic_f32")
 
 
-PAN_PASSES = 4
+# argmax / area-filter rounds enqueued up front.  The reference's loop can need at most
+# three: the first round merges duplicate stuff classes, the second counts them apart (so
+# a duplicate that only existed inside the merge can fall out), and since dropping
+# segments only ever grows the others nothing can fall out after that.
+PAN_ROUNDS = 4
 
 
 def panoptic_state_bytes():
@@ -534,11 +540,26 @@ def panoptic_state_bytes():
 
 
 def panoptic_device(masks, labels, scores, Q, num_classes, hi, wi, ho, wo, state, up, area, seg,
-                    passes=PAN_PASSES):
+                    rounds=None):
+    rounds = PAN_ROUNDS if rounds is None else rounds
     _check(lib().pn_panoptic_device_f32(
         _ptr(masks), _ptr(labels, torch.int64), _ptr(scores), Q, num_classes, hi, wi, ho, wo,
         _ptr(state, torch.uint8), _ptr(up), _ptr(area, torch.int32), _ptr(seg, torch.int64),
-        passes, _stream()), "pn_panoptic_device_f32")
+        rounds, _stream()), "pn_panoptic_device_f32")
+
+
+def panoptic_continue(state, up, area, seg, ho, wo, rounds=None):
+    rounds = PAN_ROUNDS if rounds is None else rounds
+    _check(lib().pn_panoptic_continue_f32(
+        _ptr(state, torch.uint8), _ptr(up), _ptr(area, torch.int32), _ptr(seg, torch.int64),
+        ho, wo, rounds, _stream()), "pn_panoptic_continue_f32")
+
+
+def pack_triplets(labels, r_dists, sub_pos, obj_pos, rec, R, C1):
+    i64 = torch.int64
+    _check(lib().pn_pack_triplets_f32(_ptr(labels, i64), _ptr(r_dists), _ptr(sub_pos, i64),
+                                      _ptr(obj_pos, i64), _ptr(rec), R, C1, _stream()),
+           "pn_pack_triplets_f32")
 
 
 def pack_mask_bits(masks_u8, words, rows, HW):

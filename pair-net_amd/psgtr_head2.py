@@ -110,6 +110,7 @@ class PSGTrHead2(CrossHead2):
     @torch.no_grad()
     def get_bboxes(self, cls_scores, mask_preds, img_metas, rescale=False):
         """psgtr_head2.py:1063-1085 (per image; see the module docstring)."""
+        self._pan_jobs = []          # (pan_img is the constant map of :1129: no device loop)
         return [self._get_bboxes_single(
             cls_scores["sub"][0, i], cls_scores["obj"][0, i], cls_scores["rel"][0, i],
             mask_preds["sub_seg"][0, i], mask_preds["obj_seg"][0, i],
@@ -127,9 +128,8 @@ class PSGTrHead2(CrossHead2):
         h, wd = s_seg.shape[-2:]
         labels = torch.empty(2 * Q, device=dev, dtype=torch.int64)
         sc_tmp = torch.empty(2 * Q, device=dev, dtype=torch.float32)
-        hip.cls_argmax(s_cls.contiguous(), labels[:Q], sc_tmp[:Q], Q, nc)
-        hip.cls_argmax(o_cls.contiguous(), labels[Q:], sc_tmp[Q:], Q, nc)
-        labels += 1
+        hip.cls_argmax(s_cls.contiguous(), labels[:Q], sc_tmp[:Q], Q, nc, 1)
+        hip.cls_argmax(o_cls.contiguous(), labels[Q:], sc_tmp[Q:], Q, nc, 1)
         r_dists = torch.empty(Q, nrel1, device=dev, dtype=torch.float32)
         fg = torch.empty(Q * (nrel1 - 1), device=dev, dtype=torch.float32)
         hip.softmax_fg(r_cls.contiguous(), r_dists, fg, Q, nrel1)

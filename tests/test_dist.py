@@ -9,8 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pairnet_amd.dist import (all_gather_triplets, pack_triplets, shard_indices,
-                              triplet_record_len, unpack_triplets)
+from pairnet_amd.dist import (TripletGatherer, all_gather_triplets, pack_triplets,
+                              shard_indices, triplet_record_len, unpack_triplets)
 
 
 def _record(i, R=100, C=56):
@@ -74,23 +74,77 @@ def test_all_gather_triplets_world2_gloo():
         assert torch.equal(outs[r], expect)
 
 
+def _gatherer_worker(rank, world, port, n_local, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gt = TripletGatherer(n_local, 100, 56, "cpu")
+    outs = []
+    for step in range(2):                      # the same buffers serve every step
+        for j in range(n_local):               # rank r holds images r, r + W, ...
+            gt.send[j].copy_(_record(100 * step + rank + j * world))
+        outs.append(gt.gather().clone())
+    q.put((rank, [o.numpy() for o in outs], gt.records_gathered))   # (by value)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_local", [1, 2])
+def test_preallocated_triplet_gatherer_world2_gloo(n_local):
+    """The bench's per-step collective: one all-gather into preallocated buffers, records
+    back in dataset order on every rank (rank r's j-th image is r + j*W)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, port = 2, _free_port()
+    procs = [ctx.Process(target=_gatherer_worker, args=(r, world, port, n_local, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {r: (o, n) for r, o, n in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        got, n = outs[r]
+        assert n == 2 * world * n_local
+        for step in range(2):
+            expect = torch.stack([_record(100 * step + i) for i in range(world * n_local)])
+            assert torch.equal(torch.from_numpy(got[step]), expect)
+
+
+@pytest.mark.gpu
+def test_pack_triplets_kernel_equals_the_torch_packing():
+    from pairnet_amd import hip
+    g = torch.Generator().manual_seed(3)
+    labels = torch.randint(1, 134, (200,), generator=g)
+    rel = torch.rand(100, 57, generator=g)
+    sub, obj = torch.randint(0, 100, (100,), generator=g), torch.randint(0, 100, (100,), generator=g)
+    rec = torch.empty(triplet_record_len(100, 56), device="cuda:0")
+    hip.pack_triplets(labels.cuda(), rel.cuda(), sub.cuda(), obj.cuda(), rec, 100, 57)
+    assert torch.equal(rec.cpu(), pack_triplets(labels, rel, sub, obj))
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_complete_and_report_whole_job_rate():
-    """`bench.py --gpus 2` under torch.distributed.run (the driver's launch line; gloo so
-    that two ranks can share the test box's single GPU): every rank must leave every
-    collective, and rank 0 prints one JSON line with the whole-job rate."""
+    """Plain `python bench.py --gpus 2` (no launcher: the script re-executes itself through
+    torch.distributed.run; gloo so that two ranks can share the test box's single GPU):
+    every rank must leave every collective, and rank 0 prints one JSON line with the
+    whole-job rate and the number of gathered triplet records."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PAIRNET_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "6", "--warmup", "3", "--height", "256", "--width", "320"]
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=240)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["PAIRNET_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
+           "--warmup", "3", "--height", "256", "--width", "320"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["value"] > 0
     assert rec["scaling"] == "weak" and "roofline" in rec
+    assert rec["config"]["path"] == "image" and rec["config"]["backbone"] == "ResNet-50"
+    assert rec["triplet_records_gathered"] >= 2 * 6 and rec["dist_backend"] == "gloo"

@@ -261,6 +261,42 @@ def main():
                      "what": "%s.simple_test_bboxes on the feature pyramid resident in HBM "
                              "(same pipeline, no backbone)" % type(head).__name__}
 
+    # ---- secondary: from the DECODED image (uint8 HWC BGR resident in HBM): the reference's
+    # test pipeline (resize keep-ratio / normalise / pad, pairnet.py:310-331) as one kernel in
+    # front of the backbone, on the same stream ----
+    from_decoded = None
+    if args.path == "image" and world == 1 and B == 1:
+        from pairnet_amd import TestPipeline
+        from pairnet_amd.preprocess import rescale_size
+        h0, w0 = round(H / sf), round(W / sf)
+        if rescale_size(h0, w0, (1333, 800)) == (H, W):
+            pipe = TestPipeline(device=dev)
+            raw = torch.randint(0, 256, (h0, w0, 3), generator=g, dtype=torch.uint8).to(dev)
+
+            def raw_step():
+                with torch.cuda.stream(engine.streams_a[0] if engine is not None
+                                       else torch.cuda.current_stream()):
+                    _, m = pipe(raw, out=img)
+                    if engine is None:
+                        return head.simple_test_bboxes(backbone(img), m)
+                    return engine.submit(backbone(img), m)
+            n = min(args.steps, 100)
+            for _ in range(4):
+                raw_step()
+            drain()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                raw_step()
+            drain()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            from_decoded = {"images_per_s": n / dt, "ms_per_step": 1e3 * dt / n, "steps": n,
+                            "what": "uint8 %dx%dx3 BGR image in HBM -> TestPipeline (resize to "
+                                    "%dx%d, normalise, pad; one HIP kernel) -> %s -> head"
+                                    % (h0, w0, H, W, bname)}
+            img.copy_(img_cpu)            # (the legs below run on the seeded tensor again)
+
     # ---- roofline leg: the same step again, eagerly on one stream, with HIP events
     # (recorded on the launching stream) around every GEMM / conv / MSDA launch.  Kept out
     # of the timed region above because ~150 event pairs per step cost host time there. ----
@@ -327,6 +363,8 @@ def main():
         }
         if head_only is not None:
             out["head_only"] = head_only
+        if from_decoded is not None:
+            out["from_decoded_image"] = from_decoded
         if timer and dominant:
             def roof(name):
                 agg = prof[name]

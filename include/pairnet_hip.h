@@ -373,6 +373,15 @@ int pn_panoptic_continue_f32(void* state, const float* up_scratch, int32_t* area
 int pn_pack_triplets_f32(const int64_t* labels, const float* r_dists, const int64_t* sub_pos,
                          const int64_t* obj_pos, float* rec, int R, int C1, void* stream);
 
+/* Test-time image front end (configs/mask2former/pairnet.py:310-331, mean / std :229-231):
+ * mmdet Resize(keep_ratio) [= mmcv.imresize = OpenCV INTER_LINEAR on uint8, fixed point] ->
+ * Normalize(to_rgb) -> Pad -> ImageToTensor of one decoded image, fused.
+ *   img  [H][W][3] uint8, BGR (cv2 order)        out [3][Hp][Wp] fp32, zero beyond (Hn, Wn)
+ *   (Hn, Wn) = mmcv.rescale_size of (H, W); mean3 / stdinv3: HOST pointers, output order */
+int pn_preprocess_u8_f32(const uint8_t* img, int H, int W, float* out, int Hn, int Wn, int Hp,
+                         int Wp, const float* mean3, const float* stdinv3, int to_rgb,
+                         void* stream);
+
 /* Evaluator feed (pairnet/evaluation/sgg_metrics.py:1276-1380, mask_iou :1374-1380):
  * masks as bit rows (bit i of word w = pixel 64w+i) and the exact integer counts
  * behind IoU: inter[i][j] = |pred_i & gt_j|, area_pred[i], area_gt[j]. */

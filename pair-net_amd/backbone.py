@@ -172,6 +172,7 @@ class ResNet50Hip:
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
+    @hip.on_device
     def forward(self, img):
         """img [B,3,H,W] fp32 NCHW on the GPU -> (C2, C3, C4, C5) NCHW-shaped tensors in
         channels_last memory format (views of per-shape buffers that the next call

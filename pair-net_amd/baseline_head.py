@@ -134,6 +134,7 @@ class CrossHeadBaseline(CrossHead2):
 
     # ------------------------------------------------------- post-processing
     @torch.no_grad()
+    @hip.on_device
     def get_bboxes(self, cls_scores, mask_preds, img_metas, rescale=False):
         """baseline.py:967-998."""
         self._pan_jobs = []

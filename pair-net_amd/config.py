@@ -197,8 +197,12 @@ def pairnet_swin(variant="B", num_obj_query=100):
     """`model` section: PSGTr(Swin, CrossHead2) (pairnet_swinb.py:201-240)."""
     bb = swin_backbone_cfg(variant)
     chans = [bb["embed_dims"] * 2 ** i for i in range(4)]
-    return ConfigDict(type="PSGTr", backbone=bb,
-                      bbox_head=pairnet_head_cfg(in_channels=chans, num_obj_query=num_obj_query),
+    head = pairnet_head_cfg(in_channels=chans, num_obj_query=num_obj_query)
+    # the Swin config differs from pairnet.py in two head keys: it passes `strides`
+    # (pairnet_swinb.py:237, swallowed by **kwargs) and leaves `mapper` at its default
+    head.pop("mapper")
+    head["strides"] = [4, 8, 16, 32]
+    return ConfigDict(type="PSGTr", backbone=bb, bbox_head=head,
                       test_cfg=dict(max_per_img=100))
 
 
@@ -214,6 +218,31 @@ def psgtr2_r50():
     cfg = pairnet_r50()
     cfg["bbox_head"] = psgtr2_head_cfg()
     return cfg
+
+
+IMG_NORM_CFG = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)
+
+
+def test_pipeline_cfg():
+    """`test_pipeline` of configs/mask2former/pairnet.py:310-331 (what preprocess.TestPipeline
+    .from_config consumes)."""
+    return [
+        dict(type="LoadImageFromFile"),
+        dict(type="LoadSceneGraphAnnotations", with_bbox=True, with_rel=True),
+        dict(type="MultiScaleFlipAug", img_scale=(1333, 800), flip=False, transforms=[
+            dict(type="Resize", keep_ratio=True),
+            dict(type="RandomFlip"),
+            dict(type="Normalize", **IMG_NORM_CFG),
+            dict(type="Pad", size_divisor=1),
+            dict(type="ImageToTensor", keys=["img"]),
+            dict(type="ToTensor", keys=["gt_bboxes", "gt_labels"]),
+            dict(type="ToDataContainer", fields=(dict(key="gt_bboxes"), dict(key="gt_labels"))),
+            dict(type="Collect", keys=["img"]),
+        ]),
+    ]
+
+
+test_pipeline_cfg.__test__ = False
 
 
 def load_config(path):

@@ -146,6 +146,7 @@ class PSGTr:
         self.bbox_head = heads[head_type](**head_cfg, train_cfg=None,
                                           test_cfg=test_cfg or dict(max_per_img=100))
         self.num_classes = self.bbox_head.num_classes
+        self.test_pipeline = None     # built by detect() (or set a preprocess.TestPipeline)
 
     def to(self, device):
         self.backbone.to(device)
@@ -169,6 +170,19 @@ class PSGTr:
         if hasattr(results_list, "panoptic_jobs"):
             self.bbox_head.panoptic_status(results_list)
         return [triplet2Result(t, self.bbox_head.use_mask) for t in results_list]
+
+    @torch.no_grad()
+    def detect(self, image, rescale=False):
+        """Decoded uint8 (H, W, 3) BGR image (cv2 order, host or device) -> [Result]: the
+        reference's test pipeline (configs/mask2former/pairnet.py:310-331) on the GPU
+        (preprocess.TestPipeline), then `simple_test`."""
+        if self.test_pipeline is None:
+            from .config import test_pipeline_cfg
+            from .preprocess import TestPipeline
+            self.test_pipeline = TestPipeline.from_config(test_pipeline_cfg(),
+                                                          device=self.bbox_head.device)
+        img, metas = self.test_pipeline(image)
+        return self.simple_test(img, metas, rescale=rescale)
 
     def forward(self, img=None, img_metas=None, return_loss=False, rescale=False, **kw):
         """mmdet's `model(return_loss=False, rescale=True, img=[..], img_metas=[..])`."""

@@ -786,6 +786,7 @@ class CrossHead2:
         return g
 
     @torch.no_grad()
+    @hip.on_device
     def forward(self, feats, img_metas, slot=0):
         """feats: [C2, C3, C4, C5] NCHW fp32 on the GPU; returns the reference's two
         dicts (pairnet_head.py:405-417).  Output tensors are views of per-shape
@@ -800,6 +801,7 @@ class CrossHead2:
     __call__ = forward
 
     @torch.no_grad()
+    @hip.on_device
     def forward_head(self, decoder_out, mask_feature, attn_mask_target_size):
         """Reference signature (pairnet_head.py:216): decoder_out (Q, B, C) seq-first,
         mask_feature (B, C, h, w); returns cls_pred (B,Q,nc), mask_pred (B,Q,h,w),
@@ -850,6 +852,7 @@ class CrossHead2:
         return pb
 
     @torch.no_grad()
+    @hip.on_device
     def get_bboxes(self, cls_scores, mask_preds, img_metas, rescale=False):
         """pairnet_head.py:760-786.  With `use_graphs`, the post-processing of a plan's own
         outputs is replayed as one hipGraph per (plan, image sizes)."""

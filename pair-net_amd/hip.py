@@ -84,6 +84,8 @@ _SIGS = {
                                                                         _i32, _vp]),
     "pn_panoptic_continue_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_pack_triplets_f32": (C.c_int, [_vp] * 5 + [_i32, _i32, _vp]),
+    "pn_preprocess_u8_f32": (C.c_int, [_vp, _i32, _i32, _vp] + [_i32] * 4 + [C.POINTER(_f32),
+                                                                            C.POINTER(_f32), _i32, _vp]),
     "pn_pack_mask_bits": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "pn_mask_iou_counts": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
 }
@@ -113,6 +115,39 @@ def lib():
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def on_device(fn):
+    """Method decorator: run with the object's GPU as the current device, so that the
+    launches go to THAT device's current stream (a head on cuda:1 called while cuda:0 is
+    current would otherwise launch on device 0 against device-1 pointers).  The device is
+    `self.device`, or the first device tensor among the arguments before `.to()` was called."""
+    import functools
+
+    def first_tensor(objs):
+        for o in objs:
+            if isinstance(o, torch.Tensor) and o.is_cuda:
+                return o.device
+            if isinstance(o, (list, tuple)):
+                d = first_tensor(o)
+                if d is not None:
+                    return d
+            if isinstance(o, dict):
+                d = first_tensor(o.values())
+                if d is not None:
+                    return d
+        return None
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kw):
+        dev = getattr(self, "device", None)
+        if dev is None or dev.type != "cuda":
+            dev = first_tensor(args)
+        if dev is None or dev.type != "cuda" or dev.index == torch.cuda.current_device():
+            return fn(self, *args, **kw)
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kw)
+    return wrapper
 
 
 GEMM_KERNELS = {0: "k_gemm_skinny<A_ROW>", 1: "k_gemm_skinny<A_COL>",
@@ -560,6 +595,14 @@ def pack_triplets(labels, r_dists, sub_pos, obj_pos, rec, R, C1):
     _check(lib().pn_pack_triplets_f32(_ptr(labels, i64), _ptr(r_dists), _ptr(sub_pos, i64),
                                       _ptr(obj_pos, i64), _ptr(rec), R, C1, _stream()),
            "pn_pack_triplets_f32")
+
+
+def preprocess_u8(img, H, W, out, Hn, Wn, Hp, Wp, mean, stdinv, to_rgb):
+    """mean / stdinv: 3 host floats each, in OUTPUT channel order."""
+    m = (_f32 * 3)(*[float(v) for v in mean])
+    s = (_f32 * 3)(*[float(v) for v in stdinv])
+    _check(lib().pn_preprocess_u8_f32(_ptr(img, torch.uint8), H, W, _ptr(out), Hn, Wn, Hp, Wp,
+                                      m, s, int(to_rgb), _stream()), "pn_preprocess_u8_f32")
 
 
 def pack_mask_bits(masks_u8, words, rows, HW):

@@ -21,6 +21,8 @@ independent (pairnet_head.py:260-417 has no cross-image op).
 """
 import torch
 
+from .hip import on_device
+
 
 class PipelinedHead:
     def __init__(self, head, depth=3, a_streams=1):
@@ -28,7 +30,7 @@ class PipelinedHead:
             raise RuntimeError("PipelinedHead needs a head on an MI355X (.to('cuda:N'))")
         if depth < 2 or not 1 <= a_streams < depth:
             raise ValueError("depth >= 2 and 1 <= a_streams < depth")
-        self.head, self.depth = head, depth
+        self.head, self.depth, self.device = head, depth, head.device
         with torch.cuda.device(head.device):
             # a_streams > 1: stage A of consecutive batches alternates between streams, so
             # one batch's gather / normalisation kernels can run beside another's GEMMs
@@ -89,6 +91,7 @@ class PipelinedHead:
         return self.streams_b[index % len(self.streams_b)]
 
     @torch.no_grad()
+    @on_device
     def submit(self, feats, img_metas, rescale=False):
         """Queue one batch; returns the result list of the batch submitted depth-1 calls
         earlier (None while the pipeline fills)."""
@@ -148,6 +151,7 @@ class PipelinedHead:
         return res
 
     @torch.no_grad()
+    @on_device
     def flush(self):
         """Finish every batch still in flight; returns the list of their result lists
         (oldest first)."""

@@ -108,6 +108,7 @@ class PSGTrHead2(CrossHead2):
 
     # ------------------------------------------------------- post-processing
     @torch.no_grad()
+    @hip.on_device
     def get_bboxes(self, cls_scores, mask_preds, img_metas, rescale=False):
         """psgtr_head2.py:1063-1085 (per image; see the module docstring)."""
         self._pan_jobs = []          # (pan_img is the constant map of :1129: no device loop)

@@ -187,6 +187,7 @@ class SwinTransformerHip:
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
+    @hip.on_device
     def forward(self, img):
         """img [B,3,H,W] fp32 NCHW on the GPU -> one NCHW-shaped, channels_last feature map
         per out index (views of per-shape buffers that the next call overwrites)."""

@@ -62,6 +62,31 @@ def test_reference_config_file_drops_in():
 
 
 @pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+def test_reference_swinb_config_file_drops_in():
+    """The reference's own configs/mask2former/pairnet_swinb.py (Swin-B backbone, :203-226,
+    under the same head, :227-...) builds our detector, and `pairnet_swin("B")` equals it
+    key for key -- backbone and head sections."""
+    from pairnet_amd import (CrossHead2, SwinTransformerHip, build_detector, load_config,
+                             pairnet_swin)
+    cfg = load_config(os.path.join(ref_shim.REF_ROOT, "configs/mask2former/pairnet_swinb.py"))
+    ours = pairnet_swin("B")
+    strip = lambda d: {k: v for k, v in dict(d).items()
+                       if k not in ("object_classes", "predicate_classes")}
+    as_plain = lambda d: {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in d.items()}
+    assert as_plain(dict(cfg.model.backbone)) == as_plain(dict(ours.backbone))
+    assert strip(cfg.model.bbox_head) == strip(ours.bbox_head)
+    det = build_detector(dict(cfg.model))
+    assert isinstance(det.backbone, SwinTransformerHip) and isinstance(det.bbox_head, CrossHead2)
+    assert det.bbox_head.in_channels == [128, 256, 512, 1024]
+    # mmdet's SwinTransformer state-dict layout (names from memory of mmdet 2.25.1, see
+    # SURVEY N7): what a converted checkpoint of this config would carry
+    keys = set(det.backbone.state_dict())
+    for k in ("patch_embed.projection.weight", "stages.2.blocks.17.attn.w_msa.qkv.weight",
+              "stages.0.downsample.reduction.weight", "norm3.weight"):
+        assert k in keys, k
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
 def test_sibling_heads_drop_in():
     """BASELINE config #5 / SURVEY 8f rank 3: CrossHeadBaseline and PSGTrHead2 build from
     the reference's own config files with the reference's state-dict layout."""

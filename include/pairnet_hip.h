@@ -235,6 +235,25 @@ int pn_msda_f32(const float* value, int64_t ld_value, const float* offaw,
                 const int32_t* level_h /* host */, const int32_t* level_w /* host */,
                 void* stream);
 
+/* The same operator in mmcv's OWN shape -- the entry a maintainer binds behind the
+ * unmodified `MultiScaleDeformableAttention.forward` (mmcv/ops/multi_scale_deform_attn.py,
+ * `ext_module.ms_deform_attn_forward`, configured at configs/mask2former/pairnet.py:43-54;
+ * INTEGRATION.md shows the binding), and the query-side cross-attention of the
+ * Deformable-DETR trunk under CrossHeadBBox (pairnet_bbox_head.py:193-359):
+ *   value               [B][N][ld_value]      first 8*32 floats of each row
+ *   spatial_shapes      [L][2] int64, DEVICE  (H_l, W_l), as mmcv passes them
+ *   level_start_index   [L]    int64, DEVICE
+ *   sampling_locations  [B][Nq][8][L][4][2]   normalised (x, y) in [0, 1]
+ *   attention_weights   [B][Nq][8][L][4]      already soft-maxed
+ *   out                 [B][Nq][256]
+ * Any number of queries Nq, bilinear sampling with zero padding (grid_sample,
+ * align_corners=False).  H == 8, D == 32, P == 4, L <= 4.  (im2col_step is a batching
+ * knob of mmcv's CUDA kernel without an arithmetic effect: there is none here.) */
+int pn_msda_loc_f32(const float* value, int64_t ld_value, const int64_t* spatial_shapes,
+                    const int64_t* level_start_index, const float* sampling_locations,
+                    const float* attention_weights, float* out, int B, int N, int Nq, int L,
+                    void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Positional encoding / resampling
  * ------------------------------------------------------------------------- */

@@ -196,3 +196,114 @@ extern "C" int pn_msda_f32(const float* value, int64_t ld_value, const float* of
   }
   return PN_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------
+// The operator in mmcv's own shape: arbitrary queries, explicit (already normalised)
+// sampling locations and (already soft-maxed) attention weights, level geometry read from
+// the DEVICE tensors mmcv passes -- a drop-in behind the unmodified
+// MultiScaleDeformableAttention.forward, and the cross-attention of Deformable-DETR
+// decoders (query-side sampling).  Same two phases as k_msda; the output of query q is
+//   out[b][q][h][:] = sum_{l,p} w[b][q][h][l][p] * bilinear(value_l[b][:, h, :], loc[b][q][h][l][p])
+// with zero padding, `loc` in [0, 1] x [0, 1] as (x, y).
+template <int L>
+__global__ __launch_bounds__(256) void k_msda_loc(const float* __restrict__ value,
+                                                  const int64_t* __restrict__ shapes,
+                                                  const int64_t* __restrict__ starts,
+                                                  const float* __restrict__ loc,
+                                                  const float* __restrict__ aw,
+                                                  float* __restrict__ out, const int N,
+                                                  const int Nq, const int64_t ldv) {
+  __shared__ MsdaTap taps[MSDA_TQ][8][4][4];   // [query][head][point][level]
+  __shared__ float attw[MSDA_TQ][8][4][4];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  constexpr int LP = L * 4;
+  {
+    const int qi = tid >> 7, head = (tid >> 4) & 7, pt = (tid >> 2) & 3, l = tid & 3;
+    const int q = blockIdx.x * MSDA_TQ + qi;
+    if (q < Nq && l < L) {
+      const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+      const int64_t slot = (((int64_t)b * Nq + q) * 8 + head) * LP + l * 4 + pt;
+      const float2 lc = *reinterpret_cast<const float2*>(loc + 2 * slot);
+      const float gx = 2.f * lc.x - 1.f, gy = 2.f * lc.y - 1.f;
+      const float ix = ((gx + 1.f) * (float)Wl - 1.f) * 0.5f;
+      const float iy = ((gy + 1.f) * (float)Hl - 1.f) * 0.5f;
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)Wl), y0 = (int)fminf(fmaxf(fy, -2.f), (float)Hl);
+      const float tx = ix - fx, ty = iy - fy;
+      const bool xin0 = x0 >= 0 && x0 < Wl, xin1 = x0 + 1 >= 0 && x0 + 1 < Wl;
+      const bool yin0 = y0 >= 0 && y0 < Hl, yin1 = y0 + 1 >= 0 && y0 + 1 < Hl;
+      const int xa = min(max(x0, 0), Wl - 1), xb = min(max(x0 + 1, 0), Wl - 1);
+      const int ya = min(max(y0, 0), Hl - 1), yb = min(max(y0 + 1, 0), Hl - 1);
+      MsdaTap t;
+      t.w[0] = (xin0 && yin0) ? (1.f - tx) * (1.f - ty) : 0.f;
+      t.w[1] = (xin1 && yin0) ? tx * (1.f - ty) : 0.f;
+      t.w[2] = (xin0 && yin1) ? (1.f - tx) * ty : 0.f;
+      t.w[3] = (xin1 && yin1) ? tx * ty : 0.f;
+      const unsigned row = (unsigned)ldv * 4u, base = (unsigned)starts[l];
+      t.off[0] = (base + (unsigned)(ya * Wl + xa)) * row;
+      t.off[1] = (base + (unsigned)(ya * Wl + xb)) * row;
+      t.off[2] = (base + (unsigned)(yb * Wl + xa)) * row;
+      t.off[3] = (base + (unsigned)(yb * Wl + xb)) * row;
+      taps[qi][head][pt][l] = t;
+      attw[qi][head][pt][l] = aw[slot];
+    }
+  }
+  __syncthreads();
+  const int c4 = tid & 7, p2 = (tid >> 3) & 3, h2 = tid >> 5;
+  const char* vb = reinterpret_cast<const char*>(value + (int64_t)b * N * ldv + h2 * 32 + c4 * 4);
+#pragma unroll
+  for (int qi = 0; qi < MSDA_TQ; ++qi) {
+    const int q = blockIdx.x * MSDA_TQ + qi;
+    if (q >= Nq) continue;                    // (uniform)
+    float4 v[L][4];
+    MsdaTap t[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+      t[k] = taps[qi][h2][p2][k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[k][j] = *reinterpret_cast<const float4*>(vb + t[k].off[j]);
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+      const float a = attw[qi][h2][p2][k];
+      float4 s4;
+      s4.x = ((v[k][0].x * t[k].w[0] + v[k][1].x * t[k].w[1]) + v[k][2].x * t[k].w[2]) + v[k][3].x * t[k].w[3];
+      s4.y = ((v[k][0].y * t[k].w[0] + v[k][1].y * t[k].w[1]) + v[k][2].y * t[k].w[2]) + v[k][3].y * t[k].w[3];
+      s4.z = ((v[k][0].z * t[k].w[0] + v[k][1].z * t[k].w[1]) + v[k][2].z * t[k].w[2]) + v[k][3].z * t[k].w[3];
+      s4.w = ((v[k][0].w * t[k].w[0] + v[k][1].w * t[k].w[1]) + v[k][2].w * t[k].w[2]) + v[k][3].w * t[k].w[3];
+      acc.x += s4.x * a; acc.y += s4.y * a; acc.z += s4.z * a; acc.w += s4.w * a;
+    }
+    acc.x = pt_sum(acc.x); acc.y = pt_sum(acc.y);
+    acc.z = pt_sum(acc.z); acc.w = pt_sum(acc.w);
+    if (p2 == 0) st4(out + ((int64_t)b * Nq + q) * 256 + h2 * 32 + c4 * 4, acc);
+  }
+}
+
+extern "C" int pn_msda_loc_f32(const float* value, int64_t ld_value,
+                               const int64_t* spatial_shapes, const int64_t* level_start_index,
+                               const float* sampling_locations, const float* attention_weights,
+                               float* out, int B, int N, int Nq, int L, void* stream) {
+  if (!value || !spatial_shapes || !level_start_index || !sampling_locations ||
+      !attention_weights || !out || B <= 0 || N <= 0 || Nq <= 0 || L <= 0 || L > 4)
+    return PN_BAD_ARG;
+  if (ld_value < 256 || (ld_value & 3) || ((uintptr_t)value & 15) ||
+      ((uintptr_t)sampling_locations & 7))
+    return PN_BAD_ARG;
+  if ((int64_t)N * ld_value * 4 >= ((int64_t)1 << 32)) return PN_BAD_ARG;   // 32-bit tap offsets
+  const dim3 grid((Nq + MSDA_TQ - 1) / MSDA_TQ, B);
+  hipStream_t s = (hipStream_t)stream;
+#define PN_MSDA_LOC(LL)                                                                       \
+  hipLaunchKernelGGL(k_msda_loc<LL>, grid, dim3(256), 0, s, value, spatial_shapes,            \
+                     level_start_index, sampling_locations, attention_weights, out, N, Nq,    \
+                     ld_value)
+  switch (L) {
+    case 1: PN_MSDA_LOC(1); break;
+    case 2: PN_MSDA_LOC(2); break;
+    case 3: PN_MSDA_LOC(3); break;
+    default: PN_MSDA_LOC(4); break;
+  }
+#undef PN_MSDA_LOC
+  return PN_LAUNCH_CHECK();
+}

@@ -60,6 +60,7 @@ _SIGS = {
     "pn_ffn_ln2_f32": (C.c_int, [_vp] * 12 + [_i32, _i32, _i32, _f32, _vp]),
     "pn_msda_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, C.POINTER(_i32),
                               C.POINTER(_i32), _vp]),
+    "pn_msda_loc_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_sine_pe_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "pn_bilinear_nhwc_f32": (C.c_int, [_vp, _vp] + [_i32] * 7 + [_i64, _i64, _vp]),
     "pn_bilinear_planar_f32": (C.c_int, [_vp, _vp, _i64] + [_i32] * 4 + [_vp]),
@@ -465,6 +466,16 @@ def msda(value, ld_value, offaw, ld_offaw, out, B, shapes):
            "pn_msda_f32")
 
 
+def msda_loc(value, ld_value, spatial_shapes, level_start_index, loc, aw, out, B, N, Nq, L):
+    nbytes = 4.0 * B * (N * 256 + Nq * (8 * L * 4 * 3 + 256))
+    _check(_launch("k_msda_loc", 2.0 * B * Nq * 8 * L * 4 * 4 * 32 * 2, nbytes,
+                   lambda: lib().pn_msda_loc_f32(_ptr(value), ld_value,
+                                                 _ptr(spatial_shapes, torch.int64),
+                                                 _ptr(level_start_index, torch.int64), _ptr(loc),
+                                                 _ptr(aw), _ptr(out), B, N, Nq, L, _stream())),
+           "pn_msda_loc_f32")
+
+
 def sine_pe(out, add, h, w, C_=256, temperature=10000.0):
     _check(lib().pn_sine_pe_f32(_ptr(out), _ptr(add), h, w, C_, temperature, _stream()),
            "pn_sine_pe_f32")
@@ -563,10 +574,11 @@ def panoptic(masks, labels, remap, seg, area, n, HW):
                                  _ptr(area, torch.int32), n, HW, _stream()), "pn_panoptic_f32")
 
 
-# argmax / area-filter rounds enqueued up front.  The reference's loop can need at most
-# three: the first round merges duplicate stuff classes, the second counts them apart (so
-# a duplicate that only existed inside the merge can fall out), and since dropping
-# segments only ever grows the others nothing can fall out after that.
+# argmax / area-filter rounds enqueued up front.  The reference's loop can take at most
+# three: the first round merges duplicate stuff classes into their first occurrence (the
+# duplicates end with area 0 and are dropped), the second counts the survivors without the
+# merge (so the first occurrence can lose the merged area and fall out), and since from
+# then on dropping segments only ever grows the others, the third finds nothing to drop.
 PAN_ROUNDS = 4
 
 

@@ -451,11 +451,13 @@ def test_panoptic_loop_converges_like_the_reference_or_raises(monkeypatch):
     head = _hip_head(sd)
     args = list(_crafted_postproc_inputs(11))
     all_masks, all_cls = args[0], args[1]
-    # queries 41 / 55 / 56 share stuff class 90: give 56 three pixels of its own, so that it
-    # survives round 0 inside the merge (area counted on 41) and is dropped in round 1
-    all_masks[56] = -30.0
-    all_masks[56, 10, 10:12] = 40.0
-    img_shape, sf = (24, 32, 3), [1.0, 1.0, 1.0, 1.0]            # no upsampling: 2 pixels
+    # queries 41 / 55 / 56 share stuff class 90 and are merged into 41 in round 0 (55 / 56
+    # then have area 0 and are dropped).  41 itself only owns three pixels: it survives round
+    # 0 on the merged area, loses it in round 1 (the duplicates' pixels go to whoever is next
+    # best there) and is dropped then -- the longest chain the reference's loop can take
+    all_masks[41] = -30.0
+    all_masks[41, 10, 10:13] = 40.0
+    img_shape, sf = (24, 32, 3), [1.0, 1.0, 1.0, 1.0]            # no upsampling
     ref = head_o._get_bboxes_single(*args, img_shape, sf)
     monkeypatch.setattr(hip, "PAN_ROUNDS", 1)
     got = head._get_bboxes_single(*[a.to(DEV) for a in args], img_shape, sf)

@@ -337,6 +337,58 @@ def test_msda_level_counts_batches_and_odd_bands(hip, shapes, bs):
           "msda %d levels" % nl)
 
 
+def _mmcv_inputs(shapes, bs, nq, seed, lo=-0.3, hi=1.3):
+    n = sum(h * w for h, w in shapes)
+    nl = len(shapes)
+    value = R(bs, n, 8, 32, seed=seed)
+    loc = R(bs, nq, 8, nl, 4, 2, seed=seed + 1, lo=lo, hi=hi)        # some samples off the map
+    aw = R(bs, nq, 8, nl * 4, seed=seed + 2, lo=-3, hi=3).softmax(-1).view(bs, nq, 8, nl, 4)
+    ss = torch.tensor(shapes, dtype=torch.int64)
+    starts = torch.cat([ss.new_zeros(1), (ss[:, 0] * ss[:, 1]).cumsum(0)[:-1]])
+    return value, ss, starts, loc, aw
+
+
+@pytest.mark.parametrize("shapes,bs,nq", [([(3, 4), (6, 8), (12, 16)], 2, 252),
+                                           ([(5, 7)], 1, 1), ([(2, 3), (4, 5), (7, 9), (13, 17)], 2, 301),
+                                           ([(9, 1), (17, 3)], 3, 100)])
+def test_mmcv_shaped_msda_operator(hip, shapes, bs, nq):
+    """`ms_deform_attn_forward` in mmcv's own signature (explicit sampling locations and
+    attention weights, any number of queries, level geometry from device tensors) against
+    the oracle's restatement of mmcv's formula."""
+    from pairnet_amd.mmcv_ops import ms_deform_attn_forward
+    value, ss, starts, loc, aw = _mmcv_inputs(shapes, bs, nq, 21)
+    out = ms_deform_attn_forward(value.to(DEV), ss.to(DEV), starts.to(DEV), loc.to(DEV),
+                                 aw.to(DEV), 64)
+    assert out.shape == (bs, nq, 256)
+    close(out, L.msda_core(value, shapes, loc, aw), 2e-6, "mmcv-shaped msda")
+
+
+def test_mmcv_shaped_msda_on_the_golden_fixture_equals_the_fused_entry(hip):
+    """G6 through the mmcv-shaped entry: locations / weights prepared the way
+    MultiScaleDeformableAttention.forward prepares them; same values as the fused encoder
+    entry (pn_msda_f32) bit for bit, and the recorded output."""
+    from pairnet_amd.mmcv_ops import ms_deform_attn_forward
+    fx = golden("msda")
+    shapes = [tuple(s) for s in fx["shapes"].tolist()]
+    value, off, logits = (torch.from_numpy(fx[k]) for k in ("value", "offsets", "logits"))
+    bs, n = value.shape[:2]
+    refs = []
+    for h, w in shapes:
+        yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32) + 0.5,
+                                torch.arange(w, dtype=torch.float32) + 0.5, indexing="ij")
+        refs.append(torch.stack([xx.reshape(-1) / w, yy.reshape(-1) / h], -1))
+    ref = torch.cat(refs, 0)[None, :, None].repeat(bs, 1, len(shapes), 1)
+    norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
+    loc = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    aw = logits.softmax(-1).view(bs, n, 8, len(shapes), 4)
+    ss = torch.tensor(shapes, dtype=torch.int64)
+    starts = torch.cat([ss.new_zeros(1), (ss[:, 0] * ss[:, 1]).cumsum(0)[:-1]])
+    out = ms_deform_attn_forward(value.to(DEV), ss.to(DEV), starts.to(DEV), loc.to(DEV),
+                                 aw.to(DEV))
+    close(out, torch.from_numpy(fx["out"]), 2e-6, "msda golden via the mmcv-shaped entry")
+    close(out, _run_msda(hip, value, off, logits, shapes).cpu(), 2e-6, "mmcv-shaped vs fused entry")
+
+
 # ----------------------------------------------------------------------------- PE / resize
 def test_sine_pe(hip):
     pe = L.SinePositionalEncoding(128, normalize=True)

@@ -451,6 +451,26 @@ def main():
                 step()
             drain()
             out["opt_in_bf16x3_split"] = {"images_per_s": B * 10 / dt, "ms_per_step": 1e2 * dt}
+        # deformable sampling with learned-like offsets: default-init weights give every token
+        # mmcv's +-1..4 px grid (a tight neighbourhood); the same kernel on the grid plus
+        # N(0, 8 px) noise per offset shows how far the rate depends on that locality
+        try:
+            pl = head._last_plan
+            voa = pl.VOA.clone()
+            gen = torch.Generator(device=dev).manual_seed(7)
+            voa[..., 256:448] += 8.0 * torch.randn(voa[..., 256:448].shape, device=dev, generator=gen)
+            s_out = torch.empty_like(pl.S)
+            run = lambda v: hip.msda(v, 544, v.view(-1)[256:], 544, s_out, B, pl.shapes)
+            t_init, t_spread = timeit(lambda: run(pl.VOA), 50), timeit(lambda: run(voa), 50)
+            alg = 4.0 * B * pl.SN * (256 + 8 * 3 * 4 * 3 + 256)
+            out["deformable_sampling_offsets"] = {
+                "init_grid": {"us": 1e3 * t_init, "GB/s": alg / t_init / 1e6},
+                "init_grid_plus_N(0,8px)": {"us": 1e3 * t_spread, "GB/s": alg / t_spread / 1e6},
+                "what": "pn_msda_f32 alone, back to back, on the last step's [value|offsets|"
+                        "logits] buffer and on a copy with noise added to every offset"}
+            del voa, s_out
+        except Exception as e:  # pragma: no cover
+            out["deformable_sampling_offsets"] = repr(e)
         if backbone is not None and not swin:
             try:  # comparison leg: the same backbone through PyTorch-ROCm / MIOpen
                 from pairnet_amd.detector import ResNet50

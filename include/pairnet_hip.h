@@ -410,6 +410,25 @@ int pn_mask_iou_counts(const uint64_t* pred_words, int P, const uint64_t* gt_wor
                        int64_t nwords, int32_t* inter, int32_t* area_pred, int32_t* area_gt,
                        void* stream);
 
+/* Evaluator feed, part 2: SGRecall's triplet matching (sgg_metrics.py:173-252, :1311-1371).
+ *   pn_pred_triplets   triplets[r] = (labels[r], 1 + argmax(rel_dists[r][1:]), labels[R+r]),
+ *                      scores[r] = that maximum (:207-209, :1292-1294)
+ *   pn_mask_or_rows    out[r] = words[a[r]] | words[b[r]]: the union masks of phrase
+ *                      detection (:1343-1350)
+ *   pn_triplet_match   match[p][g] = classes equal && IoU(subject) >= thr && IoU(object) >= thr
+ *                      from the counts of pn_mask_iou_counts (inter [*][ld_inter], areas),
+ *                      rows chosen through the *_row tables; phrdet: one IoU (the union
+ *                      counts passed as the subject arguments). */
+int pn_pred_triplets(const int64_t* labels, const float* r_dists, int32_t* triplets,
+                     float* scores, int R, int C1, void* stream);
+int pn_mask_or_rows(const uint64_t* words, const int32_t* a, const int32_t* b, uint64_t* out,
+                    int rows, int64_t nwords, void* stream);
+int pn_triplet_match(const int32_t* pred_triplets, const int32_t* gt_triplets, int P, int G,
+                     const int32_t* inter, const int32_t* area_pred, const int32_t* area_gt,
+                     int ld_inter, const int32_t* pred_sub_row, const int32_t* pred_obj_row,
+                     const int32_t* gt_sub_row, const int32_t* gt_obj_row, double iou_thr,
+                     int phrdet, int ignore_rel, uint8_t* match, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -512,3 +512,115 @@ extern "C" int pn_mask_iou_counts(const uint64_t* pred_words, int P, const uint6
                      (const unsigned long long*)gt_words, P, G, nwords, inter, area_pred, area_gt);
   return PN_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------
+// Evaluator feed, part 2: the triplet matching of SGRecall (pairnet/evaluation/
+// sgg_metrics.py:173-252 calculate_recall, :1311-1371 _compute_pred_matches_panseg) on the
+// device, from the integer counts of pn_mask_iou_counts.
+// ---------------------------------------------------------------------------------
+// Predicted triplets (sgg_metrics.py:207-209, :1292-1294): predicate = 1 + argmax of
+// rel_dists[:, 1:] (first index on ties, numpy argmax), score = that maximum;
+// triplet = (labels[r], predicate, labels[R + r]) since rel_pairs[r] = (r, R + r).
+__global__ __launch_bounds__(256) void k_pred_triplets(const int64_t* __restrict__ labels,
+                                                       const float* __restrict__ r_dists,
+                                                       int32_t* __restrict__ trip,
+                                                       float* __restrict__ score, int R, int C1) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* x = r_dists + (int64_t)r * C1;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = 1 + lane; c < C1; c += 64) {
+    const float v = x[c];
+    if (v > best || bi == 0x7fffffff) { best = v; bi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) {
+      best = ob; bi = oi;
+    }
+  }
+  if (lane == 0) {
+    trip[3 * r + 0] = (int32_t)labels[r];
+    trip[3 * r + 1] = bi;
+    trip[3 * r + 2] = (int32_t)labels[R + r];
+    score[r] = best;
+  }
+}
+
+extern "C" int pn_pred_triplets(const int64_t* labels, const float* r_dists, int32_t* triplets,
+                                float* scores, int R, int C1, void* stream) {
+  if (!labels || !r_dists || !triplets || !scores || R <= 0 || C1 < 2) return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_pred_triplets, dim3(pn_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream,
+                     labels, r_dists, triplets, scores, R, C1);
+  return PN_LAUNCH_CHECK();
+}
+
+// words_out[r] = words[a[r]] | words[b[r]]  (union masks of the phrase-detection mode)
+__global__ __launch_bounds__(256) void k_or_rows(const unsigned long long* __restrict__ words,
+                                                 const int32_t* __restrict__ a,
+                                                 const int32_t* __restrict__ b,
+                                                 unsigned long long* __restrict__ out,
+                                                 int64_t nwords) {
+  const int r = blockIdx.y;
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= nwords) return;
+  out[(int64_t)r * nwords + w] = words[(int64_t)a[r] * nwords + w] | words[(int64_t)b[r] * nwords + w];
+}
+
+extern "C" int pn_mask_or_rows(const uint64_t* words, const int32_t* a, const int32_t* b,
+                               uint64_t* out, int rows, int64_t nwords, void* stream) {
+  if (!words || !a || !b || !out || rows <= 0 || rows > 65535 || nwords <= 0) return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_or_rows, dim3(pn_cdiv(nwords, 256), rows), dim3(256), 0,
+                     (hipStream_t)stream, (const unsigned long long*)words, a, b,
+                     (unsigned long long*)out, nwords);
+  return PN_LAUNCH_CHECK();
+}
+
+// match[p][g] = triplet classes equal (the predicate ignored with ignore_rel) and
+//   both masks overlap: inter / (area_p + area_g - inter) >= thr for the subject pair AND
+//   the object pair (phrdet == 0), or for the one union pair (phrdet != 0: pass the union
+//   counts as the "subject" arguments).  inter_s is indexed [p_row][g_row] through the row
+//   tables: subject of prediction p = row ps[p], of gt relation g = row gs[g], etc.
+// IoU is compared as the reference does (float64 division, >=); an empty union is no match.
+__global__ __launch_bounds__(256) void k_triplet_match(
+    const int32_t* __restrict__ ptrip, const int32_t* __restrict__ gtrip, int P, int G,
+    const int32_t* __restrict__ inter, const int32_t* __restrict__ area_p,
+    const int32_t* __restrict__ area_g, int ldi, const int32_t* __restrict__ ps,
+    const int32_t* __restrict__ po, const int32_t* __restrict__ gs,
+    const int32_t* __restrict__ go, double thr, int phrdet, int ignore_rel,
+    uint8_t* __restrict__ match) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= P * G) return;
+  const int p = e / G, g = e - p * G;
+  bool ok = ptrip[3 * p] == gtrip[3 * g] && ptrip[3 * p + 2] == gtrip[3 * g + 2] &&
+            (ignore_rel || ptrip[3 * p + 1] == gtrip[3 * g + 1]);
+  auto iou_ok = [&](int pr, int gr) {
+    const int it = inter[(int64_t)pr * ldi + gr];
+    const int un = area_p[pr] + area_g[gr] - it;
+    return un > 0 && (double)it / (double)un >= thr;
+  };
+  if (ok) ok = iou_ok(ps[p], gs[g]);
+  if (ok && !phrdet) ok = iou_ok(po[p], go[g]);
+  match[e] = ok ? 1 : 0;
+}
+
+extern "C" int pn_triplet_match(const int32_t* pred_triplets, const int32_t* gt_triplets, int P,
+                                int G, const int32_t* inter, const int32_t* area_pred,
+                                const int32_t* area_gt, int ld_inter, const int32_t* pred_sub_row,
+                                const int32_t* pred_obj_row, const int32_t* gt_sub_row,
+                                const int32_t* gt_obj_row, double iou_thr, int phrdet,
+                                int ignore_rel, uint8_t* match, void* stream) {
+  if (!pred_triplets || !gt_triplets || !inter || !area_pred || !area_gt || !pred_sub_row ||
+      !gt_sub_row || !match || P <= 0 || G <= 0 || ld_inter <= 0)
+    return PN_BAD_ARG;
+  if (!phrdet && (!pred_obj_row || !gt_obj_row)) return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_triplet_match, dim3(pn_cdiv((int64_t)P * G, 256)), dim3(256), 0,
+                     (hipStream_t)stream, pred_triplets, gt_triplets, P, G, inter, area_pred,
+                     area_gt, ld_inter, pred_sub_row, pred_obj_row, gt_sub_row, gt_obj_row,
+                     iou_thr, phrdet, ignore_rel, match);
+  return PN_LAUNCH_CHECK();
+}

@@ -85,6 +85,10 @@ _SIGS = {
                                                                         _i32, _vp]),
     "pn_panoptic_continue_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_pack_triplets_f32": (C.c_int, [_vp] * 5 + [_i32, _i32, _vp]),
+    "pn_pred_triplets": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "pn_mask_or_rows": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _vp]),
+    "pn_triplet_match": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
+                                   C.c_double, _i32, _i32, _vp, _vp]),
     "pn_preprocess_u8_f32": (C.c_int, [_vp, _i32, _i32, _vp] + [_i32] * 4 + [C.POINTER(_f32),
                                                                             C.POINTER(_f32), _i32, _vp]),
     "pn_pack_mask_bits": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
@@ -627,3 +631,25 @@ def mask_iou_counts(pred_words, P, gt_words, G, nwords, inter, area_p, area_g):
                                     G, nwords, _ptr(inter, torch.int32),
                                     _ptr(area_p, torch.int32), _ptr(area_g, torch.int32),
                                     _stream()), "pn_mask_iou_counts")
+
+
+def pred_triplets(labels, r_dists, triplets, scores, R, C1):
+    _check(lib().pn_pred_triplets(_ptr(labels, torch.int64), _ptr(r_dists),
+                                  _ptr(triplets, torch.int32), _ptr(scores), R, C1, _stream()),
+           "pn_pred_triplets")
+
+
+def mask_or_rows(words, a, b, out, rows, nwords):
+    _check(lib().pn_mask_or_rows(_ptr(words, torch.int64), _ptr(a, torch.int32),
+                                 _ptr(b, torch.int32), _ptr(out, torch.int64), rows, nwords,
+                                 _stream()), "pn_mask_or_rows")
+
+
+def triplet_match(ptrip, gtrip, P, G, inter, area_p, area_g, ld_inter, ps, po, gs, go, thr, phrdet,
+                  ignore_rel, match):
+    i32 = torch.int32
+    _check(lib().pn_triplet_match(_ptr(ptrip, i32), _ptr(gtrip, i32), P, G, _ptr(inter, i32),
+                                  _ptr(area_p, i32), _ptr(area_g, i32), ld_inter, _ptr(ps, i32),
+                                  _ptr(po, i32), _ptr(gs, i32), _ptr(go, i32), float(thr),
+                                  int(phrdet), int(ignore_rel), _ptr(match, torch.uint8),
+                                  _stream()), "pn_triplet_match")

@@ -1,0 +1,98 @@
+"""The PSG evaluator's triplet matching (pairnet/evaluation/sgg_metrics.py:173-252,
+:1276-1380).  CPU: oracle/evaluation.py against the reference's own functions (imported
+from /root/reference under name-only stubs; build container only).  GPU: the device feed
+(pairnet_amd.evaluation.TripletEvaluator) against the oracle on a crafted scene with exact
+matches, near-threshold IoUs, wrong classes, duplicates and empty masks."""
+import os
+import sys
+import types
+import importlib.util
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import evaluation as OE
+from oracle import ref_shim
+
+
+def _scene(seed, R=100, H=48, W=64, nobj=7, G=9):
+    """Ground truth of rectangles + predictions derived from it with perturbations."""
+    rng = np.random.default_rng(seed)
+    gt_masks = np.zeros((nobj, H, W), bool)
+    for i in range(nobj):
+        y, x = rng.integers(0, H - 16), rng.integers(0, W - 16)
+        gt_masks[i, y:y + rng.integers(6, 16), x:x + rng.integers(6, 16)] = True
+    gt_labels = rng.integers(1, 134, nobj)
+    pairs = [(s, o) for s in range(nobj) for o in range(nobj) if s != o]
+    sel = rng.choice(len(pairs), G, replace=False)
+    gt_rels = np.array([[pairs[j][0], pairs[j][1], rng.integers(1, 57)] for j in sel])
+    labels = rng.integers(1, 134, 2 * R)
+    masks = rng.random((2 * R, H, W)) > 0.97
+    rel_dists = rng.random((R, 57)).astype(np.float32)
+    rel_dists[:, 0] = 0
+    for j, (s, o, pr) in enumerate(gt_rels):          # plant hits and near misses
+        for rep, r in enumerate((3 * j, 3 * j + 1, 3 * j + 40)):
+            labels[r], labels[R + r] = gt_labels[s], gt_labels[o]
+            rel_dists[r, pr] = 2.0 if rep != 1 else 0.0          # rep 1: wrong predicate
+            shift = (0, 1, 4)[rep]                               # rep 2: IoU near / below 0.5
+            masks[r] = np.roll(gt_masks[s], shift, axis=1)
+            masks[R + r] = np.roll(gt_masks[o], shift, axis=0)
+    masks[7] = False                                             # an empty predicted mask
+    rel_pairs = np.stack([np.arange(R), np.arange(R) + R], 1)
+    return labels, rel_pairs, rel_dists, masks, gt_rels, gt_labels, gt_masks
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+def test_evaluation_oracle_equals_the_reference_functions():
+    sys.dont_write_bytecode = True
+    for name, attrs in (("mmdet", {}), ("mmdet.core", dict(bbox_overlaps=None)),
+                        ("terminaltables", dict(AsciiTable=None))):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__dict__.update(attrs)
+            sys.modules[name] = m
+    pkg = types.ModuleType("refeval")
+    pkg.__path__ = [os.path.join(ref_shim.REF_ROOT, "pairnet/evaluation")]
+    sys.modules["refeval"] = pkg
+    mods = {}
+    for n in ("sgg_eval_util", "sgg_metrics"):
+        spec = importlib.util.spec_from_file_location(
+            "refeval." + n, os.path.join(ref_shim.REF_ROOT, "pairnet/evaluation", n + ".py"))
+        mods[n] = importlib.util.module_from_spec(spec)
+        sys.modules["refeval." + n] = mods[n]
+        spec.loader.exec_module(mods[n])
+    M = mods["sgg_metrics"]
+    for seed in (1, 2):
+        labels, rel_pairs, rel_dists, masks, gt_rels, gt_labels, gt_masks = _scene(seed)
+        ours = OE.evaluate(labels, rel_pairs, rel_dists, masks, gt_rels, gt_labels, gt_masks)
+        pred_rels = np.column_stack((rel_pairs, 1 + rel_dists[:, 1:].argmax(1)))
+        gt_t, gt_tm, _ = M._triplet_panseg(gt_rels, gt_labels, gt_masks)
+        p_t, p_tm, _ = M._triplet_panseg(pred_rels, labels, masks)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            for ph, key in ((False, "pred_to_gt"), (True, "phrdet_pred_to_gt")):
+                ref = M._compute_pred_matches_panseg(gt_t, p_t, gt_tm, p_tm, 0.5, phrdet=ph)
+                assert ref == ours[key]
+        rec = M.SGRecall({}, {}, [], detection_method="pan_seg")
+        rec.register_container("sgdet")
+        rec._calculate_single(rec.result_dict, ours["pred_to_gt"], gt_rels, "sgdet")
+        assert {k: v[0] for k, v in rec.result_dict["sgdet_recall"].items()} == ours["sgdet_recall"]
+        assert sum(len(x) for x in ours["pred_to_gt"]) >= 9      # the scene really has matches
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_device_evaluator_feed_equals_the_oracle(seed):
+    from pairnet_amd.evaluation import TripletEvaluator
+    labels, rel_pairs, rel_dists, masks, gt_rels, gt_labels, gt_masks = _scene(seed, H=61, W=83)
+    ref = OE.evaluate(labels, rel_pairs, rel_dists, masks, gt_rels, gt_labels, gt_masks)
+    dev = "cuda:0"
+    result = (None, torch.from_numpy(labels).to(dev), torch.from_numpy(rel_pairs),
+              torch.from_numpy(masks).to(dev), None, None, None,
+              torch.from_numpy(rel_dists).to(dev))
+    out = TripletEvaluator()(result, gt_rels, gt_labels, gt_masks)
+    assert out["pred_to_gt"] == ref["pred_to_gt"]
+    assert out["phrdet_pred_to_gt"] == ref["phrdet_pred_to_gt"]
+    assert out["sgdet_recall"] == ref["sgdet_recall"]
+    assert out["phrdet_recall"] == ref["phrdet_recall"]
+    assert out["sgdet_recall"][100] > 0.5                        # (the planted hits are found)

@@ -1,31 +1,27 @@
 #!/bin/bash
 # One gpurun call that regenerates the judged profile set (run on the GPU box):
-#   gpurun_out/<tag>_bench.json                  default `python bench.py` line
-#   gpurun_out/<tag>_kernel_stats.csv            rocprofv3 --kernel-trace --stats of the default command
-#   gpurun_out/<tag>_kernel_stats_head_only.csv  same of `bench.py --no-extras --no-cpu-baseline`
-#   gpurun_out/<tag>_swinl_bench.json            configs[3] shape (Swin-L widths, 200 queries) + Swin-L backbone
-#   gpurun_out/<tag>_swinl_kernel_stats.csv      rocprofv3 stats of tools/swin_probe.py L
+#   gpurun_out/<tag>_bench.json                  default `python bench.py` line (image -> triplets)
+#   gpurun_out/<tag>_kernel_stats.csv            rocprofv3 --kernel-trace --stats of
+#                                                `bench.py --no-extras --no-cpu-baseline`
+#   gpurun_out/<tag>_kernel_stats_head_only.csv  same with `--path head`
+#   gpurun_out/<tag>_swinl_bench.json            configs[3] shape (Swin-L, 200 queries), image -> triplets
 #   gpurun_out/pmc_traffic.json                  tools/pmc_traffic.sh (separate --pmc passes)
-# usage: tools/profile_round.sh r01_v7
+# usage: tools/profile_round.sh r02_v1
 set -u
-TAG="${1:-r01_vX}"
+TAG="${1:-r02_vX}"
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout 600 python "$ROOT/bench.py" 2> "$OUT/${TAG}_bench.err" | tail -1 > "$OUT/${TAG}_bench.json"
+timeout 900 python "$ROOT/bench.py" 2> "$OUT/${TAG}_bench.err" | tail -1 > "$OUT/${TAG}_bench.json"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}" -o full -- \
-  python "$ROOT/bench.py" > "$OUT/prof_${TAG}_full.log" 2>&1
+  python "$ROOT/bench.py" --no-extras --no-cpu-baseline > "$OUT/prof_${TAG}_full.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}" -o head -- \
-  python "$ROOT/bench.py" --no-extras --no-cpu-baseline > "$OUT/prof_${TAG}_head.log" 2>&1
-timeout 600 python "$ROOT/bench.py" --no-cpu-baseline --queries 200 --in-channels 192,384,768,1536 \
-  2> "$OUT/${TAG}_swinl_bench.err" | tail -1 > "$OUT/${TAG}_swinl_bench.json"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}" -o swinl -- \
-  python "$ROOT/tools/swin_probe.py" L f32 1 > "$OUT/prof_${TAG}_swinl.log" 2>&1
-for n in full head swinl; do
-  f=$(find "$OUT/prof_${TAG}" -name "${n}_kernel_stats.csv" | head -1)
-  [ -n "$f" ] && cp "$f" "$OUT/${TAG}_${n}_kernel_stats.csv"
-done
+  python "$ROOT/bench.py" --path head --no-extras --no-cpu-baseline > "$OUT/prof_${TAG}_head.log" 2>&1
+timeout 900 python "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 50 --queries 200 \
+  --in-channels 192,384,768,1536 2> "$OUT/${TAG}_swinl_bench.err" | tail -1 > "$OUT/${TAG}_swinl_bench.json"
+f=$(find "$OUT/prof_${TAG}" -name "full_kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_kernel_stats.csv"
+f=$(find "$OUT/prof_${TAG}" -name "head_kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_kernel_stats_head_only.csv"
 # drop the bulky traces, keep the summaries
 find "$OUT/prof_${TAG}" -name "*_kernel_trace.csv" -delete
 bash "$ROOT/tools/pmc_traffic.sh" > "$OUT/pmc_${TAG}.log" 2>&1

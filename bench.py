@@ -98,6 +98,11 @@ def main():
     ap.add_argument("--a-streams", type=int, default=1,
                     help="streams that stage A of consecutive batches alternates between")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly")
+    ap.add_argument("--exact-mask-order", action="store_true",
+                    help="attention masks in the reference's operation order (full-size mask "
+                         "logits, then the resize) instead of the once-resampled mask feature")
+    ap.add_argument("--grid-trim", type=int, default=None,
+                    help="persistent-GEMM workgroup slots left free for the query chains")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -144,14 +149,18 @@ def main():
     pair_ids = {"pairnet": lambda pl: (pl.sub_pos, pl.obj_pos),
                 "baseline": lambda pl: (pl.sub_ids, pl.obj_ids),
                 "psgtr2": lambda pl: (ident, ident)}[args.head]   # query i IS triplet i
+    if args.grid_trim is not None:
+        hip.gemm_set_grid_trim(args.grid_trim)
     head.init_weights(seed=0)
     head.to(dev)
     head.gemm_mode = args.gemm
+    head.exact_mask_order = args.exact_mask_order
     if args.conv:
         head.conv_algo = args.conv
     head.use_graphs = not args.no_graphs
-    engine = None if args.no_pipeline else PipelinedHead(head, depth=args.depth,
-                                                          a_streams=args.a_streams)
+    engine = None if args.no_pipeline else PipelinedHead(
+        head, depth=args.depth, a_streams=args.a_streams,
+        **({} if args.grid_trim is None else dict(grid_trim=args.grid_trim)))
     B, H, W = args.batch, args.height, args.width
     g = torch.Generator().manual_seed(1000 + rank)
     sf = 2.083
@@ -346,6 +355,8 @@ def main():
                                "normalised image tensor" if args.path == "image"
                                else "feature pyramid"),
                 "path": args.path, "backbone": bname,
+                "attention_mask_order": "reference (resize of full-size mask logits)"
+                if args.exact_mask_order else "mask feature resampled once per level",
                 "global_batch": world * B, "per_gpu_batch": B, "image": [H, W],
                 "stream_placement_calibration_ms": calibration,
                 "parallelism": "dp%d" % world,

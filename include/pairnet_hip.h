@@ -31,6 +31,10 @@ extern "C" {
 #define PN_ABI_VERSION 9
 int pn_abi_version(void);
 
+/* Scheduling knob (process-wide, performance only): leave `trim` of the persistent GEMM
+ * kernels' resident workgroup slots free for the kernels of concurrent streams. */
+void pn_gemm_set_grid_trim(int trim);
+
 /* ------------------------------------------------------------------------- *
  * Dense contraction (f32 MFMA 32x32x2, exact fp32 accumulate)
  *   C[z][m][n] = act( sum_k (A[z][m][k] + Aadd[m % aadd_rows][k]) * W[z][n][k]

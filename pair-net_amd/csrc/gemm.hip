@@ -686,8 +686,15 @@ static int launch_skinny(const GemmP& p, int batch, hipStream_t s) {
 
 // Persistent launch: at most `wg_per_cu` workgroups per CU (256 CUs), a multiple of 8 so
 // that every XCD gets the same number of them.
+// `pn_gemm_set_grid_trim(t)`: leave t workgroup slots (a multiple of 8, spread over the XCDs)
+// unoccupied, so that the small latency-bound kernels of a concurrent stream (the query
+// chains) find a resident slot without waiting for a kernel boundary.
+static int pn_grid_trim = 0;
+extern "C" void pn_gemm_set_grid_trim(int trim) { pn_grid_trim = trim < 0 ? 0 : trim / 8 * 8; }
+
 static int persistent_grid(int64_t ntiles, int wg_per_cu) {
-  const int64_t cap = 256 * wg_per_cu;
+  int64_t cap = 256 * wg_per_cu - pn_grid_trim;
+  if (cap < 256) cap = 256;
   const int64_t want = (ntiles + 7) / 8 * 8;
   return (int)(want < cap ? want : cap);
 }

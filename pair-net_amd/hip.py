@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
 
 _SIGS = {
     "pn_abi_version": (C.c_int, []),
+    "pn_gemm_set_grid_trim": (None, [_i32]),
     "pn_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "pn_gemm_variant": (C.c_int, [C.POINTER(GemmDesc)]),
     "pn_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
@@ -116,6 +117,11 @@ def lib():
             raise RuntimeError("libpairnet_hip.so ABI mismatch; rebuild")
         _lib = handle
     return _lib
+
+
+def gemm_set_grid_trim(trim):
+    """Leave `trim` persistent-GEMM workgroup slots free for concurrent streams' kernels."""
+    lib().pn_gemm_set_grid_trim(int(trim))
 
 
 def _stream():

@@ -48,10 +48,10 @@ def test_evaluation_oracle_equals_the_reference_functions():
     sys.dont_write_bytecode = True
     for name, attrs in (("mmdet", {}), ("mmdet.core", dict(bbox_overlaps=None)),
                         ("terminaltables", dict(AsciiTable=None))):
-        if name not in sys.modules:
-            m = types.ModuleType(name)
-            m.__dict__.update(attrs)
-            sys.modules[name] = m
+        m = sys.modules.setdefault(name, types.ModuleType(name))   # (ref_shim may have put
+        for k, v in attrs.items():                                 # its own stubs there)
+            if not hasattr(m, k):
+                setattr(m, k, v)
     pkg = types.ModuleType("refeval")
     pkg.__path__ = [os.path.join(ref_shim.REF_ROOT, "pairnet/evaluation")]
     sys.modules["refeval"] = pkg

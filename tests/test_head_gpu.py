@@ -98,9 +98,10 @@ def test_e2e_small_against_reference_golden():
         assert r[0].shape == (200, 5) and float(r[0].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("gemm_mode,conv_algo", [("f32", "winograd"), ("f32", "direct"),
-                                                 ("f32", "winograd4"), ("bf16x3", "winograd")])
-def test_e2e_full_800x1333_against_reference_golden(gemm_mode, conv_algo):
+@pytest.mark.parametrize("gemm_mode,conv_algo,exact_order", [
+    ("f32", "winograd", False), ("f32", "direct", False), ("f32", "winograd4", False),
+    ("bf16x3", "winograd", False), ("f32", "winograd", True)])
+def test_e2e_full_800x1333_against_reference_golden(gemm_mode, conv_algo, exact_order):
     fx = golden("e2e_full")
     head_o, sd, crc = oracle_head(int(fx["weight_seed"]), overrides_of(fx))
     assert crc == int(fx["weight_crc"])
@@ -111,6 +112,9 @@ def test_e2e_full_800x1333_against_reference_golden(gemm_mode, conv_algo):
     metas = [dict(img_shape=(H, W, 3), scale_factor=[2.083] * 4)]
     head = _hip_head(sd)
     head.gemm_mode, head.conv_algo = gemm_mode, conv_algo
+    # (True: attention masks in the reference's operation order -- full-size mask logits,
+    # then the bilinear resize -- instead of the once-resampled mask feature)
+    head.exact_mask_order = exact_order
     cls, masks = head.forward([f.to(DEV) for f in feats], metas)
     torch.cuda.synchronize()
     trace = {}
@@ -120,8 +124,8 @@ def test_e2e_full_800x1333_against_reference_golden(gemm_mode, conv_algo):
     e_imp = _err(cls["importance"], fx["importance"])
     probe = masks["mask"].flatten()[torch.from_numpy(fx["mask_probe_idx"]).to(DEV)]
     e_mask = _err(probe, fx["mask_probe"])
-    print("e2e_full [%s, %s] errors: rel %.3e cls %.3e importance %.3e mask %.3e"
-          % (gemm_mode, conv_algo, e_rel, e_cls, e_imp, e_mask))
+    print("e2e_full [%s, %s, exact_mask_order=%s] errors: rel %.3e cls %.3e importance %.3e "
+          "mask %.3e" % (gemm_mode, conv_algo, exact_order, e_rel, e_cls, e_imp, e_mask))
     assert e_rel < 1e-3 and e_cls < 1e-3 and e_imp < 1e-3
     assert e_mask < 1e-3 * max(1.0, float(np.abs(fx["mask_probe"]).max()))
     ok, exact = tie_aware_topk_match(fx["importance"][0], fx["topk_idx"][0],

@@ -215,6 +215,40 @@ int pn_ffn_ln2_f32(const float* x, const float* W1, const float* b1, const float
                    const float* gamma2, const float* beta2, float* y2, float* scratch, int M,
                    int C, int hidden, float eps, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Row chain: a short program of row-wise dense operations on the decoders' queries
+ * (M rows of 256 channels) in ONE launch, intermediates in LDS.  Replaces the chains
+ * of small nn.Linear / LayerNorm / F.normalize calls between the attention modules of
+ * a decoder layer (facebook_detr.py:311-353 out_proj + residual, :406-408 norms; the
+ * next attention's in_proj), after its FFN (the mask_embed MLP and cls_embed of
+ * forward_head, pairnet_head.py:236-243; the next layer's query projection) and of the
+ * PPN (sub / obj_query_update + F.normalize, pairnet_head.py:322-326).
+ *   buffers: three LDS row buffers 0..2 per 32-row workgroup; in0 -> buffer 0,
+ *            in1 (nullable) -> buffer 1
+ *   op.kind  0 LIN     dst/out = act((src [+ aadd[row % aadd_rows] for output columns >=
+ *                      add_from_col]) W^T + bias) [+ buffer res];  W [N][256], N <= 768;
+ *                      dst (an LDS buffer, -1 = none) needs N == 256; out (global, row
+ *                      stride ldo) may be NULL
+ *            1 LN      LayerNorm over the 256 channels of buffer src -> dst and / or out
+ *            2 L2NORM  src / max(||src||_2, eps)                     -> dst and / or out
+ * Deterministic (fixed summation order). */
+#define PN_CHAIN_MAX_OPS 8
+typedef struct pn_chain_op {
+  int32_t kind, src, dst, res;
+  int32_t N, relu, add_from_col, aadd_rows;
+  const float* W; const float* bias; const float* aadd;
+  const float* gamma; const float* beta;
+  float* out; int64_t ldo;
+  float eps;
+} pn_chain_op;
+typedef struct pn_chain_desc {
+  int32_t nops, M;
+  const float* in0; int64_t ld0;
+  const float* in1; int64_t ld1;
+  pn_chain_op op[PN_CHAIN_MAX_OPS];
+} pn_chain_desc;
+int pn_rowchain_f32(const pn_chain_desc* d, void* stream);
+
 /* y[r][:] = x[r][:] / max(||x[r]||_2, eps)   (F.normalize, pairnet_head.py:325-326) */
 int pn_l2normalize_f32(const float* x, float* y, int64_t rows, int C, float eps,
                        void* stream);

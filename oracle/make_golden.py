@@ -467,15 +467,47 @@ RES_NAMES = ("bboxes", "labels", "rel_pairs", "masks", "pan_img", "r_scores", "r
              "r_dists")
 
 
+def stable_feat_seed(head, sd, first, bs, H, W, metas, margin=1.2e-4, tries=600):
+    """First feature seed >= `first` whose run is not chaotic.  With random weights a
+    resized mask logit can sit within fp32 noise of zero; the attention masks threshold it
+    (pairnet_head.py:244-256 / the sibling heads' forward_head), and at 96x128 (12 keys on
+    the coarsest level) one flipped bit moves the outputs by 0.1.  Every bilinear resize of
+    the run is watched: a seed is accepted when the smallest |resized mask logit| over all
+    layers is >= `margin` (the typical minimum over the ~5e5 logits of a run is 2e-5; 1.2e-4 is
+    an order of magnitude above the ~1e-5 by which an fp32
+    re-association moves these logits), so that no mask bit hangs on rounding."""
+    real = F.interpolate
+    for seed in range(first, first + tries):
+        head.load_state_dict(sd, strict=True)
+        feats = seeded.seeded_feats(seed, bs, H, W)
+        mf_bias = calibrate_mask_bias(head, feats)
+        seen = []
+
+        def watch(x, *a, **k):
+            y = real(x, *a, **k)
+            if k.get("mode", None) == "bilinear" and y.shape[-2:] != tuple(feats[0].shape[-2:]):
+                seen.append(float(y.abs().min()))
+            return y
+        F.interpolate = watch
+        try:
+            with torch.no_grad():
+                head.forward(feats, metas)
+        finally:
+            F.interpolate = real
+        print("feat seed %d: smallest |resized mask logit| %.2e over %d resizes"
+              % (seed, min(seen), len(seen)))
+        if min(seen) >= margin:
+            return seed, feats, mf_bias
+    raise RuntimeError("no stable seed found")
+
+
 def gen_baseline_small():
     head = ref_shim.build_reference_baseline_head()
     shapes = OrderedDict((k, tuple(v.shape)) for k, v in head.state_dict().items())
     sd = seeded.seeded_state_dict(shapes, WEIGHT_SEED + 1)
-    head.load_state_dict(sd, strict=True)
     H, W, bs = 96, 128, 2
-    feats = seeded.seeded_feats(71, bs, H, W)
     metas = [dict(img_shape=(H, W, 3), scale_factor=[2.0, 2.0, 2.0, 2.0])] * bs
-    mf_bias = calibrate_mask_bias(head, feats)
+    feat_seed, feats, mf_bias = stable_feat_seed(head, sd, 71, bs, H, W, metas)
     with torch.no_grad():
         cls, masks = head.forward(feats, metas)
         res = head.get_bboxes(cls, masks, metas)
@@ -483,7 +515,7 @@ def gen_baseline_small():
     probe = torch.from_numpy(np.random.default_rng(72).integers(0, m[0].numel(), 4096))
     top2 = lambda x: (lambda v: (v[..., 0] - v[..., 1]).min())(x.topk(2, dim=-1)[0])
     fg = F.softmax(cls["rel"], -1)[..., 1:].flatten(1)
-    out = dict(weight_seed=WEIGHT_SEED + 1, weight_crc=seeded.checksum(sd), feat_seed=71,
+    out = dict(weight_seed=WEIGHT_SEED + 1, weight_crc=seeded.checksum(sd), feat_seed=feat_seed,
                feat_crc=seeded.checksum(feats), height=H, width=W, batch=bs,
                mask_last=_np(m[-1]), mask_probe_idx=_np(probe),
                mask_probe=_np(m.flatten(1)[:, probe]),

@@ -32,6 +32,22 @@ class GemmDesc(C.Structure):
                 ("splitk_scratch", _vp), ("splitk_scratch_floats", _i64)]
 
 
+CHAIN_MAX_OPS = 8
+CH_LIN, CH_LN, CH_L2NORM = 0, 1, 2
+
+
+class ChainOp(C.Structure):
+    _fields_ = [("kind", _i32), ("src", _i32), ("dst", _i32), ("res", _i32),
+                ("N", _i32), ("relu", _i32), ("add_from_col", _i32), ("aadd_rows", _i32),
+                ("W", _vp), ("bias", _vp), ("aadd", _vp), ("gamma", _vp), ("beta", _vp),
+                ("out", _vp), ("ldo", _i64), ("eps", _f32)]
+
+
+class ChainDesc(C.Structure):
+    _fields_ = [("nops", _i32), ("M", _i32), ("in0", _vp), ("ld0", _i64), ("in1", _vp),
+                ("ld1", _i64), ("op", ChainOp * CHAIN_MAX_OPS)]
+
+
 _SIGS = {
     "pn_abi_version": (C.c_int, []),
     "pn_gemm_set_grid_trim": (None, [_i32]),
@@ -55,6 +71,7 @@ _SIGS = {
     "pn_groupnorm_nblk": (C.c_int, [_i64]),
     "pn_groupnorm_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32,
                                         _i32, _f32, _i32, _i64, _i64, _vp]),
+    "pn_rowchain_f32": (C.c_int, [C.POINTER(ChainDesc), _vp]),
     "pn_l2normalize_f32": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _vp]),
     "pn_ffn_scratch_floats": (_i64, [_i32, _i32]),
     "pn_ffn_ln_f32": (C.c_int, [_vp] * 9 + [_i32, _i32, _i32, _f32, _vp]),
@@ -659,3 +676,52 @@ def triplet_match(ptrip, gtrip, P, G, inter, area_p, area_g, ld_inter, ps, po, g
                                   _ptr(po, i32), _ptr(gs, i32), _ptr(go, i32), float(thr),
                                   int(phrdet), int(ignore_rel), _ptr(match, torch.uint8),
                                   _stream()), "pn_triplet_match")
+
+
+def chain_lin(src, W, bias=None, dst=-1, out=None, res=-1, relu=False, aadd=None,
+              add_from_col=0):
+    """One LIN op of a row chain (see include/pairnet_hip.h pn_chain_op); tensors supply
+    pointers, `out` is a 2-D row-major view."""
+    return dict(kind=CH_LIN, src=src, dst=dst, res=res, N=W.shape[0], relu=int(relu), W=W,
+                bias=bias, aadd=aadd, add_from_col=add_from_col, out=out)
+
+
+def chain_ln(src, gamma, beta, dst=-1, out=None, eps=1e-5):
+    return dict(kind=CH_LN, src=src, dst=dst, gamma=gamma, beta=beta, out=out, eps=eps)
+
+
+def chain_l2norm(src, dst=-1, out=None, eps=1e-12):
+    return dict(kind=CH_L2NORM, src=src, dst=dst, out=out, eps=eps)
+
+
+def chain_desc(in0, ops, in1=None, M=None):
+    """Build (once, e.g. per plan) the descriptor of a row-chain launch."""
+    d = ChainDesc()
+    d.M = in0.shape[0] if M is None else M
+    d.nops = len(ops)
+    assert 0 < d.nops <= CHAIN_MAX_OPS
+    d.in0, d.ld0 = _ptr(in0), _rowmajor(in0)[1]
+    d.in1, d.ld1 = (_ptr(in1), _rowmajor(in1)[1]) if in1 is not None else (None, 0)
+    for i, o in enumerate(ops):
+        c = d.op[i]
+        c.kind, c.src, c.dst, c.res = o["kind"], o["src"], o.get("dst", -1), o.get("res", -1)
+        c.N, c.relu = o.get("N", 256), o.get("relu", 0)
+        a = o.get("aadd")
+        c.aadd, c.aadd_rows = _ptr(a), (a.shape[0] if a is not None else 0)
+        c.add_from_col = o.get("add_from_col", 0)
+        if a is not None:
+            assert a.stride(0) == 256 and a.stride(1) == 1
+        w = o.get("W")
+        if w is not None:
+            assert w.shape[1] == 256 and w.stride(0) == 256 and w.stride(1) == 1, w.shape
+        c.W, c.bias = _ptr(w), _ptr(o.get("bias"))
+        c.gamma, c.beta = _ptr(o.get("gamma")), _ptr(o.get("beta"))
+        out = o.get("out")
+        c.out, c.ldo = (_ptr(out), _rowmajor(out)[1]) if out is not None else (None, 0)
+        c.eps = o.get("eps", 0.0)
+    d._keep = (in0, in1, ops)      # the tensors the raw pointers refer to
+    return d
+
+
+def chain(desc):
+    _check(lib().pn_rowchain_f32(C.byref(desc), _stream()), "pn_rowchain_f32")

@@ -389,6 +389,69 @@ def test_mmcv_shaped_msda_on_the_golden_fixture_equals_the_fused_entry(hip):
     close(out, _run_msda(hip, value, off, logits, shapes).cpu(), 2e-6, "mmcv-shaped vs fused entry")
 
 
+# ----------------------------------------------------------------------------- row chain
+@pytest.mark.parametrize("M", [100, 200, 37, 321])
+def test_rowchain_programs(hip, M):
+    """pn_rowchain_f32: the three chain shapes the decoders use, against torch fp32."""
+    x, att = R(M, 256, seed=1), R(M, 256, seed=2)
+    pos = R(100, 256, seed=3)
+    Wo, bo = R(256, 256, seed=4, lo=-0.1, hi=0.1), R(256, seed=5)
+    g, b = R(256, seed=6, lo=0.5, hi=1.5), R(256, seed=7)
+    Wv, bv = R(768, 256, seed=8, lo=-0.1, hi=0.1), R(768, seed=9)
+    prow = pos[torch.arange(M) % 100]
+    D = lambda t: t.to(DEV)
+    # (1) out_proj + residual -> LayerNorm -> [V | Q | K] projection, pos on columns >= 256
+    y = att @ Wo.t() + bo + x
+    x1 = F.layer_norm(y, (256,), g, b, 1e-5)
+    vqk = torch.cat([x1 @ Wv[:256].t(), (x1 + prow) @ Wv[256:].t()], 1) + bv
+    o_x1, o_vqk = torch.empty(M, 256, device=DEV), torch.empty(M, 768, device=DEV)
+    dW = [D(t) for t in (Wo, bo, g, b, Wv, bv, pos)]
+    desc = hip.chain_desc(D(att), [
+        hip.chain_lin(0, dW[0], dW[1], dst=2, res=1),
+        hip.chain_ln(2, dW[2], dW[3], dst=2, out=o_x1),
+        hip.chain_lin(2, dW[4], dW[5], out=o_vqk, aadd=dW[6], add_from_col=256)], in1=D(x))
+    hip.chain(desc)
+    close(o_x1, x1, 2e-6, "chain: out_proj + LN")
+    close(o_vqk, vqk, 3e-6, "chain: vqk projection")
+    # (2) three-layer MLP on buffer 1 + a projection of (buffer 0 + pos) + a 134-wide head
+    W1, W2, W3 = (R(256, 256, seed=s, lo=-0.1, hi=0.1) for s in (11, 12, 13))
+    b1, b2, b3 = (R(256, seed=s) for s in (14, 15, 16))
+    Wq, bq = R(256, 256, seed=17, lo=-0.1, hi=0.1), R(256, seed=18)
+    Wc, bc = R(134, 256, seed=19, lo=-0.1, hi=0.1), R(134, seed=20)
+    qn = att
+    me = torch.relu(torch.relu(qn @ W1.t() + b1) @ W2.t() + b2) @ W3.t() + b3
+    qp = (x + prow) @ Wq.t() + bq
+    cls = qn @ Wc.t() + bc
+    o_me, o_qp, o_cls = (torch.empty(M, n, device=DEV) for n in (256, 256, 134))
+    dW = [D(t) for t in (W1, b1, W2, b2, W3, b3, Wq, bq, Wc, bc, pos)]
+    desc = hip.chain_desc(D(x), [
+        hip.chain_lin(1, dW[8], dW[9], out=o_cls),
+        hip.chain_lin(0, dW[6], dW[7], out=o_qp, aadd=dW[10], add_from_col=0),
+        hip.chain_lin(1, dW[0], dW[1], dst=2, relu=True),
+        hip.chain_lin(2, dW[2], dW[3], dst=0, relu=True),
+        hip.chain_lin(0, dW[4], dW[5], out=o_me)], in1=D(qn))
+    hip.chain(desc)
+    close(o_me, me, 3e-6, "chain: mask MLP")
+    close(o_qp, qp, 3e-6, "chain: query projection")
+    close(o_cls, cls, 3e-6, "chain: class head")
+    # (3) MLP + L2 normalisation (the PPN's sub / obj embeddings)
+    emb = F.normalize(torch.relu(torch.relu(x @ W1.t() + b1) @ W2.t() + b2) @ W3.t() + b3,
+                      p=2, dim=-1, eps=1e-12)
+    o_emb = torch.empty(M, 256, device=DEV)
+    desc = hip.chain_desc(D(x), [
+        hip.chain_lin(0, dW[0], dW[1], dst=1, relu=True),
+        hip.chain_lin(1, dW[2], dW[3], dst=2, relu=True),
+        hip.chain_lin(2, dW[4], dW[5], dst=1),
+        hip.chain_l2norm(1, out=o_emb)])
+    hip.chain(desc)
+    close(o_emb, emb, 2e-6, "chain: MLP + l2norm")
+    # LayerNorm is k_layernorm256's arithmetic bit for bit
+    ln_a, ln_b = torch.empty(M, 256, device=DEV), torch.empty(M, 256, device=DEV)
+    hip.layernorm(D(x), D(g), D(b), ln_a)
+    hip.chain(hip.chain_desc(D(x), [hip.chain_ln(0, D(g), D(b), out=ln_b)]))
+    assert torch.equal(ln_a, ln_b)
+
+
 # ----------------------------------------------------------------------------- PE / resize
 def test_sine_pe(hip):
     pe = L.SinePositionalEncoding(128, normalize=True)

@@ -94,9 +94,9 @@ def main():
                     help="algorithm of the 3x3 FPN convolution (default: the head's)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the stages of consecutive batches back to back on one stream")
-    ap.add_argument("--depth", type=int, default=3, help="batches in flight in the pipeline")
-    ap.add_argument("--a-streams", type=int, default=1,
-                    help="streams that stage A of consecutive batches alternates between")
+    ap.add_argument("--depth", type=int, default=4, help="batches in flight in the pipeline")
+    ap.add_argument("--a-streams", type=int, default=2,
+                    help="streams that backbone + stage A of consecutive batches alternate between")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly")
     ap.add_argument("--exact-mask-order", action="store_true",
                     help="attention masks in the reference's operation order (full-size mask "
@@ -205,19 +205,27 @@ def main():
         elif with_backbone:
             # two chip-filling kernel sequences on different streams time-slice badly
             # (DESIGN.md 6a): the backbone goes in front of stage A on its stream
-            with torch.cuda.stream(engine.streams_a[0]):
-                res = engine.submit(backbone(img), metas)
+            # (each stage-A stream has its own set of backbone buffers)
+            sl = engine.count % len(engine.streams_a)
+            with torch.cuda.stream(engine.streams_a[sl]):
+                res = engine.submit(backbone(img, slot=sl), metas)
+                if res is not None:   # (results are ordered behind the submitting stream)
+                    gather(res, *pair_ids(head._last_plan))
+            return res
         else:
             res = engine.submit(feats, metas)
         if res is not None:
             gather(res, *pair_ids(head._last_plan))
         return res
 
+    last = {}
+
     def drain():
         if engine is not None:
             while engine.queue:
                 res = engine._finish(engine.queue.pop(0))
                 gather(res, *pair_ids(head._last_plan))
+                last["res"] = res
 
     # ---- warm-up (graph capture happens in the first two steps), then the stream ->
     # hardware-queue placement of the pipeline is chosen empirically (pipeline.py) ----
@@ -258,6 +266,25 @@ def main():
         elapsed = float(t.item())
     records = gatherer.records_gathered if gatherer is not None else 0
 
+    # ---- the pipelined schedule only reorders launches: its last result must equal, bit for
+    # bit, what one eager single-stream call gives for the same input ----
+    pipeline_check = None
+    if rank == 0 and engine is not None and "res" in last:
+        got = [[t.clone() for t in (r[1], r[7], r[4])] for r in last["res"]]
+        torch.cuda.synchronize()
+        g0 = head.use_graphs
+        head.use_graphs = False
+        ref = head.simple_test_bboxes(backbone(img, slot=7) if backbone is not None else feats,
+                                      metas)
+        torch.cuda.synchronize()
+        head.use_graphs = g0
+        same = all(torch.equal(a, b) for rg, rr in zip(got, ref)
+                   for a, b in zip(rg, (rr[1], rr[7], rr[4])))
+        pipeline_check = ("labels / rel_dists / pan_img of the last pipelined batch are bitwise "
+                          "the eager single-stream result" if same else "MISMATCH")
+        if not same:
+            raise SystemExit("pipelined result differs from the eager single-stream result")
+
     # ---- secondary: the head alone on the resident pyramid (round 1's headline) ----
     head_only = None
     if args.path == "image" and world == 1:
@@ -282,13 +309,17 @@ def main():
             pipe = TestPipeline(device=dev)
             raw = torch.randint(0, 256, (h0, w0, 3), generator=g, dtype=torch.uint8).to(dev)
 
+            imgs = [img] + [torch.empty_like(img) for _ in range(
+                len(engine.streams_a) - 1 if engine is not None else 0)]
+
             def raw_step():
-                with torch.cuda.stream(engine.streams_a[0] if engine is not None
+                sl = engine.count % len(engine.streams_a) if engine is not None else 0
+                with torch.cuda.stream(engine.streams_a[sl] if engine is not None
                                        else torch.cuda.current_stream()):
-                    _, m = pipe(raw, out=img)
+                    _, m = pipe(raw, out=imgs[sl])
                     if engine is None:
-                        return head.simple_test_bboxes(backbone(img), m)
-                    return engine.submit(backbone(img), m)
+                        return head.simple_test_bboxes(backbone(imgs[sl]), m)
+                    return engine.submit(backbone(imgs[sl], slot=sl), m)
             n = min(args.steps, 100)
             for _ in range(4):
                 raw_step()
@@ -362,8 +393,9 @@ def main():
                 "parallelism": "dp%d" % world,
                 "schedule": ("eager" if args.no_graphs else "hipGraph replay per stage") + (
                     ", single stream" if args.no_pipeline else
-                    ", %d-stream pipeline (backbone + stage A of batch i beside the query "
-                    "chains of the %d previous batches)" % (args.depth, args.depth - 1)),
+                    ", %d-stream pipeline: backbone + stage A of consecutive batches alternate "
+                    "between %d stream(s), their query chains run on %d more"
+                    % (args.depth, args.a_streams, args.depth - args.a_streams)),
                 "collective": ("RCCL all-gather of triplet records, once per step"
                                if world > 1 and backend == "nccl" else
                                "gloo all-gather (functional check)" if world > 1 else "none")},
@@ -371,6 +403,7 @@ def main():
             "dist_backend": backend if world > 1 else None,
             "triplet_records_gathered": records,
             "triplet_record_bytes": 4 * gatherer.L if gatherer is not None else None,
+            "pipeline_check": pipeline_check,
         }
         if head_only is not None:
             out["head_only"] = head_only

@@ -138,8 +138,8 @@ class ResNet50Hip:
     class _Plan:
         pass
 
-    def _plan(self, B, H, W):
-        key = (B, H, W)
+    def _plan(self, B, H, W, slot=0):
+        key = (B, H, W, slot)
         if key in self._plans:
             return self._plans[key]
         if self.w is None:
@@ -173,17 +173,18 @@ class ResNet50Hip:
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     @hip.on_device
-    def forward(self, img):
+    def forward(self, img, slot=0):
         """img [B,3,H,W] fp32 NCHW on the GPU -> (C2, C3, C4, C5) NCHW-shaped tensors in
-        channels_last memory format (views of per-shape buffers that the next call
-        overwrites)."""
+        channels_last memory format (views of per-(shape, slot) buffers that the next call
+        with the same slot overwrites: callers that keep several images in flight on
+        different streams give each stream its own `slot`)."""
         if not img.is_cuda or img.dtype != torch.float32 or img.dim() != 4 or img.shape[1] != 3:
             raise RuntimeError("img must be a [B,3,H,W] fp32 device tensor")
         if self.device is None:
             self.to(img.device)
         img = img.contiguous()
         B, _, H, W = img.shape
-        pl = self._plan(B, H, W)
+        pl = self._plan(B, H, W, slot)
         if not self.use_graphs:
             return self._run(img, pl)
         # hipGraph replay of the ~55 launches: captured on the caller's image buffer when it

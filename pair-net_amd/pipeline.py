@@ -6,14 +6,23 @@ sequential query chain of the two decoders, PPN, top-k) is ~200 latency-bound la
 that each occupy a handful of CUs, followed by the post-processing (`get_bboxes`).
 Run back to back, stage B leaves most of the 256 CUs idle; run beside stage A, each of
 its small kernels queues behind resident GEMM workgroups, so its chain stretches to
-about twice its stand-alone time.  `PipelinedHead(depth=3)` therefore keeps THREE
-batches in flight on three HIP streams and three buffer sets ("slots"):
+about twice its stand-alone time.  `PipelinedHead(depth=4, a_streams=2)` therefore keeps
+FOUR batches in flight on four HIP streams and four buffer sets ("slots"):
 
-    stream A :  A(i)                      stage A of the newest batch
-    stream B0:  B(i-1)                    query chain of the previous batch ...
-    stream B1:  B(i-2), get_bboxes(i-2)   ... and of the one before, whose results
-                                          submit(i) returns (its host syncs only wait
-                                          for work queued two submissions ago)
+    stream A0:  [backbone(i)]   A(i)      producer + stage A of the even batches ...
+    stream A1:  [backbone(i-1)] A(i-1)    ... and of the odd ones: two chip-filling kernel
+                                          sequences side by side, so that the HBM-bound
+                                          kernels of one (norms, resampling, deformable
+                                          sampling, Winograd transforms) and its launch
+                                          ramps / tails overlap the other's MFMA GEMMs
+    stream B0:  B(i-2)                    query chain of an older batch ...
+    stream B1:  B(i-3), get_bboxes(i-3)   ... and of the oldest, whose results submit(i)
+                                          returns (its host syncs only wait for work
+                                          queued three submissions ago)
+
+(Measured on MI355X, image tensor -> triplets: 160 images/s with one stage-A stream and
+depth 3, 189 with two and depth 4; two stage-A streams with ONE chain stream -- depth 3 --
+lose: 145.)
 
 Results are exactly those of `CrossHead2.simple_test_bboxes` (bitwise: scheduling
 only), returned `depth-1` submissions late; `flush()` drains the rest.  Images are
@@ -26,7 +35,7 @@ from .hip import on_device
 
 
 class PipelinedHead:
-    def __init__(self, head, depth=3, a_streams=1, grid_trim=32):
+    def __init__(self, head, depth=4, a_streams=2, grid_trim=64):
         if head.device is None or head.device.type != "cuda":
             raise RuntimeError("PipelinedHead needs a head on an MI355X (.to('cuda:N'))")
         if depth < 2 or not 1 <= a_streams < depth:
@@ -46,9 +55,9 @@ class PipelinedHead:
         self.queue = []   # per in-flight batch: dict(slot, pl, metas, rescale, b_started)
         # The persistent GEMM kernels of stage A fill every workgroup slot of the chip, so a
         # query-chain kernel of the other streams only gets on at a kernel boundary.  Leaving
-        # 32 of the 1024 slots free lets the chains run beside stage A: +1.5-2 % images/s
-        # (measured: 158.2 / 159.3 / 160.5 / 160.4 at 0 / 16 / 32 / 48 free slots, 154.7 at
-        # 256).  Process-wide knob of the library.
+        # 64 of the 1024 slots free lets the chains run beside stage A (measured with one
+        # stage-A stream: 158.2 / 160.5 / 160.4 images/s at 0 / 32 / 48 free slots, 154.7 at
+        # 256; with two: 188.2 / 189.5 / 189.7 at 0 / 64 / 128).  Process-wide library knob.
         hip.gemm_set_grid_trim(grid_trim)
 
     @torch.no_grad()
@@ -101,7 +110,8 @@ class PipelinedHead:
     @on_device
     def submit(self, feats, img_metas, rescale=False):
         """Queue one batch; returns the result list of the batch submitted depth-1 calls
-        earlier (None while the pipeline fills)."""
+        earlier (None while the pipeline fills).  The returned tensors are ordered behind
+        the stream submit() was called on (torch's current stream): consume them there."""
         head = self.head
         B, shapes, hw2 = head._check_feats(feats, img_metas)
         idx = self.count

@@ -156,8 +156,8 @@ class SwinTransformerHip:
     class _Plan:
         pass
 
-    def _plan(self, B, H, W):
-        key = (B, H, W)
+    def _plan(self, B, H, W, slot=0):
+        key = (B, H, W, slot)
         if key in self._plans:
             return self._plans[key]
         if self.w is None:
@@ -188,7 +188,7 @@ class SwinTransformerHip:
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     @hip.on_device
-    def forward(self, img):
+    def forward(self, img, slot=0):
         """img [B,3,H,W] fp32 NCHW on the GPU -> one NCHW-shaped, channels_last feature map
         per out index (views of per-shape buffers that the next call overwrites)."""
         if not img.is_cuda or img.dtype != torch.float32 or img.dim() != 4 or img.shape[1] != 3:
@@ -197,7 +197,7 @@ class SwinTransformerHip:
             self.to(img.device)
         img = img.contiguous()
         B, _, H, W = img.shape
-        pl = self._plan(B, H, W)
+        pl = self._plan(B, H, W, slot)
         w, ws, sp = self.w, self.ws, self.gemm_mode == "bf16x3"
         lin = lambda x, wk, bk, out, **kw: hip.linear(x, w[wk], w[bk] if bk else None, out,
                                                       split=sp, scratch=pl.scratch, **kw)

@@ -185,3 +185,23 @@ def test_pipelined_detector_with_reused_backbone_buffers():
         for a, b in zip(want, got):
             for x, y in zip(a, b):
                 assert torch.equal(x.cpu(), y.cpu())
+    # the bench's schedule: two stage-A streams, the backbone issued ON them (hipGraph replay,
+    # one backbone buffer slot per stream), two chain streams
+    head.use_graphs = net.use_graphs = True
+    pipe = PipelinedHead(head, depth=4, a_streams=2)
+    for rep in range(3):
+        got = []
+        for im in imgs:
+            sl = pipe.count % len(pipe.streams_a)
+            pipe.streams_a[sl].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(pipe.streams_a[sl]):
+                o = pipe.submit(net(im, slot=sl), metas)
+                if o is not None:    # (the results are ordered behind THIS stream, the
+                    # one submit() was called on: consume them on it)
+                    got.append([t.clone() if t.is_cuda else t for t in o[0]])
+        got += [o[0] for o in pipe.flush()]
+        torch.cuda.synchronize()
+        assert len(got) == len(want)
+        for a, b in zip(want, got):
+            for x, y in zip(a, b):
+                assert torch.equal(x.cpu(), y.cpu()), rep

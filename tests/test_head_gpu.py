@@ -313,8 +313,8 @@ def test_graph_replay_and_two_stream_pipeline_are_bitwise_the_eager_path():
             for re_, rg in zip(e, g):
                 for n, x, y in zip(names, re_, rg):
                     assert torch.equal(x, y), (rep, n)
-    for depth in (2, 3):
-        eng = PipelinedHead(head, depth=depth)
+    for depth, a_streams in ((2, 1), (3, 1), (4, 2), (5, 2)):
+        eng = PipelinedHead(head, depth=depth, a_streams=a_streams)
         for rep in range(3):
             outs = []
             for b in batches:
@@ -326,7 +326,7 @@ def test_graph_replay_and_two_stream_pipeline_are_bitwise_the_eager_path():
             for e, g in zip(eager, outs):
                 for re_, rg in zip(e, g):
                     for n, x, y in zip(names, re_, rg):
-                        assert torch.equal(x, y), (depth, rep, n)
+                        assert torch.equal(x, y), (depth, a_streams, rep, n)
 
 
 def test_graph_reads_reused_feature_buffers_in_place():

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 9
+#define PN_ABI_VERSION 10
 int pn_abi_version(void);
 
 /* Scheduling knob (process-wide, performance only): leave `trim` of the persistent GEMM
@@ -357,9 +357,10 @@ int pn_mlearner_last_f32(const float* in, const float* w3, const float* b3,
 /* Top-k pair selection (pairnet_head.py:334-340): for each image the k largest of
  * the n = Q*Q scores, sorted descending; ties broken by the smaller flat index
  * (torch leaves tie order unspecified).  idx/sub/obj [B][k] int64:
- * sub = idx / Q (trunc), obj = idx % Q.  n <= 65536, k <= 256. */
+ * sub = idx / Q (trunc), obj = idx % Q; pair (nullable) [B][2k] = [sub | obj], the row
+ * list of the pair-feature gather (:342-351).  n <= 65536, k <= 256. */
 int pn_topk_pairs(const float* scores, int64_t* idx, int64_t* sub, int64_t* obj,
-                  int B, int Q, int k, void* stream);
+                  int64_t* pair, int B, int Q, int k, void* stream);
 /* General form: k largest of n scores per row; quot = idx / div, rem = idx % div
  * (triplet ranking of the sibling head, relation_heads/baseline.py:1033-1037). */
 int pn_topk_f32(const float* scores, int64_t* idx, int64_t* quot, int64_t* rem, int B,

@@ -89,7 +89,8 @@ __device__ __forceinline__ unsigned long long topk_key(float v, int idx) {
 __global__ __launch_bounds__(1024) void k_topk_pairs(const float* __restrict__ scores,
                                                      int64_t* __restrict__ idx_out,
                                                      int64_t* __restrict__ sub_out,
-                                                     int64_t* __restrict__ obj_out, int n, int Q,
+                                                     int64_t* __restrict__ obj_out,
+                                                     int64_t* __restrict__ pair_out, int n, int Q,
                                                      int k) {
   __shared__ int hist[256];
   __shared__ unsigned long long sel[256];
@@ -165,15 +166,19 @@ __global__ __launch_bounds__(1024) void k_topk_pairs(const float* __restrict__ s
     idx_out[o] = idx;
     sub_out[o] = idx / Q;
     obj_out[o] = idx % Q;
+    if (pair_out) {   // [B][sub k | obj k]: the row list of the pair-feature gather
+      pair_out[(int64_t)blockIdx.x * 2 * k + tid] = idx / Q;
+      pair_out[(int64_t)blockIdx.x * 2 * k + k + tid] = idx % Q;
+    }
   }
 }
 
 extern "C" int pn_topk_pairs(const float* scores, int64_t* idx, int64_t* sub, int64_t* obj,
-                             int B, int Q, int k, void* stream) {
+                             int64_t* pair, int B, int Q, int k, void* stream) {
   if (!scores || !idx || !sub || !obj || B <= 0 || Q <= 0) return PN_BAD_ARG;
   if ((int64_t)Q * Q > 65536 || k <= 0 || k > 256 || k > Q * Q) return PN_BAD_ARG;
   hipLaunchKernelGGL(k_topk_pairs, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores, idx,
-                     sub, obj, Q * Q, Q, k);
+                     sub, obj, pair, Q * Q, Q, k);
   return PN_LAUNCH_CHECK();
 }
 
@@ -185,7 +190,7 @@ extern "C" int pn_topk_f32(const float* scores, int64_t* idx, int64_t* quot, int
   if (!scores || !idx || !quot || !rem || B <= 0 || n <= 0 || div <= 0) return PN_BAD_ARG;
   if (n > 65536 || k <= 0 || k > 256 || k > n) return PN_BAD_ARG;
   hipLaunchKernelGGL(k_topk_pairs, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores, idx,
-                     quot, rem, n, div, k);
+                     quot, rem, (int64_t*)nullptr, n, div, k);
   return PN_LAUNCH_CHECK();
 }
 

@@ -397,6 +397,7 @@ class CrossHead2:
         pl.Vp = [E(B, pl.N[i % 3], 256) for i in range(nd)]
         BQ = B * Q
         pl.q, pl.q1, pl.q2, pl.qy = E(BQ, 256), E(BQ, 256), E(BQ, 256), E(BQ, 256)
+        pl.q0 = w["query_feat.weight"].unsqueeze(0).expand(B, Q, 256).reshape(BQ, 256).contiguous()
         pl.qn, pl.m1, pl.m2, pl.me = E(BQ, 256), E(BQ, 256), E(BQ, 256), E(BQ, 256)
         pl.Qp, pl.att, pl.Qp0 = E(BQ, 256), E(BQ, 256), E(BQ, 256)
         pl.VQK = E(BQ, 768)
@@ -429,6 +430,8 @@ class CrossHead2:
         # ---- relation decoder ----
         BR = B * R
         pl.r, pl.r1, pl.r2, pl.ry = E(BR, 256), E(BR, 256), E(BR, 256), E(BR, 256)
+        pl.r0 = self.w["rel_query_feat.weight"].unsqueeze(0).expand(B, R, 256).reshape(
+            BR, 256).contiguous()
         pl.rQp, pl.ratt = E(BR, 256), E(BR, 256)
         pl.rVQK = E(BR, 768)
         pl.rh = E(hip.ffn_scratch_floats(BR, self.rel_ffn))
@@ -556,11 +559,13 @@ class CrossHead2:
         hip.mask_pack(pl.ML, pl.bits, pl.rowall, B * Q, n)
 
     def _layer(self, pre, x, xpos, x1, x2, y, Qp, VQK, att, hbuf, Kp, ldk, Vp, ldv, Nk, B, nq,
-               bits, rowall, scr, ffn, self_first=False, post=None):
+               bits, rowall, scr, ffn, self_first=False, post=None, x_in=None):
         """One post-norm decoder layer (facebook_detr.py:378-432 semantics); x is updated
         in place.  Operation order (cross_attn, norm, self_attn, norm, ffn, norm), or with
         `self_first` (self_attn, norm, cross_attn, norm, ffn, norm); attentions.<j> is the
-        j-th attention in that order, as mmcv's BaseTransformerLayer numbers them."""
+        j-th attention in that order, as mmcv's BaseTransformerLayer numbers them.  `x_in`:
+        read the layer's input from there instead of x (the first layer reads the constant
+        initial queries in place: no per-image copy into x)."""
         w = self.w
         scale = 1.0 / math.sqrt(32.0)
         ac = pre + "attentions.%d.attn." % (1 if self_first else 0)
@@ -582,11 +587,12 @@ class CrossHead2:
             hip.linear(att, w[as_ + "out_proj.weight"], w[as_ + "out_proj.bias"], y, res=src)
             hip.layernorm(y, w[pre + ns + "weight"], w[pre + ns + "bias"], dst)
 
+        x_in = x if x_in is None else x_in
         if self_first:
-            self_attn(x, x1)
+            self_attn(x_in, x1)
             cross(x1, x2)
         else:
-            cross(x, x1)
+            cross(x_in, x1)
             self_attn(x1, x2)
         hip.ffn_ln(x2, w[pre + "ffns.0.layers.0.0.weight"], w[pre + "ffns.0.layers.0.0.bias"],
                    w[pre + "ffns.0.layers.1.weight"], w[pre + "ffns.0.layers.1.bias"],
@@ -640,15 +646,16 @@ class CrossHead2:
         w, B, Q = self.w, pl.B, self.num_obj_query
         if self.fuse_chains and not all_layers:
             return self._object_decoder_fused(pl, final_head)
-        pl.q.view(B, Q, 256).copy_(w["query_feat.weight"].unsqueeze(0).expand(B, Q, 256))
         qpos = w["query_embed.weight"]
         exact = self.exact_mask_order
-        # mask embedding of the INITIAL queries (learned, input-independent): computed on the
-        # plan's first call and kept (a new state dict drops the plans)
+        # the INITIAL queries are learned constants (pl.q0: `query_feat` repeated over the
+        # batch, filled when the plan is made; the first layer reads them in place), and so is
+        # their mask embedding: computed on the plan's first call and kept (a new state dict
+        # drops the plans)
         if exact:
-            self._head_embed(pl.q, pl, False, True)
+            self._head_embed(pl.q0, pl, False, True)
         elif pl.me0 is None:
-            self._head_embed(pl.q, pl, False, False)
+            self._head_embed(pl.q0, pl, False, False)
             pl.me0 = pl.me.clone()
         last = self.num_dec_layers - 1
         mp = None
@@ -660,7 +667,8 @@ class CrossHead2:
             self._attn_mask(pl, l, mp, me=pl.me0 if (i == 0 and not exact) else None)
             self._layer("transformer_decoder.layers.%d." % i, pl.q, qpos, pl.q1, pl.q2, pl.qy,
                         pl.Qp, pl.VQK, pl.att, pl.hq, pl.Kp[i], 256, pl.Vp[i], 256, pl.N[l], B,
-                        Q, pl.bits, pl.rowall, pl.scr, self.dec_ffn, post=post)
+                        Q, pl.bits, pl.rowall, pl.scr, self.dec_ffn, post=post,
+                        x_in=pl.q0 if i == 0 else None)
             if all_layers:
                 mp = pl.MP_all[i]
                 self._head_embed(pl.q, pl, True, True, pl.cls_all[i], mp, normed=True)
@@ -833,10 +841,8 @@ class CrossHead2:
         hip.conv2d_nhwc(pl.c1, w[ml + "1.0.weight"], w[ml + "1.0.bias"], pl.c2, B, Q, Q, 64, 64,
                         7, 7, 3, True)
         hip.mlearner_last(pl.c2, w[ml + "2.0.weight"], w[ml + "2.0.bias"], pl.imp, B, Q)
-        hip.topk_pairs(pl.imp, pl.topk_idx, pl.sub_pos, pl.obj_pos, B, Q, R)
+        hip.topk_pairs(pl.imp, pl.topk_idx, pl.sub_pos, pl.obj_pos, B, Q, R, pair=pl.pair_idx)
         # ---- pair features (:342-351) ----
-        pl.pair_idx[:, :R].copy_(pl.sub_pos)
-        pl.pair_idx[:, R:].copy_(pl.obj_pos)
         hip.gather_rows(pl.q, pl.pair_idx, pl.pair, B, Q, 2 * R, 256)
 
     def _relation_decoder(self, pl):
@@ -845,7 +851,6 @@ class CrossHead2:
         w, B, Q, R = self.w, pl.B, self.num_obj_query, self.num_rel_query
         if self.fuse_chains and type(self)._relation_decoder is CrossHead2._relation_decoder:
             return self._relation_decoder_fused(pl)
-        pl.r.view(B, R, 256).copy_(w["rel_query_feat.weight"].unsqueeze(0).expand(B, R, 256))
         rpos, ppos = w["rel_query_embed.weight"], w["rel_query_embed2.weight"]
         # the pair features' [V | K] projections of all six layers (layer-independent input):
         # one grouped launch
@@ -859,7 +864,7 @@ class CrossHead2:
             pvk = pl.pVK_all[i]
             self._layer(pre, pl.r, rpos, pl.r1, pl.r2, pl.ry, pl.rQp, pl.rVQK, pl.ratt, pl.rh,
                         pvk[:, 256:], 512, pvk, 512, 2 * R, B, R, None, None, pl.scr,
-                        self.rel_ffn)
+                        self.rel_ffn, x_in=pl.r0 if i == 0 else None)
         hip.linear(pl.r, w["rel_cls_embed.weight"], w["rel_cls_embed.bias"], pl.rel.view(B * R, -1))
         # ---- output gathers (:380-403) ----
         nc = self.num_classes + 1

@@ -89,7 +89,7 @@ _SIGS = {
                                    _i64, _vp, _i32, _i32, _i32, _f32, _vp]),
     "pn_mlearner_first_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_mlearner_last_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "pn_topk_pairs": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "pn_topk_pairs": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_topk_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_gather_rows_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     "pn_cls_argmax_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
@@ -113,7 +113,7 @@ _SIGS = {
     "pn_mask_iou_counts": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 9   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 10   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -550,9 +550,10 @@ def mlearner_last(x, w3, b3, out, B, S):
                                       _stream()), "pn_mlearner_last_f32")
 
 
-def topk_pairs(scores, idx, sub, obj, B, Q, k):
+def topk_pairs(scores, idx, sub, obj, B, Q, k, pair=None):
     _check(lib().pn_topk_pairs(_ptr(scores), _ptr(idx, torch.int64), _ptr(sub, torch.int64),
-                               _ptr(obj, torch.int64), B, Q, k, _stream()), "pn_topk_pairs")
+                               _ptr(obj, torch.int64), _ptr(pair, torch.int64), B, Q, k,
+                               _stream()), "pn_topk_pairs")
 
 
 def topk(scores, idx, quot, rem, B, n, div, k):

@@ -61,7 +61,7 @@ class PipelinedHead:
         hip.gemm_set_grid_trim(grid_trim)
 
     @torch.no_grad()
-    def calibrate(self, feats, img_metas, steps=8):
+    def calibrate(self, feats, img_metas, steps=8, submit=None):
         """Pick the stream -> hardware-queue placement empirically.  HIP spreads streams
         round-robin over (by default) 4 hardware queues, and which of them carries stage A
         and which the query chains changes the pipelined step time by ~8 % on MI355X
@@ -69,7 +69,9 @@ class PipelinedHead:
         created streams sit on the four queues; every rotation of the roles over them is
         timed on `steps` batches of the given input and the fastest one is kept.  Call it
         once during warm-up (the pipeline must be empty); returns the per-rotation times in
-        ms per batch."""
+        ms per batch.  `submit`: a callable that queues ONE batch the way the caller's loop
+        does (e.g. with its backbone in front, on the stage-A stream of that batch), so that
+        the placement is chosen for the real workload; default: `self.submit(feats, metas)`."""
         import time
         if self.queue:
             raise RuntimeError("calibrate() needs an empty pipeline: call flush() first")
@@ -86,13 +88,14 @@ class PipelinedHead:
         for r, cand in enumerate(cands):
             order = [pool[i] for i in cand]
             self.streams_a, self.streams_b = order[:na], order[na:]
+            one = submit if submit is not None else (lambda: self.submit(feats, img_metas))
             for _ in range(3):
-                self.submit(feats, img_metas)
+                one()
             self.flush()
             torch.cuda.synchronize(dev)
             t = time.perf_counter()
             for _ in range(steps):
-                self.submit(feats, img_metas)
+                one()
             self.flush()
             torch.cuda.synchronize(dev)
             times.append(1e3 * (time.perf_counter() - t) / steps)

@@ -80,8 +80,7 @@ class PSGTrHead2(CrossHead2):
     def _stage_b(self, pl):
         w, B, Q = self.w, pl.B, self.num_obj_query
         # the stale object mask (:404-411): obj_mask_embed on the post-normed initial queries
-        pl.q.view(B, Q, 256).copy_(w["query_feat.weight"].unsqueeze(0).expand(B, Q, 256))
-        hip.layernorm(pl.q, w["transformer_decoder.post_norm.weight"],
+        hip.layernorm(pl.q0, w["transformer_decoder.post_norm.weight"],
                       w["transformer_decoder.post_norm.bias"], pl.qn)
         self._mlp3("obj_mask_embed", pl.qn, pl.me2, pl)
         self._mask_logits(pl.me2, pl, pl.obj_seg.view(B, Q, pl.HW2))

@@ -32,7 +32,7 @@ def test_bad_arguments_are_refused_without_launching(built_lib):
     lib = hip.lib()
     d = hip.GemmDesc()  # all NULL
     assert lib.pn_gemm_f32(ctypes.byref(d), None) == -1
-    assert lib.pn_topk_pairs(None, None, None, None, 1, 100, 100, None) == -1
+    assert lib.pn_topk_pairs(None, None, None, None, None, 1, 100, 100, None) == -1
     assert lib.pn_gemm_group_f32(None, 3, None) == -1
     assert lib.pn_layernorm_f32(None, None, None, None, 4, 256, 1e-5, None) == -1
 

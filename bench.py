@@ -189,12 +189,18 @@ def main():
         feats = [f.to(dev) for f in feats_cpu]
 
     gatherer = TripletGatherer(B, R, head.num_relations, dev) if world > 1 else None
+    gather_stream = torch.cuda.Stream() if world > 1 else None
 
     def gather(res, sub_pos, obj_pos):
+        """Pack this batch's triplet records and all-gather them, on a side stream ordered
+        behind the stream the results were returned on: the collective (and the other ranks'
+        arrival at it) never stalls a compute stream."""
         if gatherer is not None and res is not None:
-            for i, r in enumerate(res):
-                gatherer.pack(i, r[1], r[7], sub_pos[i], obj_pos[i])
-            gatherer.gather(host_staging=backend != "nccl")
+            gather_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(gather_stream):
+                for i, r in enumerate(res):
+                    gatherer.pack(i, r[1], r[7], sub_pos[i], obj_pos[i])
+                gatherer.gather(host_staging=backend != "nccl")
 
     def step(with_backbone=args.path == "image"):
         """One batch.  Pipelined: backbone + stage A of this batch are queued on the stage-A

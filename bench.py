@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--exact-mask-order", action="store_true",
                     help="attention masks in the reference's operation order (full-size mask "
                          "logits, then the resize) instead of the once-resampled mask feature")
+    ap.add_argument("--grid-scale", type=int, default=None,
+                    help="probe: persistent-GEMM grid cap multiplier (large = one tile per WG)")
     ap.add_argument("--grid-trim", type=int, default=None,
                     help="persistent-GEMM workgroup slots left free for the query chains")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,6 +153,8 @@ def main():
                 "psgtr2": lambda pl: (ident, ident)}[args.head]   # query i IS triplet i
     if args.grid_trim is not None:
         hip.gemm_set_grid_trim(args.grid_trim)
+    if args.grid_scale is not None:
+        hip.gemm_set_grid_scale(args.grid_scale)
     head.init_weights(seed=0)
     head.to(dev)
     head.gemm_mode = args.gemm
@@ -235,11 +239,16 @@ def main():
 
     # ---- warm-up (graph capture happens in the first two steps), then the stream ->
     # hardware-queue placement of the pipeline is chosen empirically (pipeline.py) ----
+    # (setup, not warm-up: buffers are planned on the first call of a shape and the hipGraphs
+    # are captured on the second, per pipeline slot -- two passes over the slots)
+    for _ in range(2 * args.depth if engine is not None else 2):
+        step()
+    drain()
     for _ in range(args.warmup):
         step()
     drain()
     calibration = None
-    if engine is not None and args.warmup >= 2:
+    if engine is not None:
         calibration = engine.calibrate(feats, metas, submit=step)
         step()
         drain()

@@ -34,6 +34,9 @@ int pn_abi_version(void);
 /* Scheduling knob (process-wide, performance only): leave `trim` of the persistent GEMM
  * kernels' resident workgroup slots free for the kernels of concurrent streams. */
 void pn_gemm_set_grid_trim(int trim);
+/* Probe knob: multiply the persistent kernels' grid cap (a large value = one tile per
+ * workgroup, i.e. a non-persistent launch). */
+void pn_gemm_set_grid_scale(int scale);
 
 /* ------------------------------------------------------------------------- *
  * Dense contraction (f32 MFMA 32x32x2, exact fp32 accumulate)

@@ -692,8 +692,11 @@ static int launch_skinny(const GemmP& p, int batch, hipStream_t s) {
 static int pn_grid_trim = 0;
 extern "C" void pn_gemm_set_grid_trim(int trim) { pn_grid_trim = trim < 0 ? 0 : trim / 8 * 8; }
 
+static int pn_grid_scale = 1;   // probe: grid cap multiplier (large = one tile per workgroup)
+extern "C" void pn_gemm_set_grid_scale(int scale) { pn_grid_scale = scale < 1 ? 1 : scale; }
+
 static int persistent_grid(int64_t ntiles, int wg_per_cu) {
-  int64_t cap = 256 * wg_per_cu - pn_grid_trim;
+  int64_t cap = (int64_t)256 * wg_per_cu * pn_grid_scale - pn_grid_trim;
   if (cap < 256) cap = 256;
   const int64_t want = (ntiles + 7) / 8 * 8;
   return (int)(want < cap ? want : cap);

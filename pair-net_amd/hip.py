@@ -51,6 +51,7 @@ class ChainDesc(C.Structure):
 _SIGS = {
     "pn_abi_version": (C.c_int, []),
     "pn_gemm_set_grid_trim": (None, [_i32]),
+    "pn_gemm_set_grid_scale": (None, [_i32]),
     "pn_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "pn_gemm_variant": (C.c_int, [C.POINTER(GemmDesc)]),
     "pn_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
@@ -139,6 +140,11 @@ def lib():
 def gemm_set_grid_trim(trim):
     """Leave `trim` persistent-GEMM workgroup slots free for concurrent streams' kernels."""
     lib().pn_gemm_set_grid_trim(int(trim))
+
+
+def gemm_set_grid_scale(scale):
+    """Probe knob: persistent grid cap multiplier (large = one tile per workgroup)."""
+    lib().pn_gemm_set_grid_scale(int(scale))
 
 
 def _stream():

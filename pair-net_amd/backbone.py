@@ -75,6 +75,9 @@ class ResNet50Hip:
         self.device, self.w, self._plans = None, None, {}
         # replay the forward pass as one hipGraph after an eager warm-up call
         self.use_graphs = False
+        # 3x3 stride-1 layers of >= 256 channels on maps with even sides (stage 3 at 800x1333):
+        # "winograd" = F(2x2,3x3) around one batched GEMM, "direct" = implicit GEMM
+        self.conv_algo = "winograd"
 
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._params.items())
@@ -133,6 +136,10 @@ class ResNet50Hip:
                     co = cw.shape[0]
                     w[p + conv + ".w"] = cw.permute(0, 2, 3, 1).reshape(co, -1).contiguous().to(dev)
                     w[p + conv + ".b"] = cb.to(dev)
+                    # stride-1 3x3 layers of >= 256 channels also get their Winograd F(2x2,3x3)
+                    # weights (used when the map has even sides: stage 3 at 800x1333)
+                    if conv == "conv2" and co >= 256 and not (b == 0 and i > 0):
+                        w[p + "conv2.wino"] = hip.winograd_weights(cw.to(dev))
         self.w = w
 
     class _Plan:
@@ -157,6 +164,7 @@ class ResNet50Hip:
         # largest S x M x N the library can ask for here
         pl.scratch = E(B * 16 * 1024 * 1024 // 2)
         pl.hw, pl.out, pl.t1, pl.t2, pl.idt, pl.ping = [], [], [], [], [], []
+        nwino = 0
         for i, (planes, blocks) in enumerate(self.stages):
             hin, win = h, wd
             if i > 0:
@@ -167,6 +175,9 @@ class ResNet50Hip:
             pl.idt.append(E(B, h, wd, planes * 4))
             pl.ping.append(E(B, h, wd, planes * 4))
             pl.out.append(E(B, h, wd, planes * 4))
+            if planes >= 256 and h % 2 == 0 and wd % 2 == 0:
+                nwino = max(nwino, 16 * B * (h // 2) * (wd // 2) * planes)
+        pl.wV, pl.wM = E(max(nwino, 4)), E(max(nwino, 4))   # Winograd transform planes
         self._plans[key] = pl
         return pl
 
@@ -230,8 +241,16 @@ class ResNet50Hip:
                 hip.linear(x.view(-1, cin), w[p + "conv1.w"], w[p + "conv1.b"],
                            t1.view(-1, planes), relu=True, scratch=pl.scratch)
                 # conv2 3x3, stride on this layer ("pytorch" style) (+BN+ReLU)
-                hip.conv2d_ex(t1, w[p + "conv2.w"], w[p + "conv2.b"], None, pl.t2[i], B, hi, wi,
-                              planes, planes, 3, 3, stride, 1, relu=True, scratch=pl.scratch)
+                if self.conv_algo == "winograd" and p + "conv2.wino" in w and hi % 2 == 0 \
+                        and wi % 2 == 0:
+                    # 2.25x fewer multiplications (fp32; differs from the direct form by fp32
+                    # re-association, ~2e-6 relative)
+                    hip.conv3x3_winograd(t1, w[p + "conv2.wino"], w[p + "conv2.b"], pl.t2[i],
+                                         pl.wV, pl.wM, B, hi, wi, planes, planes, True)
+                else:
+                    hip.conv2d_ex(t1, w[p + "conv2.w"], w[p + "conv2.b"], None, pl.t2[i], B, hi,
+                                  wi, planes, planes, 3, 3, stride, 1, relu=True,
+                                  scratch=pl.scratch)
                 # shortcut: projection in the first block of a stage, identity after it
                 if b == 0:
                     if stride == 1:

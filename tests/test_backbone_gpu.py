@@ -62,13 +62,17 @@ def test_stem_and_maxpool_match_torch(B, H, W):
     assert torch.equal(pout.permute(0, 3, 1, 2).cpu(), pooled)
 
 
-@pytest.mark.parametrize("B,H,W", [(1, 96, 128), (2, 75, 101)])
-def test_backbone_matches_oracle(B, H, W):
+@pytest.mark.parametrize("B,H,W,algo", [(1, 96, 128, "winograd"), (2, 75, 101, "winograd"),
+                                        (1, 128, 192, "winograd"), (1, 128, 192, "direct")])
+def test_backbone_matches_oracle(B, H, W, algo):
+    """(128 x 192: the stage-3 map is 8 x 12, even sides, so its stride-1 3x3 layers take the
+    Winograd form when `conv_algo` says so.)"""
     from pairnet_amd import ResNet50Hip
     sd = seeded_backbone_state(31)
     oracle = OracleResNet50()
     oracle.load_state_dict(sd)
     net = ResNet50Hip()
+    net.conv_algo = algo
     net.load_state_dict(sd)
     net.to(DEV)
     img = R(B, 3, H, W, seed=8)

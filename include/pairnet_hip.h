@@ -107,8 +107,9 @@ int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float* bias,
                        int KH, int KW, int pad, int relu, int flags /* 0 or
                        PN_GEMM_SPLIT_BF16, | PN_GEMM_FORCE_TILE */, void* stream);
 
-/* Winograd F(2x2, 3x3) form of the same 3x3 "same" convolution (even H and W, C % 4 == 0):
- *   pn_winograd_f23_input_f32:  V [16][B*(H/2)*(W/2)][Cin]  = B^T d B of every 4x4 patch
+/* Winograd F(2x2, 3x3) form of the same 3x3 "same" convolution (C % 4 == 0; odd H / W: the
+ * last tile row / column is padded with zeros and clipped), T = B*ceil(H/2)*ceil(W/2) tiles:
+ *   pn_winograd_f23_input_f32:  V [16][T][Cin]  = B^T d B of every 4x4 patch
  *   16 GEMMs (one batched pn_gemm_f32 call, batch = 16):  M_xi = V_xi . U_xi^T with
  *       U [16][Cout][Cin] = G g G^T of the weights (computed once by the caller)
  *   pn_winograd_f23_output_f32: out [B][H][W][Cout] = act(A^T M A + bias)

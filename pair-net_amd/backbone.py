@@ -75,8 +75,8 @@ class ResNet50Hip:
         self.device, self.w, self._plans = None, None, {}
         # replay the forward pass as one hipGraph after an eager warm-up call
         self.use_graphs = False
-        # 3x3 stride-1 layers of >= 256 channels on maps with even sides (stage 3 at 800x1333):
-        # "winograd" = F(2x2,3x3) around one batched GEMM, "direct" = implicit GEMM
+        # 3x3 stride-1 layers of >= 128 channels (stages 2-4): "winograd" = F(2x2,3x3) around
+        # one batched GEMM (2.25x fewer multiplications), "direct" = implicit GEMM
         self.conv_algo = "winograd"
 
     def state_dict(self):
@@ -136,9 +136,10 @@ class ResNet50Hip:
                     co = cw.shape[0]
                     w[p + conv + ".w"] = cw.permute(0, 2, 3, 1).reshape(co, -1).contiguous().to(dev)
                     w[p + conv + ".b"] = cb.to(dev)
-                    # stride-1 3x3 layers of >= 256 channels also get their Winograd F(2x2,3x3)
-                    # weights (used when the map has even sides: stage 3 at 800x1333)
-                    if conv == "conv2" and co >= 256 and not (b == 0 and i > 0):
+                    # stride-1 3x3 layers of >= 128 channels also get their Winograd F(2x2,3x3)
+                    # weights (stages 2-4; the 64-channel layers of stage 1 would be K = 64
+                    # GEMMs, slower than the direct form)
+                    if conv == "conv2" and co >= 128 and not (b == 0 and i > 0):
                         w[p + "conv2.wino"] = hip.winograd_weights(cw.to(dev))
         self.w = w
 
@@ -175,8 +176,8 @@ class ResNet50Hip:
             pl.idt.append(E(B, h, wd, planes * 4))
             pl.ping.append(E(B, h, wd, planes * 4))
             pl.out.append(E(B, h, wd, planes * 4))
-            if planes >= 256 and h % 2 == 0 and wd % 2 == 0:
-                nwino = max(nwino, 16 * B * (h // 2) * (wd // 2) * planes)
+            if planes >= 128:
+                nwino = max(nwino, 16 * B * ((h + 1) // 2) * ((wd + 1) // 2) * planes)
         pl.wV, pl.wM = E(max(nwino, 4)), E(max(nwino, 4))   # Winograd transform planes
         self._plans[key] = pl
         return pl
@@ -241,8 +242,7 @@ class ResNet50Hip:
                 hip.linear(x.view(-1, cin), w[p + "conv1.w"], w[p + "conv1.b"],
                            t1.view(-1, planes), relu=True, scratch=pl.scratch)
                 # conv2 3x3, stride on this layer ("pytorch" style) (+BN+ReLU)
-                if self.conv_algo == "winograd" and p + "conv2.wino" in w and hi % 2 == 0 \
-                        and wi % 2 == 0:
+                if self.conv_algo == "winograd" and p + "conv2.wino" in w and stride == 1:
                     # 2.25x fewer multiplications (fp32; differs from the direct form by fp32
                     # re-association, ~2e-6 relative)
                     hip.conv3x3_winograd(t1, w[p + "conv2.wino"], w[p + "conv2.b"], pl.t2[i],

@@ -25,9 +25,9 @@ __global__ __launch_bounds__(256) void k_wino_f23_input(const float* __restrict_
   if (e >= tiles_total * C4) return;
   const int c = (int)(e % C4);
   const int64_t tile = e / C4;
-  const int th = H >> 1, tw = W >> 1;
-  const int b = (int)(tile / ((int64_t)th * tw));
-  const int r = (int)(tile - (int64_t)b * th * tw);
+  const int th = (H + 1) >> 1, tw = (W + 1) >> 1;   // (odd sides: the last tile row / column
+  const int b = (int)(tile / ((int64_t)th * tw));   //  sticks out, reads zeros there and
+  const int r = (int)(tile - (int64_t)b * th * tw); //  stores only its inside part)
   const int ty = r / tw, tx = r - ty * tw;
   const float* ib = in + (int64_t)b * H * W * C4 * 4 + c * 4;
   float4 d[4][4];
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_wino_f23_output(const float* __restrict
   if (e >= tiles_total * C4) return;
   const int c = (int)(e % C4);
   const int64_t tile = e / C4;
-  const int th = H >> 1, tw = W >> 1;
+  const int th = (H + 1) >> 1, tw = (W + 1) >> 1;
   const int b = (int)(tile / ((int64_t)th * tw));
   const int r = (int)(tile - (int64_t)b * th * tw);
   const int ty = r / tw, tx = r - ty * tw;
@@ -99,17 +99,19 @@ __global__ __launch_bounds__(256) void k_wino_f23_output(const float* __restrict
       y0 = make_float4(fmaxf(y0.x, 0.f), fmaxf(y0.y, 0.f), fmaxf(y0.z, 0.f), fmaxf(y0.w, 0.f));
       y1 = make_float4(fmaxf(y1.x, 0.f), fmaxf(y1.y, 0.f), fmaxf(y1.z, 0.f), fmaxf(y1.w, 0.f));
     }
-    st4(ob + ((int64_t)(2 * ty + i) * W + 2 * tx) * C4 * 4, y0);
-    st4(ob + ((int64_t)(2 * ty + i) * W + 2 * tx + 1) * C4 * 4, y1);
+    if (2 * ty + i < H) {
+      st4(ob + ((int64_t)(2 * ty + i) * W + 2 * tx) * C4 * 4, y0);
+      if (2 * tx + 1 < W) st4(ob + ((int64_t)(2 * ty + i) * W + 2 * tx + 1) * C4 * 4, y1);
+    }
   }
 }
 
 extern "C" int pn_winograd_f23_input_f32(const float* in, float* V, int B, int H, int W, int C,
                                          void* stream) {
-  if (!in || !V || B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C <= 0 || (C & 3) ||
+  if (!in || !V || B <= 0 || H < 2 || W < 2 || C <= 0 || (C & 3) ||
       (((uintptr_t)in | (uintptr_t)V) & 15))
     return PN_BAD_ARG;
-  const int64_t tiles = (int64_t)B * (H / 2) * (W / 2);
+  const int64_t tiles = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
   hipLaunchKernelGGL(k_wino_f23_input, dim3(pn_cdiv(tiles * (C / 4), 256)), dim3(256), 0,
                      (hipStream_t)stream, in, V, H, W, C / 4, tiles);
   return PN_LAUNCH_CHECK();
@@ -117,10 +119,10 @@ extern "C" int pn_winograd_f23_input_f32(const float* in, float* V, int B, int H
 
 extern "C" int pn_winograd_f23_output_f32(const float* Mx, const float* bias, float* out, int B,
                                           int H, int W, int C, int relu, void* stream) {
-  if (!Mx || !out || B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C <= 0 || (C & 3) ||
+  if (!Mx || !out || B <= 0 || H < 2 || W < 2 || C <= 0 || (C & 3) ||
       (((uintptr_t)Mx | (uintptr_t)out | (uintptr_t)bias) & 15))
     return PN_BAD_ARG;
-  const int64_t tiles = (int64_t)B * (H / 2) * (W / 2);
+  const int64_t tiles = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
   hipLaunchKernelGGL(k_wino_f23_output, dim3(pn_cdiv(tiles * (C / 4), 256)), dim3(256), 0,
                      (hipStream_t)stream, Mx, bias, out, H, W, C / 4, tiles, relu);
   return PN_LAUNCH_CHECK();

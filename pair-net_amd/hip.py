@@ -396,8 +396,8 @@ def conv3x3_winograd43(x, U, bias, out, V, Mbuf, B, H, W, Cin, Cout, relu, split
 def conv3x3_winograd(x, U, bias, out, V, Mbuf, B, H, W, Cin, Cout, relu, split=False):
     """3x3 pad-1 stride-1 convolution as Winograd F(2x2,3x3): input transform, one batched
     GEMM over the 16 transform positions, output transform.  V / Mbuf: scratch of
-    16 * B*(H/2)*(W/2) * Cin / Cout floats."""
-    T = B * (H // 2) * (W // 2)
+    16 * B*ceil(H/2)*ceil(W/2) * Cin / Cout floats."""
+    T = B * ((H + 1) // 2) * ((W + 1) // 2)
     _check(lib().pn_winograd_f23_input_f32(_ptr(x), _ptr(V), B, H, W, Cin, _stream()),
            "pn_winograd_f23_input_f32")
     gemm(V, U, Mbuf, M=T, N=Cout, K=Cin, lda=Cin, ldw=Cin, ldc=Cout, batch=16, sA=T * Cin,

@@ -209,21 +209,20 @@ def test_layernorm_l2norm(hip):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,relu", [(1, 24, 32, 256, 256, False),
-                                                 (2, 10, 14, 64, 128, True), (1, 2, 2, 32, 32, False)])
+                                                 (2, 10, 14, 64, 128, True), (1, 2, 2, 32, 32, False),
+                                                 (2, 25, 42, 128, 128, True), (1, 13, 21, 64, 32, False),
+                                                 (1, 3, 3, 32, 32, True)])
 def test_conv3x3_winograd_matches_torch(hip, B, H, W, Cin, Cout, relu):
     x, w, b = R(B, Cin, H, W, seed=1), R(Cout, Cin, 3, 3, seed=2) * 0.05, R(Cout, seed=3)
     ref = F.conv2d(x, w, b, padding=1)
     if relu:
         ref = F.relu(ref)
-    T = B * (H // 2) * (W // 2)
+    T = B * ((H + 1) // 2) * ((W + 1) // 2)    # (odd sides: the last tiles stick out)
     V, Mb = torch.empty(16, T, Cin, device=DEV), torch.empty(16, T, Cout, device=DEV)
-    out = torch.empty(B, H, W, Cout, device=DEV)
+    out = torch.full((B, H, W, Cout), float("nan"), device=DEV)
     hip.conv3x3_winograd(x.permute(0, 2, 3, 1).contiguous().to(DEV), hip.winograd_weights(w).to(DEV),
                          b.to(DEV), out, V, Mb, B, H, W, Cin, Cout, relu)
     close(out.permute(0, 3, 1, 2), ref, 3e-5 * math.sqrt(9 * Cin / 256), "winograd 3x3")
-    with pytest.raises(RuntimeError):      # odd sides are refused (callers fall back)
-        hip.conv3x3_winograd(out, hip.winograd_weights(w).to(DEV), None, out, V, Mb, B, H + 1, W,
-                             Cin, Cout, False)
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,relu", [(1, 24, 32, 256, 256, False),

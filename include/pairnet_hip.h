@@ -355,6 +355,16 @@ int pn_attention_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
  * The C->C middle layer is pn_conv2d_nhwc_f32. */
 int pn_mlearner_first_f32(const float* in, const float* w1, const float* b1,
                           float* out, int B, int S, int C, void* stream);
+/* Fused front of the PPN (pairnet_head.py:325-333, cnn_factory.py:22-29): per 8 x 8 tile of
+ * (subject, object) pairs the L2-normalised query rows its halo needs are staged in LDS,
+ * their cosine block is one MFMA tile, and the first Matrix Learner layer is applied to it
+ * on chip.  sub_embed / obj_embed [B][Q][256] are the MLP outputs BEFORE F.normalize;
+ * importance_raw [B][Q][Q] (the cosine matrix) and c1 [B][Q][Q][64] (first-layer output,
+ * ReLU) are written; w1 [64][49], b1 [64].  Equivalent to pn_l2normalize_f32 x 2 +
+ * the batched pn_gemm_f32 + pn_mlearner_first_f32. */
+int pn_ppn_front_f32(const float* sub_embed, const float* obj_embed, const float* w1,
+                     const float* b1, float* importance_raw, float* c1, int B, int Q, float eps,
+                     void* stream);
 int pn_mlearner_last_f32(const float* in, const float* w3, const float* b3,
                          float* out, int B, int S, int C, void* stream);
 

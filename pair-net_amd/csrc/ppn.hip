@@ -40,6 +40,115 @@ extern "C" int pn_mlearner_first_f32(const float* in, const float* w1, const flo
   return PN_LAUNCH_CHECK();
 }
 
+// ---- fused front of the Pair Proposal Network -------------------------------------
+// pairnet_head.py:325-333 + cnn_factory.py:22-29 in one kernel: F.normalize of the subject /
+// object embeddings, the Q x Q cosine matrix, and the Matrix Learner's first layer
+// (7x7, 1 -> 64 channels, ReLU).  A workgroup owns an 8 x 8 tile of (subject i, object j)
+// pairs (169 workgroups at Q = 100): the 14 subject rows and 14 object rows its 7x7 halo reaches are staged in LDS as
+// L2-NORMALISED query tiles, their 14 x 14 block of cosines is one 32 x 32 MFMA tile (the
+// four waves split K = 256 and reduce through LDS in wave order), the block stays in LDS
+// and every lane = output channel convolves it with its 49 weights from registers.  Rows
+// outside [0, Q) are the convolution's zero padding.
+#define PPN_T 8
+#define PPN_H (PPN_T + 6)
+__global__ __launch_bounds__(256) void k_ppn_front(const float* __restrict__ se,
+                                                   const float* __restrict__ oe,
+                                                   const float* __restrict__ w1,
+                                                   const float* __restrict__ b1,
+                                                   float* __restrict__ raw_out,
+                                                   float* __restrict__ c1, int Q, float eps) {
+  __shared__ __attribute__((aligned(16))) float sS[32 * 260], sO[32 * 260];
+  __shared__ float red[3][1024];
+  __shared__ float raw[PPN_H][PPN_H + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, i0 = blockIdx.y * PPN_T - 3, j0 = blockIdx.x * PPN_T - 3;
+  const float* sb = se + (int64_t)b * Q * 256;
+  const float* ob = oe + (int64_t)b * Q * 256;
+  // ---- stage the normalised rows: one wave per row (k_l2norm256's arithmetic), rows
+  // beyond the halo / outside [0, Q) are zero ----
+  for (int r = wave; r < 64; r += 4) {
+    const bool subj = r < 32;
+    const int rr = subj ? r : r - 32;
+    const int q = (subj ? i0 : j0) + rr;
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rr < PPN_H && q >= 0 && q < Q) {
+      const float4 v = ld4((subj ? sb : ob) + (int64_t)q * 256 + lane * 4);
+      const float n = sqrtf(wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)));
+      const float d = fmaxf(n, eps);
+      y = make_float4(v.x / d, v.y / d, v.z / d, v.w / d);
+    }
+    st4((subj ? sS : sO) + rr * 260 + lane * 4, y);
+  }
+  __syncthreads();
+  // ---- cosines: 32 x 32 tile, wave w contracts k in [64 w, 64 w + 64) ----
+  {
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* ar = sS + li * 260 + wave * 64 + 4 * lh;
+    const float* br = sO + li * 260 + wave * 64 + 4 * lh;
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const float4 av = ld4(ar + 8 * s8), bv = ld4(br + 8 * s8);
+      acc = mfma32(av.x, bv.x, acc);
+      acc = mfma32(av.y, bv.y, acc);
+      acc = mfma32(av.z, bv.z, acc);
+      acc = mfma32(av.w, bv.w, acc);
+    }
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave - 1][r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = ((acc[r] + red[0][r * 64 + lane]) + red[1][r * 64 + lane]) + red[2][r * 64 + lane];
+        const int row = mfma32_row(r, lh);           // subject index inside the halo block
+        if (row < PPN_H && li < PPN_H) {
+          raw[row][li] = v;
+          const int gi = i0 + row, gj = j0 + li;
+          // the tile's own interior is this workgroup's part of the Q x Q matrix
+          if (row >= 3 && row < 3 + PPN_T && li >= 3 && li < 3 + PPN_T && gi < Q && gj < Q)
+            raw_out[((int64_t)b * Q + gi) * Q + gj] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- first Matrix Learner layer: lane = output channel, 49 weights in registers; the
+  // taps are accumulated in k_ml_first's order (ky, kx ascending; out-of-matrix taps are
+  // exact zeros here - the staged rows outside [0, Q) are zero - and add nothing) ----
+  float wt[49];
+#pragma unroll
+  for (int t = 0; t < 49; ++t) wt[t] = w1[lane * 49 + t];
+  const float bias = b1[lane];
+  for (int p = wave; p < PPN_T * PPN_T; p += 4) {
+    const int y = p / PPN_T, x = p - y * PPN_T;
+    const int gi = i0 + 3 + y, gj = j0 + 3 + x;
+    if (gi >= Q || gj >= Q) continue;               // (uniform per wave)
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) acc += raw[y + ky][x + kx] * wt[ky * 7 + kx];
+    c1[(((int64_t)b * Q + gi) * Q + gj) * 64 + lane] = fmaxf(acc + bias, 0.f);
+  }
+}
+
+extern "C" int pn_ppn_front_f32(const float* sub_embed, const float* obj_embed, const float* w1,
+                                const float* b1, float* importance_raw, float* c1, int B, int Q,
+                                float eps, void* stream) {
+  if (!sub_embed || !obj_embed || !w1 || !b1 || !importance_raw || !c1 || B <= 0 || Q <= 0 ||
+      B > 65535 || (((uintptr_t)sub_embed | (uintptr_t)obj_embed) & 15))
+    return PN_BAD_ARG;
+  const int nt = pn_cdiv(Q, PPN_T);
+  hipLaunchKernelGGL(k_ppn_front, dim3(nt, nt, B), dim3(256), 0, (hipStream_t)stream, sub_embed,
+                     obj_embed, w1, b1, importance_raw, c1, Q, eps);
+  return PN_LAUNCH_CHECK();
+}
+
 // ---- last layer: C -> 1 (C == 64); one wave per pixel, lane = input channel ----
 __global__ __launch_bounds__(256) void k_ml_last(const float* __restrict__ in,
                                                  const float* __restrict__ w3,

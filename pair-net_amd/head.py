@@ -137,6 +137,7 @@ class CrossHead2:
         # to overlap it, where the per-Linear launches spread the same work over 32+
         # workgroups; a kernel boundary (1.5 us) is cheaper than that.  Kept, tested and off.
         self.fuse_chains = False
+        self.fuse_ppn_front = True      # normalise + cosine matrix + first Matrix Learner layer in one launch
         self.init_weights()
 
     # ------------------------------------------------------------------ params
@@ -832,12 +833,19 @@ class CrossHead2:
                 continue
             hip.linear(pl.q, w[mlp + ".0.weight"], w[mlp + ".0.bias"], pl.s1, relu=True)
             hip.linear(pl.s1, w[mlp + ".2.weight"], w[mlp + ".2.bias"], pl.s2, relu=True)
+            if self.fuse_ppn_front:    # un-normalised: k_ppn_front normalises while staging
+                hip.linear(pl.s2, w[mlp + ".4.weight"], w[mlp + ".4.bias"], dst)
+                continue
             hip.linear(pl.s2, w[mlp + ".4.weight"], w[mlp + ".4.bias"], pl.s1)
             hip.l2normalize(pl.s1, dst)
-        hip.gemm(pl.sn, pl.on, pl.imp_raw, M=Q, N=Q, K=256, lda=256, ldw=256, ldc=Q, batch=B,
-                 sA=Q * 256, sW=Q * 256, sC=Q * Q)
         ml = "update_importance.conv_layers."
-        hip.mlearner_first(pl.imp_raw, w[ml + "0.0.weight"], w[ml + "0.0.bias"], pl.c1, B, Q)
+        if self.fuse_ppn_front and not self.fuse_chains:
+            hip.ppn_front(pl.sn, pl.on, w[ml + "0.0.weight"], w[ml + "0.0.bias"], pl.imp_raw,
+                          pl.c1, B, Q)
+        else:
+            hip.gemm(pl.sn, pl.on, pl.imp_raw, M=Q, N=Q, K=256, lda=256, ldw=256, ldc=Q, batch=B,
+                     sA=Q * 256, sW=Q * 256, sC=Q * Q)
+            hip.mlearner_first(pl.imp_raw, w[ml + "0.0.weight"], w[ml + "0.0.bias"], pl.c1, B, Q)
         hip.conv2d_nhwc(pl.c1, w[ml + "1.0.weight"], w[ml + "1.0.bias"], pl.c2, B, Q, Q, 64, 64,
                         7, 7, 3, True)
         hip.mlearner_last(pl.c2, w[ml + "2.0.weight"], w[ml + "2.0.bias"], pl.imp, B, Q)
@@ -900,7 +908,8 @@ class CrossHead2:
         """Run stage 'a' or 'b' of plan `pl` on the current stream: eagerly, or (with
         `use_graphs`) as one hipGraph replay.  A stage is captured on its second call
         (the first, eager one is the warm-up torch requires before capture)."""
-        cfg = (self.gemm_mode, self.exact_mask_order, self.conv_algo, self.fuse_chains)
+        cfg = (self.gemm_mode, self.exact_mask_order, self.conv_algo, self.fuse_chains,
+               self.fuse_ppn_front)
         if pl.graph_cfg != cfg:          # a captured graph bakes these switches in
             pl.graph_a = pl.graph_b = pl.me0 = None
             pl.graph_c = {}

@@ -88,6 +88,7 @@ _SIGS = {
     "pn_attn_scratch_floats": (_i64, [_i32, _i32, _i32]),
     "pn_attention_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                                    _i64, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "pn_ppn_front_f32": (C.c_int, [_vp] * 6 + [_i32, _i32, _f32, _vp]),
     "pn_mlearner_first_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_mlearner_last_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_topk_pairs": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
@@ -544,6 +545,12 @@ def attention(q, ldq, k, ldk, v, ldv, bits, rowall, out, ldo, scratch, B, Q, Nk,
         _ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(bits, torch.int32),
         _ptr(rowall, torch.int32), _ptr(out), ldo, _ptr(scratch), B, Q, Nk, scale,
         _stream()), "pn_attention_f32")
+
+
+def ppn_front(sub_embed, obj_embed, w1, b1, imp_raw, c1, B, Q, eps=1e-12):
+    _check(lib().pn_ppn_front_f32(_ptr(sub_embed), _ptr(obj_embed), _ptr(w1), _ptr(b1),
+                                  _ptr(imp_raw), _ptr(c1), B, Q, eps, _stream()),
+           "pn_ppn_front_f32")
 
 
 def mlearner_first(x, w1, b1, out, B, S):

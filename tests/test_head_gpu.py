@@ -148,7 +148,8 @@ def test_e2e_full_800x1333_against_reference_golden(gemm_mode, conv_algo, exact_
 
 
 @pytest.mark.parametrize("name,fuse", [("e2e_small_sep", False), ("e2e_full_sep", False),
-                                       ("e2e_small_sep", True), ("e2e_full_sep", True)])
+                                       ("e2e_small_sep", True), ("e2e_full_sep", True),
+                                       ("e2e_small_sep", "front"), ("e2e_full_sep", "front")])
 def test_e2e_topk_pair_indices_bit_exact_on_separated_fixtures(name, fuse):
     """north_star: "top-k pair indices bit-exact", end to end, at 96x128 (batch 2) and at
     800x1333: strict equality of topk_idx / sub_pos / obj_pos with the reference's, relation
@@ -163,7 +164,8 @@ def test_e2e_topk_pair_indices_bit_exact_on_separated_fixtures(name, fuse):
     metas = [dict(img_shape=(H, W, 3), scale_factor=[sf] * 4)] * bs
     assert float(fx["min_gap"]) >= 1e-4 and float(fx["min_gap"]) >= 10 * float(fx["fp64_noise"])
     head = _hip_head(sd)
-    head.fuse_chains = fuse      # (True: the query side as row-chain launches, csrc/chain.hip)
+    head.fuse_chains = fuse is True     # (the query side as row-chain launches, csrc/chain.hip)
+    head.fuse_ppn_front = fuse == "front"   # (k_ppn_front: LDS-staged query tiles, csrc/ppn.hip)
     cls, masks = head.forward([f.to(DEV) for f in feats], metas)
     torch.cuda.synchronize()
     pl = head._last_plan

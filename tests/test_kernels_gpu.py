@@ -644,3 +644,33 @@ def test_cls_argmax_rel_dists_panoptic(hip):
     ids = remap.long()[ids]
     assert torch.equal(seg.cpu(), ids * 1000 + labels[ids])
     assert torch.equal(area.cpu().long(), torch.bincount(ids, minlength=n))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Q", [(1, 100), (2, 37), (1, 16), (3, 5)])
+def test_ppn_front_equals_normalise_cosine_first_layer(hip, B, Q):
+    """k_ppn_front (normalised query tiles in LDS -> cosine block on MFMA -> 7x7 1->64 conv +
+    ReLU) against F.normalize / matmul / conv2d (pairnet_head.py:325-333,
+    cnn_factory.py:22-29) and against the three-launch path it replaces."""
+    g = torch.Generator().manual_seed(7 + Q)
+    se, oe = (torch.randn(B, Q, 256, generator=g) * 3 for _ in range(2))
+    se[0, Q // 2] = 0                                    # a zero row: eps clamp
+    w1 = torch.randn(64, 1, 7, 7, generator=g) * 0.2
+    b1 = torch.randn(64, generator=g) * 0.1
+    raw_ref = F.normalize(se, dim=-1) @ F.normalize(oe, dim=-1).transpose(1, 2)
+    c1_ref = F.relu(F.conv2d(raw_ref[:, None], w1, b1, padding=3)).permute(0, 2, 3, 1)
+    d = lambda t: t.contiguous().cuda()
+    raw = torch.full((B, Q, Q), float("nan"), device="cuda")
+    c1 = torch.full((B, Q, Q, 64), float("nan"), device="cuda")
+    hip.ppn_front(d(se), d(oe), d(w1.view(64, 49)), d(b1), raw, c1, B, Q)
+    assert torch.isfinite(raw).all() and torch.isfinite(c1).all()
+    assert (raw.cpu() - raw_ref).abs().max() < 2e-6
+    assert (c1.cpu() - c1_ref).abs().max() < 1e-5
+    sn, on = torch.empty_like(d(se)), torch.empty_like(d(oe))
+    hip.l2normalize(d(se).view(-1, 256), sn.view(-1, 256))
+    hip.l2normalize(d(oe).view(-1, 256), on.view(-1, 256))
+    raw2, c12 = torch.empty_like(raw), torch.empty_like(c1)
+    hip.gemm(sn, on, raw2, M=Q, N=Q, K=256, lda=256, ldw=256, ldc=Q, batch=B, sA=Q * 256,
+             sW=Q * 256, sC=Q * Q)
+    hip.mlearner_first(raw2, d(w1.view(64, 49)), d(b1), c12, B, Q)
+    assert (raw - raw2).abs().max() < 1e-6 and (c1 - c12).abs().max() < 5e-6

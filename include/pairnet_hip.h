@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 10
+#define PN_ABI_VERSION 11
 int pn_abi_version(void);
 
 /* Scheduling knob (process-wide, performance only): leave `trim` of the persistent GEMM
@@ -304,6 +304,10 @@ int pn_msda_loc_f32(const float* value, int64_t ld_value, const int64_t* spatial
  * (pairnet_head.py:278; level_encoding add in the pixel decoder.) */
 int pn_sine_pe_f32(float* out, const float* add, int h, int w, int C,
                    float temperature, void* stream);
+/* The same with SinePositionalEncoding's `offset` (added to the 1-based row / column index
+ * before normalisation; configs/deformable_detr/cross_r101_vg.py:118-120 uses -0.5). */
+int pn_sine_pe_offset_f32(float* out, const float* add, int h, int w, int C, float temperature,
+                          float offset, void* stream);
 
 /* Bilinear resize, align_corners=False (F.interpolate semantics).
  * nhwc:   in [b][hi][wi][C] -> out [b][ho][wo][C], out = (accumulate? out:0)+v;
@@ -379,6 +383,13 @@ int pn_topk_pairs(const float* scores, int64_t* idx, int64_t* sub, int64_t* obj,
  * (triplet ranking of the sibling head, relation_heads/baseline.py:1033-1037). */
 int pn_topk_f32(const float* scores, int64_t* idx, int64_t* quot, int64_t* rem, int B,
                 int n, int div, int k, void* stream);
+/* Strided form, k <= 512: score i of row b is scores[b*row_stride + i*elem_stride] (floats).
+ * (The two-stage proposal selection of the Deformable-DETR trunk under CrossHeadBBox,
+ * `torch.topk(enc_outputs_class[..., 0], 300, dim=1)`: mmdet DeformableDetrTransformer,
+ * called at pairnet_bbox_head.py:215-228.) */
+int pn_topk_strided_f32(const float* scores, int64_t elem_stride, int64_t row_stride,
+                        int64_t* idx, int64_t* quot, int64_t* rem, int B, int n, int div, int k,
+                        void* stream);
 
 /* out[b][r][:] = in[b][index[b][r]][:], rows of `len` floats
  * (torch.gather at pairnet_head.py:342-351, 380-403). */
@@ -481,6 +492,44 @@ int pn_triplet_match(const int32_t* pred_triplets, const int32_t* gt_triplets, i
                      int ld_inter, const int32_t* pred_sub_row, const int32_t* pred_obj_row,
                      const int32_t* gt_sub_row, const int32_t* gt_obj_row, double iou_thr,
                      int phrdet, int ignore_rel, uint8_t* match, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Box trunk of the sibling head CrossHeadBBox (pairnet_bbox_head.py:193-359): the
+ * input-dependent glue of mmdet's two-stage, box-refining DeformableDetrTransformer
+ * (built at :66, called at :215-228) between this library's GEMM / deformable-attention
+ * entries.  All row-parallel and HBM-bound.
+ * ------------------------------------------------------------------------- */
+/* out[b][r][:] = valid[r] ? x[b][r][:] : 0; valid [rows] bytes (gen_encoder_output_proposals:
+ * tokens whose proposal box leaves (0.01, 0.99) are zeroed before enc_output). C % 4 == 0. */
+int pn_zero_rows_f32(const float* x, const uint8_t* valid, float* out, int B, int64_t rows,
+                     int C, void* stream);
+/* y = sigmoid(x) elementwise (enc_bbox_preds, pairnet_bbox_head.py:345-347; sigmoid(inf) = 1) */
+int pn_sigmoid_f32(const float* x, float* y, int64_t n, void* stream);
+/* Two-stage queries: ref[r][4] = sigmoid(unact[r][4]) and emb[r][512] =
+ * get_proposal_pos_embed(unact) (128 sine features per coordinate, temperature 1e4). */
+int pn_box_pos_embed_f32(const float* unact, float* ref, float* emb, int64_t rows, void* stream);
+/* Decoder cross-attention operands (mmcv MultiScaleDeformableAttention.forward with 4-d
+ * reference boxes): offaw row = [offsets 8*L*4*2 | logits 8*L*4] (stride ld floats);
+ * aw [rows][8][L][4] = softmax over each head's L*4 logits; loc [rows][8][L][4][2] =
+ * ref.xy + offset / 4 * ref.wh * 0.5 -- the operands of pn_msda_loc_f32. */
+int pn_box_sampling_f32(const float* offaw, int64_t ld, const float* ref, float* loc, float* aw,
+                        int64_t rows, int L, void* stream);
+/* Iterative box refinement: ref_out = sigmoid(delta + inverse_sigmoid(ref_in, eps=1e-5)),
+ * [rows][4] (DeformableDetrTransformerDecoder.forward; also the last layer's
+ * `outputs_coord`, pairnet_bbox_head.py:236-246). */
+int pn_box_refine_f32(const float* delta, const float* ref_in, float* ref_out, int64_t rows,
+                      void* stream);
+/* Query ranking (pairnet_bbox_head.py:252-254): score[b][q] = max over classes of
+ * softmax(logits[b], dim = the QUERY axis)[q]; logits [B][Nq][C], C <= 256. */
+int pn_query_score_f32(const float* logits, float* score, int B, int Nq, int C, void* stream);
+/* CrossHeadBBox._get_bboxes_single (:1056-1086): rows [subjects R | objects R]:
+ * labels = argmax softmax + 1, det[row] = (x1, y1, x2, y2, max softmax), boxes cxcywh ->
+ * xyxy * (img_w, img_h), clamped to the image, divided by scale_factor[4] (a HOST pointer)
+ * when rescale. */
+int pn_box_triplets_f32(const float* s_cls, const float* o_cls, const float* s_box,
+                        const float* o_box, float* det, int64_t* labels, int R, int C,
+                        float img_h, float img_w, const float* scale_factor, int rescale,
+                        void* stream);
 
 #ifdef __cplusplus
 }

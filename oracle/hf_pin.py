@@ -7,6 +7,9 @@ restates from memory can be checked against code written by somebody else.
                         input_convs / encoder.layers.N.{attentions.0,norms,ffns} /
                         level_encoding / lateral_convs / output_convs / mask_feature)
                         -> transformers Mask2FormerPixelDecoder
+  deformable_detr_to_hf oracle/deformable_detr.py ChannelMapper + DeformableDetrTransformer and
+                        the class / box branches of oracle/bbox_head.py
+                        -> transformers DeformableDetrForObjectDetection
   (oracle/swin.py::to_hf_state does the same for the Swin backbone.)
 
 Only tests/ imports this.
@@ -118,4 +121,72 @@ def self_first_layer_to_hf(sd):
             out["mlp.fc1." + leaf] = v
         elif k.startswith("ffns.0.layers.1."):
             out["mlp.fc2." + leaf] = v
+    return out
+
+
+def deformable_detr_to_hf(neck_sd, head_sd):
+    """oracle ChannelMapper (mmdet names `convs.i.{conv,gn}` / `extra_convs.j.{conv,gn}`) +
+    the trunk part of OracleCrossHeadBBox (`transformer.*`, `cls_branches.*`,
+    `reg_branches.*`; mmdet 2.25.1 DeformableDETRHead / DeformableDetrTransformer names)
+    -> transformers DeformableDetrForObjectDetection (two_stage, with_box_refine), everything
+    except its backbone.  HF's input projections carry a conv bias that mmcv's ConvModule
+    (conv followed by a norm) does not have: it is set to zero."""
+    import torch
+    out = {}
+    n_convs = len({k.split(".")[1] for k in neck_sd if k.startswith("convs.")})
+    for k, v in neck_sd.items():
+        kind, i, part, leaf = k.split(".")
+        lvl = int(i) + (n_convs if kind == "extra_convs" else 0)
+        out["model.input_proj.%d.%d.%s" % (lvl, 0 if part == "conv" else 1, leaf)] = v
+        if part == "conv":
+            out["model.input_proj.%d.0.bias" % lvl] = torch.zeros(v.shape[0])
+    for k, v in head_sd.items():
+        leaf = k.split(".")[-1]
+        if k.startswith("cls_branches."):
+            i = k.split(".")[1]
+            out["class_embed.%s.%s" % (i, leaf)] = v
+            out["model.decoder.class_embed.%s.%s" % (i, leaf)] = v
+        elif k.startswith("reg_branches."):
+            _, i, j, _ = k.split(".")
+            name = "bbox_embed.%s.layers.%d.%s" % (i, int(j) // 2, leaf)
+            out[name] = v
+            out["model.decoder." + name] = v
+        elif k == "transformer.level_embeds":
+            out["model.level_embed"] = v
+        elif k.split(".")[1] in ("enc_output", "enc_output_norm", "pos_trans", "pos_trans_norm"):
+            out["model." + k[len("transformer."):]] = v
+        elif k.startswith("transformer.encoder.layers."):
+            n = k.split(".")[3]
+            rest = ".".join(k.split(".")[4:])
+            p = "model.encoder.layers.%s." % n
+            if rest.startswith("attentions.0."):
+                out[p + "self_attn." + rest[len("attentions.0."):]] = v
+            elif rest.startswith("norms."):
+                out[p + ("self_attn_layer_norm.", "final_layer_norm.")[int(rest.split(".")[1])] + leaf] = v
+            elif rest.startswith("ffns.0.layers.0.0."):
+                out[p + "mlp.fc1." + leaf] = v
+            elif rest.startswith("ffns.0.layers.1."):
+                out[p + "mlp.fc2." + leaf] = v
+            else:
+                raise KeyError(k)
+        elif k.startswith("transformer.decoder.layers."):
+            n = k.split(".")[3]
+            rest = ".".join(k.split(".")[4:])
+            p = "model.decoder.layers.%s." % n
+            if rest.startswith("attentions.0.attn.in_proj_"):
+                for proj, part in zip(("q_proj", "k_proj", "v_proj"), v.chunk(3, 0)):
+                    out[p + "self_attn.%s.%s" % (proj, "weight" if leaf.endswith("weight") else "bias")] = part
+            elif rest.startswith("attentions.0.attn.out_proj."):
+                out[p + "self_attn.o_proj." + leaf] = v
+            elif rest.startswith("attentions.1."):
+                out[p + "encoder_attn." + rest[len("attentions.1."):]] = v
+            elif rest.startswith("norms."):
+                out[p + ("self_attn_layer_norm.", "encoder_attn_layer_norm.",
+                         "final_layer_norm.")[int(rest.split(".")[1])] + leaf] = v
+            elif rest.startswith("ffns.0.layers.0.0."):
+                out[p + "mlp.fc1." + leaf] = v
+            elif rest.startswith("ffns.0.layers.1."):
+                out[p + "mlp.fc2." + leaf] = v
+            else:
+                raise KeyError(k)
     return out

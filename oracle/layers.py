@@ -214,8 +214,15 @@ class MultiScaleDeformableAttention(nn.Module):
         shapes = [(int(h), int(w)) for h, w in spatial_shapes]
         normalizer = torch.tensor([[w, h] for h, w in shapes],
                                   dtype=query.dtype)
-        loc = reference_points[:, :, None, :, None, :] \
-            + off / normalizer[None, None, None, :, None, :]
+        if reference_points.shape[-1] == 2:
+            loc = reference_points[:, :, None, :, None, :] \
+                + off / normalizer[None, None, None, :, None, :]
+        else:   # (cx, cy, w, h) reference boxes: the decoder of a box-refining /
+            #     two-stage Deformable DETR (mmcv MultiScaleDeformableAttention)
+            assert reference_points.shape[-1] == 4
+            loc = reference_points[:, :, None, :, None, :2] \
+                + off / self.num_points \
+                * reference_points[:, :, None, :, None, 2:] * 0.5
         out = msda_core(value, shapes, loc, aw)
         out = self.output_proj(out).permute(1, 0, 2)
         return out + identity
@@ -235,14 +242,29 @@ class BaseTransformerLayer(nn.Module):
         self.operation_order = tuple(operation_order)
         self.pre_norm = self.operation_order[0] == "norm"
         assert not self.pre_norm
+        assert norm_cfg is None or dict(norm_cfg).get("type") == "LN"
         num_attn = sum(op in ("self_attn", "cross_attn")
                        for op in self.operation_order)
         self.num_attn = num_attn
         self.attentions = nn.ModuleList()
-        for _ in range(num_attn):
-            cfg = dict(attn_cfgs)
+        if isinstance(attn_cfgs, dict):
+            attn_cfgs = [attn_cfgs] * num_attn
+        assert len(attn_cfgs) == num_attn
+        for cfg in attn_cfgs:
+            cfg = dict(cfg)
             self.attentions.append(_ATTN[cfg.pop("type")](**cfg))
         self.embed_dims = self.attentions[0].embed_dims
+        # mmcv's deprecated layer-level spellings (`feedforward_channels`,
+        # `ffn_dropout`, `ffn_num_fcs`) are folded into ffn_cfgs
+        ffn_cfgs = dict(ffn_cfgs) if ffn_cfgs is not None else dict(
+            embed_dims=self.embed_dims, feedforward_channels=1024, num_fcs=2,
+            ffn_drop=0.0)
+        for old_name, new_name in (("feedforward_channels", "feedforward_channels"),
+                                   ("ffn_dropout", "ffn_drop"),
+                                   ("ffn_num_fcs", "num_fcs")):
+            if old_name in kwargs:
+                ffn_cfgs[new_name] = kwargs[old_name]
+        ffn_cfgs.setdefault("embed_dims", self.embed_dims)
         self.ffns = nn.ModuleList()
         for _ in range(self.operation_order.count("ffn")):
             cfg = dict(ffn_cfgs)

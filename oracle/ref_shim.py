@@ -70,7 +70,8 @@ def install():
     _mod("mmcv")
     _mod("mmcv.cnn", Conv2d=nn.Conv2d, Linear=nn.Linear,
          build_plugin_layer=L.build_plugin_layer,
-         caffe2_xavier_init=lambda *a, **k: None)
+         caffe2_xavier_init=lambda *a, **k: None,
+         bias_init_with_prob=None, constant_init=None)
     _mod("mmcv.cnn.bricks")
     _mod("mmcv.cnn.bricks.transformer",
          build_positional_encoding=L.build_positional_encoding,
@@ -79,9 +80,14 @@ def install():
     _mod("mmcv.runner", ModuleList=nn.ModuleList,
          force_fp32=_passthrough_decorator)
     _mod("mmdet")
+    from . import bbox_head as BH
+    from . import deformable_detr as DD
     _mod("mmdet.core", build_assigner=None, build_sampler=None,
-         multi_apply=None, reduce_mean=None, bbox_cxcywh_to_xyxy=None)
-    _mod("mmdet.models.utils", get_uncertain_point_coords_with_randomness=None)
+         multi_apply=None, reduce_mean=None,
+         bbox_cxcywh_to_xyxy=BH.bbox_cxcywh_to_xyxy, bbox_xyxy_to_cxcywh=None)
+    _mod("mmdet.models.utils", get_uncertain_point_coords_with_randomness=None,
+         build_transformer=DD.build_transformer)
+    _mod("mmdet.models.utils.transformer", inverse_sigmoid=DD.inverse_sigmoid)
     _mod("mmdet.datasets")
     _mod("mmdet.datasets.coco_panoptic", INSTANCE_OFFSET=1000)
     _mod("mmdet.models")
@@ -110,6 +116,8 @@ def install():
           "pairnet/models/relation_heads/baseline.py")
     _load("pairnet.models.relation_heads.psgtr_head2",
           "pairnet/models/relation_heads/psgtr_head2.py")
+    _load("pairnet.models.relation_heads.pairnet_bbox_head",
+          "pairnet/models/relation_heads/pairnet_bbox_head.py")
 
 
 def reference_head_cfg():
@@ -160,6 +168,24 @@ def build_reference_psgtr2_head(cfg=None):
     cls = sys.modules["pairnet.models.relation_heads.psgtr_head2"].PSGTrHead2
     cfg = L.CfgDict(cfg if cfg is not None else reference_psgtr2_cfg())
     cfg.pop("type", None)
+    return cls(**cfg, train_cfg=None).eval()
+
+
+def reference_bbox_cfg(name="cross_r101_vg"):
+    """model.{neck, bbox_head} of the reference's configs/deformable_detr/<name>.py."""
+    path = os.path.join(REF_ROOT, "configs/deformable_detr/%s.py" % name)
+    scope = {}
+    with open(path) as f:
+        exec(compile(f.read(), path, "exec"), scope)
+    return L.CfgDict(scope["model"]["neck"]), L.CfgDict(scope["model"]["bbox_head"])
+
+
+def build_reference_bbox_head(cfg=None):
+    install()
+    cls = sys.modules["pairnet.models.relation_heads.pairnet_bbox_head"].CrossHeadBBox
+    cfg = L.CfgDict(cfg if cfg is not None else reference_bbox_cfg()[1])
+    cfg.pop("type", None)
+    cfg.pop("train_cfg", None)
     return cls(**cfg, train_cfg=None).eval()
 
 

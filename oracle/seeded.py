@@ -22,7 +22,7 @@ def seeded_param(name, shape, rng):
     """One parameter of the seeded family (distribution chosen by the parameter's name)."""
     shape = tuple(shape)
     leaf = name.rsplit(".", 1)[-1]
-    is_norm = ".norms." in name or ".gn." in name or "post_norm" in name
+    is_norm = ".norms." in name or ".gn." in name or "_norm." in name
     if is_norm:
         return uniform(rng, shape, 0.5, 1.5) if leaf == "weight" else uniform(rng, shape, -0.1, 0.1)
     if len(shape) == 1:

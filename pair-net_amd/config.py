@@ -223,6 +223,50 @@ def psgtr2_r50():
 IMG_NORM_CFG = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)
 
 
+def channel_mapper_cfg(in_channels=(512, 1024, 2048)):
+    """configs/deformable_detr/cross_r101_vg.py:20-29."""
+    return dict(type="ChannelMapper", in_channels=list(in_channels), kernel_size=1,
+                out_channels=256, act_cfg=None, norm_cfg=dict(type="GN", num_groups=32),
+                num_outs=4)
+
+
+def bbox_head_cfg(num_obj_query=300, num_rel_query=100, num_classes=150, num_relations=50):
+    """The `bbox_head` of configs/deformable_detr/cross_r101_vg.py:30-117 (inference keys):
+    CrossHeadBBox on a two-stage, box-refining Deformable-DETR trunk."""
+    msda = dict(type="MultiScaleDeformableAttention", embed_dims=256)
+    trunk = dict(
+        type="DeformableDetrTransformer", as_two_stage=True,
+        encoder=dict(type="DetrTransformerEncoder", num_layers=6, transformerlayers=dict(
+            type="BaseTransformerLayer", attn_cfgs=msda, feedforward_channels=1024,
+            ffn_dropout=0.1, operation_order=("self_attn", "norm", "ffn", "norm"))),
+        decoder=dict(type="DeformableDetrTransformerDecoder", num_layers=6,
+                     return_intermediate=True, transformerlayers=dict(
+                         type="DetrTransformerDecoderLayer",
+                         attn_cfgs=[dict(type="MultiheadAttention", embed_dims=256, num_heads=8,
+                                         dropout=0.1), msda],
+                         feedforward_channels=1024, ffn_dropout=0.1, operation_order=SELF_FIRST)))
+    return ConfigDict(
+        type="CrossHeadBBox", num_classes=num_classes, num_relations=num_relations,
+        num_obj_query=num_obj_query, num_rel_query=num_rel_query, in_channels=2048,
+        sync_cls_avg_factor=True, embed_dims=256, as_two_stage=True, with_box_refine=True,
+        transformer=trunk, relation_decoder=_decoder(6, True, 0.0),
+        positional_encoding=dict(type="SinePositionalEncoding", num_feats=128, normalize=True,
+                                 offset=-0.5),
+        loss_cls=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0),
+        test_cfg=dict(max_per_img=100))
+
+
+def cross_r101_vg():
+    """configs/deformable_detr/cross_r101_vg.py:8-117: ResNet-101 (C3-C5) -> ChannelMapper ->
+    CrossHeadBBox, the box-trunk sibling of Pair-Net on Visual Genome (150 / 50 classes)."""
+    return ConfigDict(model=dict(
+        type="PSGTr",
+        backbone=dict(type="ResNet", depth=101, num_stages=4, out_indices=(1, 2, 3),
+                      frozen_stages=1, norm_cfg=dict(type="BN", requires_grad=False),
+                      norm_eval=True, style="pytorch"),
+        neck=channel_mapper_cfg(), bbox_head=bbox_head_cfg()))
+
+
 def test_pipeline_cfg():
     """`test_pipeline` of configs/mask2former/pairnet.py:310-331 (what preprocess.TestPipeline
     .from_config consumes)."""

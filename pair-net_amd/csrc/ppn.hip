@@ -200,15 +200,17 @@ __global__ __launch_bounds__(1024) void k_topk_pairs(const float* __restrict__ s
                                                      int64_t* __restrict__ sub_out,
                                                      int64_t* __restrict__ obj_out,
                                                      int64_t* __restrict__ pair_out, int n, int Q,
-                                                     int k) {
+                                                     int k, int64_t estride, int64_t rstride,
+                                                     int cap) {
+  // scores of row b: scores[b * rstride + i * estride]; cap = 256 or 512 >= k (sort width)
   __shared__ int hist[256];
-  __shared__ unsigned long long sel[256];
+  __shared__ unsigned long long sel[512];
   __shared__ unsigned long long s_prefix;
   __shared__ int s_remaining, s_count;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* sc = scores + (int64_t)blockIdx.x * n;
+  const float* sc = scores + (int64_t)blockIdx.x * rstride;
   if (tid == 0) { s_prefix = 0ull; s_remaining = k; s_count = 0; }
-  if (tid < 256) sel[tid] = 0ull;
+  if (tid < 512) sel[tid] = 0ull;
   __syncthreads();
   for (int pass = 0; pass < 6; ++pass) {
     const int shift = 40 - 8 * pass;
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(1024) void k_topk_pairs(const float* __restrict__ s
     __syncthreads();
     const unsigned long long prefix = s_prefix;
     for (int i = tid; i < n; i += 1024) {
-      const unsigned long long key = topk_key(sc[i], i);
+      const unsigned long long key = topk_key(sc[i * estride], i);
       if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8)))
         atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
     }
@@ -249,17 +251,17 @@ __global__ __launch_bounds__(1024) void k_topk_pairs(const float* __restrict__ s
   }
   const unsigned long long kth = s_prefix;
   for (int i = tid; i < n; i += 1024) {
-    const unsigned long long key = topk_key(sc[i], i);
+    const unsigned long long key = topk_key(sc[i * estride], i);
     if (key >= kth) {
       const int slot = atomicAdd(&s_count, 1);
-      if (slot < 256) sel[slot] = key;
+      if (slot < cap) sel[slot] = key;
     }
   }
   __syncthreads();
-  // bitonic sort of 256 keys, descending (zero padding sinks to the end)
-  for (int size = 2; size <= 256; size <<= 1) {
+  // bitonic sort of `cap` keys, descending (zero padding sinks to the end)
+  for (int size = 2; size <= cap; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      if (tid < 128) {
+      if (tid < (cap >> 1)) {
         const int lo = ((tid / stride) * stride * 2) + (tid % stride);
         const int hi = lo + stride;
         const bool desc = ((lo & size) == 0);
@@ -287,7 +289,7 @@ extern "C" int pn_topk_pairs(const float* scores, int64_t* idx, int64_t* sub, in
   if (!scores || !idx || !sub || !obj || B <= 0 || Q <= 0) return PN_BAD_ARG;
   if ((int64_t)Q * Q > 65536 || k <= 0 || k > 256 || k > Q * Q) return PN_BAD_ARG;
   hipLaunchKernelGGL(k_topk_pairs, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores, idx,
-                     sub, obj, pair, Q * Q, Q, k);
+                     sub, obj, pair, Q * Q, Q, k, (int64_t)1, (int64_t)Q * Q, 256);
   return PN_LAUNCH_CHECK();
 }
 
@@ -299,7 +301,23 @@ extern "C" int pn_topk_f32(const float* scores, int64_t* idx, int64_t* quot, int
   if (!scores || !idx || !quot || !rem || B <= 0 || n <= 0 || div <= 0) return PN_BAD_ARG;
   if (n > 65536 || k <= 0 || k > 256 || k > n) return PN_BAD_ARG;
   hipLaunchKernelGGL(k_topk_pairs, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores, idx,
-                     quot, rem, (int64_t*)nullptr, n, div, k);
+                     quot, rem, (int64_t*)nullptr, n, div, k, (int64_t)1, (int64_t)n, 256);
+  return PN_LAUNCH_CHECK();
+}
+
+// Strided form with k <= 512: score i of row b is scores[b * row_stride + i * elem_stride]
+// (the two-stage proposal selection of a Deformable-DETR trunk: the 300 best of column 0 of
+// the per-token class logits, `torch.topk(enc_outputs_class[..., 0], 300, dim=1)` behind
+// pairnet_bbox_head.py:215-228).
+extern "C" int pn_topk_strided_f32(const float* scores, int64_t elem_stride, int64_t row_stride,
+                                   int64_t* idx, int64_t* quot, int64_t* rem, int B, int n,
+                                   int div, int k, void* stream) {
+  if (!scores || !idx || !quot || !rem || B <= 0 || n <= 0 || div <= 0 || elem_stride <= 0)
+    return PN_BAD_ARG;
+  if (n > 65536 || k <= 0 || k > 512 || k > n) return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_topk_pairs, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores, idx,
+                     quot, rem, (int64_t*)nullptr, n, div, k, elem_stride, row_stride,
+                     k > 256 ? 512 : 256);
   return PN_LAUNCH_CHECK();
 }
 

@@ -15,7 +15,9 @@ import torch.nn.functional as F
 from .config import ConfigDict
 from .backbone import ResNet50Hip
 from .baseline_head import CrossHeadBaseline
+from .bbox_head import CrossHeadBBox
 from .head import CrossHead2
+from .neck import ChannelMapper
 from .psgtr_head2 import PSGTrHead2
 from .swin import SwinTransformerHip
 
@@ -49,11 +51,15 @@ class Result(object):
 
 
 def triplet2Result(triplets, use_mask, eval_mask_rels=False):
-    """8-tuple of `CrossHead2.get_bboxes` -> Result (psgtr.py:15-51)."""
-    if not use_mask:
-        raise NotImplementedError("bbox-only triplets are not on the Pair-Net PSG path")
-    bboxes, labels, rel_pairs, masks, pan_seg, r_scores, r_labels, r_dists = triplets
+    """8-tuple of `CrossHead2.get_bboxes` (or, without masks, the 6-tuple of
+    `CrossHeadBBox.get_bboxes`) -> Result (psgtr.py:15-71)."""
     np_ = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else t
+    if not use_mask:
+        bboxes, labels, rel_pairs, r_scores, r_labels, r_dists = triplets
+        return Result(refine_bboxes=np_(bboxes), labels=np_(labels),
+                      formatted_masks=dict(pan_results=None), rel_pair_idxes=np_(rel_pairs),
+                      rel_dists=np_(r_dists), rel_labels=np_(r_labels), pan_results=None)
+    bboxes, labels, rel_pairs, masks, pan_seg, r_scores, r_labels, r_dists = triplets
     pan_seg = np_(pan_seg)
     return Result(refine_bboxes=np_(bboxes), labels=np_(labels),
                   formatted_masks=dict(pan_results=pan_seg), rel_pair_idxes=np_(rel_pairs),
@@ -117,8 +123,15 @@ class PSGTr:
 
     def __init__(self, backbone, bbox_head, train_cfg=None, test_cfg=None, pretrained=None,
                  init_cfg=None, neck=None):
-        assert neck is None
         backbone = ConfigDict(backbone)
+        # mmdet's ResNet returns the stages named by out_indices (default: all four)
+        self.out_indices = tuple(backbone.get("out_indices", (0, 1, 2, 3)))
+        self.neck = None
+        if neck is not None:       # configs/deformable_detr/cross_r101_vg.py:20-29
+            neck = dict(neck)
+            if neck.pop("type", "ChannelMapper") != "ChannelMapper":
+                raise NotImplementedError("necks built: ChannelMapper")
+            self.neck = ChannelMapper(**neck)
         btype = backbone.get("type", "ResNet")
         if btype == "SwinTransformer":
             # pairnet_swinb.py:203-226; native only (swin.py)
@@ -139,7 +152,7 @@ class PSGTr:
                                       "(pairnet_swinb.py)")
         head_cfg = dict(bbox_head)
         heads = dict(CrossHead2=CrossHead2, CrossHeadBaseline=CrossHeadBaseline,
-                     PSGTrHead2=PSGTrHead2)
+                     PSGTrHead2=PSGTrHead2, CrossHeadBBox=CrossHeadBBox)
         head_type = head_cfg.pop("type", "CrossHead2")
         if head_type not in heads:
             raise NotImplementedError("bbox_head.type must be one of %s" % sorted(heads))
@@ -150,6 +163,8 @@ class PSGTr:
 
     def to(self, device):
         self.backbone.to(device)
+        if self.neck is not None:
+            self.neck.to(device)
         self.bbox_head.to(device)
         return self
 
@@ -157,7 +172,11 @@ class PSGTr:
         return self
 
     def extract_feat(self, img):
-        return self.backbone(img)
+        """SingleStageDetector.extract_feat: backbone (the stages of `out_indices`) -> neck."""
+        x = self.backbone(img)
+        if len(x) == 4 and self.out_indices != (0, 1, 2, 3):
+            x = tuple(x[i] for i in self.out_indices)
+        return self.neck(x) if self.neck is not None else x
 
     @torch.no_grad()
     def simple_test(self, img, img_metas, rescale=False):
@@ -201,4 +220,5 @@ def build_detector(cfg, train_cfg=None, test_cfg=None):
     if cfg.pop("type", "PSGTr") != "PSGTr":
         raise NotImplementedError("only type='PSGTr'")
     cfg.pop("train_cfg", None)
-    return PSGTr(cfg["backbone"], cfg["bbox_head"], test_cfg=cfg.get("test_cfg", test_cfg))
+    return PSGTr(cfg["backbone"], cfg["bbox_head"], test_cfg=cfg.get("test_cfg", test_cfg),
+                 neck=cfg.get("neck"))

@@ -874,7 +874,11 @@ class CrossHead2:
                         pvk[:, 256:], 512, pvk, 512, 2 * R, B, R, None, None, pl.scr,
                         self.rel_ffn, x_in=pl.r0 if i == 0 else None)
         hip.linear(pl.r, w["rel_cls_embed.weight"], w["rel_cls_embed.bias"], pl.rel.view(B * R, -1))
-        # ---- output gathers (:380-403) ----
+        self._gather_outputs(pl)
+
+    def _gather_outputs(self, pl):
+        """The subject / object gathers of the selected pairs (pairnet_head.py:380-403)."""
+        B, Q, R = pl.B, self.num_obj_query, self.num_rel_query
         nc = self.num_classes + 1
         hip.gather_rows(pl.cls, pl.sub_pos, pl.sub_cls, B, Q, R, nc)
         hip.gather_rows(pl.cls, pl.obj_pos, pl.obj_cls, B, Q, R, nc)

@@ -81,6 +81,7 @@ _SIGS = {
                               C.POINTER(_i32), _vp]),
     "pn_msda_loc_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_sine_pe_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "pn_sine_pe_offset_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp]),
     "pn_bilinear_nhwc_f32": (C.c_int, [_vp, _vp] + [_i32] * 7 + [_i64, _i64, _vp]),
     "pn_bilinear_planar_f32": (C.c_int, [_vp, _vp, _i64] + [_i32] * 4 + [_vp]),
     "pn_bilinear_planar_gt0_u8": (C.c_int, [_vp, _vp, _i64] + [_i32] * 4 + [_vp]),
@@ -93,6 +94,7 @@ _SIGS = {
     "pn_mlearner_last_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_topk_pairs": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_topk_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pn_topk_strided_f32": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_gather_rows_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     "pn_cls_argmax_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "pn_rel_dists_f32": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
@@ -113,9 +115,17 @@ _SIGS = {
                                                                             C.POINTER(_f32), _i32, _vp]),
     "pn_pack_mask_bits": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "pn_mask_iou_counts": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "pn_zero_rows_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _vp]),
+    "pn_sigmoid_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "pn_box_pos_embed_f32": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "pn_box_sampling_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "pn_box_refine_f32": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "pn_query_score_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "pn_box_triplets_f32": (C.c_int, [_vp] * 5 + [_vp, _i32, _i32, _f32, _f32, C.POINTER(_f32),
+                                                _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 10   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 11   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -510,9 +520,9 @@ def msda_loc(value, ld_value, spatial_shapes, level_start_index, loc, aw, out, B
            "pn_msda_loc_f32")
 
 
-def sine_pe(out, add, h, w, C_=256, temperature=10000.0):
-    _check(lib().pn_sine_pe_f32(_ptr(out), _ptr(add), h, w, C_, temperature, _stream()),
-           "pn_sine_pe_f32")
+def sine_pe(out, add, h, w, C_=256, temperature=10000.0, offset=0.0):
+    _check(lib().pn_sine_pe_offset_f32(_ptr(out), _ptr(add), h, w, C_, temperature, offset,
+                                       _stream()), "pn_sine_pe_offset_f32")
 
 
 def bilinear_nhwc(x, out, B, hi, wi, ho, wo, Cc, accumulate, in_bstride, out_bstride):
@@ -572,6 +582,12 @@ def topk_pairs(scores, idx, sub, obj, B, Q, k, pair=None):
 def topk(scores, idx, quot, rem, B, n, div, k):
     _check(lib().pn_topk_f32(_ptr(scores), _ptr(idx, torch.int64), _ptr(quot, torch.int64),
                              _ptr(rem, torch.int64), B, n, div, k, _stream()), "pn_topk_f32")
+
+
+def topk_strided(scores, elem_stride, row_stride, idx, quot, rem, B, n, div, k):
+    _check(lib().pn_topk_strided_f32(_ptr(scores), elem_stride, row_stride, _ptr(idx, torch.int64),
+                                     _ptr(quot, torch.int64), _ptr(rem, torch.int64), B, n, div,
+                                     k, _stream()), "pn_topk_strided_f32")
 
 
 def gather_rows(x, index, out, B, rows_in, rows_out, length):
@@ -739,3 +755,41 @@ def chain_desc(in0, ops, in1=None, M=None):
 
 def chain(desc):
     _check(lib().pn_rowchain_f32(C.byref(desc), _stream()), "pn_rowchain_f32")
+
+
+# ---- box trunk glue (csrc/detr.hip) ----
+def zero_rows(x, valid_u8, out, B, rows, Cc):
+    _check(lib().pn_zero_rows_f32(_ptr(x), _ptr(valid_u8, torch.uint8), _ptr(out), B, rows, Cc,
+                                  _stream()), "pn_zero_rows_f32")
+
+
+def sigmoid(x, out):
+    _check(lib().pn_sigmoid_f32(_ptr(x), _ptr(out), x.numel(), _stream()), "pn_sigmoid_f32")
+
+
+def box_pos_embed(unact, ref, emb, rows):
+    _check(lib().pn_box_pos_embed_f32(_ptr(unact), _ptr(ref), _ptr(emb), rows, _stream()),
+           "pn_box_pos_embed_f32")
+
+
+def box_sampling(offaw, ld, ref, loc, aw, rows, L):
+    _check(lib().pn_box_sampling_f32(_ptr(offaw), ld, _ptr(ref), _ptr(loc), _ptr(aw), rows, L,
+                                     _stream()), "pn_box_sampling_f32")
+
+
+def box_refine(delta, ref_in, ref_out, rows):
+    _check(lib().pn_box_refine_f32(_ptr(delta), _ptr(ref_in), _ptr(ref_out), rows, _stream()),
+           "pn_box_refine_f32")
+
+
+def query_score(logits, score, B, Nq, Cc):
+    _check(lib().pn_query_score_f32(_ptr(logits), _ptr(score), B, Nq, Cc, _stream()),
+           "pn_query_score_f32")
+
+
+def box_triplets(s_cls, o_cls, s_box, o_box, det, labels, R, Cc, img_h, img_w, scale_factor,
+                 rescale):
+    sf = (C.c_float * 4)(*[float(v) for v in scale_factor])
+    _check(lib().pn_box_triplets_f32(_ptr(s_cls), _ptr(o_cls), _ptr(s_box), _ptr(o_box), _ptr(det),
+                                     _ptr(labels, torch.int64), R, Cc, float(img_h), float(img_w),
+                                     sf, 1 if rescale else 0, _stream()), "pn_box_triplets_f32")

@@ -69,6 +69,70 @@ def latest_pmc():
     return files[-1] if files else None
 
 
+def bench_bbox(args, dev, rank, world):
+    """Secondary measurement: the box-trunk sibling
+    configs/deformable_detr/cross_r101_vg.py -- image tensor -> ResNet-101 (C3-C5) ->
+    ChannelMapper -> CrossHeadBBox (two-stage Deformable-DETR trunk, PPN, relation decoder) ->
+    get_bboxes, one image per step on one stream, head and backbone as hipGraph replays.  Not
+    the headline (BASELINE.json names the Mask2Former path); same JSON contract."""
+    import torch.distributed as dist
+    from pairnet_amd import build_detector, cross_r101_vg, hip
+    det = build_detector(cross_r101_vg().model).to(dev)
+    det.bbox_head.init_weights(seed=0)
+    det.bbox_head.to(dev)
+    det.bbox_head.use_graphs = det.backbone.use_graphs = not args.no_graphs
+    B, H, W = args.batch, args.height, args.width
+    img = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
+    metas = [dict(batch_input_shape=(H, W), img_shape=(H, W, 3), scale_factor=[2.083] * 4)] * B
+
+    def step():
+        feats = det.extract_feat(img)
+        return det.bbox_head.simple_test_bboxes(feats, metas, rescale=True)
+    for _ in range(max(args.warmup, 3)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt)
+    # per-kernel times of one eager step (HIP events around every launch)
+    det.bbox_head.use_graphs = det.backbone.use_graphs = False
+    step()
+    hip.TIMER = hip.KernelTimer()
+    for _ in range(3):
+        step()
+    agg = hip.TIMER.summary()
+    hip.TIMER = None
+    prof = {k: {"ms_per_step": v["ms"] / 3, "launches_per_step": v["launches"] // 3,
+                "tflops": v["flops"] / v["ms"] * 1e-9 if v["ms"] else 0.0,
+                "gbs": v["bytes"] / v["ms"] * 1e-6 if v["ms"] else 0.0}
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    out = {"metric": "images/sec (whole node), CrossHeadBBox 300-proposal 800x1333, MI355X",
+           "value": world * B * args.steps / dt, "unit": "images/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": "cross_r101_vg: ResNet-101 (C3-C5) -> ChannelMapper -> CrossHeadBBox "
+                                  "(6+6-layer two-stage box-refining Deformable-DETR trunk, 300 "
+                                  "proposals -> 100 kept queries -> PPN / Matrix Learner / top-k -> "
+                                  "6-layer relation decoder -> get_bboxes), image tensor -> triplets, "
+                                  "bs=%d per GPU, %dx%d, random-init weights" % (B, H, W),
+                      "head": "bbox", "global_batch": world * B, "image": [H, W],
+                      "parallelism": "dp%d" % world,
+                      "schedule": "one stream, backbone and head as hipGraph replays"},
+           "kernel_profile": prof, "labels_checksum": int(res[0][1].sum())}
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,7 +147,7 @@ def main():
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default="f32",
                     help="f32: exact-fp32 MFMA everywhere (headline); bf16x3: fp32-accurate "
                          "3 x bf16 operand split for the large GEMMs / 3x3 conv")
-    ap.add_argument("--head", choices=["pairnet", "baseline", "psgtr2"], default="pairnet",
+    ap.add_argument("--head", choices=["pairnet", "baseline", "psgtr2", "bbox"], default="pairnet",
                     help="pairnet = CrossHead2 (the headline); baseline / psgtr2 = the sibling "
                          "heads CrossHeadBaseline / PSGTrHead2 on the same trunk (not the "
                          "headline metric)")
@@ -133,6 +197,8 @@ def main():
         kw = dict(device_id=dev) if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
+    if args.head == "bbox":
+        return bench_bbox(args, dev, rank, world)
     from pairnet_amd import (CrossHead2, CrossHeadBaseline, PSGTrHead2, PipelinedHead,
                              ResNet50Hip, SwinTransformerHip, baseline_head_cfg, hip,
                              pairnet_head_cfg, psgtr2_head_cfg, swin_backbone_cfg)

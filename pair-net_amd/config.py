@@ -252,8 +252,7 @@ def bbox_head_cfg(num_obj_query=300, num_rel_query=100, num_classes=150, num_rel
         transformer=trunk, relation_decoder=_decoder(6, True, 0.0),
         positional_encoding=dict(type="SinePositionalEncoding", num_feats=128, normalize=True,
                                  offset=-0.5),
-        loss_cls=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0),
-        test_cfg=dict(max_per_img=100))
+        loss_cls=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0))
 
 
 def cross_r101_vg():
@@ -264,7 +263,7 @@ def cross_r101_vg():
         backbone=dict(type="ResNet", depth=101, num_stages=4, out_indices=(1, 2, 3),
                       frozen_stages=1, norm_cfg=dict(type="BN", requires_grad=False),
                       norm_eval=True, style="pytorch"),
-        neck=channel_mapper_cfg(), bbox_head=bbox_head_cfg()))
+        neck=channel_mapper_cfg(), bbox_head=bbox_head_cfg(), test_cfg=dict(max_per_img=100)))
 
 
 def test_pipeline_cfg():

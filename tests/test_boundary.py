@@ -146,3 +146,40 @@ def test_detector_builds_from_config_and_result_container():
     r = triplet2Result(t, True)
     assert isinstance(r.rel_dists, np.ndarray) and r.rel_pair_idxes.shape == (100, 2)
     assert len(r) == 1 and r[0] is r and r.formatted_masks["pan_results"] is r.pan_results
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+def test_reference_bbox_config_file_drops_in():
+    """configs/deformable_detr/cross_r101_vg.py (ResNet-101 C3-C5 -> ChannelMapper ->
+    CrossHeadBBox) builds our detector; the restated schema equals the file on every key except
+    the training losses, and the head / neck carry the reference class's state-dict layout."""
+    from pairnet_amd import (ChannelMapper, CrossHeadBBox, build_detector, cross_r101_vg,
+                             load_config)
+    from oracle.deformable_detr import ChannelMapper as OracleMapper
+    cfg = load_config(os.path.join(ref_shim.REF_ROOT, "configs/deformable_detr/cross_r101_vg.py"))
+    ours = cross_r101_vg().model
+    plain = lambda d: {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in dict(d).items()}
+    bb = plain(cfg.model.backbone)
+    bb.pop("init_cfg")
+    assert bb == plain(ours.backbone)
+    assert plain(cfg.model.neck) == plain(ours.neck)
+    ref_head, our_head = dict(cfg.model.bbox_head), dict(ours.bbox_head)
+    assert {k: ref_head[k] for k in our_head} == our_head
+    assert set(ref_head) - set(our_head) == {"rel_cls_loss", "subobj_cls_loss",
+                                             "importance_match_loss", "loss_bbox", "loss_iou"}
+    det = build_detector(dict(cfg.model))
+    assert isinstance(det.bbox_head, CrossHeadBBox) and isinstance(det.neck, ChannelMapper)
+    assert det.backbone.depth == 101 and det.out_indices == (1, 2, 3)
+    ref = ref_shim.build_reference_bbox_head()
+    assert list((k, tuple(v.shape)) for k, v in det.bbox_head.state_dict().items()) == \
+        list((k, tuple(v.shape)) for k, v in ref.state_dict().items())
+    ncfg = dict(cfg.model.neck)
+    ncfg.pop("type")
+    assert list((k, tuple(v.shape)) for k, v in det.neck.state_dict().items()) == \
+        list((k, tuple(v.shape)) for k, v in OracleMapper(**ncfg).state_dict().items())
+    for name in ("forward", "get_bboxes", "simple_test_bboxes", "simple_test"):
+        assert callable(getattr(det.bbox_head, name))
+    # the configs that are NOT consistent with the class fail loudly, like the reference
+    bad = load_config(os.path.join(ref_shim.REF_ROOT, "configs/deformable_detr/cross_r50_coco.py"))
+    with pytest.raises((ValueError, NotImplementedError, TypeError)):
+        build_detector(dict(bad.model))

@@ -1,6 +1,8 @@
 """CPU: the oracle is pinned (a) against the golden vectors recorded from the
 reference's own code and (b), when /root/reference is present (build container),
 against the reference itself run under shims."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -484,3 +486,149 @@ def test_self_first_decoder_layer_oracle_matches_transformers_detr():
                   encoder_hidden_states=mem.transpose(0, 1))
         want = (want[0] if isinstance(want, tuple) else want).transpose(0, 1)
     assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
+
+
+# ---- CrossHeadBBox (pairnet_bbox_head.py) and its Deformable-DETR trunk -------------------
+def _bbox_oracles(seed=5):
+    from oracle.bbox_head import OracleCrossHeadBBox
+    from oracle.deformable_detr import ChannelMapper
+    from pairnet_amd import bbox_head_cfg, channel_mapper_cfg
+    cfg = {k: v for k, v in bbox_head_cfg().items() if k != "type"}
+    ncfg = {k: v for k, v in channel_mapper_cfg().items() if k != "type"}
+    head, neck = OracleCrossHeadBBox(**cfg).eval(), ChannelMapper(**ncfg).eval()
+    g = torch.Generator().manual_seed(seed)
+    for m in (head, neck):
+        for k, v in m.state_dict().items():
+            v.copy_(torch.randn(v.shape, generator=g) * (0.05 if v.dim() > 1 else 0.02))
+    return head, neck, cfg, g
+
+
+def _bbox_inputs(g, H=160, W=192):
+    ins = [torch.randn(2, c, -(-H // s), -(-W // s), generator=g)
+           for c, s in ((512, 8), (1024, 16), (2048, 32))]
+    metas = [dict(batch_input_shape=(H, W), img_shape=(H, W, 3), scale_factor=[1.0] * 4),
+             dict(batch_input_shape=(H, W), img_shape=(130, 150, 3), scale_factor=[1.5] * 4)]
+    return ins, metas
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+def test_bbox_oracle_equals_shimmed_reference():
+    """oracle/bbox_head.py against the reference's own CrossHeadBBox class (executed from
+    /root/reference over the restated trunk), bit for bit, on a PADDED batch of two images:
+    forward (both dicts) and get_bboxes with rescale."""
+    head, neck, cfg, g = _bbox_oracles()
+    ref = ref_shim.build_reference_bbox_head()
+    assert list(ref.state_dict()) == list(head.state_dict())
+    ref.load_state_dict(head.state_dict())
+    ins, metas = _bbox_inputs(g)
+    with torch.no_grad():
+        nf = neck(ins)
+        a, b = ref(nf, metas), head(nf, metas)
+    for d1, d2 in zip(a, b):
+        assert set(d1) == set(d2)
+        for k in d1:
+            assert torch.equal(d1[k], d2[k]), k
+    ra, rb = ref.get_bboxes(*a, metas, rescale=True), head.get_bboxes(*b, metas, rescale=True)
+    for x, y in zip(ra, rb):
+        assert len(x) == len(y) == 6 and all(torch.equal(p, q) for p, q in zip(x, y))
+
+
+def test_deformable_detr_trunk_oracle_matches_transformers():
+    """The restated mmdet neck + two-stage, box-refining DeformableDetrTransformer + class / box
+    branches (oracle/deformable_detr.py, oracle/bbox_head.py) against HuggingFace
+    transformers' independent DeformableDetrForObjectDetection on a padded batch: memory,
+    per-token class / box heads (with the same +inf proposals), decoder states, final logits
+    and boxes."""
+    import torch.nn as nn
+    from transformers import (DeformableDetrConfig, DeformableDetrForObjectDetection,
+                              ResNetConfig)
+    from oracle import hf_pin
+    head, neck, cfg, g = _bbox_oracles()
+    hcfg = DeformableDetrConfig(
+        use_timm_backbone=False, use_pretrained_backbone=False,
+        backbone_config=ResNetConfig(depths=[1, 1, 1, 1], hidden_sizes=[64, 512, 1024, 2048],
+                                     embedding_size=8, layer_type="basic",
+                                     out_features=["stage2", "stage3", "stage4"]),
+        num_feature_levels=4, two_stage=True, with_box_refine=True, two_stage_num_proposals=300,
+        num_queries=300, encoder_layers=6, decoder_layers=6, d_model=256, encoder_ffn_dim=1024,
+        decoder_ffn_dim=1024, num_labels=150, encoder_attention_heads=8,
+        decoder_attention_heads=8, encoder_n_points=4, decoder_n_points=4, dropout=0.0)
+    hf = DeformableDetrForObjectDetection(hcfg).eval()
+    conv = hf_pin.deformable_detr_to_hf(neck.state_dict(), head.state_dict())
+    own = {k for k in hf.state_dict() if "backbone" not in k}
+    assert own == set(conv)
+    hf.load_state_dict(conv, strict=False)
+    ins, metas = _bbox_inputs(g)
+    H, W = metas[0]["batch_input_shape"]
+    pixel_mask = torch.zeros(2, H, W, dtype=torch.long)
+    pixel_mask[0] = 1
+    pixel_mask[1, :130, :150] = 1
+
+    class Stub(nn.Module):
+        intermediate_channel_sizes = [512, 1024, 2048]
+
+        def forward(self, pixel_values, pixel_mask):
+            return [(f, F.interpolate(pixel_mask[None].float(), size=f.shape[-2:])
+                     .to(torch.bool)[0]) for f in ins]
+    hf.model.backbone = Stub()
+    tr = {}
+    with torch.no_grad():
+        o = hf(pixel_values=torch.zeros(2, 3, H, W), pixel_mask=pixel_mask)
+        cls, box = head(neck(ins), metas, trace=tr)
+    tol = 2e-5
+    assert (o.encoder_last_hidden_state - tr["memory"]).abs().max() < tol
+    assert (o.intermediate_hidden_states.transpose(0, 1) - tr["hs"]).abs().max() < tol
+    assert (o.logits - tr["classes"][-1]).abs().max() < tol
+    assert (o.pred_boxes - tr["coords"][-1]).abs().max() < tol
+    assert (o.enc_outputs_class - cls["enc_cls_scores"]).abs().max() < tol
+    e = o.enc_outputs_coord_logits
+    fin = torch.isfinite(e).all(-1)
+    assert 0 < int(fin.sum()) < fin.numel()          # padded / border proposals are +inf
+    assert (e[fin].sigmoid() - cls["enc_bbox_preds"][fin]).abs().max() < tol
+    assert bool((cls["enc_bbox_preds"][~fin] == 1).any(-1).all())
+
+
+@pytest.mark.parametrize("name", ["bbox_small", "bbox_full"])
+def test_bbox_fixtures_are_separated_and_match_the_oracle(name):
+    """The recorded reference outputs are reproduced bit for bit by the oracle from the seeds
+    and ops the fixture stores, and the three index selections are separated from the fp32
+    rounding noise recorded beside them."""
+    from collections import OrderedDict
+    from oracle.bbox_head import OracleCrossHeadBBox
+    from oracle.deformable_detr import ChannelMapper
+    from pairnet_amd import bbox_head_cfg, channel_mapper_cfg
+    fx = golden(name)
+    if name == "bbox_full" and os.environ.get("PAIRNET_SKIP_SLOW"):
+        pytest.skip("slow")
+    cfg = {k: v for k, v in bbox_head_cfg().items() if k != "type"}
+    ncfg = {k: v for k, v in channel_mapper_cfg().items() if k != "type"}
+    head, neck = OracleCrossHeadBBox(**cfg).eval(), ChannelMapper(**ncfg).eval()
+    sd = seeded.seeded_state_dict(
+        OrderedDict((k, tuple(v.shape)) for k, v in head.state_dict().items()), int(fx["weight_seed"]))
+    nsd = seeded.seeded_state_dict(
+        OrderedDict((k, tuple(v.shape)) for k, v in neck.state_dict().items()), int(fx["neck_seed"]))
+    assert (seeded.checksum(sd), seeded.checksum(nsd)) == (int(fx["weight_crc"]), int(fx["neck_crc"]))
+    head.load_state_dict(seeded.apply_ops(sd, overrides_of(fx)))
+    neck.load_state_dict(nsd)
+    H, W, bs = int(fx["height"]), int(fx["width"]), int(fx["batch"])
+    per = [seeded.seeded_feats(int(s), 1, H, W)[1:] for s in fx["feat_seeds"]]
+    feats = [torch.cat([p[l] for p in per], 0) for l in range(3)]
+    assert seeded.checksum(feats) == int(fx["feat_crc"])
+    for k in ("prop", "keep", "pair"):
+        assert float(fx[k + "_gap"]) >= 5 * float(fx[k + "_noise"]), k
+    assert float(fx["pair_gap"]) >= 1e-4
+    metas = [dict(batch_input_shape=(H, W), img_shape=(H, W, 3),
+                  scale_factor=[float(v) for v in fx["img_scale"]])] * bs
+    tr = {}
+    with torch.no_grad():
+        cls, box = head(neck(feats), metas, trace=tr)
+        res = head.get_bboxes(cls, box, metas, rescale=True)
+    assert np.array_equal(tr["index"].numpy(), fx["keep_index"])
+    assert np.array_equal(tr["topk_idx"].numpy(), fx["topk_idx"])
+    for k in ("sub", "obj", "cls", "rel", "importance"):
+        assert np.array_equal(cls[k].numpy(), fx["cls_" + k]), k
+    for k in box:
+        assert np.array_equal(box[k].numpy(), fx["bbox_" + k]), k
+    for i, r in enumerate(res):
+        assert np.array_equal(r[0].numpy(), fx["res%d_det" % i])
+        assert np.array_equal(r[1].numpy(), fx["res%d_labels" % i])

@@ -601,13 +601,41 @@ def _bbox_models():
     return head, oracle, neck, cfg, sd, nsd
 
 
-def bbox_feats(seeds, H, W):
-    """One image per seed (images of a batch are independent): C3..C5 of a ResNet."""
-    per = [seeded.seeded_feats(int(s), 1, H, W)[1:] for s in seeds]
+def bbox_feats(seeds, H, W, smooth=0):
+    """One image per seed (images of a batch are independent): C3..C5 of a ResNet; `smooth`:
+    seeded.smooth_feats' coarsening factor (0: per-pixel white noise)."""
+    per = [(seeded.smooth_feats(int(s), 1, H, W, smooth) if smooth
+            else seeded.seeded_feats(int(s), 1, H, W))[1:] for s in seeds]
     return [torch.cat([p[l] for p in per], 0) for l in range(3)]
 
 
-def gen_bbox(name, H, W, bs, first_seed):
+def _by_token(trace, key, n_tokens):
+    """A per-query quantity scattered to its proposal's token index (NaN elsewhere): decoder
+    queries are identified by the token their proposal came from, whatever the order of the
+    proposal list."""
+    v = trace[key]
+    out = torch.full((v.shape[0], n_tokens), float("nan"), dtype=torch.float64)
+    return out.scatter(1, trace["topk_proposals"], v.double())
+
+
+def _kept_tokens(trace):
+    return torch.gather(trace["topk_proposals"], 1, trace["index"])
+
+
+def _keep_margin(t32, t64):
+    """(min gap between consecutive kept-query scores, fp32-vs-fp64 difference of the scores of
+    the 200 best queries compared token by token, same kept list?)"""
+    n = int(max(t32["topk_proposals"].max(), t64["topk_proposals"].max())) + 1
+    a, b = _by_token(t32, "query_score", n), _by_token(t64, "query_score", n)
+    s, o = t32["query_score"].sort(dim=-1, descending=True)
+    gap = float((s[..., :100] - s[..., 1:101]).min())
+    top_tok = torch.gather(t32["topk_proposals"], 1, o[..., :200])
+    d = (a - b).abs().gather(1, top_tok)
+    nz = float(d.nan_to_num(nan=float("inf")).max())     # a top query missing in fp64: inf
+    return gap, nz, torch.equal(_kept_tokens(t32), _kept_tokens(t64))
+
+
+def gen_bbox(name, H, W, bs, first_seed, smooth=0):
     import copy
     head, oracle, neck, cfg, sd0, nsd = _bbox_models()
     ops = {"scale_cls_branches.5.weight": np.array([BBOX_CLS_GAIN, 0, cfg["num_classes"]])}
@@ -618,22 +646,22 @@ def gen_bbox(name, H, W, bs, first_seed):
     seeds, seed = [], first_seed
     with torch.no_grad():
         while len(seeds) < bs:
-            f = bbox_feats([seed], H, W)
+            f = bbox_feats([seed], H, W, smooth)
             t32 = {}
             oracle(neck(f), meta1, trace=t32)
             s, o = t32["query_score"].sort(dim=-1, descending=True)
             gap = float((s[..., :100] - s[..., 1:101]).min())
             msg = "feat seed %d: kept-query gap %.2e" % (seed, gap)
-            if gap >= 8e-6:            # (typical fp32-vs-fp64 difference: 1-3e-6)
+            if gap >= 4e-6:            # (typical fp32-vs-fp64 difference: 0.3-3e-6)
                 t64 = {}
                 o64(n64([x.double() for x in f]), meta1, trace=t64)
-                nz = float((t32["query_score"] - t64["query_score"]).abs().gather(-1, o[..., :200]).max())
+                gap, nz, same = _keep_margin(t32, t64)
                 msg += ", fp32-vs-fp64 %.2e -> margin %.1f" % (nz, gap / nz)
-                if gap >= BBOX_MARGIN * nz and torch.equal(t32["index"], t64["index"]):
+                if gap >= BBOX_MARGIN * nz and same:
                     seeds.append(seed)
             print(msg, flush=True)
             seed += 1
-        feats = bbox_feats(seeds, H, W)
+        feats = bbox_feats(seeds, H, W, smooth)
         sf = [float(W) / round(W / 1.6), float(H) / round(H / 1.6)] * 2
         metas = [dict(batch_input_shape=(H, W), img_shape=(H, W, 3), scale_factor=sf)] * bs
         nf = neck(feats)
@@ -661,9 +689,7 @@ def gen_bbox(name, H, W, bs, first_seed):
     s0 = e0.sort(dim=-1, descending=True)[0]
     prop_gap = float((s0[:, P - 1] - s0[:, P]).min())
     prop_noise = float((e0 - e064).abs().max())
-    s, o = t32["query_score"].sort(dim=-1, descending=True)
-    keep_gap = float((s[..., :100] - s[..., 1:101]).min())
-    keep_noise = float((t32["query_score"] - t64["query_score"]).abs().gather(-1, o[..., :200]).max())
+    keep_gap, keep_noise, same_kept = _keep_margin(t32, t64)
     k = cfg["num_rel_query"]
     pair_gap = float(topk_gaps(cls["importance"], k).min())
     pair_noise = _top_noise(cls["importance"], c64["importance"], k)
@@ -672,7 +698,7 @@ def gen_bbox(name, H, W, bs, first_seed):
           % (name, prop_gap, prop_noise, keep_gap, keep_noise, pair_gap, pair_noise, dt))
     assert set(map(tuple, t32["topk_proposals"].sort(-1)[0].tolist())) == \
         set(map(tuple, t64["topk_proposals"].sort(-1)[0].tolist()))
-    assert torch.equal(t32["index"], t64["index"]) and torch.equal(t32["topk_idx"], t64["topk_idx"])
+    assert same_kept and torch.equal(t32["topk_idx"], t64["topk_idx"])
     assert prop_gap >= BBOX_MARGIN * prop_noise and keep_gap >= BBOX_MARGIN * keep_noise
     # (the pair scores inherit the trunk's rounding through queries that are 96 % common
     # component with random weights: 5 x is what a 1000-seed search reaches; the GPU test
@@ -682,7 +708,7 @@ def gen_bbox(name, H, W, bs, first_seed):
     bprobe = torch.from_numpy(np.random.default_rng(92).integers(0, box["bbox"].numel() * 0 + cls["enc_bbox_preds"].numel(), 4096))
     out = dict(weight_seed=WEIGHT_SEED + 2, neck_seed=WEIGHT_SEED + 3, weight_crc=seeded.checksum(sd0),
                neck_crc=seeded.checksum(nsd), feat_seeds=np.array(seeds), feat_crc=seeded.checksum(feats),
-               height=H, width=W, batch=bs, img_scale=np.array(sf),
+               height=H, width=W, batch=bs, img_scale=np.array(sf), feat_smooth=smooth,
                prop_gap=prop_gap, prop_noise=prop_noise, keep_gap=keep_gap, keep_noise=keep_noise,
                pair_gap=pair_gap, pair_noise=pair_noise,
                proposals=_np(t32["topk_proposals"]), keep_index=_np(t32["index"]),
@@ -739,7 +765,7 @@ def main():
     if want("bbox_small"):
         gen_bbox("bbox_small", 160, 192, 2, 300)
     if want("bbox_full"):
-        gen_bbox("bbox_full", 800, 1333, 1, 500)
+        gen_bbox("bbox_full", 800, 1333, 1, 500, smooth=16)   # (see seeded.smooth_feats)
     for f in sorted(os.listdir(OUT)):
         print("%-16s %8.1f KB" % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))
 

@@ -117,6 +117,23 @@ def seeded_feats(seed, batch, height, width, channels=(256, 512, 1024, 2048),
     return [uniform(rng, (batch, c, hh, ww), -1.0, 1.0) for c, (hh, ww) in zip(channels, sizes)]
 
 
+def smooth_feats(seed, batch, height, width, k, channels=(256, 512, 1024, 2048)):
+    """The same pyramid with spatially SMOOTH maps: white noise on a grid k times coarser,
+    bilinearly upsampled (align_corners).  Per-pixel white noise is the worst case for
+    anything that samples the maps at computed positions -- the derivative of a bilinear
+    sample is (neighbour difference) x (map width), which at 167 columns turns a 1e-6
+    perturbation of a sampling location into 1e-4 of the sample, per decoder layer; a
+    backbone's real feature maps are smooth on that scale."""
+    import torch.nn.functional as F
+    out = []
+    for f in seeded_feats(seed, batch, height, width, channels):
+        h, w = f.shape[-2:]
+        hc, wc = -(-h // k) + 1, -(-w // k) + 1
+        out.append(F.interpolate(f[..., :hc, :wc].contiguous(), size=(h, w), mode="bilinear",
+                                 align_corners=True))
+    return out
+
+
 def checksum(tensors):
     """crc32 over the raw bytes of a list/dict of tensors (order-dependent)."""
     if isinstance(tensors, dict):

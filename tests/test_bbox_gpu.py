@@ -60,8 +60,9 @@ def _hip_models(sd, nsd):
     return head, neck
 
 
-def _feats(seeds, H, W):
-    per = [seeded.seeded_feats(int(s), 1, H, W)[1:] for s in seeds]
+def _feats(seeds, H, W, smooth=0):
+    per = [(seeded.smooth_feats(int(s), 1, H, W, smooth) if smooth
+            else seeded.seeded_feats(int(s), 1, H, W))[1:] for s in seeds]
     return [torch.cat([p[l] for p in per], 0) for l in range(3)]
 
 
@@ -183,7 +184,7 @@ def _run_fixture(name):
     ohead, oneck, sd, nsd, crc = _oracles(int(fx["weight_seed"]), int(fx["neck_seed"]), ops)
     assert crc == (int(fx["weight_crc"]), int(fx["neck_crc"]))
     H, W, bs = int(fx["height"]), int(fx["width"]), int(fx["batch"])
-    feats = _feats(fx["feat_seeds"], H, W)
+    feats = _feats(fx["feat_seeds"], H, W, int(fx["feat_smooth"]) if "feat_smooth" in fx.files else 0)
     assert seeded.checksum(feats) == int(fx["feat_crc"])
     sf = [float(v) for v in fx["img_scale"]]
     metas = [dict(batch_input_shape=(H, W), img_shape=(H, W, 3), scale_factor=sf)] * bs

@@ -611,7 +611,9 @@ def test_bbox_fixtures_are_separated_and_match_the_oracle(name):
     head.load_state_dict(seeded.apply_ops(sd, overrides_of(fx)))
     neck.load_state_dict(nsd)
     H, W, bs = int(fx["height"]), int(fx["width"]), int(fx["batch"])
-    per = [seeded.seeded_feats(int(s), 1, H, W)[1:] for s in fx["feat_seeds"]]
+    k = int(fx["feat_smooth"]) if "feat_smooth" in fx.files else 0
+    per = [(seeded.smooth_feats(int(s), 1, H, W, k) if k else seeded.seeded_feats(int(s), 1, H, W))[1:]
+           for s in fx["feat_seeds"]]
     feats = [torch.cat([p[l] for p in per], 0) for l in range(3)]
     assert seeded.checksum(feats) == int(fx["feat_crc"])
     for k in ("prop", "keep", "pair"):

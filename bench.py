@@ -73,8 +73,8 @@ def bench_bbox(args, dev, rank, world):
     """Secondary measurement: the box-trunk sibling
     configs/deformable_detr/cross_r101_vg.py -- image tensor -> ResNet-101 (C3-C5) ->
     ChannelMapper -> CrossHeadBBox (two-stage Deformable-DETR trunk, PPN, relation decoder) ->
-    get_bboxes, one image per step on one stream, head and backbone as hipGraph replays.  Not
-    the headline (BASELINE.json names the Mask2Former path); same JSON contract."""
+    get_bboxes, scheduled like the headline path (hipGraph replay per stage under
+    `PipelinedHead`; `--no-pipeline`: one stream, one image in flight).  Not the headline (BASELINE.json names the Mask2Former path); same JSON contract."""
     import torch.distributed as dist
     from pairnet_amd import build_detector, cross_r101_vg, hip
     det = build_detector(cross_r101_vg().model).to(dev)
@@ -85,17 +85,41 @@ def bench_bbox(args, dev, rank, world):
     img = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
     metas = [dict(batch_input_shape=(H, W), img_shape=(H, W, 3), scale_factor=[2.083] * 4)] * B
 
+    from pairnet_amd import PipelinedHead
+    head, depth = det.bbox_head, args.depth
+    eng = None if args.no_pipeline else PipelinedHead(
+        head, depth=depth, a_streams=args.a_streams,
+        **({} if args.grid_trim is None else dict(grid_trim=args.grid_trim)))
+    count = [0]
+
     def step():
-        feats = det.extract_feat(img)
-        return det.bbox_head.simple_test_bboxes(feats, metas, rescale=True)
-    for _ in range(max(args.warmup, 3)):
+        """One image: backbone + neck + stage A on this batch's stage-A stream (per-slot
+        buffers), the query chain of older batches on the chain streams (pipeline.py)."""
+        if eng is None:
+            return head.simple_test_bboxes(det.extract_feat(img), metas, rescale=True)
+        i = count[0]
+        count[0] += 1
+        with torch.cuda.stream(eng.streams_a[i % len(eng.streams_a)]):
+            x = det.backbone(img, slot=i % depth)
+            feats = det.neck(tuple(x[j] for j in det.out_indices), slot=i % depth)
+            return eng.submit(feats, metas, rescale=True)
+
+    def drain():
+        if eng is None:
+            return []
+        with torch.cuda.stream(eng.streams_a[0]):
+            return eng.flush()
+    for _ in range(max(args.warmup, 3 * depth)):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
+    tail = drain()
+    res = tail[-1] if tail else res
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -103,8 +127,14 @@ def bench_bbox(args, dev, rank, world):
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt)
+    # scheduling only: the last pipelined batch against a plain single-stream call
+    labels, dists = res[0][1].clone(), res[0][5].clone()
+    head.use_graphs = det.backbone.use_graphs = False
+    plain = head.simple_test_bboxes(det.extract_feat(img), metas, rescale=True)
+    torch.cuda.synchronize()
+    check = bool(torch.equal(labels, plain[0][1]) and torch.equal(dists, plain[0][5]))
+    eng = None
     # per-kernel times of one eager step (HIP events around every launch)
-    det.bbox_head.use_graphs = det.backbone.use_graphs = False
     step()
     hip.TIMER = hip.KernelTimer()
     for _ in range(3):
@@ -127,8 +157,16 @@ def bench_bbox(args, dev, rank, world):
                                   "bs=%d per GPU, %dx%d, random-init weights" % (B, H, W),
                       "head": "bbox", "global_batch": world * B, "image": [H, W],
                       "parallelism": "dp%d" % world,
-                      "schedule": "one stream, backbone and head as hipGraph replays"},
-           "kernel_profile": prof, "labels_checksum": int(res[0][1].sum())}
+                      "schedule": "one stream, backbone and head as hipGraph replays" if args.no_pipeline
+                      else "hipGraph replay per stage, %d-stream pipeline: backbone + neck + stage A "
+                           "(encoder, proposals) of consecutive images alternate between %d streams, "
+                           "their query chains run on %d more" % (depth, args.a_streams,
+                                                                  depth - args.a_streams)},
+           "pipeline_check": "labels / rel_dists of the last pipelined image are bitwise the eager "
+                             "single-stream result" if check else "MISMATCH",
+           "kernel_profile": prof}
+    if not check:
+        raise SystemExit("pipelined result differs from the eager one")
     if rank == 0:
         print(json.dumps(out))
 

@@ -276,7 +276,11 @@ class CrossHeadBBox(CrossHead2):
         prop = prop.masked_fill(~valid.unsqueeze(-1), float("inf"))
         return prop, valid
 
-    def _plan(self, B, shapes, slot=0, tokens=None):
+    def _plan(self, B, shapes, hw2=None, slot=0, nhwc=False, tokens=None):
+        """(`hw2`, `nhwc`: CrossHead2's plan signature, unused here -- PipelinedHead calls
+        every head the same way.)"""
+        if tokens is None:
+            tokens = getattr(self, "_tokens", None)
         key = (B, tuple(shapes), slot, None if tokens is None else tokens.data_ptr())
         if key in self._plans:
             return self._plans[key]
@@ -293,8 +297,9 @@ class CrossHeadBBox(CrossHead2):
         if SN < self.num_proposals or SN > 65536:
             raise RuntimeError("%d encoder tokens: need between the %d proposals and 65536"
                                % (SN, self.num_proposals))
-        pl.graph = pl.graph_cfg = None
-        pl.calls = 0
+        pl.graph_a = pl.graph_b = pl.graph_cfg = None
+        pl.calls_a = pl.calls_b = 0
+        pl.feats_read = torch.cuda.Event()
         pl.chains = {}
         M, P, K = B * SN, self.num_proposals, self.KEPT
         nc = self.cls_out_channels
@@ -464,13 +469,59 @@ class CrossHeadBBox(CrossHead2):
         hip.gather_rows(pl.box, pl.sub_pos, pl.sub_box, B, K, R, 4)
         hip.gather_rows(pl.box, pl.obj_pos, pl.obj_box, B, K, R, 4)
 
-    def _run(self, pl):
+    # Stage A: what does not depend on the decoder's query chain -- encoder, per-token heads,
+    # proposal selection, the initial queries, the decoder layers' value projections: a few
+    # dozen chip-filling launches.  Stage B: the sequential chain (6 decoder layers, query
+    # ranking, PPN, top-k, 6 relation layers, gathers).  Same split as CrossHead2, so
+    # `PipelinedHead` schedules this head unchanged.
+    def _stage_a(self, feats, pl):
+        if pl.own_tokens:      # any layout but the neck's in-place views: copy into token rows
+            self._stage_a_copy(feats, pl)
         self._encoder(pl)
         self._two_stage(pl)
+
+    def _stage_b(self, pl):
         self._decoder(pl)
         self._select(pl)
         self._pair_proposal(pl)
         self._relation_decoder(pl)
+
+    def _run_stage(self, which, pl, feats=None):
+        """Stage 'a' or 'b' of plan `pl` on the current stream: eagerly, or (with `use_graphs`,
+        from the second call on) as one hipGraph replay.  A stage-A graph is tied to the
+        buffers it was captured on: the neck's in-place token rows belong to the plan (its
+        key), plain feature tensors are staged through the plan's own token rows."""
+        cfg = (self.gemm_mode, self.fuse_ppn_front)
+        if pl.graph_cfg != cfg:
+            pl.graph_a = pl.graph_b = None
+            pl.graph_cfg = cfg
+        if which == "a":
+            if pl.own_tokens:
+                self._stage_a_copy(feats, pl)
+                pl.feats_read.record()       # the caller's feature buffers are free again
+            body = lambda: (self._encoder(pl), self._two_stage(pl))
+            if self.use_graphs and pl.graph_a is None and pl.calls_a >= 1:
+                pl.graph_a = self._capture(body)
+            pl.calls_a += 1
+            if self.use_graphs and pl.graph_a is not None:
+                pl.graph_a.replay()
+            else:
+                body()
+            if not pl.own_tokens:
+                pl.feats_read.record()       # (the neck's token rows are encoded in place)
+        else:
+            if self.use_graphs and pl.graph_b is None and pl.calls_b >= 1:
+                pl.graph_b = self._capture(lambda: self._stage_b(pl))
+            pl.calls_b += 1
+            if self.use_graphs and pl.graph_b is not None:
+                pl.graph_b.replay()
+            else:
+                self._stage_b(pl)
+
+    def _stage_a_copy(self, feats, pl):
+        B = pl.B
+        for f, s, n, (h, w) in zip(feats, pl.start, pl.N, pl.shapes):
+            pl.X[:, s:s + n].view(B, h, w, 256).permute(0, 3, 1, 2).copy_(f)
 
     def _outputs(self, pl):
         return (dict(sub=pl.sub_cls, obj=pl.obj_cls, cls=pl.cls, enc_cls_scores=pl.enc_cls,
@@ -494,7 +545,10 @@ class CrossHeadBBox(CrossHead2):
                     "GPU (cross_r101_vg.py:264-288)" % (tuple(m["img_shape"][:2]), (ih, iw)))
         if self.device is None:
             self.to(feats[0].device)
-        return B, [tuple(f.shape[-2:]) for f in feats]
+        self._feats_nhwc = False
+        shapes = [tuple(f.shape[-2:]) for f in feats]
+        self._tokens = self._token_buffer(feats, shapes)
+        return B, shapes, None
 
     @staticmethod
     def _token_buffer(feats, shapes):
@@ -516,22 +570,10 @@ class CrossHeadBBox(CrossHead2):
         the GPU; returns the reference's two dicts (pairnet_bbox_head.py:343-359).  Output
         tensors are views of per-shape buffers that the next forward() of the same shape (and
         slot) overwrites."""
-        B, shapes = self._check_feats(mlvl_feats, img_metas)
-        tokens = self._token_buffer(mlvl_feats, shapes)
-        pl = self._plan(B, shapes, slot, tokens)
-        if pl.own_tokens:      # any other layout: one strided copy per level into token rows
-            for f, s, n, (h, w) in zip(mlvl_feats, pl.start, pl.N, shapes):
-                pl.X[:, s:s + n].view(B, h, w, 256).permute(0, 3, 1, 2).copy_(f)
-        cfg = (self.gemm_mode, self.fuse_ppn_front)
-        if pl.graph_cfg != cfg:
-            pl.graph, pl.graph_cfg = None, cfg
-        if self.use_graphs and pl.graph is None and pl.calls >= 1:
-            pl.graph = self._capture(lambda: self._run(pl))
-        pl.calls += 1
-        if self.use_graphs and pl.graph is not None:
-            pl.graph.replay()
-        else:
-            self._run(pl)
+        B, shapes, _ = self._check_feats(mlvl_feats, img_metas)
+        pl = self._plan(B, shapes, None, slot)
+        self._run_stage("a", pl, mlvl_feats)
+        self._run_stage("b", pl)
         self._last_plan = pl
         return self._outputs(pl)
 

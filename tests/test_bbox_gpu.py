@@ -263,9 +263,42 @@ def test_bbox_head_graph_replay_and_other_layouts_are_bitwise_the_eager_result(b
     head.use_graphs = True
     for _ in range(3):
         c3, b3 = head(plain, metas)
-    assert head._last_plan.graph is not None
+    assert head._last_plan.graph_a is not None and head._last_plan.graph_b is not None
     for k, v in list(c3.items()) + list(b3.items()):
         assert torch.equal(v, keep[k]), k
+
+
+def test_bbox_head_under_the_multi_stream_pipeline_is_bitwise_the_plain_call(built_lib):
+    """`PipelinedHead` (pipeline.py) schedules CrossHeadBBox like CrossHead2: stage A = encoder
+    + proposals, stage B = the query chain; neck + head of consecutive batches on alternating
+    streams with per-slot buffers, the bench.py --head bbox loop."""
+    import pairnet_amd as P
+    fx, head, cls, box, metas = _run_fixture("bbox_small")
+    want = head.get_bboxes(cls, box, metas, rescale=True)
+    want = [[t.clone() for t in r] for r in want]
+    H, W = int(fx["height"]), int(fx["width"])
+    _, _, _, nsd, _ = _oracles(int(fx["weight_seed"]), int(fx["neck_seed"]))
+    _, _, ncfg = _cfgs()
+    neck = P.ChannelMapper(**ncfg).to(DEV)
+    neck.load_state_dict(nsd)
+    ins = [f.to(DEV) for f in _feats(fx["feat_seeds"], H, W)]
+    noise = [torch.randn_like(f) for f in ins]
+    head.use_graphs = True
+    eng = P.PipelinedHead(head, depth=4, a_streams=2)
+    outs = []
+    for i in range(9):          # the fixture's input every third batch, noise otherwise
+        sa = eng.streams_a[i % 2]
+        with torch.cuda.stream(sa):
+            r = eng.submit(neck(ins if i % 3 == 0 else noise, slot=i % 4), metas, rescale=True)
+            if r is not None:
+                outs.append([[t.clone() for t in x] for x in r])
+    with torch.cuda.stream(eng.streams_a[0]):
+        outs += [[[t.clone() for t in x] for x in r] for r in eng.flush()]
+    torch.cuda.synchronize()
+    assert len(outs) == 9
+    for i in (0, 3, 6):
+        for a, b in zip(outs[i], want):
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
 
 
 def test_bbox_head_rejects_what_it_does_not_build(built_lib):

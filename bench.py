@@ -492,6 +492,12 @@ def main():
         for _ in range(nprof):
             head.simple_test_bboxes(backbone(img) if backbone is not None else feats, metas)
         prof = timer.summary()
+        # the dominant kernel's launches by shape (= by flop count and byte count)
+        by_shape = {}
+        for name, flops, nbytes, s_ev, e_ev in timer.records:
+            a = by_shape.setdefault((name, flops, nbytes), [0, 0.0])
+            a[0] += 1
+            a[1] += s_ev.elapsed_time(e_ev)
         hip.TIMER = None
         head.use_graphs = not args.no_graphs
         if backbone is not None and not swin:
@@ -586,6 +592,18 @@ def main():
                                 "eager single-stream steps right after the timed region" % nprof}
 
             out["roofline"] = roof(dominant)
+            if out["roofline"]["bound"] == "mfma":
+                # the same kernel per problem shape, largest share of its time first: the
+                # fraction above is a launch mix (big encoder GEMMs, mid-size backbone 1x1
+                # convolutions whose tile counts quantise badly on 1024 resident workgroups)
+                shapes = sorted(((k, v) for k, v in by_shape.items() if k[0] == dominant),
+                                key=lambda kv: -kv[1][1])[:6]
+                out["roofline"]["by_shape"] = [
+                    {"gflop_per_launch": k[1] * 1e-9, "launches_per_step": v[0] // nprof,
+                     "avg_launch_us": 1e3 * v[1] / v[0],
+                     "tflops": k[1] / (v[1] / v[0] * 1e-3) / 1e12,
+                     "frac": k[1] / (v[1] / v[0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                     "share_of_kernel_time": v[1] / prof[dominant]["ms"]} for k, v in shapes]
             # the north star's other named kernel: achieved HBM GB/s of the deformable sampling
             msda = [k for k in prof if k.startswith("k_msda")]
             if msda:

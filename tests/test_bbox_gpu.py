@@ -301,6 +301,31 @@ def test_bbox_head_under_the_multi_stream_pipeline_is_bitwise_the_plain_call(bui
             assert all(torch.equal(x, y) for x, y in zip(a, b))
 
 
+def test_proposals_tied_at_the_invalid_token_score_are_interchangeable(built_lib):
+    """Tokens whose proposal box leaves (0.01, 0.99) are zeroed before `enc_output`, so they all
+    carry ONE class score.  With these weights that score ranks inside the best 300, the
+    selection cuts through the tie, and which tied tokens are taken is unspecified in the
+    reference (torch.topk) -- but they yield identical queries (same embedding, same +inf box
+    logits), so the multiset of decoder outputs must still be the reference's."""
+    import pairnet_amd as P
+    ohead, oneck, sd, nsd, _ = _oracles(31, 32)
+    head, neck = _hip_models(sd, nsd)
+    H, W = 608, 1023
+    feats = seeded.smooth_feats(2608, 1, H, W, 8)[1:]
+    metas = [dict(batch_input_shape=(H, W), img_shape=(H, W, 3), scale_factor=[1.3] * 4)]
+    tr = {}
+    with torch.no_grad():
+        ohead(oneck(feats), metas, trace=tr)
+    head(neck([f.to(DEV) for f in feats]), metas)
+    pl = head._last_plan
+    valid = P.CrossHeadBBox.proposals(pl.shapes)[1]
+    n_inv = int((~valid[tr["topk_proposals"][0]]).sum())
+    assert 0 < n_inv < 300 and int((~valid).sum()) > n_inv      # the cut goes through the tie
+    assert int((~valid[pl.top_idx[0].cpu()]).sum()) == n_inv
+    assert _err(pl.qscore.sort(-1)[0], tr["query_score"].sort(-1)[0]) < 1e-6
+    assert _err(pl.ref[-1].view(1, -1, 4).sum(-1).sort(-1)[0], tr["coords"][-1].sum(-1).sort(-1)[0]) < 2e-5
+
+
 def test_bbox_head_rejects_what_it_does_not_build(built_lib):
     P, cfg, _ = _cfgs()
     with pytest.raises(NotImplementedError):

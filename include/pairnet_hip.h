@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 11
+#define PN_ABI_VERSION 12
 int pn_abi_version(void);
 
 /* Scheduling knob (process-wide, performance only): leave `trim` of the persistent GEMM
@@ -492,6 +492,15 @@ int pn_triplet_match(const int32_t* pred_triplets, const int32_t* gt_triplets, i
                      int ld_inter, const int32_t* pred_sub_row, const int32_t* pred_obj_row,
                      const int32_t* gt_sub_row, const int32_t* gt_obj_row, double iou_thr,
                      int phrdet, int ignore_rel, uint8_t* match, void* stream);
+/* The same triplet match on boxes, for `detection_method="bbox"` (the box-trunk sibling head):
+ * `_compute_pred_matches_bbox` (sgg_metrics.py:1212-1273) with mmdet's
+ * `bbox_overlaps(mode="iou", eps=1e-6)` in float32; boxes (x1, y1, x2, y2) in rows of ld_*
+ * floats (so `refine_bboxes` [2R][5] can be passed as it is); phrdet: union boxes. */
+int pn_triplet_match_boxes(const int32_t* pred_triplets, const int32_t* gt_triplets, int P, int G,
+                           const float* pred_boxes, int ld_pred, const float* gt_boxes, int ld_gt,
+                           const int32_t* pred_sub_row, const int32_t* pred_obj_row,
+                           const int32_t* gt_sub_row, const int32_t* gt_obj_row, float iou_thr,
+                           int phrdet, int ignore_rel, uint8_t* match, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Box trunk of the sibling head CrossHeadBBox (pairnet_bbox_head.py:193-359): the

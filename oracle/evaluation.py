@@ -59,3 +59,61 @@ def evaluate(labels, rel_pairs, rel_dists, masks, gt_rels, gt_labels, gt_masks, 
         out[name + "_recall"] = rec
         out[("" if not ph else "phrdet_") + "pred_to_gt"] = p2g
     return out
+
+
+# ---- detection_method == "bbox" (sgg_metrics.py:1181-1273) ----
+def bbox_overlaps(b1, b2, eps=1e-6):
+    """mmdet.core.bbox_overlaps(mode="iou", is_aligned=False) restated (third party, absent
+    here): float32 throughout."""
+    import torch
+    b1, b2 = torch.as_tensor(b1, dtype=torch.float32), torch.as_tensor(b2, dtype=torch.float32)
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    lt = torch.max(b1[:, None, :2], b2[None, :, :2])
+    rb = torch.min(b1[:, None, 2:], b2[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    ov = wh[..., 0] * wh[..., 1]
+    union = torch.max(a1[:, None] + a2[None, :] - ov, ov.new_tensor([eps]))
+    return ov / union
+
+
+def pred_matches_bbox(gt_trip, pred_trip, gt_boxes, pred_boxes, thr, phrdet=False, ignore_rel=False):
+    """gt_boxes (G, 8) / pred_boxes (P, 8): subject box | object box per triplet."""
+    if ignore_rel:
+        gt_trip, pred_trip = gt_trip[:, [0, 2]], pred_trip[:, [0, 2]]
+    keeps = (gt_trip[..., None] == pred_trip.T[None, ...]).all(1)
+    out = [[] for _ in range(pred_boxes.shape[0])]
+    for g in np.where(keeps.any(1))[0]:
+        idx = np.where(keeps[g])[0]
+        boxes = pred_boxes[idx]
+        if phrdet:
+            gu = gt_boxes[g].reshape(2, 4)
+            gu = np.concatenate((gu.min(0)[:2], gu.max(0)[2:]), 0)
+            bu = boxes.reshape(-1, 2, 4)
+            bu = np.concatenate((bu.min(1)[:, :2], bu.max(1)[:, 2:]), 1)
+            inds = bbox_overlaps(gu[None], bu).numpy()[0] >= thr
+        else:
+            inds = (bbox_overlaps(gt_boxes[g][None, :4], boxes[:, :4]).numpy()[0] >= thr) & \
+                   (bbox_overlaps(gt_boxes[g][None, 4:], boxes[:, 4:]).numpy()[0] >= thr)
+        for p in idx[inds]:
+            out[p].append(int(g))
+    return out
+
+
+def evaluate_boxes(labels, rel_pairs, rel_dists, boxes, gt_rels, gt_labels, gt_boxes, thr=0.5,
+                   ks=(20, 50, 100)):
+    pred_rels = np.column_stack((rel_pairs, 1 + rel_dists[:, 1:].argmax(1)))
+    trip = lambda rel, cls, bx: (np.column_stack((cls[rel[:, 0]], rel[:, 2], cls[rel[:, 1]])),
+                                 np.column_stack((bx[rel[:, 0]], bx[rel[:, 1]])))
+    gt_trip, gt_tb = trip(gt_rels, gt_labels, gt_boxes)
+    p_trip, p_tb = trip(pred_rels, labels, boxes)
+    out = {}
+    for name, ph in (("sgdet", False), ("phrdet", True)):
+        p2g = pred_matches_bbox(gt_trip, p_trip, gt_tb, p_tb, thr, phrdet=ph)
+        rec = {}
+        for k in ks:
+            match = reduce(np.union1d, p2g[:k])
+            rec[k] = float(len(match)) / float(gt_rels.shape[0])
+        out[name + "_recall"] = rec
+        out[("" if not ph else "phrdet_") + "pred_to_gt"] = p2g
+    return out

@@ -624,3 +624,68 @@ extern "C" int pn_triplet_match(const int32_t* pred_triplets, const int32_t* gt_
                      iou_thr, phrdet, ignore_rel, match);
   return PN_LAUNCH_CHECK();
 }
+
+// ---- the same match on BOXES (sgg_metrics.py `_compute_pred_matches_bbox` :1212-1273, for the
+// box-trunk sibling head's results): IoU as mmdet's `bbox_overlaps(mode="iou", eps=1e-6)` in
+// float32 -- area = (x2 - x1) * (y2 - y1), overlap = clamp(rb - lt, 0) product, union clamped
+// to eps -- and for phrase detection on the union boxes of subject and object (:1239-1259).
+__device__ __forceinline__ float box_iou_f32(float ax1, float ay1, float ax2, float ay2, float bx1,
+                                             float by1, float bx2, float by2) {
+  // no fma contraction: `union - w * h` must round the product first, like the reference's
+  // separate tensor ops.  Plain operators under the pragma: the *_rn intrinsics are inline
+  // header functions that carry the header's own (contractable) mode into the caller.
+#pragma clang fp contract(off)
+  const float a1 = (ax2 - ax1) * (ay2 - ay1);
+  const float a2 = (bx2 - bx1) * (by2 - by1);
+  const float w = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.f);
+  const float h = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.f);
+  const float ov = w * h;
+  const float sum = a1 + a2;
+  const float un = fmaxf(sum - ov, 1e-6f);
+  return ov / un;
+}
+
+__global__ __launch_bounds__(256) void k_triplet_match_boxes(
+    const int32_t* __restrict__ ptrip, const int32_t* __restrict__ gtrip, int P, int G,
+    const float* __restrict__ pbox, int ldp, const float* __restrict__ gbox, int ldg,
+    const int32_t* __restrict__ ps, const int32_t* __restrict__ po,
+    const int32_t* __restrict__ gs, const int32_t* __restrict__ go, float thr, int phrdet,
+    int ignore_rel, uint8_t* __restrict__ match) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= P * G) return;
+  const int p = e / G, g = e - p * G;
+  bool ok = ptrip[3 * p] == gtrip[3 * g] && ptrip[3 * p + 2] == gtrip[3 * g + 2] &&
+            (ignore_rel || ptrip[3 * p + 1] == gtrip[3 * g + 1]);
+  if (ok) {
+    const float* a = pbox + (int64_t)ps[p] * ldp;
+    const float* b = pbox + (int64_t)po[p] * ldp;
+    const float* c = gbox + (int64_t)gs[g] * ldg;
+    const float* d = gbox + (int64_t)go[g] * ldg;
+    if (phrdet)
+      ok = box_iou_f32(fminf(c[0], d[0]), fminf(c[1], d[1]), fmaxf(c[2], d[2]), fmaxf(c[3], d[3]),
+                       fminf(a[0], b[0]), fminf(a[1], b[1]), fmaxf(a[2], b[2]),
+                       fmaxf(a[3], b[3])) >= thr;
+    else
+      ok = box_iou_f32(c[0], c[1], c[2], c[3], a[0], a[1], a[2], a[3]) >= thr &&
+           box_iou_f32(d[0], d[1], d[2], d[3], b[0], b[1], b[2], b[3]) >= thr;
+  }
+  match[e] = ok ? 1 : 0;
+}
+
+extern "C" int pn_triplet_match_boxes(const int32_t* pred_triplets, const int32_t* gt_triplets,
+                                      int P, int G, const float* pred_boxes, int ld_pred,
+                                      const float* gt_boxes, int ld_gt,
+                                      const int32_t* pred_sub_row, const int32_t* pred_obj_row,
+                                      const int32_t* gt_sub_row, const int32_t* gt_obj_row,
+                                      float iou_thr, int phrdet, int ignore_rel, uint8_t* match,
+                                      void* stream) {
+  if (!pred_triplets || !gt_triplets || !pred_boxes || !gt_boxes || !pred_sub_row ||
+      !pred_obj_row || !gt_sub_row || !gt_obj_row || !match || P <= 0 || G <= 0 || ld_pred < 4 ||
+      ld_gt < 4)
+    return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_triplet_match_boxes, dim3(pn_cdiv((int64_t)P * G, 256)), dim3(256), 0,
+                     (hipStream_t)stream, pred_triplets, gt_triplets, P, G, pred_boxes, ld_pred,
+                     gt_boxes, ld_gt, pred_sub_row, pred_obj_row, gt_sub_row, gt_obj_row, iou_thr,
+                     phrdet, ignore_rel, match);
+  return PN_LAUNCH_CHECK();
+}

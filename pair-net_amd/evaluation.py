@@ -68,6 +68,42 @@ class TripletEvaluator:
                           phrdet, ignore_rel, match)
         return match
 
+    @torch.no_grad()
+    @hip.on_device
+    def match_boxes(self, result, gt_rels, gt_labels, gt_boxes, phrdet=False, ignore_rel=False):
+        """`detection_method="bbox"`: result = the 6-tuple of `CrossHeadBBox.get_bboxes`
+        (det_bboxes [2R,5], labels, rel_pairs, ., ., r_dists); gt_boxes (n_obj, 4) xyxy.
+        `_compute_pred_matches_bbox` (sgg_metrics.py:1212-1273) on the device; returns the uint8
+        match matrix [R][G]."""
+        det, labels, r_dists = result[0], result[1], result[5]
+        dev = det.device
+        R, C1 = r_dists.shape
+        gt_rels = torch.as_tensor(np.asarray(gt_rels), dtype=torch.int64)
+        gt_labels = torch.as_tensor(np.asarray(gt_labels), dtype=torch.int64)
+        G = int(gt_rels.shape[0])
+        gbox = torch.as_tensor(np.asarray(gt_boxes), dtype=torch.float32).to(dev).contiguous()
+        i32 = lambda t: t.to(torch.int32).to(dev).contiguous()
+        gtrip = i32(torch.stack([gt_labels[gt_rels[:, 0]], gt_rels[:, 2],
+                                 gt_labels[gt_rels[:, 1]]], 1))
+        ptrip = torch.empty(R, 3, device=dev, dtype=torch.int32)
+        score = torch.empty(R, device=dev, dtype=torch.float32)
+        hip.pred_triplets(labels, r_dists, ptrip, score, R, C1)
+        ar = torch.arange(R, dtype=torch.int32, device=dev)
+        match = torch.empty(R, G, device=dev, dtype=torch.uint8)
+        hip.triplet_match_boxes(ptrip, gtrip, R, G, det, det.stride(0), gbox, 4, ar, ar + R,
+                                i32(gt_rels[:, 0]), i32(gt_rels[:, 1]), self.iou_thr, phrdet,
+                                ignore_rel, match)
+        return match
+
+    def evaluate_boxes(self, result, gt_rels, gt_labels, gt_boxes):
+        """sgdet + phrdet recalls of one image from box results (the graph-constrained part of
+        `calculate_recall`, sgg_metrics.py:173-252)."""
+        n = len(gt_rels)
+        p2g = self.pred_to_gt(self.match_boxes(result, gt_rels, gt_labels, gt_boxes))
+        ph = self.pred_to_gt(self.match_boxes(result, gt_rels, gt_labels, gt_boxes, phrdet=True))
+        return dict(pred_to_gt=p2g, phrdet_pred_to_gt=ph, sgdet_recall=self.recall(p2g, n),
+                    phrdet_recall=self.recall(ph, n))
+
     def pred_to_gt(self, match):
         """The reference's list of lists (one D2H copy of R x G bytes)."""
         m = match.cpu().numpy().astype(bool)

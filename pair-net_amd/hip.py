@@ -111,6 +111,8 @@ _SIGS = {
     "pn_mask_or_rows": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _vp]),
     "pn_triplet_match": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
                                    C.c_double, _i32, _i32, _vp, _vp]),
+    "pn_triplet_match_boxes": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp,
+                                         _vp, _f32, _i32, _i32, _vp, _vp]),
     "pn_preprocess_u8_f32": (C.c_int, [_vp, _i32, _i32, _vp] + [_i32] * 4 + [C.POINTER(_f32),
                                                                             C.POINTER(_f32), _i32, _vp]),
     "pn_pack_mask_bits": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
@@ -125,7 +127,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 11   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 12   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -706,6 +708,15 @@ def triplet_match(ptrip, gtrip, P, G, inter, area_p, area_g, ld_inter, ps, po, g
                                   _ptr(po, i32), _ptr(gs, i32), _ptr(go, i32), float(thr),
                                   int(phrdet), int(ignore_rel), _ptr(match, torch.uint8),
                                   _stream()), "pn_triplet_match")
+
+
+def triplet_match_boxes(ptrip, gtrip, P, G, pbox, ldp, gbox, ldg, ps, po, gs, go, thr, phrdet,
+                        ignore_rel, match):
+    i32 = torch.int32
+    _check(lib().pn_triplet_match_boxes(
+        _ptr(ptrip, i32), _ptr(gtrip, i32), P, G, _ptr(pbox), ldp, _ptr(gbox), ldg, _ptr(ps, i32),
+        _ptr(po, i32), _ptr(gs, i32), _ptr(go, i32), float(thr), int(phrdet), int(ignore_rel),
+        _ptr(match, torch.uint8), _stream()), "pn_triplet_match_boxes")
 
 
 def chain_lin(src, W, bias=None, dst=-1, out=None, res=-1, relu=False, aadd=None,

@@ -96,3 +96,92 @@ def test_device_evaluator_feed_equals_the_oracle(seed):
     assert out["sgdet_recall"] == ref["sgdet_recall"]
     assert out["phrdet_recall"] == ref["phrdet_recall"]
     assert out["sgdet_recall"][100] > 0.5                        # (the planted hits are found)
+
+
+# ---- detection_method == "bbox": the box-trunk sibling head's results ----------------------
+def _box_scene(seed, R=100, nobj=8, G=10, W=640.0, H=480.0):
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(0, [W - 120, H - 120], (nobj, 2))
+    wh = rng.uniform(20, 120, (nobj, 2))
+    gt_boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+    gt_labels = rng.integers(1, 151, nobj)
+    pairs = [(s, o) for s in range(nobj) for o in range(nobj) if s != o]
+    sel = rng.choice(len(pairs), G, replace=False)
+    gt_rels = np.array([[pairs[j][0], pairs[j][1], rng.integers(1, 51)] for j in sel])
+    labels = rng.integers(1, 151, 2 * R)
+    xy = rng.uniform(0, [W - 60, H - 60], (2 * R, 2))
+    boxes = np.concatenate([xy, xy + rng.uniform(5, 60, (2 * R, 2))], 1).astype(np.float32)
+    boxes[5] = [10, 10, 10, 10]                                   # a degenerate box (zero area)
+    rel_dists = rng.random((R, 51)).astype(np.float32)
+    rel_dists[:, 0] = 0
+    for j, (s, o, pr) in enumerate(gt_rels):          # hits, wrong predicate, IoU around 0.5
+        for rep, r in enumerate((3 * j, 3 * j + 1, 3 * j + 2, 3 * j + 40)):
+            labels[r], labels[R + r] = gt_labels[s], gt_labels[o]
+            rel_dists[r, pr] = 2.0 if rep != 1 else 0.0
+            # shrink so that IoU = f: rep 2 sits exactly ON the threshold region (w * 0.5)
+            f = (1.0, 1.0, 0.5, 0.45)[rep]
+            for src, dst in ((s, r), (o, R + r)):
+                b = gt_boxes[src].copy()
+                b[2] = b[0] + (b[2] - b[0]) * f
+                boxes[dst] = b
+    scores = rng.random(2 * R).astype(np.float32)
+    det = np.concatenate([boxes, scores[:, None]], 1)
+    rel_pairs = np.stack([np.arange(R), np.arange(R) + R], 1)
+    return labels, rel_pairs, rel_dists, det, gt_rels, gt_labels, gt_boxes
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
+def test_box_evaluation_oracle_equals_the_reference_functions():
+    """oracle.evaluation.pred_matches_bbox against the reference's `_compute_pred_matches_bbox`
+    / `_triplet_bbox` (sgg_metrics.py:1181-1273) run from /root/reference, with mmdet's
+    `bbox_overlaps` (absent) supplied by the restatement the oracle itself uses."""
+    sys.dont_write_bytecode = True
+    for name, attrs in (("mmdet", {}), ("mmdet.core", dict(bbox_overlaps=OE.bbox_overlaps)),
+                        ("terminaltables", dict(AsciiTable=None))):
+        m = sys.modules.setdefault(name, types.ModuleType(name))
+        for k, v in attrs.items():
+            setattr(m, k, v)
+    pkg = types.ModuleType("refevalb")
+    pkg.__path__ = [os.path.join(ref_shim.REF_ROOT, "pairnet/evaluation")]
+    sys.modules["refevalb"] = pkg
+    mods = {}
+    for n in ("sgg_eval_util", "sgg_metrics"):
+        spec = importlib.util.spec_from_file_location(
+            "refevalb." + n, os.path.join(ref_shim.REF_ROOT, "pairnet/evaluation", n + ".py"))
+        mods[n] = importlib.util.module_from_spec(spec)
+        sys.modules["refevalb." + n] = mods[n]
+        spec.loader.exec_module(mods[n])
+    M = mods["sgg_metrics"]
+    for seed in (1, 2):
+        labels, rel_pairs, rel_dists, det, gt_rels, gt_labels, gt_boxes = _box_scene(seed)
+        ours = OE.evaluate_boxes(labels, rel_pairs, rel_dists, det[:, :4], gt_rels, gt_labels, gt_boxes)
+        pred_rels = np.column_stack((rel_pairs, 1 + rel_dists[:, 1:].argmax(1)))
+        gt_t, gt_tb, _ = M._triplet_bbox(gt_rels, gt_labels, gt_boxes)
+        p_t, p_tb, _ = M._triplet_bbox(pred_rels, labels, det[:, :4])
+        for ph, key in ((False, "pred_to_gt"), (True, "phrdet_pred_to_gt")):
+            ref = M._compute_pred_matches_bbox(gt_t, p_t, gt_tb, p_tb, 0.5, phrdet=ph)
+            assert ref == ours[key]
+        assert sum(len(x) for x in ours["pred_to_gt"]) >= 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_device_box_evaluator_feed_equals_the_oracle(seed):
+    from pairnet_amd.evaluation import TripletEvaluator
+    labels, rel_pairs, rel_dists, det, gt_rels, gt_labels, gt_boxes = _box_scene(seed)
+    ref = OE.evaluate_boxes(labels, rel_pairs, rel_dists, det[:, :4], gt_rels, gt_labels, gt_boxes)
+    dev = "cuda:0"
+    result = (torch.from_numpy(det).to(dev), torch.from_numpy(labels).to(dev),
+              torch.from_numpy(rel_pairs), None, None, torch.from_numpy(rel_dists).to(dev))
+    out = TripletEvaluator().evaluate_boxes(result, gt_rels, gt_labels, gt_boxes)
+    for k in ("pred_to_gt", "phrdet_pred_to_gt", "sgdet_recall", "phrdet_recall"):
+        assert out[k] == ref[k], k
+    assert out["sgdet_recall"][100] > 0.5
+    ig = TripletEvaluator().pred_to_gt(TripletEvaluator().match_boxes(
+        result, gt_rels, gt_labels, gt_boxes, ignore_rel=True))
+    trip = lambda rel, cls, bx: (np.column_stack((cls[rel[:, 0]], rel[:, 2], cls[rel[:, 1]])),
+                                 np.column_stack((bx[rel[:, 0]], bx[rel[:, 1]])))
+    pred_rels = np.column_stack((rel_pairs, 1 + rel_dists[:, 1:].argmax(1)))
+    gt_t, gt_tb = trip(gt_rels, gt_labels, gt_boxes)
+    p_t, p_tb = trip(pred_rels, labels, det[:, :4])
+    assert ig == OE.pred_matches_bbox(gt_t, p_t, gt_tb, p_tb, 0.5, ignore_rel=True)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 12
+#define PN_ABI_VERSION 13
 int pn_abi_version(void);
 
 /* Scheduling knob (process-wide, performance only): leave `trim` of the persistent GEMM
@@ -308,6 +308,11 @@ int pn_sine_pe_f32(float* out, const float* add, int h, int w, int C,
  * before normalisation; configs/deformable_detr/cross_r101_vg.py:118-120 uses -0.5). */
 int pn_sine_pe_offset_f32(float* out, const float* add, int h, int w, int C, float temperature,
                           float offset, void* stream);
+/* The same on a padded map: rows >= valid_h / columns >= valid_w are padding
+ * (SinePositionalEncoding on a mask: the cumulative sums stop growing there, and the
+ * normalisation divides by the valid size). */
+int pn_sine_pe_valid_f32(float* out, const float* add, int h, int w, int valid_h, int valid_w,
+                         int C, float temperature, float offset, void* stream);
 
 /* Bilinear resize, align_corners=False (F.interpolate semantics).
  * nhwc:   in [b][hi][wi][C] -> out [b][ho][wo][C], out = (accumulate? out:0)+v;
@@ -508,10 +513,13 @@ int pn_triplet_match_boxes(const int32_t* pred_triplets, const int32_t* gt_tripl
  * (built at :66, called at :215-228) between this library's GEMM / deformable-attention
  * entries.  All row-parallel and HBM-bound.
  * ------------------------------------------------------------------------- */
-/* out[b][r][:] = valid[r] ? x[b][r][:] : 0; valid [rows] bytes (gen_encoder_output_proposals:
- * tokens whose proposal box leaves (0.01, 0.99) are zeroed before enc_output). C % 4 == 0. */
+/* out[b][r][:] = valid[b][r] ? x[b][r][:] : 0 on rows of C floats at stride ld (C % 4 == 0);
+ * valid: bytes, advancing by valid_bstride per image (0: one table for the batch); x == out
+ * allowed.  (gen_encoder_output_proposals: tokens whose proposal box leaves (0.01, 0.99) and
+ * padded tokens are zeroed before enc_output; mmcv MultiScaleDeformableAttention zeroes the
+ * value rows of padded tokens, `value.masked_fill(key_padding_mask[..., None], 0)`.) */
 int pn_zero_rows_f32(const float* x, const uint8_t* valid, float* out, int B, int64_t rows,
-                     int C, void* stream);
+                     int C, int64_t ld, int64_t valid_bstride, void* stream);
 /* y = sigmoid(x) elementwise (enc_bbox_preds, pairnet_bbox_head.py:345-347; sigmoid(inf) = 1) */
 int pn_sigmoid_f32(const float* x, float* y, int64_t n, void* stream);
 /* Two-stage queries: ref[r][4] = sigmoid(unact[r][4]) and emb[r][512] =
@@ -521,8 +529,20 @@ int pn_box_pos_embed_f32(const float* unact, float* ref, float* emb, int64_t row
  * reference boxes): offaw row = [offsets 8*L*4*2 | logits 8*L*4] (stride ld floats);
  * aw [rows][8][L][4] = softmax over each head's L*4 logits; loc [rows][8][L][4][2] =
  * ref.xy + offset / 4 * ref.wh * 0.5 -- the operands of pn_msda_loc_f32. */
-int pn_box_sampling_f32(const float* offaw, int64_t ld, const float* ref, float* loc, float* aw,
+int pn_box_sampling_f32(const float* offaw, int64_t ld, const float* ref,
+                        const float* valid_ratios, int rows_per_image, float* loc, float* aw,
                         int64_t rows, int L, void* stream);
+/* (valid_ratios, nullable: [B][L][2] = (valid width / W_l, valid height / H_l) of a padded
+ * batch -- the decoder's `reference_points * cat([valid_ratios, valid_ratios])`; image of row
+ * r = r / rows_per_image.)
+ * The encoder's self-attention operands on a PADDED batch: for every token of every image the
+ * sampling locations / softmax weights with mmdet's get_reference_points,
+ * ref = (x + .5) / (vr[lq] * W_lq) * vr[ls], location = ref + offset / (W_ls, H_ls); offaw rows
+ * as above, tokens level by level; outputs are pn_msda_loc_f32's operands.  (Unpadded batches
+ * use the fused pn_msda_f32, where every valid ratio is 1.) */
+int pn_token_sampling_f32(const float* offaw, int64_t ld, const float* valid_ratios, float* loc,
+                          float* aw, int B, int L, const int32_t* level_h, const int32_t* level_w,
+                          void* stream);
 /* Iterative box refinement: ref_out = sigmoid(delta + inverse_sigmoid(ref_in, eps=1e-5)),
  * [rows][4] (DeformableDetrTransformerDecoder.forward; also the last layer's
  * `outputs_coord`, pairnet_bbox_head.py:236-246). */

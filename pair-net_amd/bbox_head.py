@@ -13,8 +13,6 @@ and attention kernels plus the glue kernels of csrc/detr.hip.  No CPU path.
 Not built (they are not what the shipped configs that construct this class run):
   * the one-stage form (`as_two_stage=False`: learned `query_embedding`, 2-d reference
     points) and the form without box refinement;
-  * padded batches: the reference's test pipeline pads to `size_divisor=1` with one image per
-    GPU (cross_r101_vg.py:264-288), so `img_shape == batch_input_shape`; anything else raises;
   * `configs/deformable_detr/pairnet_r101_vg.py`'s pre-norm RMSNorm / SwiGLU relation decoder:
     with mmcv-full 1.7.0's FFN the SwiGLU activation halves the hidden width in front of a
     Linear that expects the full one (that config does not run on the pinned mmcv), and
@@ -27,7 +25,10 @@ QUERY axis that ranks the 300 decoder queries, the literal 100 in `idx // 100`, 
 
 Device data layout (fp32): encoder tokens [B, N0+N1+N2+N3, 256] with levels high -> low
 resolution (the order of the neck's outputs), decoder queries [B*300, 256], kept queries
-[B*100, 256].
+[B*100, 256].  A padded batch (`img_shape` inside `batch_input_shape`, pairnet_bbox_head.py:
+196-213) takes the general path: per-image positional tables / proposal validity / valid
+ratios, zeroed value rows, explicit sampling operands (`pn_token_sampling_f32` +
+`pn_msda_loc_f32`) instead of the fused sampler.
 """
 import math
 from collections import OrderedDict
@@ -256,32 +257,56 @@ class CrossHeadBBox(CrossHead2):
         self.w = w
 
     @staticmethod
-    def proposals(shapes):
-        """`gen_encoder_output_proposals` for unpadded images (mmdet DeformableDetrTransformer;
-        restated in oracle/deformable_detr.py): one box per token, (x + .5) / W, (y + .5) / H,
+    def proposals(shapes, valid_hw=None):
+        """`gen_encoder_output_proposals` of one image (mmdet DeformableDetrTransformer; restated
+        in oracle/deformable_detr.py): one box per token, (x + .5) / valid_W, (y + .5) / valid_H,
         side 0.05 * 2^level, as logits; +inf and valid = 0 where a coordinate leaves
-        (0.01, 0.99).  Input-independent: computed once per shape on the host."""
-        out = []
+        (0.01, 0.99) or the token is padding.  `valid_hw`: per level (valid_h, valid_w) of a
+        padded image (default: the whole maps).  Input-independent: computed once per shape on
+        the host."""
+        out, pad = [], []
         for lvl, (h, w) in enumerate(shapes):
+            vh, vw = valid_hw[lvl] if valid_hw is not None else (h, w)
             gy, gx = torch.meshgrid(torch.linspace(0, h - 1, h, dtype=torch.float32),
                                     torch.linspace(0, w - 1, w, dtype=torch.float32),
                                     indexing="ij")
             grid = torch.cat([gx.unsqueeze(-1), gy.unsqueeze(-1)], -1)
-            grid = (grid + 0.5) / torch.tensor([w, h]).view(1, 1, 2)
+            grid = (grid + 0.5) / torch.tensor([vw, vh]).view(1, 1, 2)
             wh = torch.ones_like(grid) * 0.05 * (2.0 ** lvl)
             out.append(torch.cat((grid, wh), -1).view(-1, 4))
-        prop = torch.cat(out, 0)
-        valid = ((prop > 0.01) & (prop < 0.99)).all(-1)
+            pad.append(((gy >= vh) | (gx >= vw)).view(-1))
+        prop, pad = torch.cat(out, 0), torch.cat(pad, 0)
+        valid = ((prop > 0.01) & (prop < 0.99)).all(-1) & ~pad
         prop = torch.log(prop / (1 - prop))
         prop = prop.masked_fill(~valid.unsqueeze(-1), float("inf"))
         return prop, valid
+
+    @staticmethod
+    def level_valid_sizes(img_metas, shapes):
+        """Per image and level (valid_h, valid_w): pairnet_bbox_head.py:196-213 -- the image
+        mask is nearest-resampled to every level, and the trunk counts the unmasked rows /
+        columns of its first column / row."""
+        import torch.nn.functional as F
+        ih, iw = img_metas[0]["batch_input_shape"]
+        out = []
+        for m in img_metas:
+            h, w = m["img_shape"][:2]
+            mask = torch.ones(1, 1, ih, iw)
+            mask[..., :h, :w] = 0
+            per = []
+            for (fh, fw) in shapes:
+                ml = F.interpolate(mask, size=(fh, fw)).to(torch.bool)[0, 0]
+                per.append((int((~ml[:, 0]).sum()), int((~ml[0, :]).sum())))
+            out.append(tuple(per))
+        return tuple(out)
 
     def _plan(self, B, shapes, hw2=None, slot=0, nhwc=False, tokens=None):
         """(`hw2`, `nhwc`: CrossHead2's plan signature, unused here -- PipelinedHead calls
         every head the same way.)"""
         if tokens is None:
             tokens = getattr(self, "_tokens", None)
-        key = (B, tuple(shapes), slot, None if tokens is None else tokens.data_ptr())
+        valid_sizes = getattr(self, "_valid_sizes", None)     # None: no padding in this batch
+        key = (B, tuple(shapes), slot, None if tokens is None else tokens.data_ptr(), valid_sizes)
         if key in self._plans:
             return self._plans[key]
         if self.w is None:
@@ -304,14 +329,42 @@ class CrossHeadBBox(CrossHead2):
         M, P, K = B * SN, self.num_proposals, self.KEPT
         nc = self.cls_out_channels
         # ---- shape constants ----
-        pl.enc_pos = E(SN, 256)
-        for l, (h, wd) in enumerate(shapes):
-            hip.sine_pe(pl.enc_pos[pl.start[l]:pl.start[l] + pl.N[l]],
-                        w["transformer.level_embeds"][l], h, wd,
-                        temperature=self.pe_temperature, offset=self.pe_offset)
-        prop, valid = self.proposals(shapes)
-        pl.prop = prop.unsqueeze(0).expand(B, SN, 4).contiguous().to(dev)
-        pl.valid = valid.to(torch.uint8).to(dev)
+        pl.padded = valid_sizes is not None
+        if not pl.padded:
+            pl.enc_pos = E(SN, 256)
+            for l, (h, wd) in enumerate(shapes):
+                hip.sine_pe(pl.enc_pos[pl.start[l]:pl.start[l] + pl.N[l]],
+                            w["transformer.level_embeds"][l], h, wd,
+                            temperature=self.pe_temperature, offset=self.pe_offset)
+            prop, valid = self.proposals(shapes)
+            pl.prop = prop.unsqueeze(0).expand(B, SN, 4).contiguous().to(dev)
+            pl.valid = valid.to(torch.uint8).to(dev)
+            pl.vr = None
+        else:
+            # padded batch: per-image positional tables, validity and valid ratios
+            pl.enc_pos = E(B, SN, 256)
+            props, valids, toks, vrs = [], [], [], []
+            for b in range(B):
+                for l, (h, wd) in enumerate(shapes):
+                    hip.sine_pe(pl.enc_pos[b, pl.start[l]:pl.start[l] + pl.N[l]],
+                                w["transformer.level_embeds"][l], h, wd,
+                                temperature=self.pe_temperature, offset=self.pe_offset,
+                                valid=valid_sizes[b][l])
+                prop, valid = self.proposals(shapes, valid_sizes[b])
+                props.append(prop)
+                valids.append(valid)
+                toks.append(torch.cat([
+                    ((torch.arange(h).view(-1, 1) < vh) & (torch.arange(wd).view(1, -1) < vw)).view(-1)
+                    for (h, wd), (vh, vw) in zip(shapes, valid_sizes[b])]))
+                vrs.append(torch.stack([      # `valid_W.float() / W`: float32 quotients
+                    torch.stack([torch.tensor(vw, dtype=torch.float32) / wd,
+                                 torch.tensor(vh, dtype=torch.float32) / h])
+                    for (h, wd), (vh, vw) in zip(shapes, valid_sizes[b])]))
+            pl.prop = torch.stack(props).contiguous().to(dev)
+            pl.valid = torch.stack(valids).to(torch.uint8).contiguous().to(dev)       # [B, SN]
+            pl.tok_valid = torch.stack(toks).to(torch.uint8).contiguous().to(dev)     # [B, SN]
+            pl.vr = torch.stack(vrs).to(torch.float32).contiguous().to(dev)           # [B, 4, 2]
+            pl.tloc, pl.taw = E(B, SN, 8, 4, 4, 2), E(B, SN, 8, 4, 4)
         pl.shapes_dev = torch.tensor(shapes, dtype=torch.int64, device=dev)
         pl.starts_dev = torch.tensor(pl.start, dtype=torch.int64, device=dev)
         # ---- encoder ----
@@ -365,9 +418,17 @@ class CrossHeadBBox(CrossHead2):
             p = "transformer.encoder.layers.%d." % i
             a = p + "attentions.0."
             hip.gemm(X2, w[a + "voa.weight"], pl.VOA, M=B * SN, N=640, K=256, lda=256, ldw=256,
-                     ldc=640, bias=w[a + "voa.bias"], aadd=pl.enc_pos, ldaadd=256, aadd_rows=SN,
-                     aadd_from_col=256)
-            hip.msda(pl.VOA, 640, pl.VOA.view(-1)[256:], 640, pl.S, B, pl.shapes)
+                     ldc=640, bias=w[a + "voa.bias"], aadd=pl.enc_pos, ldaadd=256,
+                     aadd_rows=B * SN if pl.padded else SN, aadd_from_col=256)
+            if pl.padded:
+                # value rows of padded tokens are zero; the reference points carry the
+                # per-image valid ratios: explicit sampling operands + the general sampler
+                hip.zero_rows(pl.VOA, pl.tok_valid, pl.VOA, B, SN, 256, ld=640, per_image=True)
+                hip.token_sampling(pl.VOA.view(-1)[256:], 640, pl.vr, pl.tloc, pl.taw, B, pl.shapes)
+                hip.msda_loc(pl.VOA, 640, pl.shapes_dev, pl.starts_dev, pl.tloc, pl.taw, pl.S, B,
+                             SN, SN, 4)
+            else:
+                hip.msda(pl.VOA, 640, pl.VOA.view(-1)[256:], 640, pl.S, B, pl.shapes)
             hip.linear(pl.S.view(-1, 256), w[a + "output_proj.weight"], w[a + "output_proj.bias"],
                        Y2, res=X2)
             hip.layernorm(Y2, w[p + "norms.0.weight"], w[p + "norms.0.bias"], X12)
@@ -402,7 +463,10 @@ class CrossHeadBBox(CrossHead2):
             A=X2, W=w[t + "decoder.layers.%d.attentions.1.value_proj.weight" % i], C=pl.V[i],
             bias=w[t + "decoder.layers.%d.attentions.1.value_proj.bias" % i], M=B * SN, N=256,
             K=256, lda=256, ldw=256, ldc=256) for i in range(nl)])
-        hip.zero_rows(pl.X, pl.valid, pl.X1, B, SN, 256)
+        if pl.padded:    # `value.masked_fill(key_padding_mask)` of the decoder's cross-attentions
+            for i in range(nl):
+                hip.zero_rows(pl.V[i], pl.tok_valid, pl.V[i], B, SN, 256, per_image=True)
+        hip.zero_rows(pl.X, pl.valid, pl.X1, B, SN, 256, per_image=pl.padded)
         hip.linear(pl.X1.view(-1, 256), w[t + "enc_output.weight"], w[t + "enc_output.bias"],
                    pl.Y.view(-1, 256))
         hip.layernorm(pl.Y.view(-1, 256), w[t + "enc_output_norm.weight"],
@@ -434,7 +498,8 @@ class CrossHeadBBox(CrossHead2):
             hip.linear(pl.attd, w[sa + "out_proj.weight"], w[sa + "out_proj.bias"], pl.y, res=x_in)
             hip.layernorm(pl.y, w[p + "norms.0.weight"], w[p + "norms.0.bias"], pl.x1)
             hip.linear(pl.x1, w[ca + "oa.weight"], w[ca + "oa.bias"], pl.OA, aadd=qpos)
-            hip.box_sampling(pl.OA, 384, pl.ref[i], pl.loc, pl.aw, B * P, 4)
+            hip.box_sampling(pl.OA, 384, pl.ref[i], pl.loc, pl.aw, B * P, 4, valid_ratios=pl.vr,
+                             rows_per_image=P)
             hip.msda_loc(pl.V[i], 256, pl.shapes_dev, pl.starts_dev, pl.loc, pl.aw, pl.Sd, B, SN,
                          P, 4)
             hip.linear(pl.Sd, w[ca + "output_proj.weight"], w[ca + "output_proj.bias"], pl.y,
@@ -537,16 +602,15 @@ class CrossHeadBBox(CrossHead2):
             if not f.is_cuda or f.dtype != torch.float32:
                 raise RuntimeError("mlvl_feats must be fp32 device tensors")
         ih, iw = img_metas[0].get("batch_input_shape", img_metas[0]["img_shape"][:2])
-        for m in img_metas:
-            if tuple(m["img_shape"][:2]) != (ih, iw):
-                raise NotImplementedError(
-                    "padded batches (img_shape %s inside batch_input_shape %s): the trunk here "
-                    "has no key-padding-mask path; the reference tests one unpadded image per "
-                    "GPU (cross_r101_vg.py:264-288)" % (tuple(m["img_shape"][:2]), (ih, iw)))
+        shapes = [tuple(f.shape[-2:]) for f in feats]
+        self._valid_sizes = None
+        if any(tuple(m["img_shape"][:2]) != (ih, iw) for m in img_metas):
+            # a padded batch (pairnet_bbox_head.py:196-213): per-image key-padding masks
+            metas = [dict(m, batch_input_shape=(ih, iw)) for m in img_metas]
+            self._valid_sizes = self.level_valid_sizes(metas, shapes)
         if self.device is None:
             self.to(feats[0].device)
         self._feats_nhwc = False
-        shapes = [tuple(f.shape[-2:]) for f in feats]
         self._tokens = self._token_buffer(feats, shapes)
         return B, shapes, None
 

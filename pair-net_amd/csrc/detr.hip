@@ -6,6 +6,8 @@
 // whole step stays on the device with no host round trip.
 #include "common.h"
 
+struct MsdaLevelsLite { int h[4], w[4], start[4]; };
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 // mmdet `inverse_sigmoid(x, eps=1e-5)`
 __device__ __forceinline__ float inv_sigmoidf_(float x) {
@@ -13,25 +15,34 @@ __device__ __forceinline__ float inv_sigmoidf_(float x) {
   return logf(fmaxf(x, 1e-5f) / fmaxf(1.f - x, 1e-5f));
 }
 
-// ---- out[b][r][:] = valid[r] ? x[b][r][:] : 0  (gen_encoder_output_proposals: tokens whose
-// proposal box leaves (0.01, 0.99) are zeroed before enc_output) ----
+// ---- out[b][r][:] = valid[b][r] ? x[b][r][:] : 0  (gen_encoder_output_proposals: tokens whose
+// proposal box leaves (0.01, 0.99), and padded tokens, are zeroed before enc_output; the
+// deformable attentions zero the value rows of padded tokens).  Rows of C floats at stride ld;
+// `valid` advances by vstride per image (0: one table for the whole batch); in place allowed. ----
 __global__ __launch_bounds__(256) void k_zero_rows(const float* __restrict__ x,
                                                    const uint8_t* __restrict__ valid,
-                                                   float* __restrict__ out, int64_t rows, int C4) {
+                                                   float* __restrict__ out, int64_t rows, int C4,
+                                                   int64_t ld, int64_t vstride) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= rows * C4) return;
   const int64_t r = e / C4;
-  const int64_t o = ((int64_t)blockIdx.y * rows) * C4 * 4 + e * 4;
-  st4(out + o, valid[r] ? ld4(x + o) : make_float4(0.f, 0.f, 0.f, 0.f));
+  const int64_t o = ((int64_t)blockIdx.y * rows + r) * ld + (e - r * C4) * 4;
+  const bool v = valid[(int64_t)blockIdx.y * vstride + r];
+  if (x == out) {
+    if (!v) st4(out + o, make_float4(0.f, 0.f, 0.f, 0.f));
+  } else {
+    st4(out + o, v ? ld4(x + o) : make_float4(0.f, 0.f, 0.f, 0.f));
+  }
 }
 
 extern "C" int pn_zero_rows_f32(const float* x, const uint8_t* valid, float* out, int B,
-                                int64_t rows, int C, void* stream) {
-  if (!x || !valid || !out || B <= 0 || rows <= 0 || C <= 0 || (C & 3) ||
-      (((uintptr_t)x | (uintptr_t)out) & 15))
+                                int64_t rows, int C, int64_t ld, int64_t valid_bstride,
+                                void* stream) {
+  if (!x || !valid || !out || B <= 0 || rows <= 0 || C <= 0 || (C & 3) || ld < C || (ld & 3) ||
+      valid_bstride < 0 || (((uintptr_t)x | (uintptr_t)out) & 15))
     return PN_BAD_ARG;
   hipLaunchKernelGGL(k_zero_rows, dim3(pn_cdiv(rows * (C / 4), 256), B), dim3(256), 0,
-                     (hipStream_t)stream, x, valid, out, rows, C / 4);
+                     (hipStream_t)stream, x, valid, out, rows, C / 4, ld, valid_bstride);
   return PN_LAUNCH_CHECK();
 }
 
@@ -79,6 +90,7 @@ extern "C" int pn_box_pos_embed_f32(const float* unact, float* ref, float* emb, 
 template <int L>
 __global__ __launch_bounds__(256) void k_box_sampling(const float* __restrict__ offaw, int64_t ld,
                                                       const float* __restrict__ ref,
+                                                      const float* __restrict__ vr, int rows_per_img,
                                                       float* __restrict__ loc,
                                                       float* __restrict__ aw, int64_t rows) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -89,6 +101,7 @@ __global__ __launch_bounds__(256) void k_box_sampling(const float* __restrict__ 
   const float* off = offaw + r * ld + h * NP * 2;
   const float* lg = offaw + r * ld + 8 * NP * 2 + h * NP;
   const float cx = ref[r * 4], cy = ref[r * 4 + 1], bw = ref[r * 4 + 2], bh = ref[r * 4 + 3];
+  const float* v2 = vr ? vr + (r / rows_per_img) * (L * 2) : nullptr;
   float v[NP], m = -INFINITY;
 #pragma unroll
   for (int i = 0; i < NP; ++i) { v[i] = lg[i]; m = fmaxf(m, v[i]); }
@@ -99,24 +112,105 @@ __global__ __launch_bounds__(256) void k_box_sampling(const float* __restrict__ 
   float* ao = aw + (r * 8 + h) * NP;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
+    // reference_points_input = ref * (valid ratio of the sampled level), x and y apart
+    const float sx = v2 ? v2[(i >> 2) * 2] : 1.f, sy = v2 ? v2[(i >> 2) * 2 + 1] : 1.f;
     ao[i] = v[i] / s;
-    lo[2 * i] = cx + off[2 * i] / 4.f * bw * 0.5f;
-    lo[2 * i + 1] = cy + off[2 * i + 1] / 4.f * bh * 0.5f;
+    lo[2 * i] = cx * sx + off[2 * i] / 4.f * (bw * sx) * 0.5f;
+    lo[2 * i + 1] = cy * sy + off[2 * i + 1] / 4.f * (bh * sy) * 0.5f;
   }
 }
 
-extern "C" int pn_box_sampling_f32(const float* offaw, int64_t ld, const float* ref, float* loc,
+extern "C" int pn_box_sampling_f32(const float* offaw, int64_t ld, const float* ref,
+                                   const float* valid_ratios, int rows_per_image, float* loc,
                                    float* aw, int64_t rows, int L, void* stream) {
-  if (!offaw || !ref || !loc || !aw || rows <= 0 || L <= 0 || L > 4 || ld < 8 * L * 12)
+  if (!offaw || !ref || !loc || !aw || rows <= 0 || L <= 0 || L > 4 || ld < 8 * L * 12 ||
+      (valid_ratios && rows_per_image <= 0))
     return PN_BAD_ARG;
   const dim3 grid(pn_cdiv(rows * 8, 256));
   hipStream_t s = (hipStream_t)stream;
+#define PN_BOX_SAMPLING(LL)                                                                 \
+  hipLaunchKernelGGL(k_box_sampling<LL>, grid, dim3(256), 0, s, offaw, ld, ref, valid_ratios, \
+                     rows_per_image, loc, aw, rows)
   switch (L) {
-    case 1: hipLaunchKernelGGL(k_box_sampling<1>, grid, dim3(256), 0, s, offaw, ld, ref, loc, aw, rows); break;
-    case 2: hipLaunchKernelGGL(k_box_sampling<2>, grid, dim3(256), 0, s, offaw, ld, ref, loc, aw, rows); break;
-    case 3: hipLaunchKernelGGL(k_box_sampling<3>, grid, dim3(256), 0, s, offaw, ld, ref, loc, aw, rows); break;
-    default: hipLaunchKernelGGL(k_box_sampling<4>, grid, dim3(256), 0, s, offaw, ld, ref, loc, aw, rows); break;
+    case 1: PN_BOX_SAMPLING(1); break;
+    case 2: PN_BOX_SAMPLING(2); break;
+    case 3: PN_BOX_SAMPLING(3); break;
+    default: PN_BOX_SAMPLING(4); break;
   }
+#undef PN_BOX_SAMPLING
+  return PN_LAUNCH_CHECK();
+}
+
+// ---- encoder self-attention operands on a PADDED batch: the sampling locations and softmax
+// weights of every token, with the per-image valid ratios of mmdet's get_reference_points
+//   ref(b, token at level lq, sampled level ls) = (x + .5) / (vr[b][lq].x * W_lq) * vr[b][ls].x
+//   location = ref + offset / (W_ls, H_ls)
+// -> the operands of pn_msda_loc_f32.  (Unpadded batches use the fused pn_msda_f32.) ----
+template <int L>
+__global__ __launch_bounds__(256) void k_token_sampling(const float* __restrict__ offaw, int64_t ld,
+                                                        const float* __restrict__ vr,
+                                                        const MsdaLevelsLite lv,
+                                                        float* __restrict__ loc,
+                                                        float* __restrict__ aw, int64_t N) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= N * 8) return;
+  const int b = blockIdx.y;
+  const int64_t n = t >> 3;
+  const int h = (int)(t & 7);
+  constexpr int NP = L * 4;
+  int lq = 0;
+#pragma unroll
+  for (int k = 1; k < L; ++k) if (n >= lv.start[k]) lq = k;
+  const int idx = (int)(n - lv.start[lq]);
+  const int qy = idx / lv.w[lq], qx = idx - qy * lv.w[lq];
+  const float* v2 = vr + (int64_t)b * L * 2;
+  const float rx = ((float)qx + 0.5f) / (v2[lq * 2] * (float)lv.w[lq]);
+  const float ry = ((float)qy + 0.5f) / (v2[lq * 2 + 1] * (float)lv.h[lq]);
+  const int64_t r = (int64_t)b * N + n;
+  const float* off = offaw + r * ld + h * NP * 2;
+  const float* lg = offaw + r * ld + 8 * NP * 2 + h * NP;
+  float v[NP], m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) { v[i] = lg[i]; m = fmaxf(m, v[i]); }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) { v[i] = expf(v[i] - m); s += v[i]; }
+  float* lo = loc + (r * 8 + h) * NP * 2;
+  float* ao = aw + (r * 8 + h) * NP;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int ls = i >> 2;
+    ao[i] = v[i] / s;
+    lo[2 * i] = rx * v2[ls * 2] + off[2 * i] / (float)lv.w[ls];
+    lo[2 * i + 1] = ry * v2[ls * 2 + 1] + off[2 * i + 1] / (float)lv.h[ls];
+  }
+}
+
+extern "C" int pn_token_sampling_f32(const float* offaw, int64_t ld, const float* valid_ratios,
+                                     float* loc, float* aw, int B, int L, const int32_t* level_h,
+                                     const int32_t* level_w, void* stream) {
+  if (!offaw || !valid_ratios || !loc || !aw || B <= 0 || L <= 0 || L > 4 || !level_h ||
+      !level_w || ld < 8 * L * 12)
+    return PN_BAD_ARG;
+  MsdaLevelsLite lv{};
+  int64_t n = 0;
+  for (int l = 0; l < L; ++l) {
+    if (level_h[l] <= 0 || level_w[l] <= 0) return PN_BAD_ARG;
+    lv.h[l] = level_h[l]; lv.w[l] = level_w[l]; lv.start[l] = (int)n;
+    n += (int64_t)level_h[l] * level_w[l];
+  }
+  const dim3 grid(pn_cdiv(n * 8, 256), B);
+  hipStream_t s = (hipStream_t)stream;
+#define PN_TOKEN_SAMPLING(LL)                                                                  \
+  hipLaunchKernelGGL(k_token_sampling<LL>, grid, dim3(256), 0, s, offaw, ld, valid_ratios, lv, \
+                     loc, aw, n)
+  switch (L) {
+    case 1: PN_TOKEN_SAMPLING(1); break;
+    case 2: PN_TOKEN_SAMPLING(2); break;
+    case 3: PN_TOKEN_SAMPLING(3); break;
+    default: PN_TOKEN_SAMPLING(4); break;
+  }
+#undef PN_TOKEN_SAMPLING
   return PN_LAUNCH_CHECK();
 }
 

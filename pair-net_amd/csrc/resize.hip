@@ -5,7 +5,7 @@
 // for an all-valid mask: channels [pos_y | pos_x], each
 // interleaved sin (even) / cos (odd) over dim_t[i] = T^(2*(i/2)/num_feats).
 __global__ void k_sine_pe(float* __restrict__ out, const float* __restrict__ add, int h,
-                          int w, int C, float temperature, float offset) {
+                          int w, int C, float temperature, float offset, int vh, int vw) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)h * w * C;
   if (e >= total) return;
@@ -15,8 +15,14 @@ __global__ void k_sine_pe(float* __restrict__ out, const float* __restrict__ add
   const int nf = C / 2;
   const int i = (c < nf) ? c : c - nf;
   const float scale = 6.283185307179586f;
-  const float embed = (c < nf) ? (((float)(y + 1) + offset) / ((float)h + 1e-6f)) * scale
-                               : (((float)(x + 1) + offset) / ((float)w + 1e-6f)) * scale;
+  // cumulative sums of the not-padded flags down a column / along a row: inside the valid
+  // region they count, past it they stay at its size, and a fully padded column / row sums to
+  // zero everywhere, normaliser included (the reference then encodes -0.5 / eps there; those
+  // tokens are masked out of every consumer)
+  const int ye = x < vw ? min(y + 1, vh) : 0, ny = x < vw ? vh : 0;
+  const int xe = y < vh ? min(x + 1, vw) : 0, nx = y < vh ? vw : 0;
+  const float embed = (c < nf) ? (((float)ye + offset) / ((float)ny + 1e-6f)) * scale
+                               : (((float)xe + offset) / ((float)nx + 1e-6f)) * scale;
   const float dim_t = powf(temperature, (float)(2 * (i / 2)) / (float)nf);
   const float v = embed / dim_t;
   float r = (i & 1) ? cosf(v) : sinf(v);
@@ -24,13 +30,21 @@ __global__ void k_sine_pe(float* __restrict__ out, const float* __restrict__ add
   out[e] = r;
 }
 
-extern "C" int pn_sine_pe_offset_f32(float* out, const float* add, int h, int w, int C,
-                                     float temperature, float offset, void* stream) {
-  if (!out || h <= 0 || w <= 0 || C <= 0 || (C & 3)) return PN_BAD_ARG;
+extern "C" int pn_sine_pe_valid_f32(float* out, const float* add, int h, int w, int valid_h,
+                                    int valid_w, int C, float temperature, float offset,
+                                    void* stream) {
+  if (!out || h <= 0 || w <= 0 || C <= 0 || (C & 3) || valid_h <= 0 || valid_h > h ||
+      valid_w <= 0 || valid_w > w)
+    return PN_BAD_ARG;
   const int64_t total = (int64_t)h * w * C;
   hipLaunchKernelGGL(k_sine_pe, dim3(pn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     out, add, h, w, C, temperature, offset);
+                     out, add, h, w, C, temperature, offset, valid_h, valid_w);
   return PN_LAUNCH_CHECK();
+}
+
+extern "C" int pn_sine_pe_offset_f32(float* out, const float* add, int h, int w, int C,
+                                     float temperature, float offset, void* stream) {
+  return pn_sine_pe_valid_f32(out, add, h, w, h, w, C, temperature, offset, stream);
 }
 
 extern "C" int pn_sine_pe_f32(float* out, const float* add, int h, int w, int C,

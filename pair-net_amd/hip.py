@@ -117,17 +117,20 @@ _SIGS = {
                                                                             C.POINTER(_f32), _i32, _vp]),
     "pn_pack_mask_bits": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "pn_mask_iou_counts": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
-    "pn_zero_rows_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _vp]),
+    "pn_zero_rows_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i64, _i64, _vp]),
+    "pn_token_sampling_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, C.POINTER(_i32),
+                                        C.POINTER(_i32), _vp]),
+    "pn_sine_pe_valid_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp]),
     "pn_sigmoid_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "pn_box_pos_embed_f32": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
-    "pn_box_sampling_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "pn_box_sampling_f32": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp]),
     "pn_box_refine_f32": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "pn_query_score_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_box_triplets_f32": (C.c_int, [_vp] * 5 + [_vp, _i32, _i32, _f32, _f32, C.POINTER(_f32),
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 12   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 13   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -522,9 +525,11 @@ def msda_loc(value, ld_value, spatial_shapes, level_start_index, loc, aw, out, B
            "pn_msda_loc_f32")
 
 
-def sine_pe(out, add, h, w, C_=256, temperature=10000.0, offset=0.0):
-    _check(lib().pn_sine_pe_offset_f32(_ptr(out), _ptr(add), h, w, C_, temperature, offset,
-                                       _stream()), "pn_sine_pe_offset_f32")
+def sine_pe(out, add, h, w, C_=256, temperature=10000.0, offset=0.0, valid=None):
+    """valid = (valid_h, valid_w) of a padded map (default: the whole map)."""
+    vh, vw = valid if valid is not None else (h, w)
+    _check(lib().pn_sine_pe_valid_f32(_ptr(out), _ptr(add), h, w, vh, vw, C_, temperature, offset,
+                                      _stream()), "pn_sine_pe_valid_f32")
 
 
 def bilinear_nhwc(x, out, B, hi, wi, ho, wo, Cc, accumulate, in_bstride, out_bstride):
@@ -769,9 +774,19 @@ def chain(desc):
 
 
 # ---- box trunk glue (csrc/detr.hip) ----
-def zero_rows(x, valid_u8, out, B, rows, Cc):
+def zero_rows(x, valid_u8, out, B, rows, Cc, ld=None, per_image=False):
+    """valid_u8: [rows] (shared) or, with per_image, [B][rows]; rows of Cc floats at stride ld."""
     _check(lib().pn_zero_rows_f32(_ptr(x), _ptr(valid_u8, torch.uint8), _ptr(out), B, rows, Cc,
-                                  _stream()), "pn_zero_rows_f32")
+                                  Cc if ld is None else ld, rows if per_image else 0, _stream()),
+           "pn_zero_rows_f32")
+
+
+def token_sampling(offaw, ld, valid_ratios, loc, aw, B, shapes):
+    L = len(shapes)
+    hs = (C.c_int32 * L)(*[h for h, _ in shapes])
+    ws = (C.c_int32 * L)(*[w for _, w in shapes])
+    _check(lib().pn_token_sampling_f32(_ptr(offaw), ld, _ptr(valid_ratios), _ptr(loc), _ptr(aw), B,
+                                       L, hs, ws, _stream()), "pn_token_sampling_f32")
 
 
 def sigmoid(x, out):
@@ -783,9 +798,10 @@ def box_pos_embed(unact, ref, emb, rows):
            "pn_box_pos_embed_f32")
 
 
-def box_sampling(offaw, ld, ref, loc, aw, rows, L):
-    _check(lib().pn_box_sampling_f32(_ptr(offaw), ld, _ptr(ref), _ptr(loc), _ptr(aw), rows, L,
-                                     _stream()), "pn_box_sampling_f32")
+def box_sampling(offaw, ld, ref, loc, aw, rows, L, valid_ratios=None, rows_per_image=0):
+    _check(lib().pn_box_sampling_f32(_ptr(offaw), ld, _ptr(ref), _ptr(valid_ratios),
+                                     rows_per_image, _ptr(loc), _ptr(aw), rows, L, _stream()),
+           "pn_box_sampling_f32")
 
 
 def box_refine(delta, ref_in, ref_out, rows):

@@ -332,10 +332,59 @@ def test_bbox_head_rejects_what_it_does_not_build(built_lib):
         P.CrossHeadBBox(**dict(cfg, as_two_stage=False))
     with pytest.raises(ValueError):
         P.CrossHeadBBox(**dict(cfg, transformer=None))
-    head = P.CrossHeadBBox(**cfg).to(DEV)
-    feats = [torch.zeros(1, 256, h, w, device=DEV) for h, w in ((20, 24), (10, 12), (5, 6), (3, 3))]
-    with pytest.raises(NotImplementedError):       # padded image inside the batch shape
-        head(feats, [dict(batch_input_shape=(160, 192), img_shape=(150, 192, 3), scale_factor=[1.0] * 4)])
+
+
+
+def test_padded_batch_follows_the_key_padding_masks(built_lib):
+    """Two images of different sizes in one batch (pairnet_bbox_head.py:196-213): masked sine
+    encoding, valid-ratio reference points, zeroed value rows and proposals of padded tokens --
+    the general path (`pn_token_sampling_f32` + `pn_msda_loc_f32`) against the oracle, whose
+    padded-batch arithmetic is what tests/test_oracle.py pins to transformers' Deformable DETR
+    and to the reference class."""
+    ohead, oneck, sd, nsd, _ = _oracles(12347, 12348)
+    head, neck = _hip_models(sd, nsd)
+    H, W = 160, 192
+    feats = _feats([100, 101], H, W)
+    metas = [dict(batch_input_shape=(H, W), img_shape=(H, W, 3), scale_factor=[1.0] * 4),
+             dict(batch_input_shape=(H, W), img_shape=(130, 150, 3), scale_factor=[1.5] * 4)]
+    tr = {}
+    with torch.no_grad():
+        oc, ob = ohead(oneck(feats), metas, trace=tr)
+        ores = ohead.get_bboxes(oc, ob, metas, rescale=True)
+    hc, hb = head(neck([f.to(DEV) for f in feats]), metas)
+    pl = head._last_plan
+    assert pl.padded and tuple(pl.vr.shape) == (2, 4, 2) and float(pl.vr[0].min()) == 1.0
+    # (padded tokens are masked out of every consumer; their own encodings are sin / cos of
+    # -0.5 / eps in the reference: not compared)
+    tv = pl.tok_valid.bool()
+    assert _err(pl.X[tv], tr["memory"][tv.cpu()]) < 5e-5 and int((~tv).sum()) == 192
+    assert _err(hc["enc_cls_scores"], oc["enc_cls_scores"]) < 5e-5
+    fin = torch.isfinite(torch.logit(oc["enc_bbox_preds"])).all(-1)
+    assert 0 < int((~fin[1]).sum()) and int((~fin[0]).sum()) == 0      # padded tokens: +inf boxes
+    assert _err(hc["enc_bbox_preds"], oc["enc_bbox_preds"]) < 1e-5
+    # proposals: the same VALID tokens and the same number of zeroed ones (those tie exactly
+    # and are interchangeable, see the test above)
+    got, want = pl.top_idx.cpu(), tr["topk_proposals"]
+    ok = pl.valid.cpu().bool()
+    for i in range(2):
+        g, w_ = got[i], want[i]
+        assert set(g[ok[i][g]].tolist()) == set(w_[ok[i][w_]].tolist())
+        assert int((~ok[i][g]).sum()) == int((~ok[i][w_]).sum())
+    assert _err(pl.qscore.sort(-1)[0], tr["query_score"].sort(-1)[0]) < 1e-6
+    for k in ("sub", "obj", "cls", "rel", "importance"):
+        assert _err(hc[k], oc[k]) < 1e-3, k
+    for k in hb:
+        assert _err(hb[k], ob[k]) < 1e-4, k
+    # (pair ranking: unseparated weights here, near-ties allowed -- the golden fixtures above
+    # assert exact indices; the selected SCORES must agree)
+    top = lambda t: t.flatten(1).topk(100)[0]
+    assert _err(top(hc["importance"]), top(oc["importance"])) < 1e-4
+    res = head.get_bboxes(hc, hb, metas, rescale=True)
+    assert all(len(r) == 6 and tuple(r[0].shape) == (200, 5) for r in res)
+    # the same two images unpadded, one by one, give image 0's outputs again (padding of
+    # the OTHER image does not leak)
+    h0c, h0b = head(neck([f[:1].to(DEV) for f in feats]), metas[:1])
+    assert _err(h0c["rel"], oc["rel"][:1]) < 1e-3 and not head._last_plan.padded
 
 
 def test_detector_with_neck_and_bbox_head_end_to_end(built_lib):

@@ -8,6 +8,8 @@ evaluator reads.  The backbone is SURVEY.md section 8 row a1 / (f)-2: the native
 `backbone.impl="torch"` selects a plain PyTorch-ROCm (MIOpen) ResNet-50 with the same
 state dict, kept as the comparison leg of bench.py.
 """
+from collections import OrderedDict
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -171,6 +173,39 @@ class PSGTr:
     def eval(self):
         return self
 
+    # ---- checkpoints: mmdet's layout `backbone.* / neck.* / bbox_head.*` ----
+    def _parts(self):
+        parts = [("backbone.", self.backbone), ("bbox_head.", self.bbox_head)]
+        if self.neck is not None:
+            parts.insert(1, ("neck.", self.neck))
+        return parts
+
+    def state_dict(self):
+        out = OrderedDict()
+        for prefix, mod in self._parts():
+            for k, v in mod.state_dict().items():
+                out[prefix + k] = v
+        return out
+
+    def load_state_dict(self, state_dict, strict=True):
+        """The detector-level state dict of a reference checkpoint (keys prefixed with
+        `backbone.`, `neck.`, `bbox_head.`; a leading `module.` of a DDP-saved file is dropped,
+        as mmcv's load_checkpoint does).  Returns (missing, unexpected) key lists."""
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v
+              for k, v in state_dict.items()}
+        missing, unexpected, used = [], [], set()
+        for prefix, mod in self._parts():
+            sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+            used.update(prefix + k for k in sub)
+            m, u = mod.load_state_dict(sub, strict=False)
+            missing += [prefix + k for k in m]
+            unexpected += [prefix + k for k in u]
+        unexpected += [k for k in sd if k not in used]
+        if strict and (missing or unexpected):
+            raise RuntimeError("state_dict mismatch: missing %s unexpected %s"
+                               % (missing[:5], unexpected[:5]))
+        return missing, unexpected
+
     def extract_feat(self, img):
         """SingleStageDetector.extract_feat: backbone (the stages of `out_indices`) -> neck."""
         x = self.backbone(img)
@@ -212,6 +247,21 @@ class PSGTr:
         return self.simple_test(img, img_metas, rescale=rescale)
 
     __call__ = forward
+
+
+def load_checkpoint(model, filename, map_location="cpu", strict=False):
+    """`mmcv.runner.load_checkpoint(model, filename, map_location="cpu")` (tools/test.py:240)
+    for local files: a torch-saved dict with `state_dict` (and `meta`: CLASSES, PREDICATES,
+    ...), or a bare state dict.  Loads into `model` (a PSGTr, or any head / backbone / neck of
+    this package) and returns the checkpoint dict, like mmcv."""
+    ckpt = torch.load(filename, map_location=map_location, weights_only=False)
+    sd = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
+    missing, unexpected = model.load_state_dict(sd, strict=strict)
+    if missing or unexpected:
+        import warnings
+        warnings.warn("load_checkpoint: %d missing key(s) (first: %s), %d unexpected (first: %s)"
+                      % (len(missing), missing[:2], len(unexpected), unexpected[:2]))
+    return ckpt if isinstance(ckpt, dict) and "state_dict" in ckpt else dict(state_dict=sd, meta={})
 
 
 def build_detector(cfg, train_cfg=None, test_cfg=None):

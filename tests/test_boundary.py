@@ -183,3 +183,24 @@ def test_reference_bbox_config_file_drops_in():
     bad = load_config(os.path.join(ref_shim.REF_ROOT, "configs/deformable_detr/cross_r50_coco.py"))
     with pytest.raises((ValueError, NotImplementedError, TypeError)):
         build_detector(dict(bad.model))
+
+
+def test_detector_checkpoint_round_trip(tmp_path):
+    """tools/test.py:235-248: `load_checkpoint(model, path, map_location="cpu")` on an
+    mmdet-layout file (`backbone.* / neck.* / bbox_head.*`, DDP `module.` prefix, `meta`)."""
+    import torch
+    from pairnet_amd import build_detector, cross_r101_vg, load_checkpoint, pairnet_r50
+    for cfg, n_parts in ((cross_r101_vg().model, 3), (pairnet_r50(), 2)):
+        det = build_detector(dict(cfg))
+        sd = det.state_dict()
+        assert len({k.split(".")[0] for k in sd}) == n_parts
+        g = torch.Generator().manual_seed(1)
+        new = {"module." + k: torch.randn(v.shape, generator=g) for k, v in sd.items()}
+        path = str(tmp_path / "ckpt.pth")
+        torch.save(dict(state_dict=new, meta=dict(CLASSES=("a", "b"), PREDICATES=("on",))), path)
+        ckpt = load_checkpoint(det, path, map_location="cpu", strict=True)
+        assert ckpt["meta"]["CLASSES"] == ("a", "b")
+        got = det.state_dict()
+        assert all(torch.equal(got[k], new["module." + k].to(got[k].dtype)) for k in got)
+        with pytest.raises(RuntimeError):
+            det.load_state_dict({k: v for k, v in list(new.items())[1:]}, strict=True)

@@ -123,7 +123,9 @@ def bench_bbox(args, dev, rank, world):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], device=dev)
+    nccl = os.environ.get("PAIRNET_DIST_BACKEND", "nccl") == "nccl"
+    dt = torch.tensor([time.perf_counter() - t0], device=dev if nccl else "cpu",
+                      dtype=torch.float64)
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt)

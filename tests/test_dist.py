@@ -148,3 +148,25 @@ def test_bench_two_ranks_complete_and_report_whole_job_rate():
     assert rec["scaling"] == "weak" and "roofline" in rec
     assert rec["config"]["path"] == "image" and rec["config"]["backbone"] == "ResNet-50"
     assert rec["triplet_records_gathered"] >= 2 * 6 and rec["dist_backend"] == "gloo"
+
+
+@pytest.mark.gpu
+def test_bench_bbox_head_two_ranks():
+    """`python bench.py --head bbox --gpus 2` (the sibling path; same self-launch, gloo on one
+    GPU): both ranks leave the barriers and the max-over-ranks reduce, one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["PAIRNET_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--head", "bbox", "--gpus", "2",
+           "--steps", "5", "--warmup", "3", "--height", "320", "--width", "416"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["value"] > 0
+    assert rec["config"]["head"] == "bbox" and rec["pipeline_check"].startswith("labels")

@@ -568,7 +568,7 @@ def main():
                 else:
                     ach, peak, unit = agg["flops"] / sec / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
                     bound = "mfma"
-                traffic, traffic_src = None, None
+                traffic, traffic_src, mfma_util = None, None, None
                 try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE
                     # doubled per MI355X_MICROARCH.md + WRITE_SIZE), same workload, same kernel
                     src = latest_pmc()
@@ -581,11 +581,16 @@ def main():
                         traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches_profiled"]
                                           for v in hits) / n)
                         traffic_src = os.path.relpath(src, ROOT)
+                        sq = [v for v in hits if "sq" in v]
+                        if sq:   # matrix-pipe busy cycles / (4 x CU-busy cycles), PMC pass
+                            mfma_util = sum(v["sq"]["mfma_util"] * v["launches_profiled"]
+                                            for v in sq) / sum(v["launches_profiled"] for v in sq)
                 except (OSError, ValueError, KeyError, TypeError):
                     pass
                 return {
                     "kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
                     "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                    "mfma_util_pmc": mfma_util,
                     "algorithmic_bytes_per_launch": agg["bytes"] / agg["launches"],
                     "launches_per_step": agg["launches"] // nprof,
                     "avg_launch_us": 1e3 * agg["ms"] / agg["launches"],
@@ -610,6 +615,10 @@ def main():
             msda = [k for k in prof if k.startswith("k_msda")]
             if msda:
                 out["roofline_deformable_sampling"] = roof(msda[0])
+            # ... and its attention GEMMs (QK^T / PV on the fp32 MFMA, flash-style): small
+            # latency-bound launches of the query chain; matrix-pipe utilisation from the PMC pass
+            if "k_attn_chunk" in prof:
+                out["roofline_attention"] = roof("k_attn_chunk")
             out["kernel_profile"] = {
                 k: {"ms_per_step": v["ms"] / nprof, "launches_per_step": v["launches"] // nprof,
                     "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0.0,

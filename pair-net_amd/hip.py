@@ -558,10 +558,13 @@ def attn_scratch_floats(B, Q, Nk):
 
 
 def attention(q, ldq, k, ldk, v, ldv, bits, rowall, out, ldo, scratch, B, Q, Nk, scale):
-    _check(lib().pn_attention_f32(
-        _ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(bits, torch.int32),
-        _ptr(rowall, torch.int32), _ptr(out), ldo, _ptr(scratch), B, Q, Nk, scale,
-        _stream()), "pn_attention_f32")
+    # QK^T and PV: 2 x (2 * B * 8 heads * Q * Nk * 32) flops; bytes: q, k, v, out rows once
+    _check(_launch("k_attn_chunk", 8.0 * B * 8 * Q * Nk * 32 / 2,
+                   4.0 * B * 256 * (2 * Q + 2 * Nk),
+                   lambda: lib().pn_attention_f32(
+                       _ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(bits, torch.int32),
+                       _ptr(rowall, torch.int32), _ptr(out), ldo, _ptr(scratch), B, Q, Nk, scale,
+                       _stream())), "pn_attention_f32")
 
 
 def ppn_front(sub_embed, obj_embed, w1, b1, imp_raw, c1, B, Q, eps=1e-12):

@@ -6,7 +6,12 @@ One "step" = one batch through `PSGTr.simple_test`'s device work (psgtr.py:148-1
 an 800x1333 image tensor already resident in HBM -> native ResNet-50 -> `CrossHead2.
 simple_test_bboxes` (pairnet_head.py:926-930: pixel decoder, 9-layer masked decoder,
 PPN / Matrix Learner / top-k, 6-layer relation decoder, get_bboxes), 100 object / 100
-relation queries, fp32 -- BASELINE.json configs[1] on each GPU.  `--path head` times the
+relation queries, fp32 -- BASELINE.json configs[1] on each GPU; consecutive steps take
+DIFFERENT images (a rotating pool of `--pool` distinct tensors, so that neither weights nor
+activations of "the" image can sit in the 256 MB MALL).  The secondary leg
+`simple_test_incl_result_d2h` adds the rest of `simple_test`: the panoptic-loop status check
+and `triplet2Result`'s device -> host copy of every field (psgtr.py:15-51) into pinned host
+buffers on a copy stream.  `--path head` times the
 head alone on a resident feature pyramid (round 1's headline; reported by the default run
 as the secondary `head_only`).  For N > 1 one rank per GPU over RCCL: started by
 torch.distributed.run, or by this script itself when WORLD_SIZE is unset (plain `python
@@ -184,9 +189,8 @@ def main():
     ap.add_argument("--path", choices=["image", "head"], default="image",
                     help="image: image tensor -> backbone -> head -> triplets (headline); "
                          "head: the head alone on a resident feature pyramid")
-    ap.add_argument("--gemm", choices=["f32", "bf16x3"], default="f32",
-                    help="f32: exact-fp32 MFMA everywhere (headline); bf16x3: fp32-accurate "
-                         "3 x bf16 operand split for the large GEMMs / 3x3 conv")
+    ap.add_argument("--pool", type=int, default=8,
+                    help="distinct input images the steps rotate over")
     ap.add_argument("--head", choices=["pairnet", "baseline", "psgtr2", "bbox"], default="pairnet",
                     help="pairnet = CrossHead2 (the headline); baseline / psgtr2 = the sibling "
                          "heads CrossHeadBaseline / PSGTrHead2 on the same trunk (not the "
@@ -205,8 +209,6 @@ def main():
     ap.add_argument("--exact-mask-order", action="store_true",
                     help="attention masks in the reference's operation order (full-size mask "
                          "logits, then the resize) instead of the once-resampled mask feature")
-    ap.add_argument("--grid-scale", type=int, default=None,
-                    help="probe: persistent-GEMM grid cap multiplier (large = one tile per WG)")
     ap.add_argument("--grid-trim", type=int, default=None,
                     help="persistent-GEMM workgroup slots left free for the query chains")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -257,13 +259,8 @@ def main():
     pair_ids = {"pairnet": lambda pl: (pl.sub_pos, pl.obj_pos),
                 "baseline": lambda pl: (pl.sub_ids, pl.obj_ids),
                 "psgtr2": lambda pl: (ident, ident)}[args.head]   # query i IS triplet i
-    if args.grid_trim is not None:
-        hip.gemm_set_grid_trim(args.grid_trim)
-    if args.grid_scale is not None:
-        hip.gemm_set_grid_scale(args.grid_scale)
     head.init_weights(seed=0)
     head.to(dev)
-    head.gemm_mode = args.gemm
     head.exact_mask_order = args.exact_mask_order
     if args.conv:
         head.conv_algo = args.conv
@@ -271,6 +268,7 @@ def main():
     engine = None if args.no_pipeline else PipelinedHead(
         head, depth=args.depth, a_streams=args.a_streams,
         **({} if args.grid_trim is None else dict(grid_trim=args.grid_trim)))
+    pool = []
     B, H, W = args.batch, args.height, args.width
     g = torch.Generator().manual_seed(1000 + rank)
     sf = 2.083
@@ -289,10 +287,15 @@ def main():
         else:
             backbone, bname = ResNet50Hip().to(dev), "ResNet-50"
             backbone.use_graphs = not args.no_graphs
-        img_cpu = torch.randn(B, 3, H, W, generator=g)      # a normalised image batch
-        img = img_cpu.to(dev)
+        if engine is not None:   # the backbone runs on the stage-A streams: same free slots
+            backbone.grid_reserve = engine.grid_reserve
+        # a pool of DISTINCT normalised image batches; step i takes pool[i % len(pool)]
+        pool_cpu = [torch.randn(B, 3, H, W, generator=g) for _ in range(max(1, args.pool))]
+        pool = [t.to(dev) for t in pool_cpu]
+        img_cpu, img = pool_cpu[0], pool[0]
         feats_cpu = None
-        feats = [f for f in backbone(img)]
+        # (own copies: the backbone's outputs are views of per-slot buffers it reuses)
+        feats = [f.clone(memory_format=torch.preserve_format) for f in backbone(img)]
     else:
         feats_cpu = [torch.relu(torch.randn(B, c, h, w, generator=g))
                      for c, (h, w) in zip(chans, feature_shapes(H, W))]
@@ -310,38 +313,50 @@ def main():
             with torch.cuda.stream(gather_stream):
                 for i, r in enumerate(res):
                     gatherer.pack(i, r[1], r[7], sub_pos[i], obj_pos[i])
+                if engine is not None:   # the slot may be reused once this stream is here
+                    engine.consumed(res, gather_stream)
                 gatherer.gather(host_staging=backend != "nccl")
 
     def step(with_backbone=args.path == "image"):
         """One batch.  Pipelined: backbone + stage A of this batch are queued on the stage-A
         stream beside the query chains of the two previous batches (results arrive two
         steps late; drain() completes the batches still in flight)."""
+        im = pool[nstep[0] % len(pool)] if with_backbone else None
+        nstep[0] += 1
         if engine is None:
-            res = head.simple_test_bboxes(backbone(img) if with_backbone else feats, metas)
+            res = head.simple_test_bboxes(backbone(im) if with_backbone else feats, metas)
         elif with_backbone:
             # two chip-filling kernel sequences on different streams time-slice badly
             # (DESIGN.md 6a): the backbone goes in front of stage A on its stream
             # (each stage-A stream has its own set of backbone buffers)
             sl = engine.count % len(engine.streams_a)
             with torch.cuda.stream(engine.streams_a[sl]):
-                res = engine.submit(backbone(img, slot=sl), metas)
+                res = engine.submit(backbone(im, slot=sl), metas)
                 if res is not None:   # (results are ordered behind the submitting stream)
                     gather(res, *pair_ids(head._last_plan))
+                    if on_result[0] is not None:
+                        on_result[0](res)
             return res
         else:
             res = engine.submit(feats, metas)
         if res is not None:
             gather(res, *pair_ids(head._last_plan))
+            if on_result[0] is not None:
+                on_result[0](res)
         return res
 
-    last = {}
+    nstep = [0]            # steps issued so far (selects the pool image)
+    on_result = [None]     # optional consumer of every result list (legs below)
 
     def drain():
         if engine is not None:
-            while engine.queue:
-                res = engine._finish(engine.queue.pop(0))
-                gather(res, *pair_ids(head._last_plan))
-                last["res"] = res
+            sa0 = engine.streams_a[0] if args.path == "image" else torch.cuda.current_stream()
+            with torch.cuda.stream(sa0):
+                while engine.queue:
+                    res = engine._finish(engine.queue.pop(0))
+                    gather(res, *pair_ids(head._last_plan))
+                    if on_result[0] is not None:
+                        on_result[0](res)
 
     # ---- warm-up (graph capture happens in the first two steps), then the stream ->
     # hardware-queue placement of the pipeline is chosen empirically (pipeline.py) ----
@@ -387,24 +402,87 @@ def main():
         elapsed = float(t.item())
     records = gatherer.records_gathered if gatherer is not None else 0
 
-    # ---- the pipelined schedule only reorders launches: its last result must equal, bit for
-    # bit, what one eager single-stream call gives for the same input ----
+    # ---- the pipelined schedule only reorders launches: for EVERY image of the pool the
+    # pipelined result must equal, bit for bit, what one eager single-stream call gives ----
     pipeline_check = None
-    if rank == 0 and engine is not None and "res" in last:
-        got = [[t.clone() for t in (r[1], r[7], r[4])] for r in last["res"]]
+    if rank == 0 and engine is not None and world == 1:
+        n_img = len(pool) if args.path == "image" else 1
+        got = []
+        on_result[0] = lambda res: got.append(
+            [[t.clone() for t in (r[1], r[7], r[4])] for r in res])
+        nstep[0] = 0
+        for _ in range(n_img):
+            step()
+        drain()
+        on_result[0] = None
         torch.cuda.synchronize()
-        g0 = head.use_graphs
+        g0, gb = head.use_graphs, getattr(backbone, "use_graphs", False)
         head.use_graphs = False
-        ref = head.simple_test_bboxes(backbone(img, slot=7) if backbone is not None else feats,
-                                      metas)
-        torch.cuda.synchronize()
+        if backbone is not None:
+            backbone.use_graphs = False
+        same = len(got) == n_img
+        for i in range(n_img):
+            ref = head.simple_test_bboxes(
+                backbone(pool[i], slot=7) if backbone is not None else feats, metas)
+            torch.cuda.synchronize()
+            same &= all(torch.equal(a, b) for rg, rr in zip(got[i], ref)
+                        for a, b in zip(rg, (rr[1], rr[7], rr[4])))
         head.use_graphs = g0
-        same = all(torch.equal(a, b) for rg, rr in zip(got, ref)
-                   for a, b in zip(rg, (rr[1], rr[7], rr[4])))
-        pipeline_check = ("labels / rel_dists / pan_img of the last pipelined batch are bitwise "
-                          "the eager single-stream result" if same else "MISMATCH")
+        if backbone is not None:
+            backbone.use_graphs = gb
+        pipeline_check = ("labels / rel_dists / pan_img of all %d distinct images are bitwise "
+                          "the eager single-stream results" % n_img if same else "MISMATCH")
         if not same:
-            raise SystemExit("pipelined result differs from the eager single-stream result")
+            raise SystemExit("a pipelined result differs from the eager single-stream result")
+
+    # ---- secondary, headline-adjacent: the WHOLE of PSGTr.simple_test (psgtr.py:148-156):
+    # the same steps plus the panoptic-loop status check and triplet2Result's device -> host
+    # copy of every field (:15-51; 2R x H0 x W0 bool masks = 49 MB per image) into a ring of
+    # pinned host buffers on a copy stream, Results built on the host for every image ----
+    simple_test = None
+    if rank == 0 and world == 1 and engine is not None and args.path == "image":
+        from pairnet_amd import ResultStreamer
+        streamer = ResultStreamer(head, ring=args.depth + 2)
+        made = [0, None]
+
+        def to_host(res):
+            if len(streamer) >= streamer.ring - 1:
+                made[1] = streamer.pop()
+                made[0] += len(made[1])
+            streamer.push(res, engine)
+        on_result[0] = to_host
+
+        def finish():
+            while len(streamer):
+                made[1] = streamer.pop()
+                made[0] += len(made[1])
+        for _ in range(2 * args.depth):
+            step()
+        drain()
+        finish()
+        made[0] = 0
+        n = min(args.steps, 100)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        drain()
+        finish()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        on_result[0] = None
+        r0 = made[1][0]
+        simple_test = {
+            "images_per_s": B * n / dt, "ms_per_step": 1e3 * dt / n, "steps": n,
+            "results_built": made[0],
+            "d2h_bytes_per_image": int(sum(getattr(r0, k).nbytes for k in (
+                "refine_bboxes", "labels", "rel_pair_idxes", "rel_dists", "rel_labels",
+                "pan_results", "masks"))),
+            "what": "PSGTr.simple_test per step: image -> backbone -> head -> get_bboxes -> "
+                    "panoptic status check -> triplet2Result (every field copied to pinned host "
+                    "memory on a copy stream, Result objects built per image; arrays are views "
+                    "of a %d-entry ring)" % streamer.ring}
+        del streamer
 
     # ---- secondary: the head alone on the resident pyramid (round 1's headline) ----
     head_only = None
@@ -438,8 +516,8 @@ def main():
                      "what": "%s.simple_test_bboxes on the feature pyramid resident in HBM (no "
                              "backbone; 3-stream pipeline: one stage-A stream, two chain "
                              "streams)" % type(head).__name__}
-        if engine is not None:
-            hip.gemm_set_grid_trim(64 if args.grid_trim is None else args.grid_trim)
+        if engine is not None:   # (the head-only pipeline set its own reserve on the head)
+            head.grid_reserve = engine.grid_reserve
 
     # ---- secondary: from the DECODED image (uint8 HWC BGR resident in HBM): the reference's
     # test pipeline (resize keep-ratio / normalise / pad, pairnet.py:310-331) as one kernel in
@@ -526,8 +604,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.gemm == "f32" else "f32 (3 x bf16 operand split on the bf16 "
-                                                      "MFMA for the large GEMMs, fp32 accumulate)",
+            "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": what + ", %d object / %d relation queries, channels %s, bs=%d per "
@@ -536,6 +613,7 @@ def main():
                                "normalised image tensor" if args.path == "image"
                                else "feature pyramid"),
                 "path": args.path, "backbone": bname,
+                "distinct_input_images": len(pool) if args.path == "image" else 1,
                 "attention_mask_order": "reference (resize of full-size mask logits)"
                 if args.exact_mask_order else "mask feature resampled once per level",
                 "global_batch": world * B, "per_gpu_batch": B, "image": [H, W],
@@ -555,6 +633,8 @@ def main():
             "triplet_record_bytes": 4 * gatherer.L if gatherer is not None else None,
             "pipeline_check": pipeline_check,
         }
+        if simple_test is not None:
+            out["simple_test_incl_result_d2h"] = simple_test
         if head_only is not None:
             out["head_only"] = head_only
         if from_decoded is not None:
@@ -655,17 +735,6 @@ def main():
         if backbone is not None and not swin:
             backbone.use_graphs = not args.no_graphs
         out["latency_ms_single_stream_graphs"] = timeit(whole, 10)
-        if args.gemm == "f32":   # the opt-in mode, for comparison (not the headline)
-            head.gemm_mode = "bf16x3"
-            for _ in range(8):       # re-capture graphs for this mode
-                step()
-            drain()
-            dt = timed(10)
-            head.gemm_mode = "f32"
-            for _ in range(8):
-                step()
-            drain()
-            out["opt_in_bf16x3_split"] = {"images_per_s": B * 10 / dt, "ms_per_step": 1e2 * dt}
         # deformable sampling with learned-like offsets: default-init weights give every token
         # mmcv's +-1..4 px grid (a tight neighbourhood); the same kernel on the grid plus
         # N(0, 8 px) noise per offset shows how far the rate depends on that locality
@@ -688,7 +757,7 @@ def main():
             out["deformable_sampling_offsets"] = repr(e)
         if backbone is not None and not swin:
             try:  # comparison leg: the same backbone through PyTorch-ROCm / MIOpen
-                from pairnet_amd.detector import ResNet50
+                from tools.torch_resnet50 import ResNet50
                 bb = ResNet50().to(dev)
                 out["breakdown_ms"]["backbone_r50_torch_miopen"] = timeit(lambda: bb(img), 3)
                 del bb

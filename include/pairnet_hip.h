@@ -28,15 +28,8 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 13
+#define PN_ABI_VERSION 14
 int pn_abi_version(void);
-
-/* Scheduling knob (process-wide, performance only): leave `trim` of the persistent GEMM
- * kernels' resident workgroup slots free for the kernels of concurrent streams. */
-void pn_gemm_set_grid_trim(int trim);
-/* Probe knob: multiply the persistent kernels' grid cap (a large value = one tile per
- * workgroup, i.e. a non-persistent launch). */
-void pn_gemm_set_grid_scale(int scale);
 
 /* ------------------------------------------------------------------------- *
  * Dense contraction (f32 MFMA 32x32x2, exact fp32 accumulate)
@@ -59,10 +52,13 @@ void pn_gemm_set_grid_scale(int scale);
 #define PN_GEMM_FORCE_TILE128x64 32 /* tuning: 128x64 tile                          */
 #define PN_GEMM_RELU_AFTER_RES 128  /* ReLU after the residual add: relu(act(..)+Res)  */
 #define PN_GEMM_GELU 256           /* act = exact (erf) GELU; Swin FFN                  */
-#define PN_GEMM_SPLIT_BF16 64  /* opt-in: fp32-accurate 3 x bf16 operand split on the
-                                  bf16 MFMA (6 partial products, fp32 accumulate;
-                                  error <= 3*2^-24 |a||b| per product, not bitwise the
-                                  fp32 fmaf chain).  Large row-major / conv problems. */
+/* Scheduling hint carried PER CALL in `flags` (performance only, results unchanged): leave
+ * `n` (a multiple of 8, < 8192) of the persistent tile kernels' resident workgroup slots
+ * unoccupied, so that the small latency-bound kernels of a concurrent stream (the query
+ * chains) find a free slot without waiting for a kernel boundary.  There is no
+ * process-wide knob: two callers in one process cannot change each other's grids. */
+#define PN_GEMM_RESERVE_SHIFT 16
+#define PN_GEMM_RESERVE(n) ((((n) / 8) & 0x3ff) << PN_GEMM_RESERVE_SHIFT)
 
 typedef struct pn_gemm_desc {
   const float* A;     int64_t lda;    int64_t strideA;    /* [M][K] (or [K][M])    */
@@ -93,8 +89,10 @@ int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream);
 #define PN_GEMM_VARIANT_TILE_128x64   2  /* k_gemm_tile<128,64,64,32,A>      */
 #define PN_GEMM_VARIANT_TILE_128x128  4  /* k_gemm_tile<128,128,64,64,A>     */
 #define PN_GEMM_VARIANT_TILE_64x64    6  /* k_gemm_tile<64,64,32,32,A> (default) */
-#define PN_GEMM_VARIANT_SPLIT         8  /* k_gemm_split<A_ROW>                  */
 int pn_gemm_variant(const pn_gemm_desc* d);
+/* Workgroups the persistent 64x64 tile kernel is launched with for `d` (introspection: a
+ * function of the descriptor alone, PN_GEMM_RESERVE included). */
+int pn_gemm_grid_size(const pn_gemm_desc* d);
 
 /* Implicit-GEMM KHxKW convolution, stride 1, zero padding, channel-last:
  *   out[b][y][x][co] = act(sum_{ky,kx,ci} in[b][y+ky-pad][x+kx-pad][ci]
@@ -104,8 +102,8 @@ int pn_gemm_variant(const pn_gemm_desc* d);
  * Cin % 32 == 0. */
 int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float* bias,
                        float* out, int B, int H, int W, int Cin, int Cout,
-                       int KH, int KW, int pad, int relu, int flags /* 0 or
-                       PN_GEMM_SPLIT_BF16, | PN_GEMM_FORCE_TILE */, void* stream);
+                       int KH, int KW, int pad, int relu, int flags /* 0, PN_GEMM_FORCE_TILE*,
+                       PN_GEMM_RESERVE(n) */, void* stream);
 
 /* Winograd F(2x2, 3x3) form of the same 3x3 "same" convolution (C % 4 == 0; odd H / W: the
  * last tile row / column is padded with zeros and clipped), T = B*ceil(H/2)*ceil(W/2) tiles:
@@ -136,7 +134,7 @@ int pn_winograd_f43_output_f32(const float* M, const float* bias, float* out, in
 /* General form of the convolution above: stride >= 1, any padding,
  *   Ho = (H + 2 pad - KH) / stride + 1 (same for W),
  *   out = [relu_after](act(conv + bias) + res),  res/out [B][Ho][Wo][Cout],
- * flags: PN_GEMM_RELU (act), PN_GEMM_RELU_AFTER_RES, tile / split selectors. */
+ * flags: PN_GEMM_RELU (act), PN_GEMM_RELU_AFTER_RES, tile selectors, PN_GEMM_RESERVE(n). */
 int pn_conv2d_nhwc_ex_f32(const float* in, const float* Wp, const float* bias,
                           const float* res, float* out, int B, int H, int W, int Cin,
                           int Cout, int KH, int KW, int stride, int pad, int flags,
@@ -145,7 +143,8 @@ int pn_conv2d_nhwc_ex_f32(const float* in, const float* Wp, const float* bias,
 /* Stem: relu(conv7x7/2 pad 3 (NCHW RGB image) + bias) -> [B][Ho][Wo][64] channel-last.
  * Wp [64][160] = conv1.weight [64][3][7][7] flattened, zero-padded 147 -> 160. */
 int pn_stem7x7s2_f32(const float* img_nchw, const float* Wp, const float* bias,
-                     float* out, int B, int H, int W, void* stream);
+                     float* out, int B, int H, int W, int flags /* 0 or PN_GEMM_RESERVE(n) */,
+                     void* stream);
 /* F.max_pool2d(x, 3, stride=2, padding=1) on channel-last data, C % 4 == 0. */
 int pn_maxpool3x3s2_nhwc_f32(const float* in, float* out, int B, int H, int W, int C,
                              void* stream);
@@ -218,40 +217,6 @@ int pn_ffn_ln2_f32(const float* x, const float* W1, const float* b1, const float
                    const float* b2, const float* gamma, const float* beta, float* y,
                    const float* gamma2, const float* beta2, float* y2, float* scratch, int M,
                    int C, int hidden, float eps, void* stream);
-
-/* ------------------------------------------------------------------------- *
- * Row chain: a short program of row-wise dense operations on the decoders' queries
- * (M rows of 256 channels) in ONE launch, intermediates in LDS.  Replaces the chains
- * of small nn.Linear / LayerNorm / F.normalize calls between the attention modules of
- * a decoder layer (facebook_detr.py:311-353 out_proj + residual, :406-408 norms; the
- * next attention's in_proj), after its FFN (the mask_embed MLP and cls_embed of
- * forward_head, pairnet_head.py:236-243; the next layer's query projection) and of the
- * PPN (sub / obj_query_update + F.normalize, pairnet_head.py:322-326).
- *   buffers: three LDS row buffers 0..2 per 32-row workgroup; in0 -> buffer 0,
- *            in1 (nullable) -> buffer 1
- *   op.kind  0 LIN     dst/out = act((src [+ aadd[row % aadd_rows] for output columns >=
- *                      add_from_col]) W^T + bias) [+ buffer res];  W [N][256], N <= 768;
- *                      dst (an LDS buffer, -1 = none) needs N == 256; out (global, row
- *                      stride ldo) may be NULL
- *            1 LN      LayerNorm over the 256 channels of buffer src -> dst and / or out
- *            2 L2NORM  src / max(||src||_2, eps)                     -> dst and / or out
- * Deterministic (fixed summation order). */
-#define PN_CHAIN_MAX_OPS 8
-typedef struct pn_chain_op {
-  int32_t kind, src, dst, res;
-  int32_t N, relu, add_from_col, aadd_rows;
-  const float* W; const float* bias; const float* aadd;
-  const float* gamma; const float* beta;
-  float* out; int64_t ldo;
-  float eps;
-} pn_chain_op;
-typedef struct pn_chain_desc {
-  int32_t nops, M;
-  const float* in0; int64_t ld0;
-  const float* in1; int64_t ld1;
-  pn_chain_op op[PN_CHAIN_MAX_OPS];
-} pn_chain_desc;
-int pn_rowchain_f32(const pn_chain_desc* d, void* stream);
 
 /* y[r][:] = x[r][:] / max(||x[r]||_2, eps)   (F.normalize, pairnet_head.py:325-326) */
 int pn_l2normalize_f32(const float* x, float* y, int64_t rows, int C, float eps,

@@ -298,9 +298,11 @@ def _top_noise(imp32, imp64, k):
     return float((a - b).abs().gather(-1, top).max())
 
 
-def separate(oracle_cls, cfg, sd0, feats, metas, q_override=None, log=print):
+def separate(oracle_cls, cfg, sd0, feats, metas, q_override=None, log=print, feats64=None):
     """Returns (ops, report) for the seeded state dict `sd0` on this input.  With
-    `q_override` (Q,B,256) only the PPN edits are made (the ppn_sep fixture)."""
+    `q_override` (Q,B,256) only the PPN edits are made (the ppn_sep fixture).  `feats64`:
+    the features of an fp64 evaluation of whatever produced `feats` (a backbone), so that
+    the noise estimate of the seed search includes the producer's rounding."""
     import copy
     k = cfg["num_rel_query"]
     ops = {}
@@ -314,7 +316,8 @@ def separate(oracle_cls, cfg, sd0, feats, metas, q_override=None, log=print):
         out = []
         for dtype in (torch.float32, torch.float64):
             trace = {}
-            build(dtype).forward([f.to(dtype) for f in feats], metas, trace=trace)
+            fin = feats64 if (dtype == torch.float64 and feats64 is not None) else feats
+            build(dtype).forward([f.to(dtype) for f in fin], metas, trace=trace)
             out.append(trace["query_feat"])
         return out
 
@@ -435,6 +438,95 @@ def gen_e2e_sep(name, H, W, bs, feat_seed, sf):
                mask_neg_frac=float((m < 0).float().mean()), ref_seconds=dt, **ops)
     for i, r in enumerate(res):
         out["res%d_labels" % i] = _np(r[1])
+        out["res%d_r_dists" % i] = _np(r[7])
+        out["res%d_pan_img" % i] = _np(r[4]).astype(np.int32)
+        rows = np.arange(0, r[3].shape[0], 1 if H * W < 100000 else 10)   # (fixture size)
+        out["res%d_masks_rows" % i] = rows
+        out["res%d_masks" % i] = np.packbits(_np(r[3])[rows])
+        out["res%d_masks_shape" % i] = np.array((len(rows),) + tuple(r[3].shape[1:]))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
+# ---- image -> triplets fixtures (round 3): the backbone in front of the separated head ----
+# BASELINE.json configs[1] / configs[3] name a BACKBONE + head, and PSGTr.simple_test
+# (psgtr.py:148-156) starts from the image tensor.  These fixtures record the reference head
+# on the features of the oracle backbone (oracle/backbone.py / oracle/swin.py, both pinned to
+# HuggingFace transformers' implementations) for a seeded image, separated like the
+# `*_sep` fixtures above, plus probes of the backbone features themselves.
+def _backbone_oracle(kind, seed):
+    if kind == "r50":
+        from .backbone import OracleResNet50, seeded_backbone_state
+        net = OracleResNet50()
+        sd = seeded_backbone_state(seed)
+        net.load_state_dict(sd)
+        return net, sd, (256, 512, 1024, 2048)
+    from .swin import OracleSwin, seeded_swin_state
+    dims = dict(swinL=dict(embed_dims=192, depths=(2, 2, 18, 2), num_heads=(6, 12, 24, 48),
+                           window_size=12),
+                swinB=dict(embed_dims=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32),
+                           window_size=12))[kind]
+    net = OracleSwin(**dims)
+    sd = seeded_swin_state(net, seed)
+    net.load_state_dict(sd)
+    e = dims["embed_dims"]
+    return net, sd, (e, 2 * e, 4 * e, 8 * e)
+
+
+def gen_e2e_image(name, kind, H, W, bs, img_seed, bb_seed, sf, num_obj_query=100):
+    import copy
+    from .head import OracleCrossHead2
+    backbone, bsd, chans = _backbone_oracle(kind, bb_seed)
+    img = seeded.uniform(np.random.default_rng(img_seed), (bs, 3, H, W), -2.0, 2.0)
+    t0 = time.time()
+    feats = [f.contiguous() for f in backbone(img)]
+    t_bb = time.time() - t0
+    feats64 = [f.contiguous() for f in copy.deepcopy(backbone).double()(img.double())]
+    bb_noise = max(float((a.double() - b).abs().max() / b.abs().max()) for a, b in zip(feats, feats64))
+    cfg = ref_shim.reference_head_cfg()
+    cfg.pop("type", None)
+    cfg["in_channels"] = list(chans)
+    cfg["num_obj_query"] = num_obj_query
+    head = ref_shim.build_reference_head(dict(cfg))
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in head.state_dict().items())
+    sd0 = seeded.seeded_state_dict(shapes, WEIGHT_SEED)
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[sf] * 4)] * bs
+    ops, rep = separate(OracleCrossHead2, dict(cfg), sd0, feats, metas, feats64=feats64)
+    sd = seeded.apply_ops(dict(sd0), ops)
+    head.load_state_dict(sd, strict=True)
+    cls, masks, idx, dt = _run_e2e(head, feats, metas)
+    o64 = OracleCrossHead2(**cfg).eval()
+    o64.load_state_dict(sd)
+    # the fp64 evaluation starts from the IMAGE (fp64 backbone features): the recorded list
+    # must survive the backbone's own rounding as well
+    gap, noise = _sep_check(o64.double(), head, feats64, metas, cls, idx, head.num_rel_query)
+    print("%s: backbone %.1f s, fp32-vs-fp64 feature error %.2e; min gap %.3e, fp32-vs-fp64 "
+          "importance error %.3e (margin %.0f)" % (name, t_bb, bb_noise, gap, noise, gap / noise))
+    with torch.no_grad():
+        res = head.get_bboxes(cls, masks, metas)
+    m = masks["mask"]
+    probe = torch.from_numpy(np.random.default_rng(img_seed + 1).integers(0, m.numel(), 4096))
+    sub = torch.div(idx, head.num_obj_query, rounding_mode="trunc")
+    out = dict(weight_seed=WEIGHT_SEED, weight_crc=seeded.checksum(sd), img_seed=img_seed,
+               img_crc=seeded.checksum([img]), backbone_seed=bb_seed,
+               backbone_crc=seeded.checksum([v for k, v in bsd.items()
+                                             if v.dtype == torch.float32]),
+               height=H, width=W, batch=bs, img_scale=sf, num_obj_query=num_obj_query,
+               rel=_np(cls["rel"]), cls=_np(cls["cls"]), importance=_np(cls["importance"]),
+               sub=_np(cls["sub"]), obj=_np(cls["obj"]),
+               topk_idx=_np(idx), sub_pos=_np(sub), obj_pos=_np(idx - sub * head.num_obj_query),
+               min_gap=gap, fp64_noise=noise, backbone_fp64_noise=bb_noise,
+               mask_probe_idx=_np(probe), mask_probe=_np(m.flatten()[probe]),
+               mask_neg_frac=float((m < 0).float().mean()), ref_seconds=dt, **ops)
+    for l, f in enumerate(feats):
+        pi = torch.from_numpy(np.random.default_rng(img_seed + 10 + l).integers(0, f.numel(), 8192))
+        out["feat%d_shape" % l] = np.array(f.shape)
+        out["feat%d_probe_idx" % l] = _np(pi)
+        out["feat%d_probe" % l] = _np(f.flatten()[pi])
+        out["feat%d_absmax" % l] = float(f.abs().max())
+        out["feat%d_mean" % l] = float(f.double().mean())
+    for i, r in enumerate(res):
+        out["res%d_labels" % i] = _np(r[1])
+        out["res%d_rel_pairs" % i] = _np(r[2])
         out["res%d_r_dists" % i] = _np(r[7])
         out["res%d_pan_img" % i] = _np(r[4]).astype(np.int32)
         rows = np.arange(0, r[3].shape[0], 1 if H * W < 100000 else 10)   # (fixture size)
@@ -758,6 +850,10 @@ def main():
         gen_e2e_sep("e2e_small_sep", 96, 128, 2, 53, 2.0)
     if want("e2e_full_sep"):
         gen_e2e_sep("e2e_full_sep", 800, 1333, 1, 63, 2.083)
+    if want("e2e_image_full"):      # BASELINE configs[1]: R50, 100 queries, 800x1333
+        gen_e2e_image("e2e_image_full", "r50", 800, 1333, 2, 163, 31, 2.083)
+    if want("e2e_image_swinl"):     # BASELINE configs[3]: Swin-L (true dims), 200 queries
+        gen_e2e_image("e2e_image_swinl", "swinL", 256, 320, 2, 173, 41, 1.0, num_obj_query=200)
     if want("baseline_small"):
         gen_baseline_small()
     if want("psgtr2_small"):

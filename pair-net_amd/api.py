@@ -12,11 +12,12 @@ from .neck import ChannelMapper  # noqa: F401
 from .head import CrossHead2  # noqa: F401
 from .pipeline import PipelinedHead  # noqa: F401
 from .preprocess import TestPipeline  # noqa: F401
-from .detector import PSGTr, Result, build_detector, load_checkpoint, triplet2Result  # noqa: F401
+from .detector import (PSGTr, Result, ResultStreamer, build_detector, load_checkpoint,  # noqa: F401
+                       triplet2Result)
 from .dist import all_gather_triplets, shard_indices  # noqa: F401
 
 __all__ = ["ConfigDict", "load_config", "pairnet_head_cfg", "pairnet_r50", "CrossHead2",
-           "PSGTr", "Result", "build_detector", "load_checkpoint", "triplet2Result", "all_gather_triplets",
+           "PSGTr", "Result", "ResultStreamer", "build_detector", "load_checkpoint", "triplet2Result", "all_gather_triplets",
            "shard_indices", "PipelinedHead", "CrossHeadBaseline", "baseline_head_cfg",
            "baseline_r50", "PSGTrHead2", "psgtr2_head_cfg", "psgtr2_r50", "ResNet50Hip",
            "SwinTransformerHip", "pairnet_swin", "swin_backbone_cfg", "TestPipeline", "test_pipeline_cfg",

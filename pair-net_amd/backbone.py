@@ -17,6 +17,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
+from .plans import PlanCache
 
 BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}   # bottleneck ResNets (mmdet arch_settings)
 EPS = 1e-5
@@ -72,9 +73,11 @@ class ResNet50Hip:
             if v.dim() == 4:
                 fan_in = v.shape[1] * v.shape[2] * v.shape[3]
                 v.copy_(torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5)
-        self.device, self.w, self._plans = None, None, {}
+        self.device, self.w, self._plans = None, None, PlanCache()
         # replay the forward pass as one hipGraph after an eager warm-up call
         self.use_graphs = False
+        # persistent-GEMM workgroup slots left free for concurrent streams (hip.reserve_slots)
+        self.grid_reserve = 0
         # 3x3 stride-1 layers of >= 128 channels (stages 2-4): "winograd" = F(2x2,3x3) around
         # one batched GEMM (2.25x fewer multiplications), "direct" = implicit GEMM
         self.conv_algo = "winograd"
@@ -93,11 +96,11 @@ class ResNet50Hip:
                 if tuple(sd[k].shape) != tuple(p.shape):
                     raise RuntimeError("shape mismatch for %s" % k)
                 p.copy_(sd[k].detach().to(p.dtype).cpu())
-        self.w, self._plans = None, {}     # plans hold graphs captured on the old weights
+        self.w, self._plans = None, PlanCache()     # plans hold graphs captured on the old weights
         return missing, unexpected
 
     def to(self, device):
-        self.device, self.w, self._plans = torch.device(device), None, {}
+        self.device, self.w, self._plans = torch.device(device), None, PlanCache()
         return self
 
     def eval(self):
@@ -197,6 +200,8 @@ class ResNet50Hip:
         img = img.contiguous()
         B, _, H, W = img.shape
         pl = self._plan(B, H, W, slot)
+        if getattr(pl, "reserve", None) != self.grid_reserve:   # a captured graph bakes it in
+            pl.reserve, pl.graph, pl.calls = self.grid_reserve, None, min(pl.calls, 1)
         if not self.use_graphs:
             return self._run(img, pl)
         # hipGraph replay of the ~55 launches: captured on the caller's image buffer when it
@@ -226,6 +231,10 @@ class ResNet50Hip:
         return g, box["out"]
 
     def _run(self, img, pl):
+        with hip.reserve_slots(self.grid_reserve):
+            return self._run_layers(img, pl)
+
+    def _run_layers(self, img, pl):
         B, _, H, W = img.shape
         w = self.w
         hip.stem7x7s2(img, w["stem.w"], w["stem.b"], pl.stem, B, H, W)

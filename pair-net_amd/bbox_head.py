@@ -36,6 +36,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
+from .plans import PlanCache
 from .config import ConfigDict
 from .head import CrossHead2, _decoder_param_shapes
 
@@ -104,11 +105,10 @@ class CrossHeadBBox(CrossHead2):
             raise NotImplementedError("4 levels, <= 512 proposals, <= 256 classes")
         self._params = OrderedDict((k, torch.zeros(s)) for k, s in self.param_shapes().items())
         self.device, self.w = None, None
-        self._plans, self._post = {}, OrderedDict()
+        self._plans, self._post = PlanCache(), OrderedDict()
         self._pan_jobs = []
-        self.gemm_mode = "f32"
         self.use_graphs = False
-        self.fuse_chains = False
+        self.grid_reserve = 0
         self.fuse_ppn_front = True
         self.init_weights()
 
@@ -216,7 +216,7 @@ class CrossHeadBBox(CrossHead2):
             self._params["cls_branches.%d.bias" % i].fill_(bias_init)
             self._params["reg_branches.%d.4.weight" % i].zero_()
         self._params["reg_branches.0.4.bias"][2:] = -2.0
-        self.w, self._plans = None, {}
+        self.w, self._plans = None, PlanCache()
 
     # ----------------------------------------------------------------- packing
     def _pack(self):
@@ -325,7 +325,6 @@ class CrossHeadBBox(CrossHead2):
         pl.graph_a = pl.graph_b = pl.graph_cfg = None
         pl.calls_a = pl.calls_b = 0
         pl.feats_read = torch.cuda.Event()
-        pl.chains = {}
         M, P, K = B * SN, self.num_proposals, self.KEPT
         nc = self.cls_out_channels
         # ---- shape constants ----
@@ -556,7 +555,7 @@ class CrossHeadBBox(CrossHead2):
         from the second call on) as one hipGraph replay.  A stage-A graph is tied to the
         buffers it was captured on: the neck's in-place token rows belong to the plan (its
         key), plain feature tensors are staged through the plan's own token rows."""
-        cfg = (self.gemm_mode, self.fuse_ppn_front)
+        cfg = (self.fuse_ppn_front, self.grid_reserve)
         if pl.graph_cfg != cfg:
             pl.graph_a = pl.graph_b = None
             pl.graph_cfg = cfg
@@ -564,7 +563,10 @@ class CrossHeadBBox(CrossHead2):
             if pl.own_tokens:
                 self._stage_a_copy(feats, pl)
                 pl.feats_read.record()       # the caller's feature buffers are free again
-            body = lambda: (self._encoder(pl), self._two_stage(pl))
+            def body():
+                with hip.reserve_slots(self.grid_reserve):
+                    self._encoder(pl)
+                    self._two_stage(pl)
             if self.use_graphs and pl.graph_a is None and pl.calls_a >= 1:
                 pl.graph_a = self._capture(body)
             pl.calls_a += 1

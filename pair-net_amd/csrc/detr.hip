@@ -19,9 +19,10 @@ __device__ __forceinline__ float inv_sigmoidf_(float x) {
 // proposal box leaves (0.01, 0.99), and padded tokens, are zeroed before enc_output; the
 // deformable attentions zero the value rows of padded tokens).  Rows of C floats at stride ld;
 // `valid` advances by vstride per image (0: one table for the whole batch); in place allowed. ----
-__global__ __launch_bounds__(256) void k_zero_rows(const float* __restrict__ x,
+// (x and out may be the same buffer: no __restrict__ on them)
+__global__ __launch_bounds__(256) void k_zero_rows(const float* x,
                                                    const uint8_t* __restrict__ valid,
-                                                   float* __restrict__ out, int64_t rows, int C4,
+                                                   float* out, int64_t rows, int C4,
                                                    int64_t ld, int64_t vstride) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= rows * C4) return;

@@ -43,45 +43,10 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned vof
                      __uint_as_float(v.w));
 }
 
-// ---- opt-in compute mode: fp32-accurate contraction on the bf16 matrix pipe ------------
-// (PN_GEMM_SPLIT_BF16).  Every fp32 operand is split EXACTLY into three bf16 pieces
-// x = h + m + l (two mask/subtract steps: 8 + 8 + 8 significand bits) when its chunk goes
-// to LDS, and a product is taken as the six partial products of order <= 2^-16,
-//     a b ~= h_a h_b + (h_a m_b + m_a h_b) + (h_a l_b + l_a h_b + m_a m_b),
-// each an exact bf16 x bf16 -> fp32 product accumulated in fp32 by
-// v_mfma_f32_32x32x16_bf16.  The dropped terms are <= 3 * 2^-24 |a b|, one fp32 rounding:
-// fp32-class accuracy (measured error vs fp64 equal to or below the fp32 MFMA path's),
-// though not bitwise the fmaf chain of the default mode.  Six bf16 MFMAs at 32 cycles
-// replace eight fp32 MFMAs at 64.  LDS holds three bf16 planes [row][32 k] per operand:
-// 64-byte rows whose four 16-byte chunks are XOR-swizzled with (row >> 2) & 3, which makes
-// the b128 fragment reads and the b64 stores bank-conflict free.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// high halves of two dwords -> one dword {lo16 = x0 >> 16, hi16 = x1 >> 16}
-__device__ __forceinline__ uint32_t pack_hi16(uint32_t x0, uint32_t x1) {
-  return __builtin_amdgcn_perm(x1, x0, 0x07060302u);
-}
-
-__device__ __forceinline__ void split3_pack(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
-  const uint32_t M16 = 0xFFFF0000u;
-  const float x[4] = {v.x, v.y, v.z, v.w};
-  uint32_t h[4], m[4], l[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h[i] = __float_as_uint(x[i]) & M16;
-    const float r = x[i] - __uint_as_float(h[i]);   // exact
-    m[i] = __float_as_uint(r) & M16;
-    l[i] = __float_as_uint(r - __uint_as_float(m[i]));  // exact, <= 8 significant bits
-  }
-  hi = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
-  mid = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
-  lo = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
-}
-
-template <int BM, int BN, int AMODE, bool SPLIT = false>
+template <int BM, int BN, int AMODE>
 struct TileSmem {
-  static constexpr int A_ELEMS = SPLIT ? 3 * BM * 16 : (AMODE == A_COL) ? 32 * (BM + 4) : BM * 36;
-  static constexpr int FLOATS = A_ELEMS + (SPLIT ? 3 * BN * 16 : BN * 36);
+  static constexpr int A_ELEMS = (AMODE == A_COL) ? 32 * (BM + 4) : BM * 36;
+  static constexpr int FLOATS = A_ELEMS + BN * 36;
 };
 
 struct TileRef {
@@ -98,15 +63,14 @@ struct TileRef {
 // stores drain under the next tile's MFMAs.  (Measured on MI355X with
 // tools/gemm_probe.hip: 83-96 -> 99-112 TFLOP/s on the encoder shapes versus one
 // workgroup per tile; the matrix pipe alone peaks at ~140.)
-template <int BM, int BN, int WM, int WN, int AMODE, bool ADD, bool SPLIT, typename Locator>
+template <int BM, int BN, int WM, int WN, int AMODE, bool ADD, typename Locator>
 __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int ntiles,
                                                 float* smem) {
   constexpr int BK = 32, LD = BK + 4;
   constexpr int WAVES_N = BN / WN;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int LDK = BM + 4;  // k-major A tile stride (A_COL)
-  constexpr int A_ELEMS = TileSmem<BM, BN, AMODE, SPLIT>::A_ELEMS;
-  static_assert(!(SPLIT && AMODE == A_COL), "the split mode takes row-major / conv operands");
+  constexpr int A_ELEMS = TileSmem<BM, BN, AMODE>::A_ELEMS;
   constexpr int NT = 64 * (BM / WM) * WAVES_N;   // threads: one wave per WM x WN sub-tile
   constexpr int RPP = NT / 8;        // tile rows staged per pass (8 lanes per 32-float row)
   constexpr int NA = (BM * BK / 4) / NT;
@@ -333,31 +297,7 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
       for (int j = 0; j < NB; ++j)
         rb[j] = st_k0 + kc < lK ? ld4(bW + st_k0 + w_off[j] / 4u) : zero4;
     }
-    if (SPLIT) {
-      // thread (row, 4 k) -> 8 bytes of chunk (tid & 7) >> 1 of the row, in each plane
-      unsigned char* pa = reinterpret_cast<unsigned char*>(sA);
-      unsigned char* pb = reinterpret_cast<unsigned char*>(sB);
-      const int wr = tid >> 3, wsub = (tid & 1) * 8, wch = (tid & 7) >> 1;
-      uint2 h, m, l;
-#pragma unroll
-      for (int j = 0; j < NA; ++j) {
-        const int r = wr + RPP * j;
-        const int off = r * 64 + ((wch ^ ((r >> 2) & 3)) << 4) + wsub;
-        split3_pack(ra[j], h, m, l);
-        *reinterpret_cast<uint2*>(pa + off) = h;
-        *reinterpret_cast<uint2*>(pa + BM * 64 + off) = m;
-        *reinterpret_cast<uint2*>(pa + 2 * BM * 64 + off) = l;
-      }
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const int r = wr + RPP * j;
-        const int off = r * 64 + ((wch ^ ((r >> 2) & 3)) << 4) + wsub;
-        split3_pack(rb[j], h, m, l);
-        *reinterpret_cast<uint2*>(pb + off) = h;
-        *reinterpret_cast<uint2*>(pb + BN * 64 + off) = m;
-        *reinterpret_cast<uint2*>(pb + 2 * BN * 64 + off) = l;
-      }
-    } else if (AMODE == A_COL) {
+    if (AMODE == A_COL) {
 #pragma unroll
       for (int j = 0; j < NA; ++j)
         st4(sA + (tid / QM + KSTEP * j) * LDK + (tid % QM) * 4, ra[j]);
@@ -390,45 +330,7 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) fb[ni] = ld4(fB + ni * 32 * LD + kb * 8);
   };
-  // split mode: the 32-deep chunk is two k16 MFMA steps; fragments of step 1 are read
-  // while the 6 * TM * TN MFMAs of step 0 issue
-  auto read_frag_split = [&](int st, bf16x8 (&a)[TM][3], bf16x8 (&b)[TN][3]) {
-    const unsigned char* pa = reinterpret_cast<const unsigned char*>(sA);
-    const unsigned char* pb = reinterpret_cast<const unsigned char*>(sB);
-    const int chunk = ((2 * st + lh) ^ ((li >> 2) & 3)) << 4;
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-      for (int t = 0; t < TM; ++t)
-        a[t][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
-            pa + pl * BM * 64 + (wm * WM + t * 32 + li) * 64 + chunk));
-#pragma unroll
-      for (int t = 0; t < TN; ++t)
-        b[t][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
-            pb + pl * BN * 64 + (wn * WN + t * 32 + li) * 64 + chunk));
-    }
-  };
-  auto compute_split = [&]() {
-    bf16x8 a[2][TM][3], b[2][TN][3];
-    read_frag_split(0, a[0], b[0]);
-    // six partial products, smallest first; consecutive MFMAs go to different accumulators
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      if (st == 0) read_frag_split(1, a[1], b[1]);
-#pragma unroll
-      for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < TN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                a[st][mi][PA[t]], b[st][ni][PB[t]], acc[mi][ni], 0, 0, 0);
-    }
-  };
   auto compute = [&]() {
-    if (SPLIT) { compute_split(); return; }
     float4 fa[2][TM], fb[2][TN];
     read_frag(0, fa[0], fb[0]);
 #pragma unroll
@@ -539,12 +441,12 @@ struct SingleLocator {
 };
 
 // ADD: the launch has a row-periodic addend on A (positional encodings), pn_gemm_desc.Aadd
-template <int BM, int BN, int WM, int WN, int AMODE, bool ADD = false, bool SPLIT = false>
+template <int BM, int BN, int WM, int WN, int AMODE, bool ADD = false>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void k_gemm_tile(const GemmP p,
                                                                           const int batch) {
-  __shared__ __attribute__((aligned(16))) float smem[TileSmem<BM, BN, AMODE, SPLIT>::FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[TileSmem<BM, BN, AMODE>::FLOATS];
   const SingleLocator loc{p, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN};
-  gemm_persistent<BM, BN, WM, WN, AMODE, ADD, SPLIT>(loc, loc.mt * loc.nt * batch, smem);
+  gemm_persistent<BM, BN, WM, WN, AMODE, ADD>(loc, loc.mt * loc.nt * batch, smem);
 }
 
 // Several independent row-major GEMMs in ONE launch: the 64x64 tiles of all
@@ -578,7 +480,7 @@ struct GroupLocator {
 __global__ __launch_bounds__(256) void k_gemm_group(const GroupP g) {
   __shared__ __attribute__((aligned(16))) float smem[TileSmem<64, 64, A_ROW>::FLOATS];
   const GroupLocator loc{g};
-  gemm_persistent<64, 64, 32, 32, A_ROW, true, false>(loc, g.tile_start[GEMM_GROUP_MAX], smem);
+  gemm_persistent<64, 64, 32, 32, A_ROW, true>(loc, g.tile_start[GEMM_GROUP_MAX], smem);
 }
 
 // 32x32 output tile per workgroup; NW waves split K (wave w contracts a contiguous
@@ -684,19 +586,28 @@ static int launch_skinny(const GemmP& p, int batch, hipStream_t s) {
 }
 
 
-// Persistent launch: at most `wg_per_cu` workgroups per CU (256 CUs), a multiple of 8 so
-// that every XCD gets the same number of them.
-// `pn_gemm_set_grid_trim(t)`: leave t workgroup slots (a multiple of 8, spread over the XCDs)
-// unoccupied, so that the small latency-bound kernels of a concurrent stream (the query
-// chains) find a resident slot without waiting for a kernel boundary.
-static int pn_grid_trim = 0;
-extern "C" void pn_gemm_set_grid_trim(int trim) { pn_grid_trim = trim < 0 ? 0 : trim / 8 * 8; }
+// Persistent launch: at most `wg_per_cu` workgroups per CU, a multiple of 8 so that every
+// XCD gets the same number of them; `flags` may carry PN_GEMM_RESERVE(n): n workgroup slots
+// (spread over the XCDs) stay unoccupied, so that the small latency-bound kernels of a
+// concurrent stream (the query chains) find a resident slot without waiting for a kernel
+// boundary.  The hint travels with the call: no process-wide state.
+static int cu_count() {
+  // immutable hardware attribute of the current device, looked up once per device
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+      n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
 
-static int pn_grid_scale = 1;   // probe: grid cap multiplier (large = one tile per workgroup)
-extern "C" void pn_gemm_set_grid_scale(int scale) { pn_grid_scale = scale < 1 ? 1 : scale; }
-
-static int persistent_grid(int64_t ntiles, int wg_per_cu) {
-  int64_t cap = (int64_t)256 * wg_per_cu * pn_grid_scale - pn_grid_trim;
+static int persistent_grid(int64_t ntiles, int wg_per_cu, int flags) {
+  const int reserve = ((flags >> PN_GEMM_RESERVE_SHIFT) & 0x3ff) * 8;
+  int64_t cap = (int64_t)cu_count() * wg_per_cu / 8 * 8 - reserve;
   if (cap < 256) cap = 256;
   const int64_t want = (ntiles + 7) / 8 * 8;
   return (int)(want < cap ? want : cap);
@@ -712,19 +623,19 @@ static int resident_wgs(Kern kern, int cap, int threads = 256) {
   return n < cap ? n : cap;
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, bool SPLIT = false>
-static int launch_tile(const GemmP& p, int batch, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int AMODE>
+static int launch_tile(const GemmP& p, int batch, hipStream_t s, int flags) {
   const int64_t ntiles = (int64_t)pn_cdiv(p.N, BN) * pn_cdiv(p.M, BM) * batch;
   constexpr int cap = (BM * BN <= 64 * 64) ? 4 : (BM * BN <= 128 * 64) ? 3 : 2;
   constexpr int NT = 64 * (BM / WM) * (BN / WN);
   if (AMODE == A_ROW && p.Aadd) {
-    auto kern = k_gemm_tile<BM, BN, WM, WN, AMODE, AMODE == A_ROW, SPLIT>;
+    auto kern = k_gemm_tile<BM, BN, WM, WN, AMODE, AMODE == A_ROW>;
     static const int wgs = resident_wgs(kern, cap, NT);
-    hipLaunchKernelGGL(kern, dim3(persistent_grid(ntiles, wgs)), dim3(NT), 0, s, p, batch);
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(ntiles, wgs, flags)), dim3(NT), 0, s, p, batch);
   } else {
-    auto kern = k_gemm_tile<BM, BN, WM, WN, AMODE, false, SPLIT>;
+    auto kern = k_gemm_tile<BM, BN, WM, WN, AMODE, false>;
     static const int wgs = resident_wgs(kern, cap, NT);
-    hipLaunchKernelGGL(kern, dim3(persistent_grid(ntiles, wgs)), dim3(NT), 0, s, p, batch);
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(ntiles, wgs, flags)), dim3(NT), 0, s, p, batch);
   }
   return PN_LAUNCH_CHECK();
 }
@@ -778,15 +689,15 @@ static int splitk_factor(const GemmP& p, int batch, const float* scratch, int64_
 
 template <int AMODE>
 static int launch_tile64_splitk(const GemmP& p, int batch, float* scratch, int64_t scratch_floats,
-                                hipStream_t s) {
+                                hipStream_t s, int flags) {
   int cps;
   const int S = splitk_factor(p, batch, scratch, scratch_floats, &cps);
-  if (S <= 1) return launch_tile<64, 64, 32, 32, AMODE>(p, batch, s);
+  if (S <= 1) return launch_tile<64, 64, 32, 32, AMODE>(p, batch, s, flags);
   GemmP q = p;                       // pass 1: raw partial products into the scratch
   q.C = scratch; q.ldc = p.N; q.sC = (int64_t)p.M * p.N;
   q.bias = nullptr; q.Res = nullptr; q.relu = 0; q.relu_after = 0;
   q.ksplit = S; q.split_chunks = cps;
-  if (int rc = launch_tile<64, 64, 32, 32, AMODE>(q, batch * S, s)) return rc;
+  if (int rc = launch_tile<64, 64, 32, 32, AMODE>(q, batch * S, s, flags)) return rc;
   const int64_t n = (int64_t)p.M * (p.N / 4);
   hipLaunchKernelGGL(k_splitk_reduce, dim3(pn_cdiv(n, 256), batch), dim3(256), 0, s, scratch, p, S);
   return PN_LAUNCH_CHECK();
@@ -808,7 +719,6 @@ extern "C" int pn_gemm_variant(const pn_gemm_desc* d) {
   if (!d || d->M <= 0 || d->N <= 0 || d->batch <= 0) return PN_BAD_ARG;
   const int col = (d->flags & PN_GEMM_A_COLMAJOR) ? 1 : 0;
   if (gemm_use_skinny(d)) return PN_GEMM_VARIANT_SKINNY + col;
-  if ((d->flags & PN_GEMM_SPLIT_BF16) && !col) return PN_GEMM_VARIANT_SPLIT;
   if (d->flags & PN_GEMM_FORCE_TILE128x64) return PN_GEMM_VARIANT_TILE_128x64 + col;
   if (d->flags & PN_GEMM_FORCE_TILE) return PN_GEMM_VARIANT_TILE_128x128 + col;
   return PN_GEMM_VARIANT_TILE_64x64 + col;
@@ -850,24 +760,28 @@ extern "C" int pn_gemm_f32(const pn_gemm_desc* d, void* stream) {
   if (gemm_use_skinny(d)) {
     return colmajor ? launch_skinny<A_COL>(p, d->batch, s) : launch_skinny<A_ROW>(p, d->batch, s);
   }
-  if ((d->flags & PN_GEMM_SPLIT_BF16) && !colmajor)
-    return (d->flags & PN_GEMM_FORCE_TILE)
-               ? launch_tile<128, 128, 64, 64, A_ROW, true>(p, d->batch, s)
-               : launch_tile<64, 64, 32, 32, A_ROW, true>(p, d->batch, s);
   // Tile choice (measured on MI355X, tools/gemm_probe.hip / gemm_sweep.py): with
   // K = 256..1024 the persistent 64x64 tile at 4 workgroups per CU is best or within 3 %
   // of the best on every encoder shape (99-112 TFLOP/s); 128x64 and 128x128 stay
   // selectable for sweeps.
   if (d->flags & PN_GEMM_FORCE_TILE128x64)
-    return colmajor ? launch_tile<128, 64, 64, 32, A_COL>(p, d->batch, s)
-                    : launch_tile<128, 64, 64, 32, A_ROW>(p, d->batch, s);
+    return colmajor ? launch_tile<128, 64, 64, 32, A_COL>(p, d->batch, s, d->flags)
+                    : launch_tile<128, 64, 64, 32, A_ROW>(p, d->batch, s, d->flags);
   if (d->flags & PN_GEMM_FORCE_TILE)
-    return colmajor ? launch_tile<128, 128, 64, 64, A_COL>(p, d->batch, s)
-                    : launch_tile<128, 128, 64, 64, A_ROW>(p, d->batch, s);
+    return colmajor ? launch_tile<128, 128, 64, 64, A_COL>(p, d->batch, s, d->flags)
+                    : launch_tile<128, 128, 64, 64, A_ROW>(p, d->batch, s, d->flags);
   return colmajor ? launch_tile64_splitk<A_COL>(p, d->batch, d->splitk_scratch,
-                                                d->splitk_scratch_floats, s)
+                                                d->splitk_scratch_floats, s, d->flags)
                   : launch_tile64_splitk<A_ROW>(p, d->batch, d->splitk_scratch,
-                                                d->splitk_scratch_floats, s);
+                                                d->splitk_scratch_floats, s, d->flags);
+}
+
+// Grid the 64x64 tile kernel takes for `d` (introspection for tests / tuning: a function of
+// the call's own descriptor only).
+extern "C" int pn_gemm_grid_size(const pn_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->batch <= 0) return PN_BAD_ARG;
+  const int64_t tiles = (int64_t)pn_cdiv(d->M, 64) * pn_cdiv(d->N, 64) * d->batch;
+  return persistent_grid(tiles, 4, d->flags);
 }
 
 extern "C" int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream) {
@@ -884,7 +798,7 @@ extern "C" int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream)
     tiles += g.mt[i] * g.nt[i] * d[i].batch;
   }
   for (int i = count; i <= GEMM_GROUP_MAX; ++i) g.tile_start[i] = tiles;
-  hipLaunchKernelGGL(k_gemm_group, dim3(persistent_grid(tiles, 4)), dim3(256), 0,
+  hipLaunchKernelGGL(k_gemm_group, dim3(persistent_grid(tiles, 4, d[0].flags)), dim3(256), 0,
                      (hipStream_t)stream, g);
   return PN_LAUNCH_CHECK();
 }
@@ -911,15 +825,12 @@ extern "C" int pn_conv2d_nhwc_ex_f32(const float* in, const float* Wp, const flo
   p.aadd_rows = 1;
   p.H = H; p.Wd = W; p.Cin = Cin; p.KW = KW; p.pad = pad; p.stride = stride; p.Wo = Wo;
   hipStream_t s = (hipStream_t)stream;
-  if (flags & PN_GEMM_SPLIT_BF16)
-    return (flags & PN_GEMM_FORCE_TILE) ? launch_tile<128, 128, 64, 64, A_CONV, true>(p, B, s)
-                                        : launch_tile<64, 64, 32, 32, A_CONV, true>(p, B, s);
   // 64x64 tiles everywhere (3x3 FPN conv on MI355X: 625 us / 126 TFLOP/s, against 730
   // with 128x64 and 845 with 128x128 tiles, tools/gemm_probe.hip); the larger tiles stay
   // selectable for sweeps
-  if (flags & PN_GEMM_FORCE_TILE128x64) return launch_tile<128, 64, 64, 32, A_CONV>(p, B, s);
-  if (flags & PN_GEMM_FORCE_TILE) return launch_tile<128, 128, 64, 64, A_CONV>(p, B, s);
-  return launch_tile64_splitk<A_CONV>(p, B, splitk_scratch, splitk_scratch_floats, s);
+  if (flags & PN_GEMM_FORCE_TILE128x64) return launch_tile<128, 64, 64, 32, A_CONV>(p, B, s, flags);
+  if (flags & PN_GEMM_FORCE_TILE) return launch_tile<128, 128, 64, 64, A_CONV>(p, B, s, flags);
+  return launch_tile64_splitk<A_CONV>(p, B, splitk_scratch, splitk_scratch_floats, s, flags);
 }
 
 extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float* bias,
@@ -936,7 +847,7 @@ extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float*
 // + ReLU -> channel-last [B][Ho][Wo][64].  Wp is [64][160]: the PyTorch weight
 // [64][3][7][7] flattened (k = c*49 + ky*7 + kx) and zero-padded from 147 to 160.
 extern "C" int pn_stem7x7s2_f32(const float* img, const float* Wp, const float* bias, float* out,
-                                int B, int H, int W, void* stream) {
+                                int B, int H, int W, int flags, void* stream) {
   if (!img || !Wp || !out || B <= 0 || H <= 0 || W <= 0 || !aligned16(Wp)) return PN_BAD_ARG;
   if ((int64_t)3 * H * W >= ((int64_t)1 << 29)) return PN_BAD_ARG;
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
@@ -947,7 +858,7 @@ extern "C" int pn_stem7x7s2_f32(const float* img, const float* Wp, const float* 
   p.sA = (int64_t)3 * H * W; p.sW = 0; p.sC = (int64_t)Ho * Wo * 64;
   p.relu = 1; p.aadd_rows = 1;
   p.H = H; p.Wd = W; p.Cin = 0; p.KW = 7; p.pad = 3; p.stride = 2; p.Wo = Wo;
-  return launch_tile<64, 64, 32, 32, A_STEM>(p, B, (hipStream_t)stream);
+  return launch_tile<64, 64, 32, 32, A_STEM>(p, B, (hipStream_t)stream, flags);
 }
 
 extern "C" int pn_abi_version(void) { return PN_ABI_VERSION; }

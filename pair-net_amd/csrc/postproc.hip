@@ -348,17 +348,15 @@ __global__ __launch_bounds__(256) void k_pan_argmax(const float* __restrict__ up
 // One workgroup: drop the segments of area <= 4 (:893-905); nothing to drop -> converged.
 // Also clears the area counters for the next round.
 __global__ __launch_bounds__(256) void k_pan_filter(PanState* st, int32_t* __restrict__ area) {
-  __shared__ int any_small;
   if (!st->active) return;
   const int t = threadIdx.x, n = st->nkeep;
-  if (t == 0) any_small = 0;
-  __syncthreads();
   bool a = t < n && st->alive[t] != 0;
-  if (a && area[t] <= 4) { a = false; any_small = 1; }
+  const bool small = a && area[t] <= 4;
+  if (small) a = false;
   area[t] = 0;
-  __syncthreads();
+  const int some_small = __syncthreads_or(small ? 1 : 0);   // block-wide OR: no racing stores
   if (t == 0) st->first = 0;
-  if (!any_small || n == 0) {
+  if (!some_small || n == 0) {
     if (t == 0) st->active = 0;
     return;
   }

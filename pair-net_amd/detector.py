@@ -4,15 +4,13 @@
 -> `Result`), `triplet2Result` :15-51, `Result` the fields of
 pairnet/models/relation_heads/approaches/relation_util.py:20-97 that the PSG
 evaluator reads.  The backbone is SURVEY.md section 8 row a1 / (f)-2: the native
-`ResNet50Hip` (backbone.py) or `SwinTransformerHip` (swin.py) by `backbone.type`;
-`backbone.impl="torch"` selects a plain PyTorch-ROCm (MIOpen) ResNet-50 with the same
-state dict, kept as the comparison leg of bench.py.
+`ResNet50Hip` (backbone.py) or `SwinTransformerHip` (swin.py) by `backbone.type`.  There is
+one implementation per component: the PyTorch-ROCm / MIOpen ResNet-50 that bench.py times
+beside the native one lives in tools/torch_resnet50.py, not in the product package.
 """
 from collections import OrderedDict
 
 import torch
-import torch.nn as nn
-import torch.nn.functional as F
 
 from .config import ConfigDict
 from .backbone import ResNet50Hip
@@ -55,7 +53,7 @@ class Result(object):
 def triplet2Result(triplets, use_mask, eval_mask_rels=False):
     """8-tuple of `CrossHead2.get_bboxes` (or, without masks, the 6-tuple of
     `CrossHeadBBox.get_bboxes`) -> Result (psgtr.py:15-71)."""
-    np_ = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else t
+    np_ = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else t   # (numpy passes)
     if not use_mask:
         bboxes, labels, rel_pairs, r_scores, r_labels, r_dists = triplets
         return Result(refine_bboxes=np_(bboxes), labels=np_(labels),
@@ -69,55 +67,95 @@ def triplet2Result(triplets, use_mask, eval_mask_rels=False):
                   masks=np_(masks))
 
 
-class _Bottleneck(nn.Module):
-    def __init__(self, cin, planes, stride, downsample):
-        super().__init__()
-        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * 4)
-        self.downsample = None
-        if downsample:
-            self.downsample = nn.Sequential(
-                nn.Conv2d(cin, planes * 4, 1, stride=stride, bias=False),
-                nn.BatchNorm2d(planes * 4))
+class ResultStreamer:
+    """`triplet2Result` (psgtr.py:15-51) for a pipeline of images: the device -> host copies
+    of every field go to a ring of PINNED host buffers on a copy stream of their own, so that
+    the 49 MB of masks of one 800x1333 image (2R x H0 x W0 bool) cross PCIe under the next
+    images' kernels instead of stalling a compute stream, and the host never allocates
+    (a multi-MB host allocation per image is an mmap / munmap pair, and every munmap runs the
+    amdgpu MMU notifier against the busy GPU: ~75 ms stalls measured).
 
-    def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        x = F.relu(self.bn1(self.conv1(x)))
-        x = F.relu(self.bn2(self.conv2(x)))
-        return F.relu(self.bn3(self.conv3(x)) + idt)
+        streamer = ResultStreamer(head, ring=4)
+        streamer.push(results, pipe)      # results of PipelinedHead.submit() / get_bboxes()
+        ...
+        for r in streamer.pop():          # oldest pushed batch -> [Result], same fields and
+            ...                           # dtypes as triplet2Result
 
+    `pop()` waits for that batch's copies, checks its panoptic loops like `PSGTr.simple_test`
+    (IndexError when every segment was filtered, pairnet_head.py:882)
+    and returns Results whose arrays are VIEWS of the ring entry: valid until `ring` more
+    batches have been pushed (copy what must live longer).  The reference returns fresh
+    arrays; this is the documented deviation that keeps allocation out of the loop."""
 
-class ResNet50(nn.Module):
-    """depth 50, style='pytorch', out_indices (0,1,2,3), frozen BN
-    (configs/mask2former/pairnet.py:9-19)."""
+    def __init__(self, head, ring=4):
+        if head.device is None or head.device.type != "cuda":
+            raise RuntimeError("ResultStreamer needs a head on an MI355X")
+        self.head, self.device, self.ring = head, head.device, ring
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.Stream()
+        self.entries = [None] * ring      # dict(key, host buffers, event, jobs)
+        self.head_i = self.tail_i = 0     # push / pop counters
 
-    def __init__(self, **unused):
-        super().__init__()
-        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
-        cin = 64
-        for i, (planes, blocks) in enumerate(((64, 3), (128, 4), (256, 6), (512, 3))):
-            layers = []
-            for b in range(blocks):
-                layers.append(_Bottleneck(cin, planes, 2 if (b == 0 and i > 0) else 1, b == 0))
-                cin = planes * 4
-            setattr(self, "layer%d" % (i + 1), nn.Sequential(*layers))
-        self.eval()
-        for p in self.parameters():
-            p.requires_grad_(False)
+    def _host(self, key, results):
+        e = self.entries[self.head_i % self.ring]
+        if e is None or e["key"] != key:
+            bufs = [[torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                     if isinstance(t, torch.Tensor) and t.is_cuda else t for t in tup]
+                    for tup in results]
+            states = [torch.empty(16, dtype=torch.uint8, pin_memory=True) for _ in results]
+            e = self.entries[self.head_i % self.ring] = dict(
+                key=key, bufs=bufs, states=states, event=torch.cuda.Event(), jobs=(), np=None)
+        return e
 
     @torch.no_grad()
-    def forward(self, x):
-        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)
-        outs = []
-        for i in range(4):
-            x = getattr(self, "layer%d" % (i + 1))(x)
-            outs.append(x.contiguous())
-        return tuple(outs)
+    def push(self, results, pipe=None):
+        """Queue the D2H copies of one batch's `get_bboxes` tuples behind the current stream
+        (the one the results are ordered on).  `pipe`: the PipelinedHead they came from, told
+        when the copy stream has read them (`consumed`)."""
+        if self.head_i - self.tail_i >= self.ring:
+            raise RuntimeError("ResultStreamer ring is full: pop() before pushing more")
+        key = tuple(tuple((tuple(t.shape), t.dtype) if isinstance(t, torch.Tensor) else None
+                          for t in tup) for tup in results)
+        e = self._host(key, results)
+        jobs = tuple(getattr(results, "panoptic_jobs", ()))
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            for tup, host in zip(results, e["bufs"]):
+                for t, h in zip(tup, host):
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        h.copy_(t, non_blocking=True)
+            for job, st in zip(jobs, e["states"]):
+                st.copy_(job[0][:16], non_blocking=True)
+            e["event"].record(self.stream)
+            if pipe is not None:
+                pipe.consumed(results, self.stream)
+        e["jobs"] = jobs
+        self.head_i += 1
+
+    def pop(self):
+        if self.tail_i >= self.head_i:
+            raise RuntimeError("ResultStreamer is empty")
+        e = self.entries[self.tail_i % self.ring]
+        self.tail_i += 1
+        e["event"].synchronize()
+        for job, st in zip(e["jobs"], e["states"]):
+            nkeep, active, rounds, all_gone = st.view(torch.int32).tolist()
+            if all_gone:
+                raise IndexError("every panoptic segment was filtered (the reference fails "
+                                 "here too, pairnet_head.py:882)")
+            if active:
+                # The reference's drop-and-redo loop takes at most three rounds (DESIGN.md
+                # 1c) and hip.PAN_ROUNDS = 4 are enqueued, so this is unreachable unless that
+                # bound is wrong; the slot's device buffers may already be reused, so the
+                # loop cannot be continued here the way PSGTr.simple_test does -- fail loudly.
+                raise RuntimeError("panoptic loop still active after %d rounds" % rounds)
+        use_mask = self.head.use_mask
+        return [triplet2Result(tuple(h.numpy() if isinstance(h, torch.Tensor) else h
+                                     for h in host), use_mask) for host in e["bufs"]]
+
+    def __len__(self):
+        return self.head_i - self.tail_i
 
 
 class PSGTr:
@@ -139,15 +177,9 @@ class PSGTr:
             # pairnet_swinb.py:203-226; native only (swin.py)
             self.backbone = SwinTransformerHip(**{k: v for k, v in backbone.items() if k != "type"})
         elif btype == "ResNet" and backbone.get("depth", 50) in (50, 101):
-            # "hip" (default): the native fp32-MFMA backbone of backbone.py, channels_last
-            # features straight into the head; "torch": PyTorch-ROCm / MIOpen (same state dict)
-            impl = backbone.get("impl", "hip")
-            if impl not in ("hip", "torch"):
-                raise ValueError("backbone.impl must be 'hip' or 'torch'")
-            depth = backbone.get("depth", 50)
-            if impl == "torch" and depth != 50:
-                raise NotImplementedError("the PyTorch comparison backbone is ResNet-50 only")
-            self.backbone = ResNet50Hip(depth=depth) if impl == "hip" else ResNet50()
+            # the native fp32-MFMA backbone of backbone.py, channels_last features straight
+            # into the head
+            self.backbone = ResNet50Hip(depth=backbone.get("depth", 50))
         else:
             raise NotImplementedError("backbones built: ResNet depth 50 / 101 (pairnet.py, "
                                       "psgformer_r101_psg.py) and SwinTransformer "
@@ -249,12 +281,23 @@ class PSGTr:
     __call__ = forward
 
 
-def load_checkpoint(model, filename, map_location="cpu", strict=False):
+def load_checkpoint(model, filename, map_location="cpu", strict=False, trust=False):
     """`mmcv.runner.load_checkpoint(model, filename, map_location="cpu")` (tools/test.py:240)
     for local files: a torch-saved dict with `state_dict` (and `meta`: CLASSES, PREDICATES,
     ...), or a bare state dict.  Loads into `model` (a PSGTr, or any head / backbone / neck of
-    this package) and returns the checkpoint dict, like mmcv."""
-    ckpt = torch.load(filename, map_location=map_location, weights_only=False)
+    this package) and returns the checkpoint dict, like mmcv.
+
+    The file is read with `weights_only=True` (tensors, containers, strings, numbers: what a
+    state dict plus `meta` needs); a checkpoint that pickles other objects is refused unless
+    the caller vouches for it with `trust=True` (mmcv unpickles anything -- arbitrary code)."""
+    try:
+        ckpt = torch.load(filename, map_location=map_location, weights_only=True)
+    except Exception as e:   # pickle.UnpicklingError and friends: non-tensor payload
+        if not trust:
+            raise RuntimeError(
+                "%s holds pickled objects beyond tensors / plain containers (%s); pass "
+                "trust=True to unpickle it anyway (executes code from the file)" % (filename, e))
+        ckpt = torch.load(filename, map_location=map_location, weights_only=False)
     sd = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
     missing, unexpected = model.load_state_dict(sd, strict=strict)
     if missing or unexpected:

@@ -20,6 +20,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
+from .plans import PlanCache
 from .config import ConfigDict
 
 INSTANCE_OFFSET = 1000
@@ -106,18 +107,14 @@ class CrossHead2:
             (k, torch.zeros(s)) for k, s in self.param_shapes().items())
         self.device = None
         self.w = None
-        self._plans = {}
+        self._plans = PlanCache()
         self._dummies = {}
         self._post = OrderedDict()
         self._pan_jobs = []
         # True: compute attention masks in the reference's operation order (full-size mask
         # logits -> bilinear resize); False: resample the mask feature once (see _attn_mask)
         self.exact_mask_order = False
-        # "f32": every contraction on the exact-fp32 MFMA (default, the measured headline).
-        # "bf16x3": the large GEMMs / the 3x3 conv use the fp32-accurate 3 x bf16 operand
-        # split (the SPLIT mode of csrc/gemm.hip): same error class, not bitwise the fp32 chain.
-        self.gemm_mode = "f32"
-        # 3x3 FPN convolution (exact-fp32 GEMM mode): "winograd" = F(2x2,3x3), 2.25x fewer
+        # 3x3 FPN convolution (every mode is exact fp32 arithmetic on the fp32 MFMA): "winograd" = F(2x2,3x3), 2.25x fewer
         # multiplications, differs from the direct form by ~2e-6 relative, the size of the
         # direct form's own fp32 rounding error (default; needs even sides of the
         # 1/4-resolution map, else "direct" is used); "winograd4" = F(4x4,3x3), 4x fewer
@@ -128,15 +125,9 @@ class CrossHead2:
         self.conv_algo = "winograd"
         # replay each stage as one hipGraph (no per-launch host cost) after a warm-up call
         self.use_graphs = False
-        # True: run the query side of the decoders as row-chain launches (csrc/chain.hip:
-        # out_proj + residual + LayerNorm + next projection / the mask-embedding MLP + next
-        # query projection / the PPN's MLP + normalisation in ONE launch each): 146 instead of
-        # 230 launches on the dependent chain -- and SLOWER on MI355X (measured, DESIGN.md 6a:
-        # forward 7.4 ms instead of 5.6, 155.8 instead of 160.5 images/s).  A chain launch has
-        # 4-7 workgroups, each streaming every op's 256 KB of weights out of L2 with nothing
-        # to overlap it, where the per-Linear launches spread the same work over 32+
-        # workgroups; a kernel boundary (1.5 us) is cheaper than that.  Kept, tested and off.
-        self.fuse_chains = False
+        # persistent-GEMM workgroup slots stage A leaves free for concurrent streams' kernels
+        # (a per-call hint, hip.reserve_slots; PipelinedHead sets it for its own schedule)
+        self.grid_reserve = 0
         self.fuse_ppn_front = True      # normalise + cosine matrix + first Matrix Learner layer in one launch
         self.init_weights()
 
@@ -246,7 +237,7 @@ class CrossHead2:
             for n in ("value_proj", "output_proj"):
                 self._params[p + n + ".weight"].copy_(U((256, 256), math.sqrt(6.0 / 512)))
                 self._params[p + n + ".bias"].zero_()
-        self.w, self._plans = None, {}   # plans cache weight-derived buffers and graphs
+        self.w, self._plans = None, PlanCache()   # plans cache weight-derived buffers and graphs
 
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._params.items())
@@ -263,7 +254,7 @@ class CrossHead2:
                     raise RuntimeError("shape mismatch for %s: %s vs %s"
                                        % (k, tuple(sd[k].shape), tuple(p.shape)))
                 p.copy_(sd[k].detach().to(torch.float32).cpu())
-        self.w, self._plans = None, {}   # plans cache weight-derived buffers and graphs
+        self.w, self._plans = None, PlanCache()   # plans cache weight-derived buffers and graphs
         return missing, unexpected
 
     def eval(self):
@@ -272,7 +263,7 @@ class CrossHead2:
     def to(self, device):
         self.device = torch.device(device)
         self.w = None
-        self._plans = {}
+        self._plans = PlanCache()
         self._post.clear()
         return self
 
@@ -355,7 +346,6 @@ class CrossHead2:
         pl.B, pl.shapes, pl.hw2, pl.nhwc = B, list(shapes), tuple(hw2), nhwc
         pl.graph_a = pl.graph_b = pl.static_feats = pl.graph_cfg = pl.feats_read = None
         pl.graph_c = {}
-        pl.chains = {}
         pl.static_ptrs, pl.staged, pl.me0 = None, False, None
         pl.calls_a = pl.calls_b = 0
         pl.N = [h * w for h, w in shapes]
@@ -447,7 +437,6 @@ class CrossHead2:
     def _pixel_decoder(self, feats, pl):
         """MSDeformAttnPixelDecoder -> pl.X (memories), pl.MF."""
         w, B, SN = self.w, pl.B, pl.SN
-        sp = self.gemm_mode == "bf16x3"
         pd = "pixel_decoder."
         for l in range(3):
             f = feats[3 - l]
@@ -467,15 +456,15 @@ class CrossHead2:
             a = p + "attentions.0."
             hip.gemm(X2, w[a + "voa.weight"], pl.VOA, M=B * SN, N=544, K=256, lda=256, ldw=256,
                      ldc=544, bias=w[a + "voa.bias"], aadd=pl.enc_pos, ldaadd=256, aadd_rows=SN,
-                     aadd_from_col=256, split=sp)
+                     aadd_from_col=256)
             hip.msda(pl.VOA, 544, pl.VOA.view(-1)[256:], 544, pl.S, B, pl.shapes)
             hip.linear(pl.S.view(-1, 256), w[a + "output_proj.weight"], w[a + "output_proj.bias"],
-                       Y2, res=X2, split=sp)
+                       Y2, res=X2)
             hip.layernorm(Y2, w[p + "norms.0.weight"], w[p + "norms.0.bias"], X12)
             hip.linear(X12, w[p + "ffns.0.layers.0.0.weight"], w[p + "ffns.0.layers.0.0.bias"],
-                       pl.H, relu=True, split=sp)
+                       pl.H, relu=True)
             hip.linear(pl.H, w[p + "ffns.0.layers.1.weight"], w[p + "ffns.0.layers.1.bias"], Y2,
-                       res=X12, split=sp)
+                       res=X12)
             hip.layernorm(Y2, w[p + "norms.1.weight"], w[p + "norms.1.bias"], X2)
         # FPN level (C2): lateral 1x1 + GN, + bilinear-up(finest memory), 3x3 + GN + ReLU
         f = feats[0]
@@ -492,18 +481,18 @@ class CrossHead2:
                           HW2 * 256)
         if self.conv_algo == "winograd4":
             hip.conv3x3_winograd43(pl.T2, w[pd + "output_convs.0.conv.winograd4"], None, pl.T1,
-                                   pl.wV, pl.wM, B, H2, W2, 256, 256, False, split=sp)
+                                   pl.wV, pl.wM, B, H2, W2, 256, 256, False)
         elif pl.wino and self.conv_algo == "winograd":
             hip.conv3x3_winograd(pl.T2, w[pd + "output_convs.0.conv.winograd"], None, pl.T1,
-                                 pl.wV, pl.wM, B, H2, W2, 256, 256, False, split=sp)
+                                 pl.wV, pl.wM, B, H2, W2, 256, 256, False)
         else:
             hip.conv2d_nhwc(pl.T2, w[pd + "output_convs.0.conv.weight"], None, pl.T1, B, H2, W2,
-                            256, 256, 3, 3, 1, False, split=sp)
+                            256, 256, 3, 3, 1, False)
         hip.groupnorm_nhwc(pl.T1, w[pd + "output_convs.0.gn.weight"],
                            w[pd + "output_convs.0.gn.bias"], pl.T2, pl.gn_part, B, HW2,
                            self.gn_groups, True, HW2 * 256, HW2 * 256)
         hip.linear(pl.T2.view(-1, 256), w[pd + "mask_feature.weight"], w[pd + "mask_feature.bias"],
-                   pl.MF.view(-1, 256), split=sp)
+                   pl.MF.view(-1, 256))
         if not self.exact_mask_order:
             for l, (h, wd) in enumerate(pl.shapes):
                 hip.bilinear_nhwc(pl.MF, pl.MFd[l], B, H2, W2, h, wd, 256, False, HW2 * 256,
@@ -520,8 +509,7 @@ class CrossHead2:
         """out[b, q, :] = me[b, q, :] . MF[b, :, :]^T  (`einsum("bqc,bchw->bqhw")`)."""
         Q = self.num_obj_query
         hip.gemm(me, pl.MF, out, M=Q, N=pl.HW2, K=256, lda=256, ldw=256, ldc=pl.HW2,
-                 batch=pl.B, sA=Q * 256, sW=pl.HW2 * 256, sC=Q * pl.HW2,
-                 split=self.gemm_mode == "bf16x3")
+                 batch=pl.B, sA=Q * 256, sW=pl.HW2 * 256, sC=Q * pl.HW2)
 
     def _head_embed(self, q, pl, with_cls, full_mask, cls_out=None, mp_out=None, normed=False):
         """post_norm -> (cls_embed) -> mask_embed MLP -> pl.me; with `full_mask` also the
@@ -605,6 +593,10 @@ class CrossHead2:
     # mask-feature resampling, the K/V projections of all nine decoder layers): a few
     # dozen large, chip-filling launches.
     def _stage_a(self, feats, pl):
+        with hip.reserve_slots(self.grid_reserve):
+            self._stage_a_launches(feats, pl)
+
+    def _stage_a_launches(self, feats, pl):
         self._pixel_decoder(feats, pl)
         # K / V projections of all decoder layers up front (query-independent), as grouped
         # launches: 18 problems whose tile counts (9/33/131 x 2 per image) would each
@@ -645,8 +637,6 @@ class CrossHead2:
         with `all_layers` every layer's class / mask logits go to pl.cls_all / pl.MP_all;
         without `final_head` the last layer's class / mask heads are left to the caller."""
         w, B, Q = self.w, pl.B, self.num_obj_query
-        if self.fuse_chains and not all_layers:
-            return self._object_decoder_fused(pl, final_head)
         qpos = w["query_embed.weight"]
         exact = self.exact_mask_order
         # the INITIAL queries are learned constants (pl.q0: `query_feat` repeated over the
@@ -678,143 +668,6 @@ class CrossHead2:
             elif i != last:
                 self._head_embed(pl.q, pl, False, exact, normed=True)
 
-    # ---- the same decoders with the query side as row-chain launches (csrc/chain.hip) ----
-    def _chain(self, pl, name, build):
-        d = pl.chains.get(name)
-        if d is None:
-            d = pl.chains[name] = build()
-        hip.chain(d)
-
-    def _attn_chains(self, pl, pre, names, x, x1, x2, att, VQK, pos):
-        """The two chain segments around a layer's self-attention: after the cross-attention
-        (out_proj + residual + norm -> x1, then the self-attention's [V | Q | K] projection)
-        and after the self-attention (out_proj + residual + norm -> x2)."""
-        w = self.w
-        ac, as_ = pre + "attentions.0.attn.", pre + "attentions.1.attn."
-
-        def after_cross():
-            self._chain(pl, names + "c", lambda: hip.chain_desc(att, [
-                hip.chain_lin(0, w[ac + "out_proj.weight"], w[ac + "out_proj.bias"], dst=2, res=1),
-                hip.chain_ln(2, w[pre + "norms.0.weight"], w[pre + "norms.0.bias"], dst=2, out=x1),
-                hip.chain_lin(2, w[as_ + "vqk.weight"], w[as_ + "vqk.bias"], out=VQK, aadd=pos,
-                              add_from_col=256)], in1=x))
-
-        def after_self():
-            self._chain(pl, names + "s", lambda: hip.chain_desc(att, [
-                hip.chain_lin(0, w[as_ + "out_proj.weight"], w[as_ + "out_proj.bias"], dst=2, res=1),
-                hip.chain_ln(2, w[pre + "norms.1.weight"], w[pre + "norms.1.bias"], out=x2)],
-                in1=x1))
-        return after_cross, after_self
-
-    def _object_decoder_fused(self, pl, final_head=True):
-        """`_object_decoder` (pairnet_head.py:289-320) with ~10 launches per layer: mask
-        logits, mask pack, cross-attention, chain, self-attention, chain, FFN (2), chain."""
-        w, B, Q = self.w, pl.B, self.num_obj_query
-        scale = 1.0 / math.sqrt(32.0)
-        pl.q.view(B, Q, 256).copy_(w["query_feat.weight"].unsqueeze(0).expand(B, Q, 256))
-        qpos = w["query_embed.weight"]
-        exact = self.exact_mask_order
-        nd = self.num_dec_layers
-        wq = lambda i: (w["transformer_decoder.layers.%d.attentions.0.attn.in_proj_weight" % i][:256],
-                        w["transformer_decoder.layers.%d.attentions.0.attn.in_proj_bias" % i][:256])
-        mlp = lambda: [
-            hip.chain_lin(1, w["mask_embed.0.weight"], w["mask_embed.0.bias"], dst=2, relu=True),
-            hip.chain_lin(2, w["mask_embed.2.weight"], w["mask_embed.2.bias"], dst=0, relu=True),
-            hip.chain_lin(0, w["mask_embed.4.weight"], w["mask_embed.4.bias"], out=pl.me)]
-        # initial queries (learned, input-independent): post_norm, mask embedding and the
-        # first layer's query projection -- computed on the plan's first call and kept
-        if pl.me0 is None or exact:
-            self._chain(pl, "init", lambda: hip.chain_desc(pl.q, [
-                hip.chain_ln(0, w["transformer_decoder.post_norm.weight"],
-                             w["transformer_decoder.post_norm.bias"], dst=1, out=pl.qn),
-                hip.chain_lin(0, *wq(0), out=pl.Qp0, aadd=qpos, add_from_col=0)] + mlp()))
-            if exact:
-                self._mask_logits(pl.me, pl, pl.MP)
-            elif pl.me0 is None:
-                pl.me0 = pl.me.clone()
-        post = (w["transformer_decoder.post_norm.weight"], w["transformer_decoder.post_norm.bias"],
-                pl.qn)
-        for i in range(nd):
-            l = i % 3
-            pre = "transformer_decoder.layers.%d." % i
-            last = i == nd - 1
-            self._attn_mask(pl, l, None, me=pl.me0 if (i == 0 and not exact) else None)
-            hip.attention(pl.Qp0 if i == 0 else pl.Qp, 256, pl.Kp[i], 256, pl.Vp[i], 256, pl.bits,
-                          pl.rowall, pl.att, 256, pl.scr, B, Q, pl.N[l], scale)
-            after_cross, after_self = self._attn_chains(pl, pre, "obj%d" % i, pl.q, pl.q1, pl.q2,
-                                                        pl.att, pl.VQK, qpos)
-            after_cross()
-            hip.attention(pl.VQK[:, 256:], 768, pl.VQK[:, 512:], 768, pl.VQK, 768, None, None,
-                          pl.att, 256, pl.scr, B, Q, Q, scale)
-            after_self()
-            hip.ffn_ln(pl.q2, w[pre + "ffns.0.layers.0.0.weight"], w[pre + "ffns.0.layers.0.0.bias"],
-                       w[pre + "ffns.0.layers.1.weight"], w[pre + "ffns.0.layers.1.bias"],
-                       w[pre + "norms.2.weight"], w[pre + "norms.2.bias"], pl.q, pl.hq, B * Q,
-                       self.dec_ffn, post=post)
-            if last and not final_head:
-                break
-            # after the FFN: (class head), the next layer's query projection, the mask MLP
-            def build(i=i, last=last):
-                ops = []
-                if last:
-                    ops.append(hip.chain_lin(1, w["cls_embed.weight"], w["cls_embed.bias"],
-                                             out=pl.cls.view(B * Q, -1)))
-                else:
-                    ops.append(hip.chain_lin(0, *wq(i + 1), out=pl.Qp, aadd=qpos, add_from_col=0))
-                return hip.chain_desc(pl.q, ops + mlp(), in1=pl.qn)
-            self._chain(pl, "objpost%d" % i, build)
-            if exact or last:
-                self._mask_logits(pl.me, pl, pl.MP)
-
-    def _relation_decoder_fused(self, pl):
-        """`_relation_decoder` (pairnet_head.py:353-403) with the pair features' six [V | K]
-        projections as one grouped launch and ~7 launches per layer."""
-        w, B, Q, R = self.w, pl.B, self.num_obj_query, self.num_rel_query
-        scale = 1.0 / math.sqrt(32.0)
-        nl = self.num_rel_layers
-        rpos, ppos = w["rel_query_embed.weight"], w["rel_query_embed2.weight"]
-        pl.r.view(B, R, 256).copy_(w["rel_query_feat.weight"].unsqueeze(0).expand(B, R, 256))
-        wq = lambda i: (w["relation_decoder.layers.%d.attentions.0.attn.in_proj_weight" % i][:256],
-                        w["relation_decoder.layers.%d.attentions.0.attn.in_proj_bias" % i][:256])
-        if pl.rQp0 is None:                     # (rel_query_feat + pos) Wq of layer 0: constants
-            pl.rQp0 = torch.empty_like(pl.rQp)
-            hip.chain(hip.chain_desc(pl.r, [hip.chain_lin(0, *wq(0), out=pl.rQp0, aadd=rpos,
-                                                          add_from_col=0)]))
-        hip.gemm_group([dict(
-            A=pl.pair, W=w["relation_decoder.layers.%d.attentions.0.attn.vk.weight" % i],
-            C=pl.pVK_all[i], bias=w["relation_decoder.layers.%d.attentions.0.attn.vk.bias" % i],
-            M=B * 2 * R, N=512, K=256, lda=256, ldw=256, ldc=512, aadd=ppos, ldaadd=256,
-            aadd_rows=2 * R, aadd_from_col=256) for i in range(nl)])
-        for i in range(nl):
-            pre = "relation_decoder.layers.%d." % i
-            last = i == nl - 1
-            pvk = pl.pVK_all[i]
-            hip.attention(pl.rQp0 if i == 0 else pl.rQp, 256, pvk[:, 256:], 512, pvk, 512, None,
-                          None, pl.ratt, 256, pl.scr, B, R, 2 * R, scale)
-            after_cross, after_self = self._attn_chains(pl, pre, "rel%d" % i, pl.r, pl.r1, pl.r2,
-                                                        pl.ratt, pl.rVQK, rpos)
-            after_cross()
-            hip.attention(pl.rVQK[:, 256:], 768, pl.rVQK[:, 512:], 768, pl.rVQK, 768, None, None,
-                          pl.ratt, 256, pl.scr, B, R, R, scale)
-            after_self()
-            hip.ffn_ln(pl.r2, w[pre + "ffns.0.layers.0.0.weight"], w[pre + "ffns.0.layers.0.0.bias"],
-                       w[pre + "ffns.0.layers.1.weight"], w[pre + "ffns.0.layers.1.bias"],
-                       w[pre + "norms.2.weight"], w[pre + "norms.2.bias"], pl.r, pl.rh, B * R,
-                       self.rel_ffn)
-            def build(i=i, last=last):
-                if last:
-                    op = hip.chain_lin(0, w["rel_cls_embed.weight"], w["rel_cls_embed.bias"],
-                                       out=pl.rel.view(B * R, -1))
-                else:
-                    op = hip.chain_lin(0, *wq(i + 1), out=pl.rQp, aadd=rpos, add_from_col=0)
-                return hip.chain_desc(pl.r, [op])
-            self._chain(pl, "relpost%d" % i, build)
-        nc = self.num_classes + 1
-        hip.gather_rows(pl.cls, pl.sub_pos, pl.sub_cls, B, Q, R, nc)
-        hip.gather_rows(pl.cls, pl.obj_pos, pl.obj_cls, B, Q, R, nc)
-        hip.gather_rows(pl.MP, pl.sub_pos, pl.sub_seg, B, Q, R, pl.HW2)
-        hip.gather_rows(pl.MP, pl.obj_pos, pl.obj_seg, B, Q, R, pl.HW2)
-
     def _relation_stage(self, pl):
         self._pair_proposal(pl)
         self._relation_decoder(pl)
@@ -824,13 +677,6 @@ class CrossHead2:
         pl.topk_idx / sub_pos / obj_pos and the gathered pair features pl.pair."""
         w, B, Q, R = self.w, pl.B, self.num_obj_query, self.num_rel_query
         for mlp, dst in (("sub_query_update", pl.sn), ("obj_query_update", pl.on)):
-            if self.fuse_chains:       # three Linears + F.normalize: one launch
-                self._chain(pl, "ppn_" + mlp, lambda mlp=mlp, dst=dst: hip.chain_desc(pl.q, [
-                    hip.chain_lin(0, w[mlp + ".0.weight"], w[mlp + ".0.bias"], dst=1, relu=True),
-                    hip.chain_lin(1, w[mlp + ".2.weight"], w[mlp + ".2.bias"], dst=2, relu=True),
-                    hip.chain_lin(2, w[mlp + ".4.weight"], w[mlp + ".4.bias"], dst=1),
-                    hip.chain_l2norm(1, out=dst)]))
-                continue
             hip.linear(pl.q, w[mlp + ".0.weight"], w[mlp + ".0.bias"], pl.s1, relu=True)
             hip.linear(pl.s1, w[mlp + ".2.weight"], w[mlp + ".2.bias"], pl.s2, relu=True)
             if self.fuse_ppn_front:    # un-normalised: k_ppn_front normalises while staging
@@ -839,7 +685,7 @@ class CrossHead2:
             hip.linear(pl.s2, w[mlp + ".4.weight"], w[mlp + ".4.bias"], pl.s1)
             hip.l2normalize(pl.s1, dst)
         ml = "update_importance.conv_layers."
-        if self.fuse_ppn_front and not self.fuse_chains:
+        if self.fuse_ppn_front:
             hip.ppn_front(pl.sn, pl.on, w[ml + "0.0.weight"], w[ml + "0.0.bias"], pl.imp_raw,
                           pl.c1, B, Q)
         else:
@@ -857,8 +703,6 @@ class CrossHead2:
         """Relation Fusion decoder (pairnet_head.py:353-378) over pl.pair ([B][sub R | obj R]
         rows) -> pl.rel, then the output gathers (:380-403)."""
         w, B, Q, R = self.w, pl.B, self.num_obj_query, self.num_rel_query
-        if self.fuse_chains and type(self)._relation_decoder is CrossHead2._relation_decoder:
-            return self._relation_decoder_fused(pl)
         rpos, ppos = w["rel_query_embed.weight"], w["rel_query_embed2.weight"]
         # the pair features' [V | K] projections of all six layers (layer-independent input):
         # one grouped launch
@@ -912,8 +756,7 @@ class CrossHead2:
         """Run stage 'a' or 'b' of plan `pl` on the current stream: eagerly, or (with
         `use_graphs`) as one hipGraph replay.  A stage is captured on its second call
         (the first, eager one is the warm-up torch requires before capture)."""
-        cfg = (self.gemm_mode, self.exact_mask_order, self.conv_algo, self.fuse_chains,
-               self.fuse_ppn_front)
+        cfg = (self.exact_mask_order, self.conv_algo, self.fuse_ppn_front, self.grid_reserve)
         if pl.graph_cfg != cfg:          # a captured graph bakes these switches in
             pl.graph_a = pl.graph_b = pl.me0 = None
             pl.graph_c = {}

@@ -4,8 +4,10 @@ torch is used here only for what the boundary needs from it: device memory
 (`Tensor.data_ptr()`) and the current HIP stream.  There is NO fallback: if the
 library is missing or a launch fails, a RuntimeError is raised.
 """
+import contextlib
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -32,32 +34,15 @@ class GemmDesc(C.Structure):
                 ("splitk_scratch", _vp), ("splitk_scratch_floats", _i64)]
 
 
-CHAIN_MAX_OPS = 8
-CH_LIN, CH_LN, CH_L2NORM = 0, 1, 2
-
-
-class ChainOp(C.Structure):
-    _fields_ = [("kind", _i32), ("src", _i32), ("dst", _i32), ("res", _i32),
-                ("N", _i32), ("relu", _i32), ("add_from_col", _i32), ("aadd_rows", _i32),
-                ("W", _vp), ("bias", _vp), ("aadd", _vp), ("gamma", _vp), ("beta", _vp),
-                ("out", _vp), ("ldo", _i64), ("eps", _f32)]
-
-
-class ChainDesc(C.Structure):
-    _fields_ = [("nops", _i32), ("M", _i32), ("in0", _vp), ("ld0", _i64), ("in1", _vp),
-                ("ld1", _i64), ("op", ChainOp * CHAIN_MAX_OPS)]
-
-
 _SIGS = {
     "pn_abi_version": (C.c_int, []),
-    "pn_gemm_set_grid_trim": (None, [_i32]),
-    "pn_gemm_set_grid_scale": (None, [_i32]),
     "pn_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "pn_gemm_variant": (C.c_int, [C.POINTER(GemmDesc)]),
+    "pn_gemm_grid_size": (C.c_int, [C.POINTER(GemmDesc)]),
     "pn_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
     "pn_conv2d_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 10 + [_vp]),
     "pn_conv2d_nhwc_ex_f32": (C.c_int, [_vp] * 5 + [_i32] * 10 + [_vp, _i64, _vp]),
-    "pn_stem7x7s2_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "pn_stem7x7s2_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_maxpool3x3s2_nhwc_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_winograd_f23_input_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_winograd_f23_output_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -72,7 +57,6 @@ _SIGS = {
     "pn_groupnorm_nblk": (C.c_int, [_i64]),
     "pn_groupnorm_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32,
                                         _i32, _f32, _i32, _i64, _i64, _vp]),
-    "pn_rowchain_f32": (C.c_int, [C.POINTER(ChainDesc), _vp]),
     "pn_l2normalize_f32": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _vp]),
     "pn_ffn_scratch_floats": (_i64, [_i32, _i32]),
     "pn_ffn_ln_f32": (C.c_int, [_vp] * 9 + [_i32, _i32, _i32, _f32, _vp]),
@@ -130,7 +114,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 13   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 14   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -153,14 +137,40 @@ def lib():
     return _lib
 
 
-def gemm_set_grid_trim(trim):
-    """Leave `trim` persistent-GEMM workgroup slots free for concurrent streams' kernels."""
-    lib().pn_gemm_set_grid_trim(int(trim))
+class _Reserve(threading.local):
+    slots = 0
 
 
-def gemm_set_grid_scale(scale):
-    """Probe knob: persistent grid cap multiplier (large = one tile per workgroup)."""
-    lib().pn_gemm_set_grid_scale(int(scale))
+_reserve = _Reserve()
+
+
+@contextlib.contextmanager
+def reserve_slots(n):
+    """Within the block, every persistent tile-kernel launch of THIS thread carries
+    PN_GEMM_RESERVE(n): n resident workgroup slots stay free for the kernels of concurrent
+    streams.  A per-call hint in the descriptor's flags (include/pairnet_hip.h); nothing
+    process-wide is changed, and a captured hipGraph keeps the grids it was captured with."""
+    old = _reserve.slots
+    _reserve.slots = max(0, int(n)) // 8 * 8
+    try:
+        yield
+    finally:
+        _reserve.slots = old
+
+
+def with_reserve(fn):
+    """Method decorator: run under `reserve_slots(self.grid_reserve)`."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kw):
+        with reserve_slots(getattr(self, "grid_reserve", 0)):
+            return fn(self, *args, **kw)
+    return wrapper
+
+
+def _reserve_flag():
+    return ((_reserve.slots // 8) & 0x3ff) << 16
 
 
 def _stream():
@@ -203,9 +213,7 @@ def on_device(fn):
 GEMM_KERNELS = {0: "k_gemm_skinny<A_ROW>", 1: "k_gemm_skinny<A_COL>",
                 2: "k_gemm_tile<128,64,64,32,A_ROW>", 3: "k_gemm_tile<128,64,64,32,A_COL>",
                 4: "k_gemm_tile<128,128,64,64,A_ROW>", 5: "k_gemm_tile<128,128,64,64,A_COL>",
-                6: "k_gemm_tile<64,64,32,32,A_ROW>", 7: "k_gemm_tile<64,64,32,32,A_COL>",
-                8: "k_gemm_tile<64,64,32,32,A_ROW,bf16x3>"}
-GEMM_SPLIT_BF16 = 64
+                6: "k_gemm_tile<64,64,32,32,A_ROW>", 7: "k_gemm_tile<64,64,32,32,A_COL>"}
 
 
 class KernelTimer:
@@ -268,7 +276,7 @@ def _rowmajor(t):
 
 def gemm_desc(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaadd=0,
               aadd_rows=0, aadd_from_col=0, res=None, ldres=0, batch=1, sA=0, sW=0, sC=0,
-              sRes=0, relu=False, colmajor=False, force=None, split=False, into=None,
+              sRes=0, relu=False, colmajor=False, force=None, into=None,
               relu_after=False, scratch=None, gelu=False):
     """Fill a pn_gemm_desc; tensors only supply base pointers."""
     d = into if into is not None else GemmDesc()
@@ -281,7 +289,7 @@ def gemm_desc(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaad
     d.M, d.N, d.K, d.batch = M, N, K, batch
     d.flags = (GEMM_RELU if relu else 0) | (GEMM_A_COLMAJOR if colmajor else 0) | \
         {None: 0, "tile": GEMM_FORCE_TILE, "skinny": GEMM_FORCE_SKINNY, "tile64": 16,
-         "tile128x64": 32}[force] | (GEMM_SPLIT_BF16 if split else 0) | \
+         "tile128x64": 32}[force] | _reserve_flag() | \
         (GEMM_RELU_AFTER_RES if relu_after else 0) | (GEMM_GELU if gelu else 0)
     d.splitk_scratch = _ptr(scratch)
     d.splitk_scratch_floats = scratch.numel() if scratch is not None else 0
@@ -316,7 +324,7 @@ def gemm_group(problems):
 
 
 def linear(x, weight, bias, out, *, aadd=None, aadd_from_col=0, res=None, relu=False,
-           force=None, split=False, relu_after=False, scratch=None, gelu=False):
+           force=None, relu_after=False, scratch=None, gelu=False):
     """out = act((x + aadd[row % len(aadd)]) @ weight.T + bias) + res on 2-D views
     (aadd only feeds output columns >= aadd_from_col)."""
     M, lda = _rowmajor(x)
@@ -332,23 +340,22 @@ def linear(x, weight, bias, out, *, aadd=None, aadd_from_col=0, res=None, relu=F
         assert rr == M
         kw.update(res=res, ldres=ldr)
     gemm(x, weight, out, M=M, N=N, K=x.shape[1], lda=lda, ldw=ldw, ldc=ldc, bias=bias,
-         relu=relu, force=force, split=split, relu_after=relu_after, scratch=scratch, gelu=gelu,
+         relu=relu, force=force, relu_after=relu_after, scratch=scratch, gelu=gelu,
          **kw)
 
 
-def conv2d_nhwc(x, wp, bias, out, B, H, W, Cin, Cout, KH, KW, pad, relu, split=False,
-                big_tile=False, tile=None):
+def conv2d_nhwc(x, wp, bias, out, B, H, W, Cin, Cout, KH, KW, pad, relu, big_tile=False,
+                tile=None):
     """tile: None (library default: 64x64), "128x64" or "128" (sweeps)."""
     tflag = {None: 0, "128": GEMM_FORCE_TILE, "128x64": GEMM_FORCE_TILE128x64}[tile]
-    name = "k_gemm_tile<A_CONV,bf16x3>" if split else (
-        "k_gemm_tile<128,64,64,32,A_CONV>" if tile == "128x64" else
-        "k_gemm_tile<128,128,64,64,A_CONV>" if tile == "128" else
-        "k_gemm_tile<64,64,32,32,A_CONV>")
+    name = ("k_gemm_tile<128,64,64,32,A_CONV>" if tile == "128x64" else
+            "k_gemm_tile<128,128,64,64,A_CONV>" if tile == "128" else
+            "k_gemm_tile<64,64,32,32,A_CONV>")
     flops = 2.0 * B * H * W * Cout * KH * KW * Cin
     nbytes = 4.0 * (B * H * W * (Cin + Cout) + Cout * KH * KW * Cin)
     _check(_launch(name, flops, nbytes, lambda: lib().pn_conv2d_nhwc_f32(
         _ptr(x), _ptr(wp), _ptr(bias), _ptr(out), B, H, W, Cin, Cout, KH, KW, pad, int(relu),
-        (GEMM_SPLIT_BF16 if split else 0) | (GEMM_FORCE_TILE if big_tile else 0) | tflag,
+        (GEMM_FORCE_TILE if big_tile else 0) | tflag | _reserve_flag(),
         _stream())), "pn_conv2d_nhwc_f32")
 
 
@@ -359,7 +366,8 @@ def conv2d_ex(x, wp, bias, res, out, B, H, W, Cin, Cout, KH, KW, stride, pad, re
     flops = 2.0 * B * Ho * Wo * Cout * KH * KW * Cin
     nbytes = 4.0 * (B * (H * W * Cin + Ho * Wo * Cout * (2 if res is not None else 1))
                     + Cout * KH * KW * Cin)
-    flags = (GEMM_RELU if relu else 0) | (GEMM_RELU_AFTER_RES if relu_after else 0)
+    flags = (GEMM_RELU if relu else 0) | (GEMM_RELU_AFTER_RES if relu_after else 0) | \
+        _reserve_flag()
     _check(_launch("k_gemm_tile<64,64,32,32,A_CONV>", flops, nbytes,
                    lambda: lib().pn_conv2d_nhwc_ex_f32(
                        _ptr(x), _ptr(wp), _ptr(bias), _ptr(res), _ptr(out), B, H, W, Cin, Cout,
@@ -373,7 +381,8 @@ def stem7x7s2(img, wp, bias, out, B, H, W):
     _check(_launch("k_gemm_tile<64,64,32,32,A_STEM>", 2.0 * B * Ho * Wo * 64 * 147,
                    4.0 * B * (3 * H * W + Ho * Wo * 64),
                    lambda: lib().pn_stem7x7s2_f32(_ptr(img), _ptr(wp), _ptr(bias), _ptr(out), B,
-                                                  H, W, _stream())), "pn_stem7x7s2_f32")
+                                                  H, W, _reserve_flag(), _stream())),
+           "pn_stem7x7s2_f32")
 
 
 def maxpool3x3s2(x, out, B, H, W, Cc):
@@ -398,18 +407,18 @@ def winograd43_weights(w):
     return U.reshape(36, w.shape[0], w.shape[1]).float().contiguous()
 
 
-def conv3x3_winograd43(x, U, bias, out, V, Mbuf, B, H, W, Cin, Cout, relu, split=False):
+def conv3x3_winograd43(x, U, bias, out, V, Mbuf, B, H, W, Cin, Cout, relu):
     """F(4x4,3x3) form; V / Mbuf: 36 * B*ceil(H/4)*ceil(W/4) * Cin / Cout floats."""
     T = B * ((H + 3) // 4) * ((W + 3) // 4)
     _check(lib().pn_winograd_f43_input_f32(_ptr(x), _ptr(V), B, H, W, Cin, _stream()),
            "pn_winograd_f43_input_f32")
     gemm(V, U, Mbuf, M=T, N=Cout, K=Cin, lda=Cin, ldw=Cin, ldc=Cout, batch=36, sA=T * Cin,
-         sW=Cout * Cin, sC=T * Cout, split=split)
+         sW=Cout * Cin, sC=T * Cout)
     _check(lib().pn_winograd_f43_output_f32(_ptr(Mbuf), _ptr(bias), _ptr(out), B, H, W, Cout,
                                             int(relu), _stream()), "pn_winograd_f43_output_f32")
 
 
-def conv3x3_winograd(x, U, bias, out, V, Mbuf, B, H, W, Cin, Cout, relu, split=False):
+def conv3x3_winograd(x, U, bias, out, V, Mbuf, B, H, W, Cin, Cout, relu):
     """3x3 pad-1 stride-1 convolution as Winograd F(2x2,3x3): input transform, one batched
     GEMM over the 16 transform positions, output transform.  V / Mbuf: scratch of
     16 * B*ceil(H/2)*ceil(W/2) * Cin / Cout floats."""
@@ -417,7 +426,7 @@ def conv3x3_winograd(x, U, bias, out, V, Mbuf, B, H, W, Cin, Cout, relu, split=F
     _check(lib().pn_winograd_f23_input_f32(_ptr(x), _ptr(V), B, H, W, Cin, _stream()),
            "pn_winograd_f23_input_f32")
     gemm(V, U, Mbuf, M=T, N=Cout, K=Cin, lda=Cin, ldw=Cin, ldc=Cout, batch=16, sA=T * Cin,
-         sW=Cout * Cin, sC=T * Cout, split=split)
+         sW=Cout * Cin, sC=T * Cout)
     _check(lib().pn_winograd_f23_output_f32(_ptr(Mbuf), _ptr(bias), _ptr(out), B, H, W, Cout,
                                             int(relu), _stream()), "pn_winograd_f23_output_f32")
 
@@ -725,55 +734,6 @@ def triplet_match_boxes(ptrip, gtrip, P, G, pbox, ldp, gbox, ldg, ps, po, gs, go
         _ptr(ptrip, i32), _ptr(gtrip, i32), P, G, _ptr(pbox), ldp, _ptr(gbox), ldg, _ptr(ps, i32),
         _ptr(po, i32), _ptr(gs, i32), _ptr(go, i32), float(thr), int(phrdet), int(ignore_rel),
         _ptr(match, torch.uint8), _stream()), "pn_triplet_match_boxes")
-
-
-def chain_lin(src, W, bias=None, dst=-1, out=None, res=-1, relu=False, aadd=None,
-              add_from_col=0):
-    """One LIN op of a row chain (see include/pairnet_hip.h pn_chain_op); tensors supply
-    pointers, `out` is a 2-D row-major view."""
-    return dict(kind=CH_LIN, src=src, dst=dst, res=res, N=W.shape[0], relu=int(relu), W=W,
-                bias=bias, aadd=aadd, add_from_col=add_from_col, out=out)
-
-
-def chain_ln(src, gamma, beta, dst=-1, out=None, eps=1e-5):
-    return dict(kind=CH_LN, src=src, dst=dst, gamma=gamma, beta=beta, out=out, eps=eps)
-
-
-def chain_l2norm(src, dst=-1, out=None, eps=1e-12):
-    return dict(kind=CH_L2NORM, src=src, dst=dst, out=out, eps=eps)
-
-
-def chain_desc(in0, ops, in1=None, M=None):
-    """Build (once, e.g. per plan) the descriptor of a row-chain launch."""
-    d = ChainDesc()
-    d.M = in0.shape[0] if M is None else M
-    d.nops = len(ops)
-    assert 0 < d.nops <= CHAIN_MAX_OPS
-    d.in0, d.ld0 = _ptr(in0), _rowmajor(in0)[1]
-    d.in1, d.ld1 = (_ptr(in1), _rowmajor(in1)[1]) if in1 is not None else (None, 0)
-    for i, o in enumerate(ops):
-        c = d.op[i]
-        c.kind, c.src, c.dst, c.res = o["kind"], o["src"], o.get("dst", -1), o.get("res", -1)
-        c.N, c.relu = o.get("N", 256), o.get("relu", 0)
-        a = o.get("aadd")
-        c.aadd, c.aadd_rows = _ptr(a), (a.shape[0] if a is not None else 0)
-        c.add_from_col = o.get("add_from_col", 0)
-        if a is not None:
-            assert a.stride(0) == 256 and a.stride(1) == 1
-        w = o.get("W")
-        if w is not None:
-            assert w.shape[1] == 256 and w.stride(0) == 256 and w.stride(1) == 1, w.shape
-        c.W, c.bias = _ptr(w), _ptr(o.get("bias"))
-        c.gamma, c.beta = _ptr(o.get("gamma")), _ptr(o.get("beta"))
-        out = o.get("out")
-        c.out, c.ldo = (_ptr(out), _rowmajor(out)[1]) if out is not None else (None, 0)
-        c.eps = o.get("eps", 0.0)
-    d._keep = (in0, in1, ops)      # the tensors the raw pointers refer to
-    return d
-
-
-def chain(desc):
-    _check(lib().pn_rowchain_f32(C.byref(desc), _stream()), "pn_rowchain_f32")
 
 
 # ---- box trunk glue (csrc/detr.hip) ----

@@ -27,6 +27,12 @@ lose: 145.)
 Results are exactly those of `CrossHead2.simple_test_bboxes` (bitwise: scheduling
 only), returned `depth-1` submissions late; `flush()` drains the rest.  Images are
 independent (pairnet_head.py:260-417 has no cross-image op).
+
+Result lifetime: the returned tensors are views of the slot's buffers, ordered behind the
+stream `submit()` / `flush()` was called on; work queued on THAT stream before the next
+`submit()` is safe.  A caller that reads them on another stream (a D2H copy stream, the
+all-gather's side stream) says so with `consumed(results, stream)`: the slot is not
+reused before that stream has passed the recorded point.
 """
 import torch
 
@@ -51,14 +57,20 @@ class PipelinedHead:
                               for _ in range(max(1, depth - a_streams))]
             self.a_done = [torch.cuda.Event() for _ in range(depth)]
             self.b_done = [torch.cuda.Event() for _ in range(depth)]
+        self.read_done = [[] for _ in range(depth)]   # per slot: events of foreign-stream readers
         self.count = 0
         self.queue = []   # per in-flight batch: dict(slot, pl, metas, rescale, b_started)
         # The persistent GEMM kernels of stage A fill every workgroup slot of the chip, so a
         # query-chain kernel of the other streams only gets on at a kernel boundary.  Leaving
         # 64 of the 1024 slots free lets the chains run beside stage A (measured with one
         # stage-A stream: 158.2 / 160.5 / 160.4 images/s at 0 / 32 / 48 free slots, 154.7 at
-        # 256; with two: 188.2 / 189.5 / 189.7 at 0 / 64 / 128).  Process-wide library knob.
-        hip.gemm_set_grid_trim(grid_trim)
+        # 256; with two: 188.2 / 189.5 / 189.7 at 0 / 64 / 128).  A property of THIS head's
+        # stage-A launches (a per-call hint in the GEMM descriptors, hip.reserve_slots) --
+        # nothing process-wide: other heads / pipelines in the process keep their own grids.
+        # A producer the caller runs in front of stage A (the backbone) takes the same hint
+        # through its own `grid_reserve` attribute.
+        self.grid_reserve = grid_trim
+        head.grid_reserve = grid_trim
 
     @torch.no_grad()
     def calibrate(self, feats, img_metas, steps=8, submit=None):
@@ -125,6 +137,9 @@ class PipelinedHead:
         sa.wait_stream(cur)                                # feats produced on the caller's stream
         if idx >= self.depth:
             sa.wait_event(self.b_done[slot])               # slot's buffers are free again
+        for ev in self.read_done[slot]:                    # ... also for foreign-stream readers
+            sa.wait_event(ev)
+        self.read_done[slot] = []
         with torch.cuda.stream(sa):
             head._run_stage("a", pl, feats)
             self.a_done[slot].record(sa)
@@ -168,7 +183,26 @@ class PipelinedHead:
             for t in tup:
                 if isinstance(t, torch.Tensor) and t.is_cuda:
                     t.record_stream(cur)
+        try:
+            res.pipeline_slot = item["slot"]
+        except AttributeError:                 # a plain list: give it a place for the tag
+            from .head import CrossHead2
+            res = CrossHead2.ResultList(res)
+            res.pipeline_slot = item["slot"]
         return res
+
+    def consumed(self, results, stream=None):
+        """Declare that `results` (a list submit() / flush() returned) are read on `stream`
+        (default: the current one) up to this point: the slot's buffers are not overwritten
+        before that stream gets here.  Needed only for readers on a stream other than the one
+        the results were returned on."""
+        slot = getattr(results, "pipeline_slot", None)
+        if slot is None:
+            raise ValueError("consumed(): not a result list returned by submit() / flush()")
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self.read_done[slot].append(ev)
 
     @torch.no_grad()
     @on_device

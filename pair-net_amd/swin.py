@@ -22,6 +22,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
+from .plans import PlanCache
 
 EPS = 1e-5
 
@@ -49,8 +50,8 @@ class SwinTransformerHip:
         self._params = OrderedDict((k, torch.zeros(s, dtype=dt))
                                    for k, (s, dt) in self._param_shapes().items())
         self.init_weights(0)
-        self.device, self.w, self._plans = None, None, {}
-        self.gemm_mode = "f32"
+        self.device, self.w, self._plans = None, None, PlanCache()
+        self.grid_reserve = 0
 
     # ------------------------------------------------------------------ parameters
     def _param_shapes(self):
@@ -125,7 +126,7 @@ class SwinTransformerHip:
         return missing, unexpected
 
     def to(self, device):
-        self.device, self.w, self._plans = torch.device(device), None, {}
+        self.device, self.w, self._plans = torch.device(device), None, PlanCache()
         return self
 
     def eval(self):
@@ -188,6 +189,7 @@ class SwinTransformerHip:
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     @hip.on_device
+    @hip.with_reserve
     def forward(self, img, slot=0):
         """img [B,3,H,W] fp32 NCHW on the GPU -> one NCHW-shaped, channels_last feature map
         per out index (views of per-shape buffers that the next call overwrites)."""
@@ -198,9 +200,9 @@ class SwinTransformerHip:
         img = img.contiguous()
         B, _, H, W = img.shape
         pl = self._plan(B, H, W, slot)
-        w, ws, sp = self.w, self.ws, self.gemm_mode == "bf16x3"
+        w, ws = self.w, self.ws
         lin = lambda x, wk, bk, out, **kw: hip.linear(x, w[wk], w[bk] if bk else None, out,
-                                                      split=sp, scratch=pl.scratch, **kw)
+                                                      scratch=pl.scratch, **kw)
         hip.patch_im2col4(img, pl.cols, B, H, W)
         x = pl.x[0]
         hip.linear(pl.cols, w["patch_embed.projection.weight"], w["patch_embed.projection.bias"],

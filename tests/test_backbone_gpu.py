@@ -134,17 +134,16 @@ def test_head_reads_channels_last_features():
 
 
 def test_detector_end_to_end_native_backbone():
+    """The native backbone inside the detector against the PyTorch-ROCm / MIOpen ResNet-50
+    (tools/torch_resnet50.py, the bench's comparison leg) with the same state dict."""
     from pairnet_amd import build_detector, pairnet_r50
-    cfg = pairnet_r50()
-    det = build_detector(cfg).to(DEV)
-    cfg_t = pairnet_r50()
-    cfg_t["backbone"]["impl"] = "torch"
-    det_t = build_detector(cfg_t).to(DEV)
-    det_t.backbone.load_state_dict(det.backbone.state_dict())
-    det_t.bbox_head.load_state_dict(det.bbox_head.state_dict())
+    from tools.torch_resnet50 import ResNet50
+    det = build_detector(pairnet_r50()).to(DEV)
+    ref = ResNet50().to(DEV)
+    ref.load_state_dict(det.backbone.state_dict())
     img = R(1, 3, 128, 160, seed=9).to(DEV)
     metas = [dict(img_shape=(128, 160, 3), scale_factor=[1.0] * 4)]
-    fa, fb = det.extract_feat(img), det_t.extract_feat(img)
+    fa, fb = det.extract_feat(img), ref(img)
     for x, y in zip(fa, fb):
         assert rel(x, y.cpu()) < 1e-4
     res = det.simple_test(img, metas)

@@ -204,3 +204,83 @@ def test_detector_checkpoint_round_trip(tmp_path):
         assert all(torch.equal(got[k], new["module." + k].to(got[k].dtype)) for k in got)
         with pytest.raises(RuntimeError):
             det.load_state_dict({k: v for k, v in list(new.items())[1:]}, strict=True)
+
+
+def test_no_process_wide_scheduling_state(built_lib):
+    """The header promises "no global state": the persistent-grid hint travels in each call's
+    descriptor (PN_GEMM_RESERVE), there is no setter, and the grid of one caller's GEMM does
+    not depend on what another caller in the process asked for."""
+    from pairnet_amd import hip
+    lib = hip.lib()
+    assert not hasattr(lib, "pn_gemm_set_grid_trim") and not hasattr(lib, "pn_gemm_set_grid_scale")
+    header = open(os.path.join(ROOT, "include", "pairnet_hip.h")).read()
+    assert "pn_gemm_set" not in header and "process-wide knob" in header
+
+    def desc():
+        d = hip.GemmDesc()
+        d.M, d.N, d.K, d.batch = 21950, 1024, 256, 1
+        d.flags = hip._reserve_flag()
+        return d
+    alone = lib.pn_gemm_grid_size(ctypes.byref(desc()))
+    assert alone == 1024                                   # 256 CUs x 4 resident workgroups
+    with hip.reserve_slots(64):
+        assert lib.pn_gemm_grid_size(ctypes.byref(desc())) == 960
+        with hip.reserve_slots(128):
+            assert lib.pn_gemm_grid_size(ctypes.byref(desc())) == 896
+        assert lib.pn_gemm_grid_size(ctypes.byref(desc())) == 960
+        # another thread (another head / pipeline of the process) is not affected
+        import threading
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(lib.pn_gemm_grid_size(ctypes.byref(desc()))))
+        t.start()
+        t.join()
+        assert seen == [alone]
+    assert lib.pn_gemm_grid_size(ctypes.byref(desc())) == alone
+    small = desc()
+    small.M = 640                                          # 10 x 16 tiles: grid = tile count
+    assert lib.pn_gemm_grid_size(ctypes.byref(small)) == 160
+
+
+def test_plan_caches_are_bounded():
+    """Per-shape plans (device buffers + graphs) live in LRU caches (a keep-ratio
+    evaluation pass meets hundreds of shapes)."""
+    from pairnet_amd.plans import PlanCache
+    c = PlanCache(max_plans=3)
+    for i in range(5):
+        c[("shape", i)] = i
+    assert list(c) == [("shape", 2), ("shape", 3), ("shape", 4)] and c.evictions == 2
+    assert c[("shape", 2)] == 2                            # a hit refreshes the entry
+    c[("shape", 5)] = 5
+    assert ("shape", 2) in c and ("shape", 3) not in c
+    from pairnet_amd import CrossHead2, CrossHeadBBox, ResNet50Hip, SwinTransformerHip, ChannelMapper
+    from pairnet_amd import bbox_head_cfg, channel_mapper_cfg
+    head = CrossHead2(**head_cfg())
+    assert isinstance(head._plans, PlanCache)
+    head.load_state_dict(head.state_dict())
+    assert isinstance(head._plans, PlanCache)
+    assert isinstance(ResNet50Hip()._plans, PlanCache)
+    assert isinstance(SwinTransformerHip(embed_dims=32, depths=(2, 2, 2, 2),
+                                         num_heads=(1, 2, 4, 8), window_size=4)._plans, PlanCache)
+    ncfg = channel_mapper_cfg()
+    ncfg.pop("type")
+    assert isinstance(ChannelMapper(**ncfg)._plans, PlanCache)
+    bcfg = bbox_head_cfg()
+    bcfg.pop("type")
+    assert isinstance(CrossHeadBBox(**bcfg)._plans, PlanCache)
+
+
+def test_load_checkpoint_refuses_pickled_code_by_default(tmp_path):
+    from pairnet_amd import CrossHead2, load_checkpoint
+
+    class Payload:                       # an arbitrary pickled object
+        def __reduce__(self):
+            return (print, ("code from the checkpoint ran",))
+    head = CrossHead2(**head_cfg())
+    path = os.path.join(tmp_path, "evil.pth")
+    torch.save(dict(state_dict=head.state_dict(), meta=dict(x=Payload())), path)
+    with pytest.raises(RuntimeError):
+        load_checkpoint(head, path)
+    load_checkpoint(head, path, trust=True)               # the caller vouches for the file
+    good = os.path.join(tmp_path, "good.pth")
+    torch.save(dict(state_dict=head.state_dict(), meta=dict(CLASSES=("a", "b"))), good)
+    assert load_checkpoint(head, good)["meta"]["CLASSES"] == ("a", "b")

@@ -98,10 +98,9 @@ def test_e2e_small_against_reference_golden():
         assert r[0].shape == (200, 5) and float(r[0].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("gemm_mode,conv_algo,exact_order", [
-    ("f32", "winograd", False), ("f32", "direct", False), ("f32", "winograd4", False),
-    ("bf16x3", "winograd", False), ("f32", "winograd", True)])
-def test_e2e_full_800x1333_against_reference_golden(gemm_mode, conv_algo, exact_order):
+@pytest.mark.parametrize("conv_algo,exact_order", [
+    ("winograd", False), ("direct", False), ("winograd4", False), ("winograd", True)])
+def test_e2e_full_800x1333_against_reference_golden(conv_algo, exact_order):
     fx = golden("e2e_full")
     head_o, sd, crc = oracle_head(int(fx["weight_seed"]), overrides_of(fx))
     assert crc == int(fx["weight_crc"])
@@ -111,7 +110,7 @@ def test_e2e_full_800x1333_against_reference_golden(gemm_mode, conv_algo, exact_
     assert [tuple(f.shape) for f in feats] == [tuple(s) for s in fx["feat_shapes"].tolist()]
     metas = [dict(img_shape=(H, W, 3), scale_factor=[2.083] * 4)]
     head = _hip_head(sd)
-    head.gemm_mode, head.conv_algo = gemm_mode, conv_algo
+    head.conv_algo = conv_algo
     # (True: attention masks in the reference's operation order -- full-size mask logits,
     # then the bilinear resize -- instead of the once-resampled mask feature)
     head.exact_mask_order = exact_order
@@ -124,8 +123,8 @@ def test_e2e_full_800x1333_against_reference_golden(gemm_mode, conv_algo, exact_
     e_imp = _err(cls["importance"], fx["importance"])
     probe = masks["mask"].flatten()[torch.from_numpy(fx["mask_probe_idx"]).to(DEV)]
     e_mask = _err(probe, fx["mask_probe"])
-    print("e2e_full [%s, %s, exact_mask_order=%s] errors: rel %.3e cls %.3e importance %.3e "
-          "mask %.3e" % (gemm_mode, conv_algo, exact_order, e_rel, e_cls, e_imp, e_mask))
+    print("e2e_full [%s, exact_mask_order=%s] errors: rel %.3e cls %.3e importance %.3e "
+          "mask %.3e" % (conv_algo, exact_order, e_rel, e_cls, e_imp, e_mask))
     assert e_rel < 1e-3 and e_cls < 1e-3 and e_imp < 1e-3
     assert e_mask < 1e-3 * max(1.0, float(np.abs(fx["mask_probe"]).max()))
     ok, exact = tie_aware_topk_match(fx["importance"][0], fx["topk_idx"][0],
@@ -148,7 +147,6 @@ def test_e2e_full_800x1333_against_reference_golden(gemm_mode, conv_algo, exact_
 
 
 @pytest.mark.parametrize("name,fuse", [("e2e_small_sep", False), ("e2e_full_sep", False),
-                                       ("e2e_small_sep", True), ("e2e_full_sep", True),
                                        ("e2e_small_sep", "front"), ("e2e_full_sep", "front")])
 def test_e2e_topk_pair_indices_bit_exact_on_separated_fixtures(name, fuse):
     """north_star: "top-k pair indices bit-exact", end to end, at 96x128 (batch 2) and at
@@ -164,7 +162,6 @@ def test_e2e_topk_pair_indices_bit_exact_on_separated_fixtures(name, fuse):
     metas = [dict(img_shape=(H, W, 3), scale_factor=[sf] * 4)] * bs
     assert float(fx["min_gap"]) >= 1e-4 and float(fx["min_gap"]) >= 10 * float(fx["fp64_noise"])
     head = _hip_head(sd)
-    head.fuse_chains = fuse is True     # (the query side as row-chain launches, csrc/chain.hip)
     head.fuse_ppn_front = fuse == "front"   # (k_ppn_front: LDS-staged query tiles, csrc/ppn.hip)
     cls, masks = head.forward([f.to(DEV) for f in feats], metas)
     torch.cuda.synchronize()
@@ -251,9 +248,8 @@ def test_relation_decoder_on_golden_pair_features():
     assert e < 1e-4
 
 
-@pytest.mark.parametrize("exact_mask_order,gemm_mode", [(False, "f32"), (True, "f32"),
-                                                        (False, "bf16x3")])
-def test_against_oracle_other_seed_and_batch_consistency(exact_mask_order, gemm_mode):
+@pytest.mark.parametrize("exact_mask_order", [False, True])
+def test_against_oracle_other_seed_and_batch_consistency(exact_mask_order):
     head_o, sd, _ = oracle_head(1234)
     H, W = 64, 96
     feats = seeded.seeded_feats(99, 2, H, W)
@@ -263,7 +259,6 @@ def test_against_oracle_other_seed_and_batch_consistency(exact_mask_order, gemm_
     ref_cls, ref_masks = head_o.forward(feats, metas, trace=trace)
     head = _hip_head(sd)
     head.exact_mask_order = exact_mask_order
-    head.gemm_mode = gemm_mode
     cls, masks = head.forward([f.to(DEV) for f in feats], metas)
     torch.cuda.synchronize()
     for k in ("cls", "importance"):

@@ -140,40 +140,6 @@ def test_gemm_group_and_column_split_add(hip):
     close(out, ref, 2e-5, "column-split add")
 
 
-@pytest.mark.parametrize("big", [False, True])
-def test_gemm_bf16x3_split_is_fp32_accurate(hip, big):
-    """The opt-in 3 x bf16 operand split: error vs an fp64 reference no larger than the
-    exact-fp32 MFMA path's (both ~K * 2^-24 relative), on a wide dynamic range."""
-    M, N, K = 1000, 320, 512
-    g = torch.Generator().manual_seed(3)
-    x = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g) * 3)
-    w = torch.randn(N, K, generator=g) * 0.1
-    b, res, pos = R(N, seed=1), R(M, N, seed=2), R(250, K, seed=3)
-    ref = F.relu((x + pos.repeat(4, 1)).double() @ w.double().t() + b.double()) + res.double()
-    outs = {}
-    for name, kw in (("f32", dict(force="tile64")), ("split", dict(split=True, force="tile" if big else None))):
-        out = torch.empty(M, N, device=DEV)
-        hip.linear(x.to(DEV), w.to(DEV), b.to(DEV), out, aadd=pos.to(DEV), res=res.to(DEV),
-                   relu=True, **kw)
-        outs[name] = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
-    print(outs)
-    assert outs["split"] <= max(2 * outs["f32"], 2e-6)
-    # exact on integer-valued operands, like the fp32 chain
-    xi = torch.randint(-8, 9, (256, 512)).float()
-    wi = torch.randint(-8, 9, (256, 512)).float()
-    out = torch.empty(256, 256, device=DEV)
-    hip.linear(xi.to(DEV), wi.to(DEV), None, out, split=True, force="tile" if big else None)
-    assert torch.equal(out.cpu(), xi @ wi.t())
-    # conv path
-    xc, wc = R(1, 32, 17, 23, seed=5), R(64, 32, 3, 3, seed=6, lo=-0.1, hi=0.1)
-    refc = F.conv2d(xc.double(), wc.double(), padding=1)
-    o = torch.empty(1, 17, 23, 64, device=DEV)
-    hip.conv2d_nhwc(xc.permute(0, 2, 3, 1).contiguous().to(DEV),
-                    wc.permute(0, 2, 3, 1).reshape(64, -1).contiguous().to(DEV), None, o, 1, 17, 23,
-                    32, 64, 3, 3, 1, False, split=True, big_tile=big)
-    assert (o.permute(0, 3, 1, 2).cpu().double() - refc).abs().max().item() < 5e-6
-
-
 def test_gemm_is_an_fmaf_chain(hip):
     """The f32 MFMA is exact fp32: with integer-valued operands the result is exact."""
     x = torch.randint(-8, 9, (256, 512)).float()
@@ -386,69 +352,6 @@ def test_mmcv_shaped_msda_on_the_golden_fixture_equals_the_fused_entry(hip):
                                  aw.to(DEV))
     close(out, torch.from_numpy(fx["out"]), 2e-6, "msda golden via the mmcv-shaped entry")
     close(out, _run_msda(hip, value, off, logits, shapes).cpu(), 2e-6, "mmcv-shaped vs fused entry")
-
-
-# ----------------------------------------------------------------------------- row chain
-@pytest.mark.parametrize("M", [100, 200, 37, 321])
-def test_rowchain_programs(hip, M):
-    """pn_rowchain_f32: the three chain shapes the decoders use, against torch fp32."""
-    x, att = R(M, 256, seed=1), R(M, 256, seed=2)
-    pos = R(100, 256, seed=3)
-    Wo, bo = R(256, 256, seed=4, lo=-0.1, hi=0.1), R(256, seed=5)
-    g, b = R(256, seed=6, lo=0.5, hi=1.5), R(256, seed=7)
-    Wv, bv = R(768, 256, seed=8, lo=-0.1, hi=0.1), R(768, seed=9)
-    prow = pos[torch.arange(M) % 100]
-    D = lambda t: t.to(DEV)
-    # (1) out_proj + residual -> LayerNorm -> [V | Q | K] projection, pos on columns >= 256
-    y = att @ Wo.t() + bo + x
-    x1 = F.layer_norm(y, (256,), g, b, 1e-5)
-    vqk = torch.cat([x1 @ Wv[:256].t(), (x1 + prow) @ Wv[256:].t()], 1) + bv
-    o_x1, o_vqk = torch.empty(M, 256, device=DEV), torch.empty(M, 768, device=DEV)
-    dW = [D(t) for t in (Wo, bo, g, b, Wv, bv, pos)]
-    desc = hip.chain_desc(D(att), [
-        hip.chain_lin(0, dW[0], dW[1], dst=2, res=1),
-        hip.chain_ln(2, dW[2], dW[3], dst=2, out=o_x1),
-        hip.chain_lin(2, dW[4], dW[5], out=o_vqk, aadd=dW[6], add_from_col=256)], in1=D(x))
-    hip.chain(desc)
-    close(o_x1, x1, 2e-6, "chain: out_proj + LN")
-    close(o_vqk, vqk, 3e-6, "chain: vqk projection")
-    # (2) three-layer MLP on buffer 1 + a projection of (buffer 0 + pos) + a 134-wide head
-    W1, W2, W3 = (R(256, 256, seed=s, lo=-0.1, hi=0.1) for s in (11, 12, 13))
-    b1, b2, b3 = (R(256, seed=s) for s in (14, 15, 16))
-    Wq, bq = R(256, 256, seed=17, lo=-0.1, hi=0.1), R(256, seed=18)
-    Wc, bc = R(134, 256, seed=19, lo=-0.1, hi=0.1), R(134, seed=20)
-    qn = att
-    me = torch.relu(torch.relu(qn @ W1.t() + b1) @ W2.t() + b2) @ W3.t() + b3
-    qp = (x + prow) @ Wq.t() + bq
-    cls = qn @ Wc.t() + bc
-    o_me, o_qp, o_cls = (torch.empty(M, n, device=DEV) for n in (256, 256, 134))
-    dW = [D(t) for t in (W1, b1, W2, b2, W3, b3, Wq, bq, Wc, bc, pos)]
-    desc = hip.chain_desc(D(x), [
-        hip.chain_lin(1, dW[8], dW[9], out=o_cls),
-        hip.chain_lin(0, dW[6], dW[7], out=o_qp, aadd=dW[10], add_from_col=0),
-        hip.chain_lin(1, dW[0], dW[1], dst=2, relu=True),
-        hip.chain_lin(2, dW[2], dW[3], dst=0, relu=True),
-        hip.chain_lin(0, dW[4], dW[5], out=o_me)], in1=D(qn))
-    hip.chain(desc)
-    close(o_me, me, 3e-6, "chain: mask MLP")
-    close(o_qp, qp, 3e-6, "chain: query projection")
-    close(o_cls, cls, 3e-6, "chain: class head")
-    # (3) MLP + L2 normalisation (the PPN's sub / obj embeddings)
-    emb = F.normalize(torch.relu(torch.relu(x @ W1.t() + b1) @ W2.t() + b2) @ W3.t() + b3,
-                      p=2, dim=-1, eps=1e-12)
-    o_emb = torch.empty(M, 256, device=DEV)
-    desc = hip.chain_desc(D(x), [
-        hip.chain_lin(0, dW[0], dW[1], dst=1, relu=True),
-        hip.chain_lin(1, dW[2], dW[3], dst=2, relu=True),
-        hip.chain_lin(2, dW[4], dW[5], dst=1),
-        hip.chain_l2norm(1, out=o_emb)])
-    hip.chain(desc)
-    close(o_emb, emb, 2e-6, "chain: MLP + l2norm")
-    # LayerNorm is k_layernorm256's arithmetic bit for bit
-    ln_a, ln_b = torch.empty(M, 256, device=DEV), torch.empty(M, 256, device=DEV)
-    hip.layernorm(D(x), D(g), D(b), ln_a)
-    hip.chain(hip.chain_desc(D(x), [hip.chain_ln(0, D(g), D(b), out=ln_b)]))
-    assert torch.equal(ln_a, ln_b)
 
 
 # ----------------------------------------------------------------------------- PE / resize

@@ -11,6 +11,7 @@ import torch.nn.functional as F
 from helpers import golden, oracle_head, overrides_of
 from oracle import layers as L
 from oracle import ref_shim, seeded
+from oracle.head import OracleCrossHead2
 from oracle.matrix_learner import MatrixLearnerTiny
 
 
@@ -144,6 +145,73 @@ def test_separated_fixtures_are_tie_free_and_match_the_oracle():
     assert float(fx["min_gap"]) >= 1e-4 and float(fx["min_gap"]) >= 10 * float(fx["fp64_noise"])
     assert np.array_equal(np.argsort(-fx["importance"].reshape(1, -1), axis=1)[:, :100],
                           fx["topk_idx"])
+
+
+@pytest.mark.parametrize("name,kind,images", [("e2e_image_swinl", "swinL", (0, 1)),
+                                              ("e2e_image_full", "r50", (1,))])
+def test_image_fixtures_match_the_oracle_chain(name, kind, images):
+    """The image -> triplets fixtures (recorded from the REFERENCE head class on the oracle
+    backbone's features, oracle/make_golden.py gen_e2e_image) are reproduced by the oracle
+    chain from the seeds alone: backbone features at the probes, every head output and the
+    pair list -- bit for bit on the torch build that recorded them, and within fp32 noise
+    (far below the recorded gap) anywhere else.  The full-size case runs one of its two
+    images to keep the CPU suite short."""
+    from collections import OrderedDict
+    fx = golden(name)
+    bs, H, W = int(fx["batch"]), int(fx["height"]), int(fx["width"])
+    Q, sf = int(fx["num_obj_query"]), float(fx["img_scale"])
+    if kind == "r50":
+        from oracle.backbone import OracleResNet50, seeded_backbone_state
+        bb = OracleResNet50()
+        bsd = seeded_backbone_state(int(fx["backbone_seed"]))
+        chans = (256, 512, 1024, 2048)
+    else:
+        from oracle.swin import OracleSwin, seeded_swin_state
+        bb = OracleSwin(embed_dims=192, depths=(2, 2, 18, 2), num_heads=(6, 12, 24, 48),
+                        window_size=12)
+        bsd = seeded_swin_state(bb, int(fx["backbone_seed"]))
+        chans = (192, 384, 768, 1536)
+    assert seeded.checksum([v for v in bsd.values() if v.dtype == torch.float32]) == \
+        int(fx["backbone_crc"])
+    bb.load_state_dict(bsd)
+    img = seeded.uniform(np.random.default_rng(int(fx["img_seed"])), (bs, 3, H, W), -2.0, 2.0)
+    assert seeded.checksum([img]) == int(fx["img_crc"])
+    rows = list(images)
+    with torch.no_grad():
+        feats = [f.contiguous() for f in bb(img[rows].contiguous())]
+    for l, f in enumerate(feats):
+        shape = tuple(fx["feat%d_shape" % l])
+        per = int(np.prod(shape[1:]))
+        idx = torch.from_numpy(fx["feat%d_probe_idx" % l])
+        for j, b in enumerate(rows):
+            keep = (idx // per) == b
+            got = f[j].flatten()[idx[keep] - b * per]
+            want = torch.from_numpy(fx["feat%d_probe" % l][keep.numpy()])
+            assert float((got - want).abs().max()) <= 2e-5 * float(fx["feat%d_absmax" % l])
+    from pairnet_amd import pairnet_head_cfg
+    cfg = pairnet_head_cfg(in_channels=chans, num_obj_query=Q)
+    cfg.pop("type")
+    head = OracleCrossHead2(**cfg).eval()
+    sd = seeded.seeded_state_dict(
+        OrderedDict((k, tuple(v.shape)) for k, v in head.state_dict().items()),
+        int(fx["weight_seed"]))
+    seeded.apply_ops(sd, overrides_of(fx))
+    assert seeded.checksum(sd) == int(fx["weight_crc"])
+    head.load_state_dict(sd, strict=True)
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[sf] * 4)] * len(rows)
+    trace = {}
+    cls, masks = head.forward(feats, metas, trace=trace)
+    gap = float(fx["min_gap"])
+    assert gap >= 1e-4 and gap >= 10 * float(fx["fp64_noise"])
+    for k in ("topk_idx", "sub_pos", "obj_pos"):
+        assert np.array_equal(trace[k].numpy(), fx[k][rows]), k
+    for k in ("rel", "cls", "sub", "obj", "importance"):
+        e = float(np.abs(cls[k].numpy() - fx[k][rows]).max())
+        assert e < (gap / 10 if k == "importance" else 2e-4), (k, e)
+    res = head.get_bboxes(cls, masks, metas)
+    for r, i in zip(res, rows):
+        assert np.array_equal(r[1].numpy(), fx["res%d_labels" % i])
+        assert float((r[4].numpy() != fx["res%d_pan_img" % i]).mean()) < 1e-3
 
 
 def test_fixture_ops_apply_in_their_documented_order():

@@ -1,0 +1,282 @@
+"""GPU: parity at the PRODUCTION shapes BASELINE.json names, from the image tensor.
+
+  configs[1]  Pair-Net R50 + Mask2Former, 100 / 100 queries, bs = 1, 800x1333
+  configs[2]  the same with 2 images per GPU
+  configs[3]  Pair-Net Swin-L (embed 192, depths 2-2-18-2, heads 6-12-24-48, window 12)
+              + Mask2Former, 200 object queries
+
+Fixtures `e2e_image_full` / `e2e_image_swinl` (oracle/make_golden.py `gen_e2e_image`): a
+seeded image -> the oracle backbone (pinned to HuggingFace transformers) -> the REFERENCE's
+own CrossHead2 class (run from /root/reference under the shims), separated like the `*_sep`
+fixtures so that strict top-k equality is a meaningful assertion; the generator also runs
+the whole chain in fp64 FROM THE IMAGE and insists on the same pair list and a score margin
+>= 10 x the fp32-vs-fp64 difference.  Here the image goes through `PSGTr.simple_test`
+(psgtr.py:148-156: native backbone -- at 800x1333 with its split-K stage-3/4 layers and the
+odd-sided 100x167 Winograd maps -- then head, get_bboxes, triplet2Result), eagerly and
+through the bench's hipGraph + 4-stream schedule.
+
+Tolerances: backbone features 1e-4 of their scale; relation / class logits 1e-3 (fp32,
+BASELINE north_star); pair indices, labels, rel_pairs exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, overrides_of
+from oracle import seeded
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _err(a, b):
+    return float((torch.as_tensor(a).detach().cpu().double() - torch.as_tensor(b).double()).abs().max())
+
+
+def _detector(fx, kind):
+    """The detector the fixture was recorded for, with the fixture's weights."""
+    from collections import OrderedDict
+    from pairnet_amd import build_detector, pairnet_r50, pairnet_swin
+    Q = int(fx["num_obj_query"])
+    if kind == "r50":
+        from oracle.backbone import seeded_backbone_state
+        cfg = pairnet_r50()
+        bsd = seeded_backbone_state(int(fx["backbone_seed"]))
+    else:
+        from oracle.swin import OracleSwin, seeded_swin_state
+        cfg = pairnet_swin("L", num_obj_query=Q)
+        b = cfg["backbone"]
+        assert (b["embed_dims"], tuple(b["depths"]), tuple(b["num_heads"]), b["window_size"]) == \
+            (192, (2, 2, 18, 2), (6, 12, 24, 48), 12)
+        bsd = seeded_swin_state(OracleSwin(**{k: b[k] for k in ("embed_dims", "depths",
+                                                                "num_heads", "window_size")}),
+                                int(fx["backbone_seed"]))
+    assert seeded.checksum([v for v in bsd.values() if v.dtype == torch.float32]) == \
+        int(fx["backbone_crc"])
+    det = build_detector(cfg)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in det.bbox_head.state_dict().items())
+    sd = seeded.seeded_state_dict(shapes, int(fx["weight_seed"]))
+    seeded.apply_ops(sd, overrides_of(fx))
+    assert seeded.checksum(sd) == int(fx["weight_crc"])
+    det.backbone.load_state_dict(bsd)
+    det.bbox_head.load_state_dict(sd)
+    return det.to(DEV)
+
+
+def _image(fx):
+    bs, H, W = int(fx["batch"]), int(fx["height"]), int(fx["width"])
+    img = seeded.uniform(np.random.default_rng(int(fx["img_seed"])), (bs, 3, H, W), -2.0, 2.0)
+    assert seeded.checksum([img]) == int(fx["img_crc"])
+    sf = float(fx["img_scale"])
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[sf] * 4)] * bs
+    return img, metas
+
+
+def _check_features(fx, feats, images):
+    for l, f in enumerate(feats):
+        shape = tuple(fx["feat%d_shape" % l])
+        assert tuple(f.shape[1:]) == shape[1:]
+        full = torch.zeros(shape)          # probes index the recorded (batch, C, h, w) tensor
+        full[list(images)] = f.detach().cpu().float()
+        idx = torch.from_numpy(fx["feat%d_probe_idx" % l])
+        per = int(np.prod(shape[1:]))
+        keep = torch.isin(idx // per, torch.tensor(list(images)))
+        e = _err(full.flatten()[idx[keep]], fx["feat%d_probe" % l][keep.numpy()])
+        scale = float(fx["feat%d_absmax" % l])
+        print("C%d %s: max err %.2e of scale %.1f (%d probes)" % (l + 2, shape, e, scale,
+                                                                  int(keep.sum())))
+        assert int(keep.sum()) > 1000 and e < 1e-4 * scale
+
+
+def _check_head(fx, det, images, n_img):
+    """Strict indices + logits of the head's last plan against the fixture rows `images`."""
+    pl = det.bbox_head._last_plan
+    rows = list(images)
+    assert float(fx["min_gap"]) >= 1e-4 and float(fx["min_gap"]) >= 10 * float(fx["fp64_noise"])
+    assert np.array_equal(pl.topk_idx.cpu().numpy(), fx["topk_idx"][rows])
+    assert np.array_equal(pl.sub_pos.cpu().numpy(), fx["sub_pos"][rows])
+    assert np.array_equal(pl.obj_pos.cpu().numpy(), fx["obj_pos"][rows])
+    imp = pl.imp.cpu().numpy().reshape(n_img, -1)
+    ref = fx["importance"][rows].reshape(n_img, -1)
+    top = np.argsort(-ref, axis=1)[:, :200]
+    e_top = float(np.abs(np.take_along_axis(imp - ref, top, 1)).max())
+    errs = dict(rel=_err(pl.rel, fx["rel"][rows]), cls=_err(pl.cls, fx["cls"][rows]),
+                sub=_err(pl.sub_cls, fx["sub"][rows]), obj=_err(pl.obj_cls, fx["obj"][rows]),
+                importance=float(np.abs(imp - ref).max()) / max(1.0, float(np.abs(ref).max())))
+    print("min gap %.3e, GPU score error on the top pairs %.3e (the reference's fp32-vs-fp64 "
+          "error from the image: %.3e); errors %s" % (float(fx["min_gap"]), e_top,
+                                                      float(fx["fp64_noise"]), errs))
+    assert e_top < float(fx["min_gap"]) / 4
+    assert all(e < 1e-3 for e in errs.values()), errs
+
+
+def _check_results(fx, results, images, Q):
+    """`triplet2Result` fields (psgtr.py:15-51) against the reference's get_bboxes tuple."""
+    H0 = round(int(fx["height"]) / float(fx["img_scale"]))
+    W0 = round(int(fx["width"]) / float(fx["img_scale"]))
+    for r, i in zip(results, images):
+        assert isinstance(r.labels, np.ndarray) and isinstance(r.masks, np.ndarray)
+        assert np.array_equal(r.labels, fx["res%d_labels" % i])
+        assert np.array_equal(r.rel_pair_idxes, fx["res%d_rel_pairs" % i])
+        assert r.rel_dists.shape == (100, 57) and _err(r.rel_dists, fx["res%d_r_dists" % i]) < 1e-3
+        assert r.refine_bboxes.shape == (200, 5) and float(np.abs(r.refine_bboxes).sum()) == 0.0
+        assert r.rel_labels.shape == (100,)
+        assert r.masks.shape == (200, H0, W0) and r.masks.dtype == np.bool_
+        shape = tuple(fx["res%d_masks_shape" % i])
+        ref_masks = np.unpackbits(fx["res%d_masks" % i])[:int(np.prod(shape))].reshape(shape)
+        got = r.masks[fx["res%d_masks_rows" % i]]
+        mism = float((got != ref_masks.astype(bool)).mean())
+        pan = float((r.pan_results != fx["res%d_pan_img" % i]).mean())
+        print("image %d: mask bit mismatch %.2e, panoptic map mismatch %.2e" % (i, mism, pan))
+        assert mism < 1e-3 and pan < 5e-3
+        assert r.formatted_masks["pan_results"] is r.pan_results
+        assert r.pan_results.shape == (H0, W0)
+
+
+@pytest.mark.parametrize("images", [(0,), (1,), (0, 1)])
+def test_r50_800x1333_image_to_triplets_matches_the_reference(images):
+    """configs[1] (one image) and configs[2] (two images per GPU) at 800x1333 through
+    `PSGTr.simple_test`."""
+    fx = golden("e2e_image_full")
+    det = _detector(fx, "r50")
+    img, metas = _image(fx)
+    img = img[list(images)].contiguous().to(DEV)
+    metas = metas[:len(images)]
+    _check_features(fx, det.extract_feat(img), images)
+    results = det.simple_test(img, metas)
+    _check_head(fx, det, images, len(images))
+    _check_results(fx, results, images, 100)
+
+
+def test_r50_800x1333_graph_replay_and_pipeline_give_the_eager_result():
+    """The bench's schedule (backbone + stages as hipGraph replays on the 4-stream pipeline,
+    two stage-A streams) on the fixture's two images alternately: strict indices against the
+    reference for every submission, results bitwise the eager ones."""
+    from pairnet_amd import PipelinedHead
+    fx = golden("e2e_image_full")
+    det = _detector(fx, "r50")
+    img, metas = _image(fx)
+    imgs = [img[i:i + 1].contiguous().to(DEV) for i in range(2)]
+    head, net = det.bbox_head, det.backbone
+    eager = []
+    for im in imgs:
+        r = head.simple_test_bboxes(net(im), metas[:1])[0]
+        eager.append([t.clone() for t in (r[1], r[7], r[4], head._last_plan.topk_idx)])
+    head.use_graphs = net.use_graphs = True
+    pipe = PipelinedHead(head, depth=4, a_streams=2)
+    order = [0, 1, 1, 0, 0, 1, 0, 1, 1, 0, 1, 0]
+    got = []
+
+    def take(res):
+        pl = head._last_plan
+        got.append([t.clone() for t in (res[0][1], res[0][7], res[0][4], pl.topk_idx)])
+    for i in order:
+        sl = pipe.count % len(pipe.streams_a)
+        pipe.streams_a[sl].wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(pipe.streams_a[sl]):
+            res = pipe.submit(net(imgs[i], slot=sl), metas[:1])
+            if res is not None:
+                take(res)
+    while pipe.queue:
+        take(pipe._finish(pipe.queue.pop(0)))
+    torch.cuda.synchronize()
+    assert len(got) == len(order)
+    for i, g in zip(order, got):
+        assert np.array_equal(g[3].cpu().numpy(), fx["topk_idx"][i:i + 1])
+        for a, b in zip(eager[i], g):
+            assert torch.equal(a, b)
+
+
+def test_swin_l_200_queries_image_to_triplets_matches_the_reference():
+    """configs[3]: the TRUE Swin-L backbone (197 M parameters, 18-block third stage) under
+    the 200-query head, batch 2, strict pair indices."""
+    fx = golden("e2e_image_swinl")
+    det = _detector(fx, "swinL")
+    img, metas = _image(fx)
+    img = img.to(DEV)
+    _check_features(fx, det.extract_feat(img), (0, 1))
+    results = det.simple_test(img, metas)
+    assert det.bbox_head._last_plan.imp.shape == (2, 200, 200)
+    _check_head(fx, det, (0, 1), 2)
+    _check_results(fx, results, (0, 1), 200)
+
+
+def test_result_streamer_equals_simple_test():
+    """`ResultStreamer` (pinned ring, copy stream, `PipelinedHead.consumed`) hands back the
+    same `Result` fields as `PSGTr.simple_test` -> `triplet2Result`, for a different image in
+    every step of the 4-stream pipeline."""
+    from oracle.backbone import seeded_backbone_state
+    from pairnet_amd import PipelinedHead, ResultStreamer, build_detector, pairnet_r50
+    det = build_detector(pairnet_r50())
+    det.backbone.load_state_dict(seeded_backbone_state(41))
+    det.to(DEV)
+    H, W = 160, 224
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[2.0] * 4)]
+    g = torch.Generator().manual_seed(3)
+    imgs = [torch.randn(1, 3, H, W, generator=g).to(DEV) for _ in range(7)]
+    fields = ("refine_bboxes", "labels", "rel_pair_idxes", "rel_dists", "rel_labels",
+              "pan_results", "masks")
+    want = [det.simple_test(im, metas)[0] for im in imgs]
+    want = [{k: np.array(getattr(r, k)) for k in fields} for r in want]
+    head, net = det.bbox_head, det.backbone
+    for graphs in (False, True):
+        head.use_graphs = net.use_graphs = graphs
+        pipe = PipelinedHead(head, depth=4, a_streams=2)
+        streamer = ResultStreamer(head, ring=3)
+        for rep in range(2):
+            got = []
+
+            def take(res):
+                if len(streamer) == streamer.ring:
+                    got.extend(streamer.pop())
+                streamer.push(res, pipe)
+            for im in imgs:
+                sl = pipe.count % len(pipe.streams_a)
+                pipe.streams_a[sl].wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(pipe.streams_a[sl]):
+                    res = pipe.submit(net(im, slot=sl), metas)
+                    if res is not None:
+                        take(res)
+            with torch.cuda.stream(pipe.streams_a[0]):
+                for res in pipe.flush():
+                    take(res)
+            while len(streamer):
+                got.extend(streamer.pop())
+            assert len(got) == len(want)
+            for r, w in zip(got, want):
+                for k in fields:
+                    a = getattr(r, k)
+                    assert isinstance(a, np.ndarray) and a.dtype == w[k].dtype, k
+                    assert np.array_equal(a, w[k]), (graphs, rep, k)
+                assert r.formatted_masks["pan_results"] is r.pan_results
+    with pytest.raises(RuntimeError):
+        ResultStreamer(head, ring=1).pop()
+
+
+def test_two_heads_in_one_process_keep_their_own_grids():
+    """a pipeline on one head (64 / 128 reserved workgroup slots) does not
+    change another head's launches: its results stay bitwise what they were alone, and its
+    `grid_reserve` stays 0."""
+    from helpers import head_cfg, oracle_head
+    from pairnet_amd import CrossHead2, PipelinedHead
+    _, sd, _ = oracle_head(7)
+    heads = []
+    for _ in range(2):
+        h = CrossHead2(**head_cfg())
+        h.load_state_dict(sd)
+        heads.append(h.to(DEV))
+    a, b = heads
+    H, W = 96, 128
+    feats = [f.to(DEV) for f in seeded.seeded_feats(5, 1, H, W)]
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[1.0] * 4)]
+    alone = [t.clone() for t in a.simple_test_bboxes(feats, metas)[0] if t.is_cuda]
+    pipe = PipelinedHead(b, depth=3, a_streams=1, grid_trim=128)
+    assert b.grid_reserve == 128 and a.grid_reserve == 0
+    for _ in range(4):
+        pipe.submit(feats, metas)
+    with_b = pipe.flush()[-1][0]
+    again = [t for t in a.simple_test_bboxes(feats, metas)[0] if t.is_cuda]
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(alone, again))
+    # (the reserve changes which workgroup computes which tile, never a result)
+    assert all(torch.equal(x, y) for x, y in zip(alone, [t for t in with_b if t.is_cuda]))

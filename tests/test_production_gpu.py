@@ -226,9 +226,15 @@ def test_result_streamer_equals_simple_test():
         for rep in range(2):
             got = []
 
+            def keep(results):
+                # (the arrays are views of the ring entry: copy what outlives `ring` pushes)
+                for r in results:
+                    assert r.formatted_masks["pan_results"] is r.pan_results
+                    got.append({k: np.array(getattr(r, k)) for k in fields})
+
             def take(res):
                 if len(streamer) == streamer.ring:
-                    got.extend(streamer.pop())
+                    keep(streamer.pop())
                 streamer.push(res, pipe)
             for im in imgs:
                 sl = pipe.count % len(pipe.streams_a)
@@ -241,14 +247,11 @@ def test_result_streamer_equals_simple_test():
                 for res in pipe.flush():
                     take(res)
             while len(streamer):
-                got.extend(streamer.pop())
+                keep(streamer.pop())
             assert len(got) == len(want)
             for r, w in zip(got, want):
                 for k in fields:
-                    a = getattr(r, k)
-                    assert isinstance(a, np.ndarray) and a.dtype == w[k].dtype, k
-                    assert np.array_equal(a, w[k]), (graphs, rep, k)
-                assert r.formatted_masks["pan_results"] is r.pan_results
+                    assert r[k].dtype == w[k].dtype and np.array_equal(r[k], w[k]), (graphs, rep, k)
     with pytest.raises(RuntimeError):
         ResultStreamer(head, ring=1).pop()
 

@@ -23,26 +23,6 @@
 #include "common.h"
 #include "gemm_common.h"
 
-// 16-byte load through a buffer descriptor: address = rsrc.base + voff (per lane, bytes)
-// + soff (wave-uniform SGPR, bytes).  The k advance of the GEMM loops rides in soff, so
-// the loop issues NO per-lane address arithmetic (flat loads need a 64-bit VALU add per
-// load, and VALU issued between MFMAs on one accumulator costs ~43 cycles a piece).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
-  // raw buffer, no bounds clamp (callers keep offsets inside the operand)
-  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes,
-                                         int soff_bytes) {
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff_bytes, soff_bytes, 0));
-}
-__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes,
-                                          int soff_bytes) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, soff_bytes, 0);
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
-                     __uint_as_float(v.w));
-}
-
 template <int BM, int BN, int AMODE>
 struct TileSmem {
   static constexpr int A_ELEMS = (AMODE == A_COL) ? 32 * (BM + 4) : BM * 36;

@@ -149,38 +149,57 @@ extern "C" int pn_ppn_front_f32(const float* sub_embed, const float* obj_embed, 
   return PN_LAUNCH_CHECK();
 }
 
-// ---- last layer: C -> 1 (C == 64); one wave per pixel, lane = input channel ----
+// ---- last layer: C -> 1 (C == 64), 7x7, pad 3 ----
+// A workgroup owns an 8 x 8 tile of output pixels: the 14 x 14 x 64 input patch its halo
+// reaches is staged in LDS once (coalesced 256-byte rows; positions outside the map are the
+// convolution's zero padding) together with the 49 x 64 weights, then each of the 4 waves
+// takes 16 pixels with lane = input channel: 49 LDS multiply-adds in (ky, kx) order and one
+// butterfly sum per pixel.  (Round 2 ran one wave per pixel straight from L2: 49 dependent
+// 256-byte loads per wave, 30 us for the 100 x 100 map; this form takes ~8.)
+#define MLL_T 8
+#define MLL_H (MLL_T + 6)
 __global__ __launch_bounds__(256) void k_ml_last(const float* __restrict__ in,
                                                  const float* __restrict__ w3,
                                                  const float* __restrict__ b3,
                                                  float* __restrict__ out, int S) {
-  const int lane = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int b = blockIdx.y;
-  const int pix = blockIdx.x * 4 + pl;
-  if (pix >= S * S) return;
-  const int y = pix / S, x = pix - y * S;
+  __shared__ __attribute__((aligned(16))) float patch[MLL_H * MLL_H * 64];
+  __shared__ __attribute__((aligned(16))) float wt[49 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, y0 = blockIdx.y * MLL_T - 3, x0 = blockIdx.x * MLL_T - 3;
   const float* ib = in + (int64_t)b * S * S * 64;
-  float acc = 0.f;
-#pragma unroll
-  for (int ky = 0; ky < 7; ++ky) {
-    const int yy = y + ky - 3;
-    if (yy < 0 || yy >= S) continue;
-#pragma unroll
-    for (int kx = 0; kx < 7; ++kx) {
-      const int xx = x + kx - 3;
-      if (xx < 0 || xx >= S) continue;
-      acc += ib[((int64_t)yy * S + xx) * 64 + lane] * w3[(ky * 7 + kx) * 64 + lane];
-    }
+  for (int e = tid; e < MLL_H * MLL_H * 16; e += 256) {     // one float4 per (position, 4 ch)
+    const int pos = e >> 4, c4 = (e & 15) * 4;
+    const int yy = y0 + pos / MLL_H, xx = x0 + pos % MLL_H;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (yy >= 0 && yy < S && xx >= 0 && xx < S) v = ld4(ib + ((int64_t)yy * S + xx) * 64 + c4);
+    st4(patch + pos * 64 + c4, v);
   }
-  acc = wave_sum(acc);
-  if (lane == 0) out[(int64_t)b * S * S + pix] = acc + b3[0];
+  for (int e = tid; e < 49 * 16; e += 256) st4(wt + e * 4, ld4(w3 + e * 4));
+  __syncthreads();
+  const float bias = b3[0];
+  for (int p = wave; p < MLL_T * MLL_T; p += 4) {
+    const int y = p / MLL_T, x = p - y * MLL_T;
+    const int gy = y0 + 3 + y, gx = x0 + 3 + x;
+    if (gy >= S || gx >= S) continue;                       // (uniform per wave)
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx)
+        acc += patch[((y + ky) * MLL_H + (x + kx)) * 64 + lane] * wt[(ky * 7 + kx) * 64 + lane];
+    acc = wave_sum(acc);
+    if (lane == 0) out[(int64_t)b * S * S + (int64_t)gy * S + gx] = acc + bias;
+  }
 }
 
 extern "C" int pn_mlearner_last_f32(const float* in, const float* w3, const float* b3,
                                     float* out, int B, int S, int C, void* stream) {
-  if (!in || !w3 || !b3 || !out || C != 64 || B <= 0 || S <= 0) return PN_BAD_ARG;
-  hipLaunchKernelGGL(k_ml_last, dim3(pn_cdiv((int64_t)S * S, 4), B), dim3(256), 0,
-                     (hipStream_t)stream, in, w3, b3, out, S);
+  if (!in || !w3 || !b3 || !out || C != 64 || B <= 0 || S <= 0 || B > 65535 ||
+      (((uintptr_t)in | (uintptr_t)w3) & 15))
+    return PN_BAD_ARG;
+  const int nt = pn_cdiv(S, MLL_T);
+  hipLaunchKernelGGL(k_ml_last, dim3(nt, nt, B), dim3(256), 0, (hipStream_t)stream, in, w3, b3,
+                     out, S);
   return PN_LAUNCH_CHECK();
 }
 

@@ -414,6 +414,9 @@ class CrossHead2:
         pl.s1, pl.s2, pl.sn, pl.on = E(BQ, 256), E(BQ, 256), E(BQ, 256), E(BQ, 256)
         pl.imp_raw, pl.imp = E(B, Q, Q), E(B, Q, Q)
         pl.c1, pl.c2 = E(B, Q * Q, 64), E(B, Q * Q, 64)
+        # split-K workspace of the 64 -> 64 Matrix Learner layer (few output tiles, K = 3136)
+        tiles = B * ((Q * Q + 63) // 64)
+        pl.ppn_splitk = E(8 * B * Q * Q * 64) if tiles < 512 else None
         i64 = lambda *s: torch.empty(*s, device=dev, dtype=torch.int64)
         pl.topk_idx, pl.sub_pos, pl.obj_pos = i64(B, R), i64(B, R), i64(B, R)
         pl.pair_idx = i64(B, 2 * R)
@@ -692,8 +695,10 @@ class CrossHead2:
             hip.gemm(pl.sn, pl.on, pl.imp_raw, M=Q, N=Q, K=256, lda=256, ldw=256, ldc=Q, batch=B,
                      sA=Q * 256, sW=Q * 256, sC=Q * Q)
             hip.mlearner_first(pl.imp_raw, w[ml + "0.0.weight"], w[ml + "0.0.bias"], pl.c1, B, Q)
-        hip.conv2d_nhwc(pl.c1, w[ml + "1.0.weight"], w[ml + "1.0.bias"], pl.c2, B, Q, Q, 64, 64,
-                        7, 7, 3, True)
+        # (157 output tiles x K = 3136 at Q = 100: the K contraction is split, which takes the
+        # layer from 112 to ~45 us on the dependent chain)
+        hip.conv2d_ex(pl.c1, w[ml + "1.0.weight"], w[ml + "1.0.bias"], None, pl.c2, B, Q, Q, 64,
+                      64, 7, 7, 1, 3, relu=True, scratch=pl.ppn_splitk)
         hip.mlearner_last(pl.c2, w[ml + "2.0.weight"], w[ml + "2.0.bias"], pl.imp, B, Q)
         hip.topk_pairs(pl.imp, pl.topk_idx, pl.sub_pos, pl.obj_pos, B, Q, R, pair=pl.pair_idx)
         # ---- pair features (:342-351) ----

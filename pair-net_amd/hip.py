@@ -224,6 +224,7 @@ class KernelTimer:
     def __init__(self, only=None):
         self.only = set(only) if only else None
         self.records = []   # (name, flops, bytes, start_event, end_event)
+        self.meta = []      # per record: problem description (GEMMs: M, N, K, batch) or None
 
     def summary(self):
         torch.cuda.synchronize()
@@ -240,7 +241,7 @@ class KernelTimer:
 TIMER = None
 
 
-def _launch(name, flops, nbytes, fn):
+def _launch(name, flops, nbytes, fn, meta=None):
     t = TIMER
     if t is None or (t.only is not None and name not in t.only):
         return fn()
@@ -249,6 +250,7 @@ def _launch(name, flops, nbytes, fn):
     r = fn()
     e.record()
     t.records.append((name, flops, nbytes, s, e))
+    t.meta.append(meta)
     return r
 
 
@@ -305,7 +307,8 @@ def gemm(A, W, Cout, **kw):
     name = GEMM_KERNELS[lib().pn_gemm_variant(C.byref(d))]
     nbytes = 4.0 * d.batch * (d.M * d.K + d.N * d.K + d.M * d.N)
     _check(_launch(name, 2.0 * d.M * d.N * d.K * d.batch, nbytes,
-                   lambda: lib().pn_gemm_f32(C.byref(d), _stream())), "pn_gemm_f32")
+                   lambda: lib().pn_gemm_f32(C.byref(d), _stream()),
+                   meta=(d.M, d.N, d.K, d.batch, bool(d.splitk_scratch))), "pn_gemm_f32")
 
 
 def gemm_group(problems):

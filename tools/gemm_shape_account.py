@@ -19,10 +19,11 @@ for _ in range(REP):
     head.simple_test_bboxes(bb(img), metas)
 torch.cuda.synchronize()
 agg = {}
-for name, flops, nbytes, s, e in hip.TIMER.records:
+for (name, flops, nbytes, s, e), meta in zip(hip.TIMER.records, hip.TIMER.meta):
     if "k_gemm_tile" not in name and "k_gemm_group" not in name:
         continue
-    a = agg.setdefault((name, flops, nbytes), [0, 0.0])
+    a = agg.setdefault((name + (" %dx%dx%d b%d%s" % (meta[:4] + ("s" if meta[4] else "",)) if meta else ""),
+                        flops, nbytes), [0, 0.0])
     a[0] += 1; a[1] += s.elapsed_time(e)
 hip.TIMER = None
 rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
@@ -30,6 +31,6 @@ tot = sum(v[1] for _, v in rows) / REP
 print("total %.3f ms/step over %d shapes" % (tot, len(rows)))
 for (name, flops, nbytes), (n, ms) in rows:
     ms1 = ms / n
-    print("%-36s x%-3d %7.1f us  %6.1f TF  %5.2f TB/s  %6.2f GF  %6.1f MB  (%.1f%%)" % (
-        name[-28:], n // REP, ms1 * 1e3, flops / ms1 * 1e-9, nbytes / ms1 * 1e-9, flops * 1e-9,
+    print("%-46s x%-3d %7.1f us  %6.1f TF  %5.2f TB/s  %6.2f GF  %6.1f MB  (%.1f%%)" % (
+        name[-44:], n // REP, ms1 * 1e3, flops / ms1 * 1e-9, nbytes / ms1 * 1e-9, flops * 1e-9,
         nbytes * 1e-6, 100 * ms / REP / tot))

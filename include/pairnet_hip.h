@@ -59,6 +59,10 @@ int pn_abi_version(void);
  * process-wide knob: two callers in one process cannot change each other's grids. */
 #define PN_GEMM_RESERVE_SHIFT 16
 #define PN_GEMM_RESERVE(n) ((((n) / 8) & 0x3ff) << PN_GEMM_RESERVE_SHIFT)
+/* Tuning: force the number of K slices of the split-K path (1 = never split; 0 = the
+ * library's own choice; needs splitk_scratch). */
+#define PN_GEMM_KSPLIT_SHIFT 26
+#define PN_GEMM_KSPLIT(n) (((n) & 31) << PN_GEMM_KSPLIT_SHIFT)
 
 typedef struct pn_gemm_desc {
   const float* A;     int64_t lda;    int64_t strideA;    /* [M][K] (or [K][M])    */

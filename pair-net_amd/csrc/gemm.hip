@@ -649,16 +649,18 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
 // Number of K splits for a 64x64-tile launch: enough work items for ~4 workgroups per CU,
 // at least 4 chunks (128 k) per split, and the partials must fit the caller's scratch.
 static int splitk_factor(const GemmP& p, int batch, const float* scratch, int64_t scratch_floats,
-                         int* chunks_per_split) {
+                         int* chunks_per_split, int flags) {
   const int nk = pn_cdiv(p.K, 32);
   const int64_t tiles = (int64_t)pn_cdiv(p.M, 64) * pn_cdiv(p.N, 64) * batch;
   *chunks_per_split = nk;
-  if (!scratch || tiles >= 512 || nk < 8 || (p.N & 3) || !aligned16(p.bias) ||
-      ((uintptr_t)scratch & 15))
+  const int forced = (flags >> PN_GEMM_KSPLIT_SHIFT) & 31;   // tuning: PN_GEMM_KSPLIT(n)
+  if (!scratch || (p.N & 3) || !aligned16(p.bias) || ((uintptr_t)scratch & 15) || forced == 1)
     return 1;
-  int S = (int)((1024 + tiles - 1) / tiles);
+  if (!forced && (tiles >= 512 || nk < 8)) return 1;
+  int S = forced ? forced : (int)((1024 + tiles - 1) / tiles);
   if (S > 16) S = 16;
-  if (S > nk / 4) S = nk / 4;
+  if (!forced && S > nk / 4) S = nk / 4;
+  if (S > nk) S = nk;
   const int64_t per = (int64_t)batch * p.M * p.N;
   if ((int64_t)S * per > scratch_floats) S = (int)(scratch_floats / per);
   if (S < 2) return 1;
@@ -671,7 +673,7 @@ template <int AMODE>
 static int launch_tile64_splitk(const GemmP& p, int batch, float* scratch, int64_t scratch_floats,
                                 hipStream_t s, int flags) {
   int cps;
-  const int S = splitk_factor(p, batch, scratch, scratch_floats, &cps);
+  const int S = splitk_factor(p, batch, scratch, scratch_floats, &cps, flags);
   if (S <= 1) return launch_tile<64, 64, 32, 32, AMODE>(p, batch, s, flags);
   GemmP q = p;                       // pass 1: raw partial products into the scratch
   q.C = scratch; q.ldc = p.N; q.sC = (int64_t)p.M * p.N;

@@ -279,7 +279,7 @@ def _rowmajor(t):
 def gemm_desc(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaadd=0,
               aadd_rows=0, aadd_from_col=0, res=None, ldres=0, batch=1, sA=0, sW=0, sC=0,
               sRes=0, relu=False, colmajor=False, force=None, into=None,
-              relu_after=False, scratch=None, gelu=False):
+              relu_after=False, scratch=None, gelu=False, ksplit=0):
     """Fill a pn_gemm_desc; tensors only supply base pointers."""
     d = into if into is not None else GemmDesc()
     d.A, d.lda, d.strideA = _ptr(A), lda, sA
@@ -291,7 +291,7 @@ def gemm_desc(A, W, Cout, *, M, N, K, lda, ldw, ldc, bias=None, aadd=None, ldaad
     d.M, d.N, d.K, d.batch = M, N, K, batch
     d.flags = (GEMM_RELU if relu else 0) | (GEMM_A_COLMAJOR if colmajor else 0) | \
         {None: 0, "tile": GEMM_FORCE_TILE, "skinny": GEMM_FORCE_SKINNY, "tile64": 16,
-         "tile128x64": 32}[force] | _reserve_flag() | \
+         "tile128x64": 32}[force] | _reserve_flag() | ((ksplit & 31) << 26) | \
         (GEMM_RELU_AFTER_RES if relu_after else 0) | (GEMM_GELU if gelu else 0)
     d.splitk_scratch = _ptr(scratch)
     d.splitk_scratch_floats = scratch.numel() if scratch is not None else 0

@@ -186,8 +186,8 @@ extern "C" int pn_msda_f32(const float* value, int64_t ld_value, const float* of
     if (c > per_band) per_band = c;
   }
   if ((int64_t)n * ld_value * 4 >= ((int64_t)1 << 32)) return PN_BAD_ARG;   // 32-bit tap offsets
-  const dim3 grid((per_band + MSDA_TQ - 1) / MSDA_TQ * 8, B);
   hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((per_band + MSDA_TQ - 1) / MSDA_TQ * 8, B);
   switch (L) {
     case 1: hipLaunchKernelGGL(k_msda<1>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
     case 2: hipLaunchKernelGGL(k_msda<2>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;

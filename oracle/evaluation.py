@@ -117,3 +117,63 @@ def evaluate_boxes(labels, rel_pairs, rel_dists, boxes, gt_rels, gt_labels, gt_b
         out[name + "_recall"] = rec
         out[("" if not ph else "phrdet_") + "pred_to_gt"] = p2g
     return out
+
+
+# ---- dataset-level aggregation: SGRecall / SGMeanRecall / SGPairAccuracy ----------------
+# pairnet/evaluation/sgg_metrics.py: recall lists are averaged over images (:100-141,
+# `np.mean(v)` in _print_single); SGMeanRecall collects per image, per predicate, the recall
+# of that predicate's ground-truth relations (`_collect_single` :741-766; index 0 collects
+# "all predicates") and averages per predicate over the images that have it, then over the
+# num_rel - 1 predicates (`_calculate_single` :768-792; a predicate no image has counts as
+# 0); SGPairAccuracy (:537-667) is a no-op in sgdet mode apart from `prepare_gtpair` (:632-641).
+def mean_recall_collect(pred_to_gt, gt_rels, num_rel, ks=(20, 50, 100)):
+    """One image -> {k: {predicate n: recall of its gt relations}} (only predicates present)."""
+    out = {}
+    for k in ks:
+        match = reduce(np.union1d, pred_to_gt[:k])
+        hit, count = [0] * num_rel, [0] * num_rel
+        for idx in range(gt_rels.shape[0]):
+            count[int(gt_rels[idx, 2])] += 1
+            count[0] += 1
+        for idx in range(len(match)):
+            hit[int(gt_rels[int(match[idx]), 2])] += 1
+            hit[0] += 1
+        out[k] = {n: float(hit[n] / count[n]) for n in range(num_rel) if count[n] > 0}
+    return out
+
+
+def mean_recall(collected, num_rel, ks=(20, 50, 100)):
+    """`collected`: the per-image dicts of mean_recall_collect -> ({k: mR@k}, {k: per-predicate
+    list over predicates 1..num_rel-1})."""
+    mr, lists = {}, {}
+    for k in ks:
+        per = [[] for _ in range(num_rel)]
+        for img in collected:
+            for n, v in img[k].items():
+                per[n].append(v)
+        lst = [0.0 if len(per[n + 1]) == 0 else float(np.mean(per[n + 1]))
+               for n in range(num_rel - 1)]
+        lists[k] = lst
+        mr[k] = sum(lst) / float(num_rel - 1)
+    return mr, lists
+
+
+def pred_pair_in_gt(rel_pairs, gt_rels):
+    p = rel_pairs[:, 0] * 10000 + rel_pairs[:, 1]
+    g = gt_rels[:, 0] * 10000 + gt_rels[:, 1]
+    return (p[:, None] == g[None, :]).sum(-1) > 0
+
+
+def iou_panseg(gt_triplets, pred_classes, gt_triplet_masks, pred_masks):
+    """`_compute_iou_panseg` (:1087-1131): for every ground-truth triplet whose subject
+    (object) class occurs among the predicted classes, the best mask IoU over the predictions
+    of that class."""
+    subs, objs = [], []
+    for col, which, out in ((0, 0, subs), (2, 1, objs)):
+        keep = gt_triplets[:, col][:, None] == pred_classes[None, :]
+        for g in np.where(keep.any(1))[0]:
+            best = 0
+            for pm in pred_masks[keep[g]]:
+                best = max(mask_iou(gt_triplet_masks[g, which], pm), best)
+            out.append(best)
+    return np.array(subs), np.array(objs)

@@ -15,10 +15,12 @@ from .preprocess import TestPipeline  # noqa: F401
 from .detector import (PSGTr, Result, ResultStreamer, build_detector, load_checkpoint,  # noqa: F401
                        triplet2Result)
 from .dist import all_gather_triplets, shard_indices  # noqa: F401
+from .evaluation import SceneGraphMetrics, TripletEvaluator  # noqa: F401
 
 __all__ = ["ConfigDict", "load_config", "pairnet_head_cfg", "pairnet_r50", "CrossHead2",
            "PSGTr", "Result", "ResultStreamer", "build_detector", "load_checkpoint", "triplet2Result", "all_gather_triplets",
            "shard_indices", "PipelinedHead", "CrossHeadBaseline", "baseline_head_cfg",
            "baseline_r50", "PSGTrHead2", "psgtr2_head_cfg", "psgtr2_r50", "ResNet50Hip",
            "SwinTransformerHip", "pairnet_swin", "swin_backbone_cfg", "TestPipeline", "test_pipeline_cfg",
-           "CrossHeadBBox", "ChannelMapper", "bbox_head_cfg", "channel_mapper_cfg", "cross_r101_vg"]
+           "CrossHeadBBox", "ChannelMapper", "bbox_head_cfg", "channel_mapper_cfg", "cross_r101_vg",
+           "TripletEvaluator", "SceneGraphMetrics"]

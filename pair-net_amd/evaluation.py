@@ -9,7 +9,13 @@ order (:95-99).  `TripletEvaluator` produces the same `pred_to_gt` lists and rec
 the device-resident 8-tuple of `get_bboxes`, so the 200 full-size masks never leave the
 GPU: masks are bit-packed (`pn_pack_mask_bits`), the IoU counts are exact integer popcounts
 (`pn_mask_iou_counts`), the match matrix is one small kernel (`pn_triplet_match`); only
-that R x G byte matrix is copied to the host.
+that R x G byte matrix is copied to the host.  `SceneGraphMetrics` is the dataset-level
+aggregation on top: R@K averaged over images (:100-141), the reference's headline metric
+mean recall (`SGMeanRecall`, :669-916: per-predicate recall averaged over the images that
+have the predicate, then over the predicates), phrase-detection variants, and the
+subject / object IoU statistic (`_compute_iou_panseg`, :1087-1131, from the same exact
+popcounts).  Images without ground-truth relations are skipped, as the reference's
+`sgg_evaluate` loop does.
 """
 import numpy as np
 import torch
@@ -99,6 +105,10 @@ class TripletEvaluator:
         """sgdet + phrdet recalls of one image from box results (the graph-constrained part of
         `calculate_recall`, sgg_metrics.py:173-252)."""
         n = len(gt_rels)
+        if n == 0:
+            R = int(result[5].shape[0])
+            return dict(pred_to_gt=[[] for _ in range(R)], phrdet_pred_to_gt=[[] for _ in range(R)],
+                        sgdet_recall=None, phrdet_recall=None)
         p2g = self.pred_to_gt(self.match_boxes(result, gt_rels, gt_labels, gt_boxes))
         ph = self.pred_to_gt(self.match_boxes(result, gt_rels, gt_labels, gt_boxes, phrdet=True))
         return dict(pred_to_gt=p2g, phrdet_pred_to_gt=ph, sgdet_recall=self.recall(p2g, n),
@@ -119,10 +129,140 @@ class TripletEvaluator:
             out[k] = len(hit) / float(num_gt)
         return out
 
+    @torch.no_grad()
+    @hip.on_device
+    def iou_stats(self, result, gt_rels, gt_labels, gt_masks):
+        """`_compute_iou_panseg` (sgg_metrics.py:1087-1131) from device-resident masks: for
+        every ground-truth triplet whose subject (object) class occurs among the 2R predicted
+        labels, the best mask IoU over the predictions of that class.  Returns two float64
+        arrays (subjects, objects), in ground-truth triplet order."""
+        labels, masks = result[1], result[3]
+        dev = masks.device
+        H, W = masks.shape[-2:]
+        gt_rels = np.asarray(gt_rels)
+        gt_labels_np = np.asarray(gt_labels)
+        nobj, P = int(gt_labels_np.shape[0]), int(masks.shape[0])
+        gm = torch.as_tensor(np.asarray(gt_masks)).to(dev).view(nobj, H, W)
+        nw = (H * W + 63) // 64
+        pw = torch.empty(P, nw, device=dev, dtype=torch.int64)
+        gw = torch.empty(nobj, nw, device=dev, dtype=torch.int64)
+        hip.pack_mask_bits(masks.view(torch.uint8), pw, P, H * W)
+        hip.pack_mask_bits(gm.to(torch.uint8), gw, nobj, H * W)
+        inter = torch.empty(P, nobj, device=dev, dtype=torch.int32)
+        ap = torch.empty(P, device=dev, dtype=torch.int32)
+        ag = torch.empty(nobj, device=dev, dtype=torch.int32)
+        hip.mask_iou_counts(pw, P, gw, nobj, nw, inter, ap, ag)
+        inter, ap, ag = (t.cpu().numpy().astype(np.int64) for t in (inter, ap, ag))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            iou = inter.astype(np.float64) / (ap[:, None] + ag[None, :] - inter).astype(np.float64)
+        pl = labels.cpu().numpy()
+        out = []
+        for col in (0, 1):
+            vals = []
+            for g in range(gt_rels.shape[0]):
+                o = int(gt_rels[g, col])
+                same = pl == gt_labels_np[o]
+                if same.any():
+                    best = 0
+                    for v in iou[same, o]:      # (python max: a NaN IoU never replaces `best`)
+                        best = max(v, best)
+                    vals.append(best)
+            out.append(np.array(vals))
+        return out[0], out[1]
+
     def __call__(self, result, gt_rels, gt_labels, gt_masks):
-        """sgdet + phrdet recalls of one image, as `calculate_recall` records them."""
+        """sgdet + phrdet recalls of one image, as `calculate_recall` records them.  An image
+        without ground-truth relations has nothing to match (the reference's loop skips it):
+        empty lists, no recalls."""
         n = len(gt_rels)
+        if n == 0:
+            R = int(result[7].shape[0])
+            return dict(pred_to_gt=[[] for _ in range(R)], phrdet_pred_to_gt=[[] for _ in range(R)],
+                        sgdet_recall=None, phrdet_recall=None)
         p2g = self.pred_to_gt(self.match(result, gt_rels, gt_labels, gt_masks))
         ph = self.pred_to_gt(self.match(result, gt_rels, gt_labels, gt_masks, phrdet=True))
         return dict(pred_to_gt=p2g, phrdet_pred_to_gt=ph, sgdet_recall=self.recall(p2g, n),
                     phrdet_recall=self.recall(ph, n))
+
+
+class SceneGraphMetrics:
+    """Dataset-level aggregation of `TripletEvaluator` outputs: what the reference's
+    `sgg_evaluate` prints for mode "sgdet" -- R@K and mR@K (graph constraint), their
+    phrase-detection variants, and the subject / object IoU lists.
+
+        metrics = SceneGraphMetrics(num_predicates=56)
+        for each image:  metrics.add(evaluator(result, gt_rels, gt_labels, gt_masks), gt_rels)
+        metrics.summary()   ->  {"sgdet_recall": {20: .., 50: .., 100: ..},
+                                 "sgdet_mean_recall": {...}, "sgdet_mean_recall_list": {...},
+                                 "phrdet_recall": ..., "phrdet_mean_recall": ..., "images": n}
+    """
+
+    def __init__(self, num_predicates, ks=(20, 50, 100)):
+        self.num_rel = int(num_predicates) + 1        # + __background__ (:681-683)
+        self.ks = tuple(ks)
+        self.recalls = {m: {k: [] for k in self.ks} for m in ("sgdet", "phrdet")}
+        self.collect = {m: {k: [[] for _ in range(self.num_rel)] for k in self.ks}
+                        for m in ("sgdet", "phrdet")}
+        self.sub_iou, self.obj_iou = [], []
+        self.images = self.skipped = 0
+
+    def _collect(self, mode, pred_to_gt, gt_rels):
+        """`SGMeanRecall._collect_single` (:741-766)."""
+        for k in self.ks:
+            match = set()
+            for lst in pred_to_gt[:k]:
+                match.update(lst)
+            hit, count = [0] * self.num_rel, [0] * self.num_rel
+            for g in range(gt_rels.shape[0]):
+                count[int(gt_rels[g, 2])] += 1
+                count[0] += 1
+            for g in match:
+                hit[int(gt_rels[int(g), 2])] += 1
+                hit[0] += 1
+            for n in range(self.num_rel):
+                if count[n] > 0:
+                    self.collect[mode][k][n].append(float(hit[n] / count[n]))
+
+    def add(self, image_eval, gt_rels, iou=None):
+        """`image_eval`: what `TripletEvaluator.__call__` / `evaluate_boxes` returned for the
+        image; `iou`: optionally `TripletEvaluator.iou_stats(...)` of the same image."""
+        gt_rels = np.asarray(gt_rels).reshape(-1, 3)
+        if gt_rels.shape[0] == 0:
+            self.skipped += 1
+            return
+        self.images += 1
+        for mode, key in (("sgdet", "pred_to_gt"), ("phrdet", "phrdet_pred_to_gt")):
+            for k in self.ks:
+                self.recalls[mode][k].append(image_eval[mode + "_recall"][k])
+            self._collect(mode, image_eval[key], gt_rels)
+        if iou is not None:
+            self.sub_iou.extend(iou[0])
+            self.obj_iou.extend(iou[1])
+
+    def summary(self):
+        """`SGRecall._print_single` / `SGMeanRecall._calculate_single` (:768-792)."""
+        out = dict(images=self.images, skipped=self.skipped)
+        for mode in ("sgdet", "phrdet"):
+            out[mode + "_recall"] = {k: float(np.mean(v)) if v else 0.0
+                                     for k, v in self.recalls[mode].items()}
+            mr, lists = {}, {}
+            for k in self.ks:
+                per = self.collect[mode][k]
+                lst = [0.0 if len(per[n + 1]) == 0 else float(np.mean(per[n + 1]))
+                       for n in range(self.num_rel - 1)]
+                lists[k] = lst
+                mr[k] = sum(lst) / float(self.num_rel - 1)
+            out[mode + "_mean_recall"], out[mode + "_mean_recall_list"] = mr, lists
+        if self.sub_iou or self.obj_iou:
+            out["subject-IoU"] = float(np.mean(self.sub_iou)) if self.sub_iou else 0.0
+            out["object-IoU"] = float(np.mean(self.obj_iou)) if self.obj_iou else 0.0
+        return out
+
+    @staticmethod
+    def pred_pair_in_gt(rel_pairs, gt_rels):
+        """`SGPairAccuracy.prepare_gtpair` (:632-641).  (The accuracy itself is only
+        accumulated for modes other than "sgdet", :571-585: nothing to add for PSG.)"""
+        rel_pairs, gt_rels = np.asarray(rel_pairs), np.asarray(gt_rels)
+        p = rel_pairs[:, 0] * 10000 + rel_pairs[:, 1]
+        g = gt_rels[:, 0] * 10000 + gt_rels[:, 1]
+        return (p[:, None] == g[None, :]).sum(-1) > 0

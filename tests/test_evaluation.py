@@ -78,6 +78,43 @@ def test_evaluation_oracle_equals_the_reference_functions():
         rec._calculate_single(rec.result_dict, ours["pred_to_gt"], gt_rels, "sgdet")
         assert {k: v[0] for k, v in rec.result_dict["sgdet_recall"].items()} == ours["sgdet_recall"]
         assert sum(len(x) for x in ours["pred_to_gt"]) >= 9      # the scene really has matches
+        # the subject / object IoU statistic (:1087-1131)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            rs, ro = M._compute_iou_panseg(gt_t, labels, gt_tm, masks)
+            os_, oo = OE.iou_panseg(gt_t, labels, gt_tm, masks)
+        assert np.array_equal(rs, os_) and np.array_equal(ro, oo) and len(rs) > 0
+    # ---- dataset level: SGMeanRecall (:669-916) over several images ----
+    num_rel = 57
+    mr = M.SGMeanRecall({}, {}, [], num_rel, ["bg"] + ["p%d" % i for i in range(1, num_rel)],
+                        detection_method="pan_seg")
+    mr.register_container("sgdet")
+    collected, recalls = [], {k: [] for k in (20, 50, 100)}
+    from pairnet_amd.evaluation import SceneGraphMetrics
+    agg = SceneGraphMetrics(num_predicates=56)
+    for seed in (1, 2, 3, 4):
+        labels, rel_pairs, rel_dists, masks, gt_rels, gt_labels, gt_masks = _scene(seed)
+        ours = OE.evaluate(labels, rel_pairs, rel_dists, masks, gt_rels, gt_labels, gt_masks)
+        local = dict(pred_to_gt=ours["pred_to_gt"], phrdet_pred_to_gt=ours["phrdet_pred_to_gt"],
+                     gt_rels=gt_rels)
+        mr.collect_mean_recall_items({}, local, "sgdet")
+        collected.append((OE.mean_recall_collect(ours["pred_to_gt"], gt_rels, num_rel),
+                          OE.mean_recall_collect(ours["phrdet_pred_to_gt"], gt_rels, num_rel)))
+        agg.add(ours, gt_rels)
+        holder = types.SimpleNamespace()
+        M.SGPairAccuracy.prepare_gtpair(holder, dict(pred_rel_inds=rel_pairs, gt_rels=gt_rels))
+        assert np.array_equal(holder.pred_pair_in_gt, OE.pred_pair_in_gt(rel_pairs, gt_rels))
+        assert np.array_equal(holder.pred_pair_in_gt,
+                              SceneGraphMetrics.pred_pair_in_gt(rel_pairs, gt_rels))
+    agg.add(dict(pred_to_gt=[], phrdet_pred_to_gt=[], sgdet_recall=None, phrdet_recall=None),
+            np.zeros((0, 3), int))                              # an image without relations
+    mr.calculate_mean_recall("sgdet")
+    for mode, j in (("sgdet", 0), ("phrdet", 1)):
+        want, want_list = mr.result_dict[mode + "_mean_recall"], mr.result_dict[mode + "_mean_recall_list"]
+        got, got_list = OE.mean_recall([c[j] for c in collected], num_rel)
+        assert got == want and got_list == want_list
+        summ = agg.summary()
+        assert summ[mode + "_mean_recall"] == want and summ[mode + "_mean_recall_list"] == want_list
+    assert summ["images"] == 4 and summ["skipped"] == 1 and summ["sgdet_mean_recall"][100] > 0
 
 
 @pytest.mark.gpu
@@ -96,6 +133,16 @@ def test_device_evaluator_feed_equals_the_oracle(seed):
     assert out["sgdet_recall"] == ref["sgdet_recall"]
     assert out["phrdet_recall"] == ref["phrdet_recall"]
     assert out["sgdet_recall"][100] > 0.5                        # (the planted hits are found)
+    # the IoU statistic from the same device popcounts
+    ev = TripletEvaluator()
+    gt_t, gt_tm = OE.triplets(gt_rels, gt_labels, gt_masks)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want_s, want_o = OE.iou_panseg(gt_t, labels, gt_tm, masks)
+    got_s, got_o = ev.iou_stats(result, gt_rels, gt_labels, gt_masks)
+    assert np.array_equal(got_s, want_s) and np.array_equal(got_o, want_o)
+    # an image without ground-truth relations is skipped, not an error
+    empty = ev(result, np.zeros((0, 3), int), gt_labels, gt_masks)
+    assert empty["sgdet_recall"] is None and len(empty["pred_to_gt"]) == 100
 
 
 # ---- detection_method == "bbox": the box-trunk sibling head's results ----------------------

@@ -95,6 +95,8 @@ def bench_bbox(args, dev, rank, world):
     eng = None if args.no_pipeline else PipelinedHead(
         head, depth=depth, a_streams=args.a_streams,
         **({} if args.grid_trim is None else dict(grid_trim=args.grid_trim)))
+    if eng is not None:     # the producers in front of stage A run on the stage-A streams too
+        det.backbone.grid_reserve = det.neck.grid_reserve = eng.grid_reserve
     count = [0]
 
     def step():
@@ -735,6 +737,25 @@ def main():
         if backbone is not None and not swin:
             backbone.use_graphs = not args.no_graphs
         out["latency_ms_single_stream_graphs"] = timeit(whole, 10)
+        if engine is not None and not args.exact_mask_order:
+            # the same pipelined steps with the attention masks in the REFERENCE's operation
+            # order (full-size mask logits -> bilinear resize -> threshold, pairnet_head.py:
+            # 244-256) instead of the once-resampled mask feature of the headline
+            head.exact_mask_order = True
+            for _ in range(2 * args.depth):      # (graphs are re-captured for the new setting)
+                step()
+            drain()
+            dt = timed(min(args.steps, 40))
+            head.exact_mask_order = False
+            for _ in range(2 * args.depth):
+                step()
+            drain()
+            n = min(args.steps, 40)
+            out["reference_mask_order"] = {
+                "images_per_s": B * n / dt, "ms_per_step": 1e3 * dt / n, "steps": n,
+                "what": "headline schedule with exact_mask_order=True: every decoder layer's "
+                        "attention mask from the full-size mask logits, resized, thresholded "
+                        "(the reference's order of operations)"}
         # deformable sampling with learned-like offsets: default-init weights give every token
         # mmcv's +-1..4 px grid (a tight neighbourhood); the same kernel on the grid plus
         # N(0, 8 px) noise per offset shows how far the rate depends on that locality

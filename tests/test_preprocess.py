@@ -34,7 +34,7 @@ def test_rescale_size_is_mmcv_keep_ratio_arithmetic():
 
 
 @pytest.mark.parametrize("h,w", [(384, 640), (97, 131), (1000, 1500)])
-def test_fixed_point_resize_is_within_one_grey_level_of_float_bilinear(h, w):
+def test_fixed_point_resize_UNPINNED_against_opencv_is_within_one_grey_level_of_float_bilinear(h, w):
     img = _image(3, h, w)
     hn, wn = OP.rescale_size(h, w)
     got = OP.resize_linear_u8(img, hn, wn).astype(np.int32)

@@ -13,12 +13,12 @@ AMODE = {"0": "A_ROW", "1": "A_COL", "2": "A_CONV"}
 
 
 def bench_name(name):
-    m = re.match(r"void k_gemm_tile<(\d+), (\d+), (\d+), (\d+), (\d), (true|false), (true|false)>",
-                 name)
-    if m:   # <BM, BN, WM, WN, AMODE, positional add, bf16x3 split>
-        base = "k_gemm_tile<%s,%s,%s,%s,%s" % (m.group(1), m.group(2), m.group(3), m.group(4),
-                                                AMODE.get(m.group(5), "A_STEM"))
-        return base + (",bf16x3>" if m.group(7) == "true" else ">")
+    m = re.match(r"void k_gemm_tile<(\d+), (\d+), (\d+), (\d+), (\d), (true|false)>", name)
+    if m:   # <BM, BN, WM, WN, AMODE, positional add>
+        return "k_gemm_tile<%s,%s,%s,%s,%s>" % (m.group(1), m.group(2), m.group(3), m.group(4),
+                                                 AMODE.get(m.group(5), "A_STEM"))
+    if name.startswith("void k_attn_small") or name.startswith("k_attn_chunk"):
+        return "k_attn_chunk"     # (bench.py reports both attention kernels under this name)
     m = re.match(r"void k_gemm_skinny<(\d), \d+>", name)
     if m:
         return "k_gemm_skinny<%s>" % AMODE[m.group(1)]

@@ -1,18 +1,17 @@
 """Tuning aid: time the native Swin backbone at 800x1333 and list its kernels.
-usage: swin_probe.py [T|B|L] [f32|bf16x3] [batch]"""
+usage: swin_probe.py [T|B|L] [batch]"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pairnet_amd import SwinTransformerHip, swin_backbone_cfg, hip
 dev = "cuda:0"
 variant = sys.argv[1] if len(sys.argv) > 1 else "L"
-mode = sys.argv[2] if len(sys.argv) > 2 else "f32"
-B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+mode = "f32"
 H, W = 800, 1333
 cfg = swin_backbone_cfg(variant)
 cfg.pop("type")
 img = torch.randn(B, 3, H, W, device=dev)
 nb = SwinTransformerHip(**cfg).to(dev)
-nb.gemm_mode = mode
 for _ in range(2): nb(img)
 torch.cuda.synchronize()
 t = time.perf_counter()

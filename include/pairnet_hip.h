@@ -430,6 +430,13 @@ int pn_panoptic_continue_f32(void* state, const float* up_scratch, int32_t* area
 int pn_pack_triplets_f32(const int64_t* labels, const float* r_dists, const int64_t* sub_pos,
                          const int64_t* obj_pos, float* rec, int R, int C1, void* stream);
 
+/* Byte copy with a bounded CU footprint (`wgs` workgroups): the device -> pinned-host copy of
+ * `triplet2Result`'s fields (psgtr.py:15-51; 51 MB per 800x1333 image), which as a
+ * hipMemcpyAsync runs as a chip-wide blit kernel that takes workgroup slots from concurrent
+ * GEMMs.  `dst` may be pinned host memory (mapped in the device's address space) or device
+ * memory; src / dst 16-byte aligned. */
+int pn_copy_stream(const void* src, void* dst, int64_t bytes, int wgs, void* stream);
+
 /* Test-time image front end (configs/mask2former/pairnet.py:310-331, mean / std :229-231):
  * mmdet Resize(keep_ratio) [= mmcv.imresize = OpenCV INTER_LINEAR on uint8, fixed point] ->
  * Normalize(to_rgb) -> Pad -> ImageToTensor of one decoded image, fused.

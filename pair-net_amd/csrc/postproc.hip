@@ -687,3 +687,42 @@ extern "C" int pn_triplet_match_boxes(const int32_t* pred_triplets, const int32_
                      phrdet, ignore_rel, match);
   return PN_LAUNCH_CHECK();
 }
+
+// ---- result copy with a bounded CU footprint -------------------------------------------
+// `triplet2Result` (psgtr.py:15-51) moves 51 MB per 800x1333 image to the host (2R x H0 x W0
+// bool masks).  hipMemcpyAsync to pinned memory runs as a chip-wide blit kernel on this
+// stack (rocprofv3: __amd_rocclr_copyBuffer, up to 0.9 ms each) that takes workgroup slots
+// from the persistent GEMMs of the other streams: +1.1 ms per pipelined step.  PCIe needs no
+// width: `wgs` workgroups (16 by default: 16 of 1024 slots) stream the bytes with 16-byte
+// loads / stores into the pinned buffer, which is mapped in the device's address space.
+// src / dst 16-byte aligned; the last bytes % 16 go one by one.
+__global__ __launch_bounds__(256) void k_copy_stream(const uint4* __restrict__ src,
+                                                     uint4* __restrict__ dst, int64_t n16,
+                                                     int64_t bytes) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // four independent 16-byte transfers in flight per thread
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+  if (blockIdx.x == 0) {
+    const unsigned char* s8 = reinterpret_cast<const unsigned char*>(src);
+    unsigned char* d8 = reinterpret_cast<unsigned char*>(dst);
+    for (int64_t t = n16 * 16 + threadIdx.x; t < bytes; t += 256) d8[t] = s8[t];
+  }
+}
+
+extern "C" int pn_copy_stream(const void* src, void* dst, int64_t bytes, int wgs, void* stream) {
+  if (!src || !dst || bytes <= 0 || wgs <= 0 || wgs > 1024 ||
+      (((uintptr_t)src | (uintptr_t)dst) & 15))
+    return PN_BAD_ARG;
+  const int64_t n16 = bytes / 16;
+  int grid = (int)((n16 + 255) / 256);
+  if (grid < 1) grid = 1;
+  if (grid > wgs) grid = wgs;
+  hipLaunchKernelGGL(k_copy_stream, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)src, (uint4*)dst, n16, bytes);
+  return PN_LAUNCH_CHECK();
+}

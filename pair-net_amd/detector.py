@@ -12,6 +12,7 @@ from collections import OrderedDict
 
 import torch
 
+from . import hip
 from .config import ConfigDict
 from .backbone import ResNet50Hip
 from .baseline_head import CrossHeadBaseline
@@ -68,12 +69,14 @@ def triplet2Result(triplets, use_mask, eval_mask_rels=False):
 
 
 class ResultStreamer:
-    """`triplet2Result` (psgtr.py:15-51) for a pipeline of images: the device -> host copies
-    of every field go to a ring of PINNED host buffers on a copy stream of their own, so that
-    the 49 MB of masks of one 800x1333 image (2R x H0 x W0 bool) cross PCIe under the next
-    images' kernels instead of stalling a compute stream, and the host never allocates
-    (a multi-MB host allocation per image is an mmap / munmap pair, and every munmap runs the
-    amdgpu MMU notifier against the busy GPU: ~75 ms stalls measured).
+    """`triplet2Result` (psgtr.py:15-51) for a pipeline of images: every field of a batch's
+    `get_bboxes` tuples is first copied device -> device into ONE staging blob of this ring
+    (51 MB per 800x1333 image: 2R x H0 x W0 bool masks; ~25 us of HBM time on the stream the
+    results are ordered on), which releases the pipeline slot at once; a single copy kernel on
+    a copy stream of its own then moves the blob to a PINNED host buffer, under the next
+    images' kernels, and the host never allocates (a multi-MB host allocation per image is an
+    mmap / munmap pair, and every munmap runs the amdgpu MMU notifier against the busy GPU:
+    ~75 ms stalls measured).
 
         streamer = ResultStreamer(head, ring=4)
         streamer.push(results, pipe)      # results of PipelinedHead.submit() / get_bboxes()
@@ -81,82 +84,93 @@ class ResultStreamer:
         for r in streamer.pop():          # oldest pushed batch -> [Result], same fields and
             ...                           # dtypes as triplet2Result
 
-    `pop()` waits for that batch's copies, checks its panoptic loops like `PSGTr.simple_test`
-    (IndexError when every segment was filtered, pairnet_head.py:882)
-    and returns Results whose arrays are VIEWS of the ring entry: valid until `ring` more
-    batches have been pushed (copy what must live longer).  The reference returns fresh
-    arrays; this is the documented deviation that keeps allocation out of the loop."""
+    What it costs (tools/d2h_probe.py, 800x1333, 51 MB per image): staging alone is free
+    (195 images/s with or without it); moving the bytes over PCIe takes ~1 ms out of every
+    5.1 ms step whichever way it is done -- hipMemcpyAsync per field (which runs as a blit
+    KERNEL on this stack: rocprofv3 shows __amd_rocclr_copyBuffer up to 0.9 ms, no SDMA copy
+    record) 169, `pn_copy_stream` per field with 1 / 4 / 16 / 64 workgroups 142 / 173 / 163 /
+    153, one blob + one launch 156-165 images/s -- i.e. it is the outstanding PCIe writes that
+    slow the concurrent GEMMs down (the memory fabric they share), not the copy kernel's
+    width or the number of launches.  One blob, one launch is kept for its simplicity.
 
-    def __init__(self, head, ring=4, stage_on_device=True):
-        """`stage_on_device`: first copy the results device -> device (51 MB per 800x1333
-        image: ~25 us of HBM time on the stream they are ordered on) into this ring's own
-        device buffers and release the pipeline slot at once; the PCIe copy (~2 ms) then reads
-        the staged copy, so a slow host link never holds back the slot's next image."""
+    `pop()` waits for that batch's copy, checks its panoptic loops like `PSGTr.simple_test`
+    (IndexError when every segment was filtered, pairnet_head.py:882) and returns Results
+    whose arrays are VIEWS of the ring entry: valid until `ring` more batches have been pushed
+    (copy what must live longer).  The reference returns fresh arrays; this is the documented
+    deviation that keeps allocation out of the loop."""
+
+    ALIGN = 256
+
+    def __init__(self, head, ring=4, copy_wgs=8):
+        """`copy_wgs`: workgroups of the device -> pinned-host copy kernel (`pn_copy_stream`):
+        PCIe needs no width (one workgroup moves 7 GB/s; 8 keep the copy well under a step)."""
         if head.device is None or head.device.type != "cuda":
             raise RuntimeError("ResultStreamer needs a head on an MI355X")
         self.head, self.device, self.ring = head, head.device, ring
-        self.stage_on_device = stage_on_device
+        self.copy_wgs = max(1, int(copy_wgs))
         with torch.cuda.device(self.device):
             self.stream = torch.cuda.Stream()
-        self.entries = [None] * ring      # dict(key, host buffers, event, jobs)
+        self.entries = [None] * ring      # dict(key, blobs, field views, event, jobs)
         self.head_i = self.tail_i = 0     # push / pop counters
 
-    def _host(self, key, results):
+    def _entry(self, key, results, n_jobs):
         e = self.entries[self.head_i % self.ring]
-        if e is None or e["key"] != key:
-            bufs = [[torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-                     if isinstance(t, torch.Tensor) and t.is_cuda else t for t in tup]
-                    for tup in results]
-            states = [torch.empty(16, dtype=torch.uint8, pin_memory=True) for _ in results]
-            dev = None
-            if self.stage_on_device:
-                dev = [[torch.empty_like(t) if isinstance(t, torch.Tensor) and t.is_cuda else None
-                        for t in tup] for tup in results]
-                dev_states = [torch.empty(16, dtype=torch.uint8, device=self.device)
-                              for _ in results]
-            e = self.entries[self.head_i % self.ring] = dict(
-                key=key, bufs=bufs, states=states, event=torch.cuda.Event(), jobs=(), dev=dev,
-                dev_states=dev_states if dev is not None else None,
-                staged=torch.cuda.Event())
+        if e is not None and e["key"] == key:
+            return e
+        # blob layout: every device tensor of every tuple, then 16 status bytes per image
+        off, slots = 0, []
+        for tup in results:
+            row = []
+            for t in tup:
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    n = t.numel() * t.element_size()
+                    row.append((off, n, t.dtype, tuple(t.shape)))
+                    off += -(-n // self.ALIGN) * self.ALIGN
+                else:
+                    row.append(t)             # (host-side constants pass through)
+            slots.append(row)
+        state_off = off
+        off += self.ALIGN * max(1, n_jobs)
+        dev = torch.empty(off, dtype=torch.uint8, device=self.device)
+        host = torch.empty(off, dtype=torch.uint8, pin_memory=True)
+
+        def views(blob):
+            return [[blob[s[0]:s[0] + s[1]].view(s[2]).view(s[3]) if isinstance(s, tuple) else s
+                     for s in row] for row in slots]
+        e = self.entries[self.head_i % self.ring] = dict(
+            key=key, dev=dev, host=host, dev_fields=views(dev), host_fields=views(host),
+            dev_states=[dev[state_off + i * self.ALIGN:][:16] for i in range(n_jobs)],
+            host_states=[host[state_off + i * self.ALIGN:][:16] for i in range(n_jobs)],
+            event=torch.cuda.Event(), jobs=0)
         return e
 
     @torch.no_grad()
     def push(self, results, pipe=None):
-        """Queue the D2H copies of one batch's `get_bboxes` tuples behind the current stream
-        (the one the results are ordered on).  `pipe`: the PipelinedHead they came from, told
-        when the copy stream has read them (`consumed`)."""
+        """Stage one batch's `get_bboxes` tuples (ordered on the current stream) and queue
+        their copy to the host.  `pipe`: the PipelinedHead they came from; its slot is released
+        as soon as the staging copies are queued (`consumed`)."""
         if self.head_i - self.tail_i >= self.ring:
             raise RuntimeError("ResultStreamer ring is full: pop() before pushing more")
-        key = tuple(tuple((tuple(t.shape), t.dtype) if isinstance(t, torch.Tensor) else None
-                          for t in tup) for tup in results)
-        e = self._host(key, results)
         jobs = tuple(getattr(results, "panoptic_jobs", ()))
+        key = tuple(tuple((tuple(t.shape), t.dtype) if isinstance(t, torch.Tensor) and t.is_cuda
+                          else None for t in tup) for tup in results) + (len(jobs),)
+        e = self._entry(key, results, len(jobs))
+        # (the ring entry's blobs are free again: pop() waited for its copy, and push()
+        # refuses to overtake pop())
         cur = torch.cuda.current_stream(self.device)
-        src, src_states = results, [job[0][:16] for job in jobs]
-        if e["dev"] is not None:
-            # (a ring entry's device copy is free again: pop() waited for its D2H event, and
-            # push() refuses to overtake pop())
-            for tup, stage in zip(results, e["dev"]):
-                for t, d in zip(tup, stage):
-                    if d is not None:
-                        d.copy_(t)
-            for st, d in zip(src_states, e["dev_states"]):
-                d.copy_(st)
-            if pipe is not None:
-                pipe.consumed(results, cur)
-            src, src_states = e["dev"], e["dev_states"]
+        for tup, stage in zip(results, e["dev_fields"]):
+            for t, d in zip(tup, stage):
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    d.copy_(t)
+        for job, d in zip(jobs, e["dev_states"]):
+            d.copy_(job[0][:16])
+        if pipe is not None:
+            pipe.consumed(results, cur)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            for tup, host in zip(src, e["bufs"]):
-                for t, h in zip(tup, host):
-                    if isinstance(t, torch.Tensor) and t.is_cuda:
-                        h.copy_(t, non_blocking=True)
-            for st, h in zip(src_states, e["states"]):
-                h.copy_(st, non_blocking=True)
+            hip.copy_stream(e["dev"], e["host"], self.copy_wgs)
             e["event"].record(self.stream)
-            if pipe is not None and e["dev"] is None:
-                pipe.consumed(results, self.stream)
-        e["jobs"] = jobs
+        e["jobs"] = len(jobs)
         self.head_i += 1
 
     def pop(self):
@@ -165,7 +179,7 @@ class ResultStreamer:
         e = self.entries[self.tail_i % self.ring]
         self.tail_i += 1
         e["event"].synchronize()
-        for job, st in zip(e["jobs"], e["states"]):
+        for st in e["host_states"][:e["jobs"]]:
             nkeep, active, rounds, all_gone = st.view(torch.int32).tolist()
             if all_gone:
                 raise IndexError("every panoptic segment was filtered (the reference fails "
@@ -178,7 +192,7 @@ class ResultStreamer:
                 raise RuntimeError("panoptic loop still active after %d rounds" % rounds)
         use_mask = self.head.use_mask
         return [triplet2Result(tuple(h.numpy() if isinstance(h, torch.Tensor) else h
-                                     for h in host), use_mask) for host in e["bufs"]]
+                                     for h in host), use_mask) for host in e["host_fields"]]
 
     def __len__(self):
         return self.head_i - self.tail_i

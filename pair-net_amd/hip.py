@@ -91,6 +91,7 @@ _SIGS = {
                                                                         _i32, _vp]),
     "pn_panoptic_continue_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_pack_triplets_f32": (C.c_int, [_vp] * 5 + [_i32, _i32, _vp]),
+    "pn_copy_stream": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "pn_pred_triplets": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "pn_mask_or_rows": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _vp]),
     "pn_triplet_match": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
@@ -686,6 +687,20 @@ def pack_triplets(labels, r_dists, sub_pos, obj_pos, rec, R, C1):
     _check(lib().pn_pack_triplets_f32(_ptr(labels, i64), _ptr(r_dists), _ptr(sub_pos, i64),
                                       _ptr(obj_pos, i64), _ptr(rec), R, C1, _stream()),
            "pn_pack_triplets_f32")
+
+
+def copy_stream(src, dst, wgs=16):
+    """dst <- src (same dtype / shape, both contiguous); `dst` may be a PINNED host tensor: the
+    kernel writes it over PCIe from `wgs` workgroups, on torch's current stream."""
+    if src.dtype != dst.dtype or src.numel() != dst.numel() or not (
+            src.is_contiguous() and dst.is_contiguous()):
+        raise RuntimeError("copy_stream takes contiguous tensors of one dtype and size")
+    if not src.is_cuda or not (dst.is_cuda or dst.is_pinned()):
+        raise RuntimeError("copy_stream: device source, device or pinned-host destination")
+    nbytes = src.numel() * src.element_size()
+    if nbytes:
+        _check(lib().pn_copy_stream(src.data_ptr(), dst.data_ptr(), nbytes, int(wgs), _stream()),
+               "pn_copy_stream")
 
 
 def preprocess_u8(img, H, W, out, Hn, Wn, Hp, Wp, mean, stdinv, to_rgb):

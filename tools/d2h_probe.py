@@ -10,43 +10,88 @@ H, W = 800, 1333
 metas = [dict(img_shape=(H, W, 3), scale_factor=[2.083] * 4)]
 g = torch.Generator().manual_seed(1)
 pool = [torch.randn(1, 3, H, W, generator=g).to(dev) for _ in range(8)]
+pipe = PipelinedHead(head, depth=4, a_streams=2)
+net.grid_reserve = pipe.grid_reserve
+cnt = [0]
+take = [None]
 
 
-def run(variant, ring, depth=4, n=60):
-    pipe = PipelinedHead(head, depth=depth, a_streams=2)
-    net.grid_reserve = pipe.grid_reserve
-    st = None if variant == "none" else ResultStreamer(head, ring=ring, stage_on_device=variant == "staged")
-    cnt = [0]
+def one():
+    sl = pipe.count % 2
+    with torch.cuda.stream(pipe.streams_a[sl]):
+        r = pipe.submit(net(pool[cnt[0] % 8], slot=sl), metas)
+        cnt[0] += 1
+        if r is not None and take[0] is not None:
+            take[0](r)
 
-    def take(res):
-        if st is None:
-            return
-        if len(st) >= st.ring - 1:
-            st.pop()
-        st.push(res, pipe)
 
-    def steps(k):
-        for _ in range(k):
-            sl = pipe.count % 2
-            with torch.cuda.stream(pipe.streams_a[sl]):
-                r = pipe.submit(net(pool[cnt[0] % 8], slot=sl), metas)
-                cnt[0] += 1
-                if r is not None:
-                    take(r)
-        with torch.cuda.stream(pipe.streams_a[0]):
-            for r in pipe.flush():
-                take(r)
-        while st is not None and len(st):
-            st.pop()
-    steps(3 * depth)
+def flush():
+    with torch.cuda.stream(pipe.streams_a[0]):
+        for r in pipe.flush():
+            if take[0] is not None:
+                take[0](r)
+
+
+for _ in range(12):
+    one()
+flush()
+pipe.calibrate(None, metas, submit=one)
+
+
+def run(name, mk, n=100):
+    st = mk()
+    host = [0.0]
+
+    def tk(res):
+        t = time.perf_counter()
+        if st is not None:
+            if len(st) >= st.ring - 1:
+                st.pop()
+            st.push(res, pipe)
+        host[0] += time.perf_counter() - t
+    take[0] = tk if st is not None else None
+    for _ in range(10):
+        one()
+    flush()
+    while st is not None and len(st):
+        st.pop()
+    host[0] = 0.0
     torch.cuda.synchronize()
     t = time.perf_counter()
-    steps(n)
+    for _ in range(n):
+        one()
+    flush()
+    while st is not None and len(st):
+        st.pop()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / n
-    print("%-8s ring %d depth %d: %.3f ms/step  %.1f images/s" % (variant, ring, depth, 1e3 * dt, 1 / dt), flush=True)
+    print("%-28s %.3f ms/step  %.1f images/s  (host in push/pop %.3f ms/step)" % (name, 1e3 * dt, 1 / dt, 1e3 * host[0] / n), flush=True)
 
 
-for variant, ring, depth in (("none", 0, 4), ("direct", 6, 4), ("staged", 6, 4), ("staged", 3, 4),
-                             ("direct", 8, 6), ("staged", 8, 5), ("none", 0, 4)):
-    run(variant, ring, depth)
+class ThrottleOnly(ResultStreamer):   # events + host pacing, no copies at all
+    def push(self, results, pipe=None):
+        key = ("x",)
+        e = self.entries[self.head_i % self.ring]
+        if e is None:
+            e = self.entries[self.head_i % self.ring] = dict(key=key, event=torch.cuda.Event())
+        cur = torch.cuda.current_stream()
+        if MODE == "copystream":
+            self.stream.wait_stream(cur)
+            e["event"].record(self.stream)
+        else:
+            e["event"].record(cur)
+        self.head_i += 1
+
+    def pop(self):
+        e = self.entries[self.tail_i % self.ring]
+        self.tail_i += 1
+        e["event"].synchronize()
+        return []
+
+
+run("no result copies", lambda: None)
+MODE = "cur"
+run("host pacing only (event on cur)", lambda: ThrottleOnly(head, ring=6))
+for w in (2, 4, 8, 16):
+    run("one blob, copy kernel %d WGs" % w, lambda w=w: ResultStreamer(head, ring=6, copy_wgs=w))
+run("no result copies", lambda: None)

@@ -283,3 +283,45 @@ def test_two_heads_in_one_process_keep_their_own_grids():
     assert all(torch.equal(x, y) for x, y in zip(alone, again))
     # (the reserve changes which workgroup computes which tile, never a result)
     assert all(torch.equal(x, y) for x, y in zip(alone, [t for t in with_b if t.is_cuda]))
+
+
+@pytest.mark.parametrize("H,W", [(160, 112), (101, 149), (224, 136)])
+def test_keep_ratio_shapes_portrait_and_odd_sides(H, W):
+    """The test pipeline's keep-ratio resize (configs/mask2former/pairnet.py:310-331) hands
+    over portrait images and odd sides (mask feature 40x28 / 26x38 / 56x34: the odd ones take
+    the direct 3x3 FPN convolution, the even ones Winograd): image -> native backbone -> head
+    against the oracle chain, every output within the fp32 bar."""
+    from helpers import head_cfg, oracle_head, tie_aware_topk_match
+    from oracle.backbone import OracleResNet50, seeded_backbone_state
+    from pairnet_amd import build_detector, pairnet_r50
+    head_o, sd, _ = oracle_head(1234)
+    bsd = seeded_backbone_state(31)
+    bb_o = OracleResNet50()
+    bb_o.load_state_dict(bsd)
+    det = build_detector(pairnet_r50())
+    det.backbone.load_state_dict(bsd)
+    det.bbox_head.load_state_dict(sd)
+    det.to(DEV)
+    img = seeded.uniform(np.random.default_rng(H * 1000 + W), (1, 3, H, W), -2.0, 2.0)
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[1.0] * 4)]
+    with torch.no_grad():
+        feats_o = [f.contiguous() for f in bb_o(img)]
+    trace = {}
+    ref_cls, ref_masks = head_o.forward(feats_o, metas, trace=trace)
+    feats = det.extract_feat(img.to(DEV))
+    for f, o in zip(feats, feats_o):
+        assert tuple(f.shape) == tuple(o.shape)
+        assert _err(f, o) < 1e-4 * float(o.abs().max())
+    res = det.simple_test(img.to(DEV), metas)
+    pl = det.bbox_head._last_plan
+    assert pl.wino == (pl.hw2[0] % 2 == 0 and pl.hw2[1] % 2 == 0)
+    for k, got in (("cls", pl.cls), ("importance", pl.imp)):
+        assert _err(got, ref_cls[k]) < 1e-3, k
+    scale = max(1.0, float(ref_masks["mask"].abs().max()))
+    assert _err(pl.MP.view_as(ref_masks["mask"]), ref_masks["mask"]) < 1e-3 * scale
+    ok, exact = tie_aware_topk_match(ref_cls["importance"][0].numpy(), trace["topk_idx"][0].numpy(),
+                                     pl.topk_idx[0].cpu().numpy(), 3e-6)
+    assert ok
+    if exact == 100:
+        assert _err(pl.rel, ref_cls["rel"]) < 1e-3
+    assert res[0].masks.shape == (200, H, W) and res[0].pan_results.shape == (H, W)

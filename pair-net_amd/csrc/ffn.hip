@@ -29,6 +29,14 @@ __global__ __launch_bounds__(512) void k_ffn_partial(const float* __restrict__ x
   const int li = lane & 31, lh = lane >> 5;
   const int c = blockIdx.x, m0 = blockIdx.y * 32;
   const int am = min(m0 + li, M - 1);
+  // phase 2's W2 fragment does not depend on phase 1: its loads are issued first and land
+  // under phase 1's loads / MFMAs / reduction
+  float4 w2f[8];
+  {
+    const float* wrow = W2 + (int64_t)(wave * 32 + li) * hidden + c * FFN_HC;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) w2f[s] = ld4(wrow + 8 * s + 4 * lh);
+  }
 
   // ---- phase 1: wave = (column tile ct, K quarter kq); K = 256 ----
   {
@@ -67,13 +75,12 @@ __global__ __launch_bounds__(512) void k_ffn_partial(const float* __restrict__ x
 
   // ---- phase 2: wave w owns output columns [32w, 32w+32); K = 64 hidden columns ----
   {
-    const float* wrow = W2 + (int64_t)(wave * 32 + li) * hidden + c * FFN_HC;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const float4 b = ld4(wrow + 8 * s + 4 * lh);
+      const float4 b = w2f[s];
       const float4 a = ld4(hs + li * (FFN_HC + 4) + 8 * s + 4 * lh);
       acc = mfma32(a.x, b.x, acc);
       acc = mfma32(a.y, b.y, acc);
@@ -102,8 +109,20 @@ __global__ __launch_bounds__(256) void k_reduce_ln(const float* __restrict__ par
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  float4 v = ld4(partial + row * 256 + lane * 4);
-  for (int s = 1; s < S; ++s) v = add4(v, ld4(partial + ((int64_t)s * rows + row) * 256 + lane * 4));
+  // the S partials are added in slice order; their loads are issued eight at a time (the same
+  // sum as a one-by-one loop, without 31 dependent round trips to L2)
+  const float* pp = partial + row * 256 + lane * 4;
+  const int64_t ps = rows * 256;
+  float4 v = ld4(pp);
+  int s = 1;
+  for (; s + 8 <= S; s += 8) {
+    float4 t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = ld4(pp + (s + j) * ps);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v = add4(v, t[j]);
+  }
+  for (; s < S; ++s) v = add4(v, ld4(pp + s * ps));
   if (bias) v = add4(v, ld4(bias + lane * 4));
   if (res) v = add4(ld4(res + row * 256 + lane * 4), v);
   const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.f / 256.f);

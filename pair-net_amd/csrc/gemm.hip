@@ -633,7 +633,13 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
   const int64_t mn = (int64_t)p.M * p.N;
   const float* pp = part + (int64_t)b * S * mn + (int64_t)row * p.N + col;
   float4 v = ld4(pp);
-  for (int s = 1; s < S; ++s) v = add4(v, ld4(pp + s * mn));
+  int s = 1;
+  for (; s + 4 <= S; s += 4) {     // (slice order kept; four loads in flight)
+    const float4 t0 = ld4(pp + s * mn), t1 = ld4(pp + (s + 1) * mn);
+    const float4 t2 = ld4(pp + (s + 2) * mn), t3 = ld4(pp + (s + 3) * mn);
+    v = add4(add4(add4(add4(v, t0), t1), t2), t3);
+  }
+  for (; s < S; ++s) v = add4(v, ld4(pp + s * mn));
   if (p.bias) v = add4(v, ld4(p.bias + col));
   v = make_float4(gemm_act(v.x, p.relu), gemm_act(v.y, p.relu), gemm_act(v.z, p.relu), gemm_act(v.w, p.relu));
   if (p.Res) {

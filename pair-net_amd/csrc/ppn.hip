@@ -205,15 +205,18 @@ extern "C" int pn_mlearner_last_f32(const float* in, const float* w3, const floa
 
 // ---- top-k pair selection ------------------------------------------------------
 // 48-bit unique keys: (order-preserving float bits << 16) | (0xFFFF - flat index), so
-// "larger key" == larger score, ties -> smaller index.  MSB-first 8-bit radix select
-// (LDS histogram + one-wave suffix scan per pass) finds the key of the k-th largest;
-// the k survivors are compacted and bitonic-sorted descending in LDS.
+// "larger key" == larger score, ties -> smaller index.  The keys live in registers (formed
+// once); an MSB-first 8-bit radix select (LDS histogram + one-wave suffix scan per pass,
+// stopping as soon as a whole bucket is taken) finds the key of the k-th largest; the k
+// survivors are compacted into LDS and ordered by rank counting (unique keys).
 __device__ __forceinline__ unsigned long long topk_key(float v, int idx) {
   uint32_t u = __float_as_uint(v + 0.0f);  // -0 -> +0
   u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
   return ((unsigned long long)u << 16) | (unsigned long long)(0xFFFF - idx);
 }
 
+// KPT = keys per thread held in registers (n <= 1024 * KPT); the keys are formed once.
+template <int KPT>
 __global__ __launch_bounds__(1024) void k_topk_pairs(const float* __restrict__ scores,
                                                      int64_t* __restrict__ idx_out,
                                                      int64_t* __restrict__ sub_out,
@@ -221,25 +224,30 @@ __global__ __launch_bounds__(1024) void k_topk_pairs(const float* __restrict__ s
                                                      int64_t* __restrict__ pair_out, int n, int Q,
                                                      int k, int64_t estride, int64_t rstride,
                                                      int cap) {
-  // scores of row b: scores[b * rstride + i * estride]; cap = 256 or 512 >= k (sort width)
+  // scores of row b: scores[b * rstride + i * estride]; cap = 256 or 512 >= k
   __shared__ int hist[256];
   __shared__ unsigned long long sel[512];
   __shared__ unsigned long long s_prefix;
-  __shared__ int s_remaining, s_count;
+  __shared__ int s_remaining, s_count, s_done;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* sc = scores + (int64_t)blockIdx.x * rstride;
-  if (tid == 0) { s_prefix = 0ull; s_remaining = k; s_count = 0; }
-  if (tid < 512) sel[tid] = 0ull;
+  unsigned long long key[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const int i = tid + 1024 * j;
+    key[j] = i < n ? topk_key(sc[(int64_t)min(i, n - 1) * estride], i) : 0ull;
+  }
+  if (tid == 0) { s_prefix = 0ull; s_remaining = k; s_count = 0; s_done = 0; }
   __syncthreads();
   for (int pass = 0; pass < 6; ++pass) {
     const int shift = 40 - 8 * pass;
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
     const unsigned long long prefix = s_prefix;
-    for (int i = tid; i < n; i += 1024) {
-      const unsigned long long key = topk_key(sc[i * estride], i);
-      if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8)))
-        atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      if (tid + 1024 * j < n && (pass == 0 || (key[j] >> (shift + 8)) == (prefix >> (shift + 8))))
+        atomicAdd(&hist[(int)((key[j] >> shift) & 255ull)], 1);
     }
     __syncthreads();
     if (wave == 0) {
@@ -264,51 +272,62 @@ __global__ __launch_bounds__(1024) void k_topk_pairs(const float* __restrict__ s
         }
         s_prefix = prefix | ((unsigned long long)digit << shift);
         s_remaining = remaining - cum;
+        // the whole bucket of this digit is taken: every key >= the prefix (lower bits zero)
+        // is selected and nothing remains to refine (distinct scores get here after the
+        // passes over the 32 value bits: four instead of six)
+        if (hb[digit & 3] == remaining - cum) s_done = 1;
       }
     }
     __syncthreads();
+    if (s_done) break;
   }
   const unsigned long long kth = s_prefix;
-  for (int i = tid; i < n; i += 1024) {
-    const unsigned long long key = topk_key(sc[i * estride], i);
-    if (key >= kth) {
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    if (tid + 1024 * j < n && key[j] >= kth) {
       const int slot = atomicAdd(&s_count, 1);
-      if (slot < cap) sel[slot] = key;
+      if (slot < cap) sel[slot] = key[j];
     }
   }
   __syncthreads();
-  // bitonic sort of `cap` keys, descending (zero padding sinks to the end)
-  for (int size = 2; size <= cap; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      if (tid < (cap >> 1)) {
-        const int lo = ((tid / stride) * stride * 2) + (tid % stride);
-        const int hi = lo + stride;
-        const bool desc = ((lo & size) == 0);
-        const unsigned long long a = sel[lo], b = sel[hi];
-        if ((a < b) == desc) { sel[lo] = b; sel[hi] = a; }
-      }
-      __syncthreads();
-    }
-  }
+  // order: the keys are unique, so the rank of a selected key = the number of selected keys
+  // above it; thread t counts for key t (k broadcast LDS reads, no barrier) and writes its
+  // row of the output at that rank
   if (tid < k) {
-    const int64_t idx = 0xFFFF - (int)(sel[tid] & 0xFFFFull);
-    const int64_t o = (int64_t)blockIdx.x * k + tid;
+    const unsigned long long mine = sel[tid];
+    int rank = 0;
+    for (int j = 0; j < k; ++j) rank += sel[j] > mine ? 1 : 0;
+    const int64_t idx = 0xFFFF - (int)(mine & 0xFFFFull);
+    const int64_t o = (int64_t)blockIdx.x * k + rank;
     idx_out[o] = idx;
     sub_out[o] = idx / Q;
     obj_out[o] = idx % Q;
     if (pair_out) {   // [B][sub k | obj k]: the row list of the pair-feature gather
-      pair_out[(int64_t)blockIdx.x * 2 * k + tid] = idx / Q;
-      pair_out[(int64_t)blockIdx.x * 2 * k + k + tid] = idx % Q;
+      pair_out[(int64_t)blockIdx.x * 2 * k + rank] = idx / Q;
+      pair_out[(int64_t)blockIdx.x * 2 * k + k + rank] = idx % Q;
     }
   }
+}
+
+static void launch_topk(const float* scores, int64_t* idx, int64_t* quot, int64_t* rem,
+                        int64_t* pair, int B, int n, int div, int k, int64_t estride,
+                        int64_t rstride, int cap, hipStream_t s) {
+#define PN_TOPK(KPT)                                                                           \
+  hipLaunchKernelGGL(k_topk_pairs<KPT>, dim3(B), dim3(1024), 0, s, scores, idx, quot, rem, pair, \
+                     n, div, k, estride, rstride, cap)
+  if (n <= 1024 * 10) PN_TOPK(10);
+  else if (n <= 1024 * 24) PN_TOPK(24);
+  else if (n <= 1024 * 40) PN_TOPK(40);
+  else PN_TOPK(64);
+#undef PN_TOPK
 }
 
 extern "C" int pn_topk_pairs(const float* scores, int64_t* idx, int64_t* sub, int64_t* obj,
                              int64_t* pair, int B, int Q, int k, void* stream) {
   if (!scores || !idx || !sub || !obj || B <= 0 || Q <= 0) return PN_BAD_ARG;
   if ((int64_t)Q * Q > 65536 || k <= 0 || k > 256 || k > Q * Q) return PN_BAD_ARG;
-  hipLaunchKernelGGL(k_topk_pairs, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores, idx,
-                     sub, obj, pair, Q * Q, Q, k, (int64_t)1, (int64_t)Q * Q, 256);
+  launch_topk(scores, idx, sub, obj, pair, B, Q * Q, Q, k, 1, (int64_t)Q * Q, 256,
+              (hipStream_t)stream);
   return PN_LAUNCH_CHECK();
 }
 
@@ -319,8 +338,8 @@ extern "C" int pn_topk_f32(const float* scores, int64_t* idx, int64_t* quot, int
                            int n, int div, int k, void* stream) {
   if (!scores || !idx || !quot || !rem || B <= 0 || n <= 0 || div <= 0) return PN_BAD_ARG;
   if (n > 65536 || k <= 0 || k > 256 || k > n) return PN_BAD_ARG;
-  hipLaunchKernelGGL(k_topk_pairs, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores, idx,
-                     quot, rem, (int64_t*)nullptr, n, div, k, (int64_t)1, (int64_t)n, 256);
+  launch_topk(scores, idx, quot, rem, nullptr, B, n, div, k, 1, (int64_t)n, 256,
+              (hipStream_t)stream);
   return PN_LAUNCH_CHECK();
 }
 
@@ -334,9 +353,8 @@ extern "C" int pn_topk_strided_f32(const float* scores, int64_t elem_stride, int
   if (!scores || !idx || !quot || !rem || B <= 0 || n <= 0 || div <= 0 || elem_stride <= 0)
     return PN_BAD_ARG;
   if (n > 65536 || k <= 0 || k > 512 || k > n) return PN_BAD_ARG;
-  hipLaunchKernelGGL(k_topk_pairs, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores, idx,
-                     quot, rem, (int64_t*)nullptr, n, div, k, elem_stride, row_stride,
-                     k > 256 ? 512 : 256);
+  launch_topk(scores, idx, quot, rem, nullptr, B, n, div, k, elem_stride, row_stride,
+              k > 256 ? 512 : 256, (hipStream_t)stream);
   return PN_LAUNCH_CHECK();
 }
 

@@ -36,7 +36,6 @@ reused before that stream has passed the recorded point.
 """
 import torch
 
-from . import hip
 from .hip import on_device
 
 

@@ -756,18 +756,50 @@ def main():
                 "what": "headline schedule with exact_mask_order=True: every decoder layer's "
                         "attention mask from the full-size mask logits, resized, thresholded "
                         "(the reference's order of operations)"}
+        if engine is not None and B == 1 and args.path == "image":
+            # BASELINE configs[2] is 2 images per GPU (bs = 16 over 8 GPUs): the same schedule
+            # with two distinct images per launch sequence (plans and graphs of their own)
+            pool2 = [torch.cat([pool[i], pool[(i + 1) % len(pool)]], 0)
+                     for i in range(0, len(pool), 2)]
+            metas2, k2 = metas * 2, [0]
+
+            def step2():
+                sl = engine.count % len(engine.streams_a)
+                with torch.cuda.stream(engine.streams_a[sl]):
+                    engine.submit(backbone(pool2[k2[0] % len(pool2)], slot=sl), metas2)
+                k2[0] += 1
+
+            def run2(n):
+                for _ in range(n):
+                    step2()
+                with torch.cuda.stream(engine.streams_a[0]):
+                    engine.flush()
+            run2(2 * args.depth)
+            run2(4)
+            torch.cuda.synchronize()
+            n2 = min(args.steps, 40)
+            t0 = time.perf_counter()
+            run2(n2)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out["two_images_per_gpu"] = {
+                "images_per_s": 2 * n2 / dt, "ms_per_step": 1e3 * dt / n2, "steps": n2,
+                "what": "BASELINE configs[2]'s per-GPU batch: two distinct images per step "
+                        "through the same pipeline (one launch per layer for both)"}
+            del pool2
         # deformable sampling with learned-like offsets: default-init weights give every token
         # mmcv's +-1..4 px grid (a tight neighbourhood); the same kernel on the grid plus
         # N(0, 8 px) noise per offset shows how far the rate depends on that locality
         try:
-            pl = head._last_plan
+            pl = head._plan(B, [tuple(f.shape[-2:]) for f in feats[:0:-1]],
+                            tuple(feats[0].shape[-2:]), 0, getattr(head, "_feats_nhwc", False))
             voa = pl.VOA.clone()
             gen = torch.Generator(device=dev).manual_seed(7)
             voa[..., 256:448] += 8.0 * torch.randn(voa[..., 256:448].shape, device=dev, generator=gen)
             s_out = torch.empty_like(pl.S)
-            run = lambda v: hip.msda(v, 544, v.view(-1)[256:], 544, s_out, B, pl.shapes)
+            run = lambda v: hip.msda(v, 544, v.view(-1)[256:], 544, s_out, pl.B, pl.shapes)
             t_init, t_spread = timeit(lambda: run(pl.VOA), 50), timeit(lambda: run(voa), 50)
-            alg = 4.0 * B * pl.SN * (256 + 8 * 3 * 4 * 3 + 256)
+            alg = 4.0 * pl.B * pl.SN * (256 + 8 * 3 * 4 * 3 + 256)
             out["deformable_sampling_offsets"] = {
                 "init_grid": {"us": 1e3 * t_init, "GB/s": alg / t_init / 1e6},
                 "init_grid_plus_N(0,8px)": {"us": 1e3 * t_spread, "GB/s": alg / t_spread / 1e6},

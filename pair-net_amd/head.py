@@ -871,15 +871,26 @@ class CrossHead2:
         panoptic_jobs = ()
 
     def _post_buffers(self, anchor, key, build):
-        """Per-(input buffer, output size) post-processing buffers: `anchor` is the tensor
-        whose storage identifies the caller's buffer (a plan's outputs keep their address,
-        so the hot loop allocates nothing); bounded, oldest entry dropped first."""
+        """Post-processing buffers per (input buffer, output size): `anchor` is the tensor whose
+        storage identifies the caller's buffer.  For the head's own outputs (the hot loop: a
+        plan's outputs keep their address, so nothing is allocated per call) the buffers live
+        IN the plan and are freed with it when the LRU evicts the plan; for foreign inputs a
+        small bounded table is kept, oldest entry dropped first."""
         k = (anchor.data_ptr(), str(anchor.device)) + tuple(key)
-        pb = self._post.get(k)
+        pl = getattr(self, "_last_plan", None)
+        owner = None
+        if pl is not None:
+            for name in ("cls", "sub_cls"):
+                t = getattr(pl, name, None)
+                if t is not None and t.data_ptr() <= anchor.data_ptr() < \
+                        t.data_ptr() + t.numel() * t.element_size():
+                    owner = pl.__dict__.setdefault("post", {})
+        table = owner if owner is not None else self._post
+        pb = table.get(k)
         if pb is None:
-            if len(self._post) >= 64:
+            if owner is None and len(self._post) >= 8:
                 self._post.pop(next(iter(self._post)))
-            pb = self._post[k] = build()
+            pb = table[k] = build()
         return pb
 
     @torch.no_grad()

@@ -325,3 +325,43 @@ def test_keep_ratio_shapes_portrait_and_odd_sides(H, W):
     if exact == 100:
         assert _err(pl.rel, ref_cls["rel"]) < 1e-3
     assert res[0].masks.shape == (200, H, W) and res[0].pan_results.shape == (H, W)
+
+
+def test_plan_caches_stay_bounded_over_many_shapes():
+    """ADVICE r2 (medium): a keep-ratio evaluation pass meets hundreds of distinct shapes;
+    plans (buffers + captured graphs) are LRU-bounded, device memory stays flat, and a shape
+    that comes back after its plan was evicted gives bit-for-bit the same result."""
+    from oracle.backbone import seeded_backbone_state
+    from pairnet_amd import build_detector, pairnet_r50
+    det = build_detector(pairnet_r50())
+    det.backbone.load_state_dict(seeded_backbone_state(41))
+    det.to(DEV)
+    det.bbox_head.use_graphs = det.backbone.use_graphs = True
+    for cache in (det.bbox_head._plans, det.backbone._plans):
+        cache.max_plans = 3
+    g = torch.Generator().manual_seed(11)
+    shapes = [(96 + 8 * (i % 7), 128 + 16 * (i % 5)) for i in range(35)]   # 35 distinct (H, W)
+    assert len(set(shapes)) == 35
+
+    def run(H, W, seed):
+        img = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(seed)).to(DEV)
+        metas = [dict(img_shape=(H, W, 3), scale_factor=[1.0] * 4)]
+        out = None
+        for _ in range(3):                      # eager warm-up, capture, replay
+            r = det.bbox_head.simple_test_bboxes(det.extract_feat(img), metas)[0]
+            out = [t.clone() for t in (r[1], r[7], r[4])]
+        return out
+    first = run(*shapes[0], seed=1)
+    torch.cuda.synchronize()
+    mem = []
+    for i, (H, W) in enumerate(shapes[1:]):
+        run(H, W, seed=2 + i)
+        torch.cuda.synchronize()
+        mem.append(torch.cuda.memory_allocated())
+    assert len(det.bbox_head._plans) <= 3 and det.bbox_head._plans.evictions >= 30
+    assert len(det.backbone._plans) <= 3
+    # flat: the last third of the pass allocates no more than the first third did
+    assert max(mem[-10:]) <= 1.25 * max(mem[:10]), (max(mem[:10]), max(mem[-10:]))
+    again = run(*shapes[0], seed=1)              # its plan was evicted long ago
+    for a, b in zip(first, again):
+        assert torch.equal(a, b)

@@ -70,11 +70,11 @@ def triplet2Result(triplets, use_mask, eval_mask_rels=False):
 
 class ResultStreamer:
     """`triplet2Result` (psgtr.py:15-51) for a pipeline of images: every field of a batch's
-    `get_bboxes` tuples is first copied device -> device into ONE staging blob of this ring
+    `get_bboxes` tuples is first copied device -> device into this ring's own staging buffers
     (51 MB per 800x1333 image: 2R x H0 x W0 bool masks; ~25 us of HBM time on the stream the
-    results are ordered on), which releases the pipeline slot at once; a single copy kernel on
-    a copy stream of its own then moves the blob to a PINNED host buffer, under the next
-    images' kernels, and the host never allocates (a multi-MB host allocation per image is an
+    results are ordered on), which releases the pipeline slot at once; copy kernels on a copy
+    stream of their own then move the fields to PINNED host buffers, under the next images'
+    kernels, and the host never allocates (a multi-MB host allocation per image is an
     mmap / munmap pair, and every munmap runs the amdgpu MMU notifier against the busy GPU:
     ~75 ms stalls measured).
 
@@ -84,91 +84,86 @@ class ResultStreamer:
         for r in streamer.pop():          # oldest pushed batch -> [Result], same fields and
             ...                           # dtypes as triplet2Result
 
-    What it costs (tools/d2h_probe.py, 800x1333, 51 MB per image): staging alone is free
-    (195 images/s with or without it); moving the bytes over PCIe takes ~1 ms out of every
-    5.1 ms step whichever way it is done -- hipMemcpyAsync per field (which runs as a blit
-    KERNEL on this stack: rocprofv3 shows __amd_rocclr_copyBuffer up to 0.9 ms, no SDMA copy
-    record) 169, `pn_copy_stream` per field with 1 / 4 / 16 / 64 workgroups 142 / 173 / 163 /
-    153, one blob + one launch 156-165 images/s -- i.e. it is the outstanding PCIe writes that
-    slow the concurrent GEMMs down (the memory fabric they share), not the copy kernel's
-    width or the number of launches.  One blob, one launch is kept for its simplicity.
+    What it costs (tools/d2h_probe.py, one variant per process, 800x1333, 51 MB per image,
+    196 images/s without any result copy): staging alone is free; hipMemcpyAsync per field
+    (which runs as a chip-wide blit KERNEL on this stack: rocprofv3 shows
+    __amd_rocclr_copyBuffer up to 0.9 ms, no SDMA copy record) 162 images/s; `pn_copy_stream`
+    per field with 1 / 4 / 16 workgroups 146 / **175** / 153: one workgroup is copy-bound
+    (7 GB/s), wide copies put more PCIe writes in flight than the link drains and slow the
+    concurrent GEMMs through the memory fabric they share.  Four workgroups are the default:
+    0.89 of the headline rate for the whole of `simple_test`.
 
-    `pop()` waits for that batch's copy, checks its panoptic loops like `PSGTr.simple_test`
+    `pop()` waits for that batch's copies, checks its panoptic loops like `PSGTr.simple_test`
     (IndexError when every segment was filtered, pairnet_head.py:882) and returns Results
     whose arrays are VIEWS of the ring entry: valid until `ring` more batches have been pushed
     (copy what must live longer).  The reference returns fresh arrays; this is the documented
     deviation that keeps allocation out of the loop."""
 
-    ALIGN = 256
-
-    def __init__(self, head, ring=4, copy_wgs=8):
+    def __init__(self, head, ring=4, copy_wgs=4):
         """`copy_wgs`: workgroups of the device -> pinned-host copy kernel (`pn_copy_stream`):
-        PCIe needs no width (one workgroup moves 7 GB/s; 8 keep the copy well under a step)."""
+        PCIe needs no width (one workgroup moves 7 GB/s; 4 keep a 51 MB image well under a
+        step); 0 = hipMemcpyAsync."""
         if head.device is None or head.device.type != "cuda":
             raise RuntimeError("ResultStreamer needs a head on an MI355X")
         self.head, self.device, self.ring = head, head.device, ring
-        self.copy_wgs = max(1, int(copy_wgs))
+        self.copy_wgs = max(0, int(copy_wgs))
         with torch.cuda.device(self.device):
             self.stream = torch.cuda.Stream()
-        self.entries = [None] * ring      # dict(key, blobs, field views, event, jobs)
+        self.entries = [None] * ring      # dict(key, staging / host fields, event, jobs)
         self.head_i = self.tail_i = 0     # push / pop counters
 
     def _entry(self, key, results, n_jobs):
         e = self.entries[self.head_i % self.ring]
         if e is not None and e["key"] == key:
             return e
-        # blob layout: every device tensor of every tuple, then 16 status bytes per image
-        off, slots = 0, []
-        for tup in results:
-            row = []
-            for t in tup:
-                if isinstance(t, torch.Tensor) and t.is_cuda:
-                    n = t.numel() * t.element_size()
-                    row.append((off, n, t.dtype, tuple(t.shape)))
-                    off += -(-n // self.ALIGN) * self.ALIGN
-                else:
-                    row.append(t)             # (host-side constants pass through)
-            slots.append(row)
-        state_off = off
-        off += self.ALIGN * max(1, n_jobs)
-        dev = torch.empty(off, dtype=torch.uint8, device=self.device)
-        host = torch.empty(off, dtype=torch.uint8, pin_memory=True)
-
-        def views(blob):
-            return [[blob[s[0]:s[0] + s[1]].view(s[2]).view(s[3]) if isinstance(s, tuple) else s
-                     for s in row] for row in slots]
+        is_dev = lambda t: isinstance(t, torch.Tensor) and t.is_cuda
         e = self.entries[self.head_i % self.ring] = dict(
-            key=key, dev=dev, host=host, dev_fields=views(dev), host_fields=views(host),
-            dev_states=[dev[state_off + i * self.ALIGN:][:16] for i in range(n_jobs)],
-            host_states=[host[state_off + i * self.ALIGN:][:16] for i in range(n_jobs)],
+            key=key,
+            dev=[[torch.empty(t.shape, dtype=t.dtype, device=self.device) if is_dev(t) else None
+                  for t in tup] for tup in results],
+            host=[[torch.empty(t.shape, dtype=t.dtype, pin_memory=True) if is_dev(t) else t
+                   for t in tup] for tup in results],    # (host-side constants pass through)
+            dev_states=torch.empty(max(1, n_jobs), 16, dtype=torch.uint8, device=self.device),
+            host_states=torch.empty(max(1, n_jobs), 16, dtype=torch.uint8, pin_memory=True),
             event=torch.cuda.Event(), jobs=0)
         return e
+
+    def _to_host(self, src, dst):
+        if self.copy_wgs > 0:
+            hip.copy_stream(src, dst, self.copy_wgs)
+        else:
+            dst.copy_(src, non_blocking=True)
 
     @torch.no_grad()
     def push(self, results, pipe=None):
         """Stage one batch's `get_bboxes` tuples (ordered on the current stream) and queue
-        their copy to the host.  `pipe`: the PipelinedHead they came from; its slot is released
-        as soon as the staging copies are queued (`consumed`)."""
+        their copies to the host.  `pipe`: the PipelinedHead they came from; its slot is
+        released as soon as the staging copies are queued (`consumed`)."""
         if self.head_i - self.tail_i >= self.ring:
             raise RuntimeError("ResultStreamer ring is full: pop() before pushing more")
         jobs = tuple(getattr(results, "panoptic_jobs", ()))
         key = tuple(tuple((tuple(t.shape), t.dtype) if isinstance(t, torch.Tensor) and t.is_cuda
                           else None for t in tup) for tup in results) + (len(jobs),)
         e = self._entry(key, results, len(jobs))
-        # (the ring entry's blobs are free again: pop() waited for its copy, and push()
+        # (the ring entry's buffers are free again: pop() waited for its copies, and push()
         # refuses to overtake pop())
         cur = torch.cuda.current_stream(self.device)
-        for tup, stage in zip(results, e["dev_fields"]):
+        for tup, stage in zip(results, e["dev"]):
             for t, d in zip(tup, stage):
-                if isinstance(t, torch.Tensor) and t.is_cuda:
+                if d is not None:
                     d.copy_(t)
-        for job, d in zip(jobs, e["dev_states"]):
-            d.copy_(job[0][:16])
+        for i, job in enumerate(jobs):
+            e["dev_states"][i].copy_(job[0][:16])
         if pipe is not None:
             pipe.consumed(results, cur)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            hip.copy_stream(e["dev"], e["host"], self.copy_wgs)
+            for stage, host in zip(e["dev"], e["host"]):
+                for d, h in zip(stage, host):
+                    if d is not None:
+                        self._to_host(d, h)
+            if jobs:
+                self._to_host(e["dev_states"], e["host_states"])
             e["event"].record(self.stream)
         e["jobs"] = len(jobs)
         self.head_i += 1
@@ -179,8 +174,8 @@ class ResultStreamer:
         e = self.entries[self.tail_i % self.ring]
         self.tail_i += 1
         e["event"].synchronize()
-        for st in e["host_states"][:e["jobs"]]:
-            nkeep, active, rounds, all_gone = st.view(torch.int32).tolist()
+        for i in range(e["jobs"]):
+            nkeep, active, rounds, all_gone = e["host_states"][i].view(torch.int32).tolist()
             if all_gone:
                 raise IndexError("every panoptic segment was filtered (the reference fails "
                                  "here too, pairnet_head.py:882)")
@@ -192,7 +187,7 @@ class ResultStreamer:
                 raise RuntimeError("panoptic loop still active after %d rounds" % rounds)
         use_mask = self.head.use_mask
         return [triplet2Result(tuple(h.numpy() if isinstance(h, torch.Tensor) else h
-                                     for h in host), use_mask) for host in e["host_fields"]]
+                                     for h in host), use_mask) for host in e["host"]]
 
     def __len__(self):
         return self.head_i - self.tail_i

@@ -89,9 +89,15 @@ class ThrottleOnly(ResultStreamer):   # events + host pacing, no copies at all
         return []
 
 
-run("no result copies", lambda: None)
+# one variant per process (allocations of earlier variants shift the later ones' numbers):
+#   d2h_probe.py none | pacing | <copy_wgs>
+which = sys.argv[1] if len(sys.argv) > 1 else "4"
 MODE = "cur"
-run("host pacing only (event on cur)", lambda: ThrottleOnly(head, ring=6))
-for w in (2, 4, 8, 16):
-    run("one blob, copy kernel %d WGs" % w, lambda w=w: ResultStreamer(head, ring=6, copy_wgs=w))
-run("no result copies", lambda: None)
+if which == "none":
+    run("no result copies", lambda: None)
+elif which == "pacing":
+    run("host pacing only (event on cur)", lambda: ThrottleOnly(head, ring=6))
+else:
+    w = int(which)
+    run("staged, per field, copy kernel %d WGs" % w if w else "staged, per field, hipMemcpyAsync",
+        lambda: ResultStreamer(head, ring=6, copy_wgs=w))

@@ -577,3 +577,31 @@ def test_ppn_front_equals_normalise_cosine_first_layer(hip, B, Q):
              sW=Q * 256, sC=Q * Q)
     hip.mlearner_first(raw2, d(w1.view(64, 49)), d(b1), c12, B, Q)
     assert (raw - raw2).abs().max() < 1e-6 and (c1 - c12).abs().max() < 5e-6
+
+
+# ----------------------------------------------------------------------------- result copy
+@pytest.mark.parametrize("nbytes,wgs", [(1, 1), (15, 4), (16, 4), (4099, 2), (1 << 20, 4),
+                                        (51_147_680 // 8 + 7, 16)])
+def test_copy_stream_to_pinned_host_and_device(hip, nbytes, wgs):
+    """pn_copy_stream: device -> pinned host (the D2H of triplet2Result's fields) and device ->
+    device, any byte count (16-byte body + byte tail), any workgroup count."""
+    g = torch.Generator().manual_seed(nbytes)
+    src = torch.randint(0, 256, (nbytes,), generator=g, dtype=torch.uint8)
+    d = src.to(DEV)
+    host = torch.zeros(nbytes, dtype=torch.uint8, pin_memory=True)
+    dev2 = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    hip.copy_stream(d, host, wgs)
+    hip.copy_stream(d, dev2, wgs)
+    torch.cuda.synchronize()
+    assert torch.equal(host, src) and torch.equal(dev2.cpu(), src)
+    # typed tensors, and the argument contract
+    f = torch.randn(33, 7, generator=g).to(DEV)
+    fh = torch.empty(33, 7, pin_memory=True)
+    hip.copy_stream(f, fh)
+    torch.cuda.synchronize()
+    assert torch.equal(fh, f.cpu())
+    with pytest.raises(RuntimeError):
+        hip.copy_stream(f, torch.empty(33, 7))                 # pageable host memory
+    with pytest.raises(RuntimeError):
+        hip.copy_stream(f, torch.empty(7, 33, pin_memory=True).t())   # not contiguous
+    assert hip.lib().pn_copy_stream(None, None, 16, 4, None) == -1

@@ -1,13 +1,13 @@
 // fp32 contractions on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
 // bitwise an fmaf chain).  The kernels behind pn_gemm_f32 / pn_gemm_group_f32 /
-// pn_conv2d_nhwc(_ex)_f32 / pn_stem7x7s2_f32:
+// pn_conv2d_nhwc(_ex)_f32 (the ResNet stem has its own kernel, stem.hip):
 //
 //   k_gemm_tile   persistent workgroups (4 waves) walking BMxBN output tiles, 32-deep
 //                 k-chunks staged global -> registers -> one LDS stage, MFMA operand
 //                 fragments double-buffered in registers.  A rows come from a
 //                 row-major matrix, a column-major matrix (an NCHW feature map read as
-//                 [K][M]), an on-the-fly im2col of a channel-last image (implicit-GEMM
-//                 convolution, any stride) or of the NCHW RGB image (ResNet stem).
+//                 [K][M]) or an on-the-fly im2col of a channel-last image (implicit-GEMM
+//                 convolution, any stride).
 //   k_splitk_reduce  second pass of the deterministic split-K used when a problem has
 //                 too few output tiles to fill 256 CUs.
 //   k_gemm_skinny 32x32 output tile per workgroup, the 4 waves split K and reduce
@@ -123,7 +123,7 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         const int gm = min(m0 + (tid >> 3) + RPP * j, p.M - 1);
-        if (AMODE == A_CONV || AMODE == A_STEM) {
+        if (AMODE == A_CONV) {
           // output pixel -> input coordinates of tap (0, 0) + pad
           const int oy = gm / p.Wo, ox = gm - oy * p.Wo;
           cy[j] = oy * p.stride;
@@ -175,29 +175,6 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
           ra[j].w = buf_ld1(rA, a_off1[j][3], soff);
         }
       }
-    } else if (AMODE == A_STEM) {
-      // K index k = c * 49 + ky * 7 + kx (PyTorch weight order), 147 real + 13 zero
-      // columns; the image is NCHW, so the 4 k of a lane are 4 scalar gathers
-      const GemmP& p = loc.P(lpi);
-      st_in = 0;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = k0 + kc + e;
-        const int c = k / 49, r = k - c * 49;
-        const int ky = r / 7 - p.pad, kx = r - (r / 7) * 7 - p.pad;
-        const bool kvalid = k < 147;
-        const int cc = min(c, 2);
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-          const int iy = cy[j] + ky, ix = cx[j] + kx;
-          const bool in = kvalid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd;
-          const int yc = min(max(iy, 0), p.H - 1), xc = min(max(ix, 0), p.Wd - 1);
-          const float v = buf_ld1(rA, (unsigned)((cc * p.H + yc) * p.Wd + xc) * 4u, 0);
-          if (e == 0) ra[j].x = v; else if (e == 1) ra[j].y = v;
-          else if (e == 2) ra[j].z = v; else ra[j].w = v;
-          st_in |= (in ? 1u : 0u) << (j * 4 + e);
-        }
-      }
     } else if (AMODE == A_CONV) {
       const GemmP& p = loc.P(lpi);
       const int tap = k0 / p.Cin;
@@ -238,13 +215,6 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
     for (int j = 0; j < NA; ++j) {
       if (ADD && st_add) ra[j] = add4(ra[j], rad[j]);
       if (AMODE == A_CONV && !((st_in >> j) & 1u)) ra[j] = zero4;
-      if (AMODE == A_STEM) {
-        const unsigned m = st_in >> (j * 4);
-        ra[j].x = (m & 1u) ? ra[j].x : 0.f;
-        ra[j].y = (m & 2u) ? ra[j].y : 0.f;
-        ra[j].z = (m & 4u) ? ra[j].z : 0.f;
-        ra[j].w = (m & 8u) ? ra[j].w : 0.f;
-      }
     }
     if (st_ragged) {   // uniform, rare: the ragged chunk was loaded from k = 0; reload it
       // synchronously with per-element bounds (slow path, correctness only)
@@ -829,24 +799,6 @@ extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float*
   return pn_conv2d_nhwc_ex_f32(in, Wp, bias, nullptr, out, B, H, W, Cin, Cout, KH, KW, 1, pad,
                                (flags & ~PN_GEMM_RELU) | (relu ? PN_GEMM_RELU : 0), nullptr, 0,
                                stream);
-}
-
-// ResNet stem: 7x7 stride-2 pad-3 convolution of the NCHW RGB image + folded BatchNorm
-// + ReLU -> channel-last [B][Ho][Wo][64].  Wp is [64][160]: the PyTorch weight
-// [64][3][7][7] flattened (k = c*49 + ky*7 + kx) and zero-padded from 147 to 160.
-extern "C" int pn_stem7x7s2_f32(const float* img, const float* Wp, const float* bias, float* out,
-                                int B, int H, int W, int flags, void* stream) {
-  if (!img || !Wp || !out || B <= 0 || H <= 0 || W <= 0 || !aligned16(Wp)) return PN_BAD_ARG;
-  if ((int64_t)3 * H * W >= ((int64_t)1 << 29)) return PN_BAD_ARG;
-  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-  GemmP p{};
-  p.A = img; p.W = Wp; p.bias = bias; p.C = out;
-  p.M = Ho * Wo; p.N = 64; p.K = 160;
-  p.lda = 0; p.ldw = 160; p.ldc = 64;
-  p.sA = (int64_t)3 * H * W; p.sW = 0; p.sC = (int64_t)Ho * Wo * 64;
-  p.relu = 1; p.aadd_rows = 1;
-  p.H = H; p.Wd = W; p.Cin = 0; p.KW = 7; p.pad = 3; p.stride = 2; p.Wo = Wo;
-  return launch_tile<64, 64, 32, 32, A_STEM>(p, B, (hipStream_t)stream, flags);
 }
 
 extern "C" int pn_abi_version(void) { return PN_ABI_VERSION; }

@@ -13,13 +13,13 @@ struct GemmP {
   // contracts the 32-deep chunks [s * split_chunks, (s+1) * split_chunks) into its own
   // partial C (k_splitk_reduce sums the partials in split order and applies the epilogue)
   int ksplit, split_chunks;
-  // conv modes: input H x Wd x Cin (A_STEM: NCHW, Cin = 3), output rows M = Ho * Wo
+  // conv mode: input H x Wd x Cin channel-last, output rows M = Ho * Wo
   int H, Wd, Cin, KW, pad, stride, Wo;
 };
 
 // A operand: row-major matrix | column-major matrix | implicit im2col of a channel-last
 // image | implicit im2col of the NCHW RGB image for ResNet's 7x7/2 stem (K = 147 -> 160)
-enum { A_ROW = 0, A_COL = 1, A_CONV = 2, A_STEM = 3 };
+enum { A_ROW = 0, A_COL = 1, A_CONV = 2 };
 
 
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }

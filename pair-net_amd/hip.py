@@ -382,7 +382,7 @@ def conv2d_ex(x, wp, bias, res, out, B, H, W, Cin, Cout, KH, KW, stride, pad, re
 
 def stem7x7s2(img, wp, bias, out, B, H, W):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    _check(_launch("k_gemm_tile<64,64,32,32,A_STEM>", 2.0 * B * Ho * Wo * 64 * 147,
+    _check(_launch("k_stem7x7s2", 2.0 * B * Ho * Wo * 64 * 147,
                    4.0 * B * (3 * H * W + Ho * Wo * 64),
                    lambda: lib().pn_stem7x7s2_f32(_ptr(img), _ptr(wp), _ptr(bias), _ptr(out), B,
                                                   H, W, _reserve_flag(), _stream())),

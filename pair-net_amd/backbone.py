@@ -79,8 +79,11 @@ class ResNet50Hip:
         # persistent-GEMM workgroup slots left free for concurrent streams (hip.reserve_slots)
         self.grid_reserve = 0
         # 3x3 stride-1 layers of >= 128 channels (stages 2-4): "winograd" = F(2x2,3x3) around
-        # one batched GEMM (2.25x fewer multiplications), "direct" = implicit GEMM
-        self.conv_algo = "winograd"
+        # one batched GEMM (2.25x fewer multiplications); "winograd4" = F(4x4,3x3) (4x fewer)
+        # on the maps where its 36 GEMMs of ceil(h/4)*ceil(w/4) rows cover fewer padded 64-row
+        # tiles than the 16 of F(2x2,3x3) -- stages 2 and 3 at 800x1333, not the 25x42 map of
+        # stage 4; "direct" = implicit GEMM
+        self.conv_algo = "winograd4"
 
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._params.items())
@@ -144,6 +147,7 @@ class ResNet50Hip:
                     # GEMMs, slower than the direct form)
                     if conv == "conv2" and co >= 128 and not (b == 0 and i > 0):
                         w[p + "conv2.wino"] = hip.winograd_weights(cw.to(dev))
+                        w[p + "conv2.wino4"] = hip.winograd43_weights(cw.to(dev))
         self.w = w
 
     class _Plan:
@@ -167,7 +171,7 @@ class ResNet50Hip:
         # split-K workspace for the late stages (few output tiles, long K): sized for the
         # largest S x M x N the library can ask for here
         pl.scratch = E(B * 16 * 1024 * 1024 // 2)
-        pl.hw, pl.out, pl.t1, pl.t2, pl.idt, pl.ping = [], [], [], [], [], []
+        pl.hw, pl.out, pl.t1, pl.t2, pl.idt, pl.ping, pl.f43 = [], [], [], [], [], [], []
         nwino = 0
         for i, (planes, blocks) in enumerate(self.stages):
             hin, win = h, wd
@@ -180,7 +184,12 @@ class ResNet50Hip:
             pl.ping.append(E(B, h, wd, planes * 4))
             pl.out.append(E(B, h, wd, planes * 4))
             if planes >= 128:
-                nwino = max(nwino, 16 * B * ((h + 1) // 2) * ((wd + 1) // 2) * planes)
+                t2, t4 = B * ((h + 1) // 2) * ((wd + 1) // 2), B * ((h + 3) // 4) * ((wd + 3) // 4)
+                nwino = max(nwino, 16 * t2 * planes, 36 * t4 * planes)
+                # F(4x4,3x3) where it multiplies fewer (64-row padded) GEMM rows
+                pl.f43.append(36 * (-(-t4 // 64)) < 16 * (-(-t2 // 64)))
+            else:
+                pl.f43.append(False)
         pl.wV, pl.wM = E(max(nwino, 4)), E(max(nwino, 4))   # Winograd transform planes
         self._plans[key] = pl
         return pl
@@ -251,7 +260,13 @@ class ResNet50Hip:
                 hip.linear(x.view(-1, cin), w[p + "conv1.w"], w[p + "conv1.b"],
                            t1.view(-1, planes), relu=True, scratch=pl.scratch)
                 # conv2 3x3, stride on this layer ("pytorch" style) (+BN+ReLU)
-                if self.conv_algo == "winograd" and p + "conv2.wino" in w and stride == 1:
+                wino = self.conv_algo in ("winograd", "winograd4") and p + "conv2.wino" in w \
+                    and stride == 1
+                if wino and self.conv_algo == "winograd4" and pl.f43[i]:
+                    # 4x fewer multiplications (fp32; ~1.6e-5 relative to the direct form)
+                    hip.conv3x3_winograd43(t1, w[p + "conv2.wino4"], w[p + "conv2.b"], pl.t2[i],
+                                           pl.wV, pl.wM, B, hi, wi, planes, planes, True)
+                elif wino:
                     # 2.25x fewer multiplications (fp32; differs from the direct form by fp32
                     # re-association, ~2e-6 relative)
                     hip.conv3x3_winograd(t1, w[p + "conv2.wino"], w[p + "conv2.b"], pl.t2[i],

@@ -114,15 +114,13 @@ class CrossHead2:
         # True: compute attention masks in the reference's operation order (full-size mask
         # logits -> bilinear resize); False: resample the mask feature once (see _attn_mask)
         self.exact_mask_order = False
-        # 3x3 FPN convolution (every mode is exact fp32 arithmetic on the fp32 MFMA): "winograd" = F(2x2,3x3), 2.25x fewer
-        # multiplications, differs from the direct form by ~2e-6 relative, the size of the
-        # direct form's own fp32 rounding error (default; needs even sides of the
-        # 1/4-resolution map, else "direct" is used); "winograd4" = F(4x4,3x3), 4x fewer
-        # multiplications and +5 % images/s, but ~2e-5 relative: with the seeded random
-        # weights of the tests, whose hard attention masks amplify perturbations over the
-        # nine decoder layers, that is enough to push one fixture's class logits past 1e-3,
-        # so it stays opt-in; "direct" = implicit GEMM (bitwise an fmaf chain)
-        self.conv_algo = "winograd"
+        # 3x3 FPN convolution (every mode is fp32 arithmetic on the fp32 MFMA): "winograd4" =
+        # F(4x4,3x3), 4x fewer multiplications, ~1.6e-5 relative to the direct form (default:
+        # the end-to-end errors against the reference are the same to three digits for all
+        # three modes, tests/test_head_gpu.py::test_e2e_full_800x1333_...); "winograd" =
+        # F(2x2,3x3), 2.25x fewer, ~2e-6 (needs even sides of the 1/4-resolution map, else
+        # "direct" is used); "direct" = implicit GEMM (bitwise an fmaf chain)
+        self.conv_algo = "winograd4"
         # replay each stage as one hipGraph (no per-launch host cost) after a warm-up call
         self.use_graphs = False
         # persistent-GEMM workgroup slots stage A leaves free for concurrent streams' kernels

@@ -63,10 +63,13 @@ def test_stem_and_maxpool_match_torch(B, H, W):
 
 
 @pytest.mark.parametrize("B,H,W,algo", [(1, 96, 128, "winograd"), (2, 75, 101, "winograd"),
-                                        (1, 128, 192, "winograd"), (1, 128, 192, "direct")])
+                                        (1, 128, 192, "winograd"), (1, 128, 192, "direct"),
+                                        (1, 128, 192, "winograd4"), (2, 75, 101, "winograd4"),
+                                        (1, 416, 544, "winograd4")])
 def test_backbone_matches_oracle(B, H, W, algo):
     """(128 x 192: the stage-3 map is 8 x 12, even sides, so its stride-1 3x3 layers take the
-    Winograd form when `conv_algo` says so.)"""
+    Winograd form when `conv_algo` says so; "winograd4", the default, takes F(4x4,3x3) only on
+    maps where that multiplies fewer padded GEMM rows -- stages 2 and 3 of the 416 x 544 case.)"""
     from pairnet_amd import ResNet50Hip
     sd = seeded_backbone_state(31)
     oracle = OracleResNet50()

@@ -367,20 +367,22 @@ def main():
     for _ in range(2 * args.depth if engine is not None else 2):
         step()
     drain()
-    for _ in range(args.warmup):
-        step()
-    drain()
     calibration = None
     if engine is not None:
         calibration = engine.calibrate(feats, metas, submit=step)
-        step()
-        drain()
     # Python's cyclic GC (gen-2 passes of 50-100 ms over torch's object graph) would
     # land inside the timed region at random: collect now, then keep it off, as a
     # serving loop would.
     gc.collect()
     gc.freeze()
     gc.disable()
+    # ---- the W untimed warm-up steps, directly in front of the timed region: the setup
+    # above leaves the GPU idle for tens of ms (host-side calibration bookkeeping, the GC
+    # pass), and the first 20 steps after >= 50 ms of idle take 3 % longer than the same 20
+    # steps issued back to back (tools/filldrain_probe.py: 101.1 vs 97.9 ms) ----
+    for _ in range(args.warmup):
+        step()
+    drain()
 
     def timed(n, **kw):
         torch.cuda.synchronize()

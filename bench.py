@@ -441,8 +441,9 @@ def main():
 
     # ---- secondary, headline-adjacent: the WHOLE of PSGTr.simple_test (psgtr.py:148-156):
     # the same steps plus the panoptic-loop status check and triplet2Result's device -> host
-    # copy of every field (:15-51; 2R x H0 x W0 bool masks = 49 MB per image) into a ring of
-    # pinned host buffers on a copy stream, Results built on the host for every image ----
+    # copy of every field (:15-51; the 2R x H0 x W0 bool masks, 49 MB per image, travel as
+    # 6 MB of bits) into a ring of pinned host buffers, Results built on the host for every
+    # image ----
     simple_test = None
     if rank == 0 and world == 1 and engine is not None and args.path == "image":
         from pairnet_amd import ResultStreamer
@@ -479,13 +480,18 @@ def main():
         simple_test = {
             "images_per_s": B * n / dt, "ms_per_step": 1e3 * dt / n, "steps": n,
             "results_built": made[0],
-            "d2h_bytes_per_image": int(sum(getattr(r0, k).nbytes for k in (
+            "result_bytes_per_image": int(sum(getattr(r0, k).nbytes for k in (
                 "refine_bboxes", "labels", "rel_pair_idxes", "rel_dists", "rel_labels",
                 "pan_results", "masks"))),
+            "d2h_bytes_per_image": int(sum(
+                h.numel() * h.element_size() for e in streamer.entries[:1] if e is not None
+                for host in e["host"] for h in host if isinstance(h, torch.Tensor))) // B,
             "what": "PSGTr.simple_test per step: image -> backbone -> head -> get_bboxes -> "
-                    "panoptic status check -> triplet2Result (every field copied to pinned host "
-                    "memory on a copy stream, Result objects built per image; arrays are views "
-                    "of a %d-entry ring)" % streamer.ring}
+                    "panoptic status check -> triplet2Result (every field to pinned host memory "
+                    "behind the image's query chain, the 2R x H0 x W0 bool masks as bits packed "
+                    "on the device and expanded by host threads; Result objects built per image, "
+                    "same fields / dtypes as the reference's; arrays are views of a %d-entry "
+                    "ring)" % streamer.ring}
         del streamer
 
     # ---- secondary: the head alone on the resident pyramid (round 1's headline) ----

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 14
+#define PN_ABI_VERSION 15
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -436,6 +436,13 @@ int pn_pack_triplets_f32(const int64_t* labels, const float* r_dists, const int6
  * GEMMs.  `dst` may be pinned host memory (mapped in the device's address space) or device
  * memory; src / dst 16-byte aligned. */
 int pn_copy_stream(const void* src, void* dst, int64_t bytes, int wgs, void* stream);
+
+/* `triplet2Result`'s masks (psgtr.py:38-46: 2R x H0 x W0 numpy bool, 49 of the 51 MB) cross
+ * PCIe as bits.  Device: `n` mask bytes (any non-zero = set; `bools` 8-byte aligned) ->
+ * (n + 7) / 8 bytes, byte i bit j = element 8 i + j.  Host (no GPU call, runs on `threads`
+ * host threads, 1..64): the inverse, one 0 / 1 byte per element = numpy bool. */
+int pn_pack_bool_bits(const uint8_t* bools, uint8_t* bits, int64_t n, void* stream);
+int pn_unpack_bits_host(const uint8_t* bits, uint8_t* bools, int64_t n, int threads);
 
 /* Test-time image front end (configs/mask2former/pairnet.py:310-331, mean / std :229-231):
  * mmdet Resize(keep_ratio) [= mmcv.imresize = OpenCV INTER_LINEAR on uint8, fixed point] ->

@@ -726,3 +726,79 @@ extern "C" int pn_copy_stream(const void* src, void* dst, int64_t bytes, int wgs
                      (const uint4*)src, (uint4*)dst, n16, bytes);
   return PN_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------
+// triplet2Result's masks (psgtr.py:38-46: 2R x H0 x W0 numpy bool, 49 MB per 800x1333 image)
+// cross PCIe as BITS: packed on the device (8 mask bytes -> 1 byte, byte i bit j = element
+// 8 i + j), copied (6 MB), expanded to the reference's bool array by the host helper below.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_bool_bits(const uint8_t* __restrict__ m,
+                                                        uint8_t* __restrict__ bits, int64_t n) {
+  const int64_t nb = (n + 7) >> 3, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) {
+    unsigned long long x = 0;
+    if (8 * i + 8 <= n) {
+      x = *reinterpret_cast<const unsigned long long*>(m + 8 * i);
+    } else {
+      for (int j = 0; 8 * i + j < n; ++j) x |= (unsigned long long)m[8 * i + j] << (8 * j);
+    }
+    // any non-zero byte -> 1, then gather the eight low bits (byte j -> bit j)
+    const unsigned long long lo = 0x7f7f7f7f7f7f7f7fULL;
+    x = ((((x & lo) + lo) | x) >> 7) & 0x0101010101010101ULL;
+    bits[i] = (uint8_t)((x * 0x0102040810204080ULL) >> 56);
+  }
+}
+
+extern "C" int pn_pack_bool_bits(const uint8_t* bools, uint8_t* bits, int64_t n, void* stream) {
+  if (!bools || !bits || n <= 0 || ((uintptr_t)bools & 7)) return PN_BAD_ARG;
+  const int64_t nb = (n + 7) / 8;
+  int64_t grid = (nb + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_pack_bool_bits, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                     bools, bits, n);
+  return PN_LAUNCH_CHECK();
+}
+
+// HOST side of the same transfer (no GPU involved): bits -> one byte (0 / 1) per element,
+// split over `threads` host threads; the caller holds no lock (ctypes releases the GIL).
+#include <string.h>
+#include <thread>
+#include <vector>
+static void unpack_range(const uint8_t* bits, uint8_t* bools, int64_t b0, int64_t b1, int64_t n,
+                         const uint64_t* lut) {
+  for (int64_t i = b0; i < b1; ++i) {
+    if (8 * i + 8 <= n) {
+      memcpy(bools + 8 * i, &lut[bits[i]], 8);
+    } else {
+      for (int j = 0; 8 * i + j < n; ++j) bools[8 * i + j] = (bits[i] >> j) & 1;
+    }
+  }
+}
+
+extern "C" int pn_unpack_bits_host(const uint8_t* bits, uint8_t* bools, int64_t n, int threads) {
+  if (!bits || !bools || n <= 0 || threads < 1 || threads > 64) return PN_BAD_ARG;
+  static uint64_t lut[256];
+  static bool ready = false;
+  if (!ready) {            // (idempotent: concurrent first calls write the same values)
+    for (int b = 0; b < 256; ++b) {
+      uint64_t v = 0;
+      for (int j = 0; j < 8; ++j) v |= (uint64_t)((b >> j) & 1) << (8 * j);
+      lut[b] = v;
+    }
+    ready = true;
+  }
+  const int64_t nb = (n + 7) / 8;
+  if (threads == 1 || nb < (1 << 16)) {
+    unpack_range(bits, bools, 0, nb, n, lut);
+    return 0;
+  }
+  std::vector<std::thread> pool;
+  const int64_t per = (nb + threads - 1) / threads;
+  for (int t = 1; t < threads; ++t) {
+    const int64_t b0 = t * per, b1 = b0 + per < nb ? b0 + per : nb;
+    if (b0 < b1) pool.emplace_back(unpack_range, bits, bools, b0, b1, n, lut);
+  }
+  unpack_range(bits, bools, 0, per < nb ? per : nb, n, lut);
+  for (auto& th : pool) th.join();
+  return 0;
+}

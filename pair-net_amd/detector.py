@@ -10,6 +10,9 @@ beside the native one lives in tools/torch_resnet50.py, not in the product packa
 """
 from collections import OrderedDict
 
+import queue
+import threading
+
 import torch
 
 from . import hip
@@ -69,14 +72,15 @@ def triplet2Result(triplets, use_mask, eval_mask_rels=False):
 
 
 class ResultStreamer:
-    """`triplet2Result` (psgtr.py:15-51) for a pipeline of images: every field of a batch's
-    `get_bboxes` tuples is first copied device -> device into this ring's own staging buffers
-    (51 MB per 800x1333 image: 2R x H0 x W0 bool masks; ~25 us of HBM time on the stream the
-    results are ordered on), which releases the pipeline slot at once; copy kernels on a copy
-    stream of their own then move the fields to PINNED host buffers, under the next images'
-    kernels, and the host never allocates (a multi-MB host allocation per image is an
-    mmap / munmap pair, and every munmap runs the amdgpu MMU notifier against the busy GPU:
-    ~75 ms stalls measured).
+    """`triplet2Result` (psgtr.py:15-51) for a pipeline of images.  The fields of a batch's
+    `get_bboxes` tuples are staged device -> device into this ring's own buffers on the chain
+    stream that produced them (which releases the pipeline slot at once) -- the 2R x H0 x W0
+    bool masks, 49 of the 51 MB per 800x1333 image, as BITS (`pn_pack_bool_bits`) -- and copied
+    to PINNED host buffers behind that on the same stream, under the next images' kernels; a
+    worker thread of this object waits for the copy and expands the bits into the bool arrays
+    the Results hold (`pn_unpack_bits_host`).  The host never allocates (a multi-MB host
+    allocation per image is an mmap / munmap pair, and every munmap runs the amdgpu MMU
+    notifier against the busy GPU: ~75 ms stalls measured).
 
         streamer = ResultStreamer(head, ring=4)
         streamer.push(results, pipe)      # results of PipelinedHead.submit() / get_bboxes()
@@ -84,14 +88,17 @@ class ResultStreamer:
         for r in streamer.pop():          # oldest pushed batch -> [Result], same fields and
             ...                           # dtypes as triplet2Result
 
-    What it costs (tools/d2h_probe.py, one variant per process, 800x1333, 51 MB per image,
-    196 images/s without any result copy): staging alone is free; hipMemcpyAsync per field
-    (which runs as a chip-wide blit KERNEL on this stack: rocprofv3 shows
-    __amd_rocclr_copyBuffer up to 0.9 ms, no SDMA copy record) 162 images/s; `pn_copy_stream`
-    per field with 1 / 4 / 16 workgroups 146 / **175** / 153: one workgroup is copy-bound
-    (7 GB/s), wide copies put more PCIe writes in flight than the link drains and slow the
-    concurrent GEMMs through the memory fabric they share.  Four workgroups are the default:
-    0.89 of the headline rate for the whole of `simple_test`.
+    What it costs (tools/d2h_probe.py, one variant per process, 800x1333; 208 images/s with no
+    result copy at all): masks as bits, 8 MB per image: 203 images/s with the bounded copy
+    kernel (`pn_copy_stream`, 4 workgroups per field), 200-201 with 16 / 64 workgroups, 206
+    with hipMemcpyAsync (a chip-wide blit KERNEL on this stack: rocprofv3 shows
+    __amd_rocclr_copyBuffer, no SDMA copy record); masks as bytes, 51 MB per image: 193.
+    Before the copies moved onto the producing chain stream they ran on a stream of this
+    object's own, which HIP places on one of its 4 hardware queues by creation order --
+    beside a stage-A stream or a chain stream: 182 or 196 images/s from one process to the
+    next (bytes: 146 / 175 / 153 / 162 with 1 / 4 / 16 workgroups / hipMemcpyAsync; wide
+    copies of 51 MB keep more PCIe writes in flight than the link drains and slow the
+    concurrent GEMMs through the memory fabric they share).
 
     `pop()` waits for that batch's copies, checks its panoptic loops like `PSGTr.simple_test`
     (IndexError when every segment was filtered, pairnet_head.py:882) and returns Results
@@ -99,14 +106,24 @@ class ResultStreamer:
     (copy what must live longer).  The reference returns fresh arrays; this is the documented
     deviation that keeps allocation out of the loop."""
 
-    def __init__(self, head, ring=4, copy_wgs=4):
+    PACK_MIN = 1 << 16     # bool fields of at least this many elements travel as bits
+
+    def __init__(self, head, ring=4, copy_wgs=4, pack_masks=True, unpack_threads=4):
         """`copy_wgs`: workgroups of the device -> pinned-host copy kernel (`pn_copy_stream`):
         PCIe needs no width (one workgroup moves 7 GB/s; 4 keep a 51 MB image well under a
-        step); 0 = hipMemcpyAsync."""
+        step); 0 = hipMemcpyAsync.  `pack_masks`: bool fields (the 2R x H0 x W0 masks, 49 of
+        the 51 MB) are packed to bits on the device (`pn_pack_bool_bits`), cross PCIe as
+        6 MB and are expanded to the reference's numpy bool arrays by `unpack_threads` host
+        threads in `pop()` (`pn_unpack_bits_host`)."""
         if head.device is None or head.device.type != "cuda":
             raise RuntimeError("ResultStreamer needs a head on an MI355X")
         self.head, self.device, self.ring = head, head.device, ring
         self.copy_wgs = max(0, int(copy_wgs))
+        self.pack_masks, self.unpack_threads = bool(pack_masks), int(unpack_threads)
+        # the host half of the packed transfer runs on a worker thread of this object: it
+        # waits for an entry's copy event and expands its bits while the caller's thread
+        # keeps submitting images (both waits and the expansion run without the GIL)
+        self._jobs, self._worker = queue.Queue(), None
         with torch.cuda.device(self.device):
             self.stream = torch.cuda.Stream()
         self.entries = [None] * ring      # dict(key, staging / host fields, event, jobs)
@@ -117,15 +134,24 @@ class ResultStreamer:
         if e is not None and e["key"] == key:
             return e
         is_dev = lambda t: isinstance(t, torch.Tensor) and t.is_cuda
+        packed = lambda t: (self.pack_masks and is_dev(t) and t.dtype == torch.bool
+                            and t.numel() >= self.PACK_MIN)
+        nbits = lambda t: ((t.numel() + 7) // 8 + 15) // 16 * 16
         e = self.entries[self.head_i % self.ring] = dict(
             key=key,
-            dev=[[torch.empty(t.shape, dtype=t.dtype, device=self.device) if is_dev(t) else None
-                  for t in tup] for tup in results],
-            host=[[torch.empty(t.shape, dtype=t.dtype, pin_memory=True) if is_dev(t) else t
+            dev=[[torch.empty(nbits(t), dtype=torch.uint8, device=self.device) if packed(t)
+                  else torch.empty(t.shape, dtype=t.dtype, device=self.device) if is_dev(t)
+                  else None for t in tup] for tup in results],
+            host=[[torch.empty(nbits(t), dtype=torch.uint8, pin_memory=True) if packed(t)
+                   else torch.empty(t.shape, dtype=t.dtype, pin_memory=True) if is_dev(t) else t
                    for t in tup] for tup in results],    # (host-side constants pass through)
+            # packed fields: the bool arrays the Results hold (ordinary host memory, written
+            # by the host threads of pop())
+            bools=[[torch.empty(t.shape, dtype=torch.bool) if packed(t) else None for t in tup]
+                   for tup in results],
             dev_states=torch.empty(max(1, n_jobs), 16, dtype=torch.uint8, device=self.device),
             host_states=torch.empty(max(1, n_jobs), 16, dtype=torch.uint8, pin_memory=True),
-            event=torch.cuda.Event(), jobs=0)
+            event=torch.cuda.Event(), jobs=0, ready=threading.Event(), error=None)
         return e
 
     def _to_host(self, src, dst):
@@ -147,32 +173,77 @@ class ResultStreamer:
         e = self._entry(key, results, len(jobs))
         # (the ring entry's buffers are free again: pop() waited for its copies, and push()
         # refuses to overtake pop())
-        cur = torch.cuda.current_stream(self.device)
-        for tup, stage in zip(results, e["dev"]):
-            for t, d in zip(tup, stage):
-                if d is not None:
-                    d.copy_(t)
-        for i, job in enumerate(jobs):
-            e["dev_states"][i].copy_(job[0][:16])
-        if pipe is not None:
-            pipe.consumed(results, cur)
-        self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
+        # Results of a PipelinedHead are staged on the chain stream that produced them
+        # (ordered behind get_bboxes there, not behind the image the caller has just queued on
+        # its own stream), and their copies to the host follow on the same stream: a stream of
+        # this object's own would share one of the 4 hardware queues with a pipeline stream
+        # picked by creation order -- 182 or 196 images/s from one process to the next.
+        src = getattr(results, "pipeline_stream", None) if pipe is not None else None
+        cur = src if src is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(cur):
+            for tup, stage, bools in zip(results, e["dev"], e["bools"]):
+                for t, d, b in zip(tup, stage, bools):
+                    if b is not None:
+                        hip.pack_bool_bits(t.contiguous(), d)
+                    elif d is not None:
+                        d.copy_(t)
+            for i, job in enumerate(jobs):
+                e["dev_states"][i].copy_(job[0][:16])
+            if pipe is not None:
+                pipe.consumed(results, cur)
+        copy_stream = cur if src is not None else self.stream
+        if copy_stream is not cur:
+            copy_stream.wait_stream(cur)
+        with torch.cuda.stream(copy_stream):
             for stage, host in zip(e["dev"], e["host"]):
                 for d, h in zip(stage, host):
                     if d is not None:
                         self._to_host(d, h)
             if jobs:
                 self._to_host(e["dev_states"], e["host_states"])
-            e["event"].record(self.stream)
+            e["event"].record(copy_stream)
         e["jobs"] = len(jobs)
         self.head_i += 1
+        if any(b is not None for bools in e["bools"] for b in bools):
+            if self._worker is None:
+                self._worker = threading.Thread(target=self._unpack_loop, daemon=True)
+                self._worker.start()
+            e["ready"].clear()
+            self._jobs.put(e)
+        else:
+            e["ready"].set()
+
+    def _unpack_loop(self):
+        while True:
+            e = self._jobs.get()
+            if e is None:
+                return
+            try:
+                e["event"].synchronize()
+                for host, bools in zip(e["host"], e["bools"]):
+                    for h, b in zip(host, bools):
+                        if b is not None:
+                            hip.unpack_bits_host(h, b, self.unpack_threads)
+                e["error"] = None
+            except BaseException as exc:      # handed to the thread that pops this entry
+                e["error"] = exc
+            e["ready"].set()
+
+    def close(self):
+        """Stop the worker thread (it is a daemon: optional)."""
+        if self._worker is not None:
+            self._jobs.put(None)
+            self._worker.join()
+            self._worker = None
 
     def pop(self):
         if self.tail_i >= self.head_i:
             raise RuntimeError("ResultStreamer is empty")
         e = self.entries[self.tail_i % self.ring]
         self.tail_i += 1
+        e["ready"].wait()
+        if e.get("error") is not None:
+            raise e["error"]
         e["event"].synchronize()
         for i in range(e["jobs"]):
             nkeep, active, rounds, all_gone = e["host_states"][i].view(torch.int32).tolist()
@@ -186,8 +257,14 @@ class ResultStreamer:
                 # loop cannot be continued here the way PSGTr.simple_test does -- fail loudly.
                 raise RuntimeError("panoptic loop still active after %d rounds" % rounds)
         use_mask = self.head.use_mask
-        return [triplet2Result(tuple(h.numpy() if isinstance(h, torch.Tensor) else h
-                                     for h in host), use_mask) for host in e["host"]]
+        out = []
+        for host, bools in zip(e["host"], e["bools"]):
+            fields = []
+            for h, b in zip(host, bools):
+                h = b if b is not None else h          # (expanded by the worker thread)
+                fields.append(h.numpy() if isinstance(h, torch.Tensor) else h)
+            out.append(triplet2Result(tuple(fields), use_mask))
+        return out
 
     def __len__(self):
         return self.head_i - self.tail_i

@@ -92,6 +92,8 @@ _SIGS = {
     "pn_panoptic_continue_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_pack_triplets_f32": (C.c_int, [_vp] * 5 + [_i32, _i32, _vp]),
     "pn_copy_stream": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "pn_pack_bool_bits": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "pn_unpack_bits_host": (C.c_int, [_vp, _vp, _i64, _i32]),
     "pn_pred_triplets": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "pn_mask_or_rows": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _vp]),
     "pn_triplet_match": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
@@ -115,7 +117,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 14   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 15   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -701,6 +703,33 @@ def copy_stream(src, dst, wgs=16):
     if nbytes:
         _check(lib().pn_copy_stream(src.data_ptr(), dst.data_ptr(), nbytes, int(wgs), _stream()),
                "pn_copy_stream")
+
+
+def pack_bool_bits(src, bits):
+    """bits[(n + 7) // 8] uint8 <- the n elements of the bool / uint8 device tensor `src` (byte i
+    bit j = element 8 i + j), on torch's current stream."""
+    n = src.numel()
+    if not src.is_cuda or not bits.is_cuda or src.element_size() != 1 or not src.is_contiguous() \
+            or bits.dtype != torch.uint8 or bits.numel() < (n + 7) // 8 or not bits.is_contiguous():
+        raise RuntimeError("pack_bool_bits: contiguous 1-byte device source, uint8 device "
+                           "destination of (n + 7) // 8 bytes")
+    if n:
+        _check(lib().pn_pack_bool_bits(src.data_ptr(), bits.data_ptr(), n, _stream()),
+               "pn_pack_bool_bits")
+
+
+def unpack_bits_host(bits, out, threads=4):
+    """The host half: `out` (a HOST bool / uint8 tensor of n elements) <- the packed bytes in
+    the host tensor `bits` (once their copy has completed).  No GPU call; ctypes drops the GIL
+    for its duration."""
+    n = out.numel()
+    if bits.is_cuda or out.is_cuda or out.element_size() != 1 or bits.dtype != torch.uint8 \
+            or not (bits.is_contiguous() and out.is_contiguous()) or bits.numel() < (n + 7) // 8:
+        raise RuntimeError("unpack_bits_host: contiguous host tensors, uint8 bits of "
+                           "(n + 7) // 8 bytes")
+    if n:
+        _check(lib().pn_unpack_bits_host(bits.data_ptr(), out.data_ptr(), n, int(threads)),
+               "pn_unpack_bits_host")
 
 
 def preprocess_u8(img, H, W, out, Hn, Wn, Hp, Wp, mean, stdinv, to_rgb):

@@ -188,6 +188,10 @@ class PipelinedHead:
             from .head import CrossHead2
             res = CrossHead2.ResultList(res)
             res.pipeline_slot = item["slot"]
+        # the chain stream the results were produced on: a consumer that queues its reads
+        # THERE (ResultStreamer) is ordered behind get_bboxes without waiting for whatever
+        # the caller has queued on its own stream since
+        res.pipeline_stream = sb
         return res
 
     def consumed(self, results, stream=None):

@@ -284,3 +284,22 @@ def test_load_checkpoint_refuses_pickled_code_by_default(tmp_path):
     good = os.path.join(tmp_path, "good.pth")
     torch.save(dict(state_dict=head.state_dict(), meta=dict(CLASSES=("a", "b"))), good)
     assert load_checkpoint(head, good)["meta"]["CLASSES"] == ("a", "b")
+
+
+def test_host_unpack_of_mask_bits_needs_no_gpu():
+    """`pn_unpack_bits_host`, the host half of the bit-packed mask transfer of
+    `triplet2Result`: numpy.unpackbits(bitorder="little"), any length, any thread count."""
+    import numpy as np
+    from pairnet_amd import hip
+    for n in (1, 8, 13, 65536 * 8 + 5, 200 * 96 * 128):
+        rng = np.random.default_rng(n)
+        bits = torch.from_numpy(rng.integers(0, 256, (n + 7) // 8, dtype=np.uint8))
+        want = np.unpackbits(bits.numpy(), bitorder="little")[:n].astype(bool)
+        for threads in (1, 4, 7):
+            out = torch.zeros(n + 2, dtype=torch.bool)
+            hip.unpack_bits_host(bits, out[:n], threads)
+            assert np.array_equal(out[:n].numpy(), want) and not out[n:].any()
+    with pytest.raises(RuntimeError):
+        hip.unpack_bits_host(bits[:3], torch.zeros(100, dtype=torch.bool))
+    assert hip.lib().pn_unpack_bits_host(None, None, 8, 1) == -1
+    assert hip.lib().pn_unpack_bits_host(bits.data_ptr(), out.data_ptr(), 8, 0) == -1

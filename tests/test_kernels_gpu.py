@@ -605,3 +605,27 @@ def test_copy_stream_to_pinned_host_and_device(hip, nbytes, wgs):
     with pytest.raises(RuntimeError):
         hip.copy_stream(f, torch.empty(7, 33, pin_memory=True).t())   # not contiguous
     assert hip.lib().pn_copy_stream(None, None, 16, 4, None) == -1
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 4099, 200 * 80 * 112, 2 * 384 * 640 + 3])
+def test_mask_bits_round_trip(hip, n):
+    """pn_pack_bool_bits (device) against numpy.packbits(bitorder="little"), any length, any
+    non-zero byte = set; pn_unpack_bits_host gives back the bool array."""
+    g = torch.Generator().manual_seed(n)
+    b = torch.rand(n, generator=g) < 0.37
+    want = np.packbits(b.numpy(), bitorder="little")
+    bits = torch.zeros((n + 7) // 8 + 5, dtype=torch.uint8, device=DEV)
+    hip.pack_bool_bits(b.to(DEV), bits)
+    assert np.array_equal(bits.cpu().numpy()[:len(want)], want)
+    assert not bits[len(want):].any()                       # nothing written past the end
+    raw = torch.where(b, torch.randint(1, 256, (n,), generator=g), 0).to(torch.uint8)
+    bits.zero_()
+    hip.pack_bool_bits(raw.to(DEV), bits)
+    assert np.array_equal(bits.cpu().numpy()[:len(want)], want)
+    for threads in (1, 3):
+        out = torch.ones(n + 3, dtype=torch.bool)
+        hip.unpack_bits_host(bits.cpu(), out[:n], threads)
+        assert torch.equal(out[:n], b) and bool(out[n:].all())
+    with pytest.raises(RuntimeError):
+        hip.pack_bool_bits(b.to(DEV), torch.zeros(max(1, (n + 7) // 8 - 1), dtype=torch.uint8,
+                                                  device=DEV)[:(n + 7) // 8 - 1])

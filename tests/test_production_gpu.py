@@ -219,10 +219,11 @@ def test_result_streamer_equals_simple_test():
     want = [det.simple_test(im, metas)[0] for im in imgs]
     want = [{k: np.array(getattr(r, k)) for k in fields} for r in want]
     head, net = det.bbox_head, det.backbone
-    for graphs in (False, True):
+    # (the 200 x 80 x 112 bool masks travel as bits unless pack_masks=False)
+    for graphs, pack in ((False, True), (True, True), (True, False)):
         head.use_graphs = net.use_graphs = graphs
         pipe = PipelinedHead(head, depth=4, a_streams=2)
-        streamer = ResultStreamer(head, ring=3)
+        streamer = ResultStreamer(head, ring=3, pack_masks=pack)
         for rep in range(2):
             got = []
 
@@ -251,7 +252,7 @@ def test_result_streamer_equals_simple_test():
             assert len(got) == len(want)
             for r, w in zip(got, want):
                 for k in fields:
-                    assert r[k].dtype == w[k].dtype and np.array_equal(r[k], w[k]), (graphs, rep, k)
+                    assert r[k].dtype == w[k].dtype and np.array_equal(r[k], w[k]), (graphs, pack, rep, k)
     with pytest.raises(RuntimeError):
         ResultStreamer(head, ring=1).pop()
 

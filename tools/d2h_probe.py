@@ -90,7 +90,7 @@ class ThrottleOnly(ResultStreamer):   # events + host pacing, no copies at all
 
 
 # one variant per process (allocations of earlier variants shift the later ones' numbers):
-#   d2h_probe.py none | pacing | <copy_wgs>
+#   d2h_probe.py none | pacing | <copy_wgs> (masks as bits) | <copy_wgs>u (masks as bytes)
 which = sys.argv[1] if len(sys.argv) > 1 else "4"
 MODE = "cur"
 if which == "none":
@@ -98,6 +98,8 @@ if which == "none":
 elif which == "pacing":
     run("host pacing only (event on cur)", lambda: ThrottleOnly(head, ring=6))
 else:
-    w = int(which)
-    run("staged, per field, copy kernel %d WGs" % w if w else "staged, per field, hipMemcpyAsync",
-        lambda: ResultStreamer(head, ring=6, copy_wgs=w))
+    pack = not which.endswith("u")
+    w = int(which.rstrip("u"))
+    run(("staged, per field, copy kernel %d WGs" % w if w else "staged, per field, hipMemcpyAsync") +
+        (", masks as bits" if pack else ", masks as bytes"),
+        lambda: ResultStreamer(head, ring=6, copy_wgs=w, pack_masks=pack))

@@ -208,9 +208,13 @@ def main():
     ap.add_argument("--a-streams", type=int, default=2,
                     help="streams that backbone + stage A of consecutive batches alternate between")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly")
-    ap.add_argument("--exact-mask-order", action="store_true",
-                    help="attention masks in the reference's operation order (full-size mask "
-                         "logits, then the resize) instead of the once-resampled mask feature")
+    ap.add_argument("--mask-order", choices=["reference", "dense", "resampled"],
+                    default="reference",
+                    help="attention masks: 'reference' = the reference's operation order "
+                         "(full-size mask logits -> bilinear resize -> threshold), evaluated only "
+                         "at the logits the resize reads (default); 'dense' = the same with all "
+                         "full-size logits (bit-identical); 'resampled' = the opt-in shortcut: "
+                         "logits against the once-resampled mask feature")
     ap.add_argument("--grid-trim", type=int, default=None,
                     help="persistent-GEMM workgroup slots left free for the query chains")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -263,7 +267,8 @@ def main():
                 "psgtr2": lambda pl: (ident, ident)}[args.head]   # query i IS triplet i
     head.init_weights(seed=0)
     head.to(dev)
-    head.exact_mask_order = args.exact_mask_order
+    MASK_ORDER = {"reference": True, "dense": "full", "resampled": False}
+    head.exact_mask_order = MASK_ORDER[args.mask_order]
     if args.conv:
         head.conv_algo = args.conv
     head.use_graphs = not args.no_graphs
@@ -624,8 +629,12 @@ def main():
                                else "feature pyramid"),
                 "path": args.path, "backbone": bname,
                 "distinct_input_images": len(pool) if args.path == "image" else 1,
-                "attention_mask_order": "reference (resize of full-size mask logits)"
-                if args.exact_mask_order else "mask feature resampled once per level",
+                "attention_mask_order": {
+                    "reference": "the reference's: bilinear resize of full-size mask logits, "
+                                 "computed at the 4 logits per key the resize reads",
+                    "dense": "the reference's: all full-size mask logits, then the resize",
+                    "resampled": "shortcut: logits against the mask feature resampled once per "
+                                 "level"}[args.mask_order],
                 "global_batch": world * B, "per_gpu_batch": B, "image": [H, W],
                 "stream_placement_calibration_ms": calibration,
                 "parallelism": "dp%d" % world,
@@ -745,25 +754,26 @@ def main():
         if backbone is not None and not swin:
             backbone.use_graphs = not args.no_graphs
         out["latency_ms_single_stream_graphs"] = timeit(whole, 10)
-        if engine is not None and not args.exact_mask_order:
-            # the same pipelined steps with the attention masks in the REFERENCE's operation
-            # order (full-size mask logits -> bilinear resize -> threshold, pairnet_head.py:
-            # 244-256) instead of the once-resampled mask feature of the headline
-            head.exact_mask_order = True
+        if engine is not None and args.mask_order == "reference":
+            # the same pipelined steps with the opt-in shortcut for the attention masks: the
+            # mask feature is resampled to each level once per image and every layer's logits
+            # are a Q x N_l GEMM against it (resize(me . MF) == me . resize(MF) up to fp32
+            # re-association) instead of the reference's operation order of the headline
+            head.exact_mask_order = False
             for _ in range(2 * args.depth):      # (graphs are re-captured for the new setting)
                 step()
             drain()
             dt = timed(min(args.steps, 40))
-            head.exact_mask_order = False
+            head.exact_mask_order = True
             for _ in range(2 * args.depth):
                 step()
             drain()
             n = min(args.steps, 40)
-            out["reference_mask_order"] = {
+            out["resampled_mask_feature_shortcut"] = {
                 "images_per_s": B * n / dt, "ms_per_step": 1e3 * dt / n, "steps": n,
-                "what": "headline schedule with exact_mask_order=True: every decoder layer's "
-                        "attention mask from the full-size mask logits, resized, thresholded "
-                        "(the reference's order of operations)"}
+                "what": "headline schedule with exact_mask_order=False (opt-in): attention-mask "
+                        "logits against the once-resampled mask feature instead of the "
+                        "reference's order of operations"}
         if engine is not None and B == 1 and args.path == "image":
             # BASELINE configs[2] is 2 images per GPU (bs = 16 over 8 GPUs): the same schedule
             # with two distinct images per launch sequence (plans and graphs of their own)

@@ -294,6 +294,14 @@ int pn_bilinear_nhwc_f32(const float* in, float* out, int B, int hi, int wi,
                          int64_t out_bstride, void* stream);
 int pn_bilinear_planar_f32(const float* in, float* out, int64_t P, int hi,
                            int wi, int ho, int wo, void* stream);
+/* The rows a bilinear resize of a channel-last map reads: out[b][t][p][:] = in[b][tap t of
+ * output pixel p][:], t = 0..3 <-> (y0,x0), (y0,x1), (y1,x0), (y1,x1).  As the W operand of the
+ * mask-logit GEMM they yield exactly the full-resolution logits `F.interpolate(mask_pred)`
+ * reads for a level (pairnet_head.py:244-246) -- Q x 4 N_l instead of Q x H2 W2 per layer;
+ * pn_mask_pack_stencil blends, thresholds and packs them. */
+int pn_bilinear_stencil_rows_f32(const float* in, float* out, int B, int hi, int wi, int ho,
+                                 int wo, int C, int64_t in_bstride, int64_t out_bstride,
+                                 void* stream);
 /* planar resize + (sigmoid(v) > 0.5  <=>  v > 0) -> uint8 {0,1}  (:834,:842) */
 int pn_bilinear_planar_gt0_u8(const float* in, uint8_t* out, int64_t P, int hi,
                               int wi, int ho, int wo, void* stream);
@@ -307,6 +315,11 @@ int pn_bilinear_planar_gt0_u8(const float* in, uint8_t* out, int64_t P, int hi,
  * logits [R][Nk]; bits [R][nwords], nwords = (Nk+31)/32. */
 int pn_mask_pack(const float* logits, uint32_t* bits, int32_t* rowall,
                  int64_t R, int Nk, void* stream);
+/* The same from logits4 [R][4][Nk = ho*wo], the four stencil logits per key (tap-major, see
+ * pn_bilinear_stencil_rows_f32): bit = (bilinear blend of the four, as pn_bilinear_planar_f32
+ * computes it from the (hi, wi) map) < 0. */
+int pn_mask_pack_stencil(const float* logits4, uint32_t* bits, int32_t* rowall, int64_t R,
+                         int hi, int wi, int ho, int wo, void* stream);
 
 /* softmax(q k^T * scale + mask) v per head, flash-style over key chunks
  * (f32 MFMA for both contractions), then a combine pass.

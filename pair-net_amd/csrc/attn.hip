@@ -70,6 +70,58 @@ extern "C" int pn_mask_pack(const float* logits, uint32_t* bits, int32_t* rowall
   return PN_LAUNCH_CHECK();
 }
 
+// The same from the four full-resolution logits of each key's bilinear stencil (logits4
+// [R][4][Nk], tap-major as pn_bilinear_stencil_rows_f32 orders the rows): the resized logit
+// is blended exactly as pn_bilinear_planar_f32 blends it, thresholded, packed.
+__global__ __launch_bounds__(256) void k_mask_pack_stencil(const float* __restrict__ logits4,
+                                                           uint32_t* __restrict__ bits,
+                                                           int32_t* __restrict__ rowall, int hi,
+                                                           int wi, int ho, int wo) {
+  const int Nk = ho * wo;
+  const int64_t row = blockIdx.x;
+  const int nwords = (Nk + 31) / 32;
+  const float* lr = logits4 + row * 4 * Nk;
+  uint32_t* br = bits + row * nwords;
+  bool seen = false;
+  for (int base = 0; base < Nk; base += 512) {     // two 256-key strips, 8 loads in flight
+    float v[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = min(base + 256 * j + (int)threadIdx.x, Nk - 1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[j][t] = lr[(int64_t)t * Nk + i];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = base + 256 * j + threadIdx.x;
+      const bool valid = i < Nk;
+      const int ic = valid ? i : Nk - 1;
+      const int oy = ic / wo, ox = ic - oy * wo;
+      const float r = tap_blend(make_tap(oy, hi, ho), make_tap(ox, wi, wo), v[j][0], v[j][1],
+                                v[j][2], v[j][3]);
+      const bool masked = valid && r < 0.f;
+      seen |= valid && !masked;
+      const unsigned long long bal = __ballot(masked);
+      const int lane = threadIdx.x & 63;
+      const int w0 = (base + 256 * j + (threadIdx.x & ~63)) / 32;
+      if (lane == 0 && w0 < nwords) br[w0] = (uint32_t)bal;
+      if (lane == 32 && w0 + 1 < nwords) br[w0 + 1] = (uint32_t)(bal >> 32);
+    }
+  }
+  const int some = __syncthreads_or(seen ? 1 : 0);
+  if (threadIdx.x == 0) rowall[row] = some ? 0 : 1;
+}
+
+extern "C" int pn_mask_pack_stencil(const float* logits4, uint32_t* bits, int32_t* rowall,
+                                    int64_t R, int hi, int wi, int ho, int wo, void* stream) {
+  if (!logits4 || !bits || !rowall || R <= 0 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0 ||
+      (int64_t)ho * wo >= ((int64_t)1 << 29))
+    return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_mask_pack_stencil, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream,
+                     logits4, bits, rowall, hi, wi, ho, wo);
+  return PN_LAUNCH_CHECK();
+}
+
 struct AttnP {
   const float* q; const float* k; const float* v;
   const uint32_t* bits; const int32_t* rowall;

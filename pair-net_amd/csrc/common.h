@@ -79,3 +79,26 @@ __device__ __forceinline__ int xcd_tile_index(int L, int ntiles) {
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + j;
 }
+
+// ATen's upsample_bilinear2d source index (align_corners=False, no scale factor):
+//   src = max(scale * (dst + 0.5) - 0.5, 0), scale = in / out;
+//   i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1.
+struct Tap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Tap make_tap(int dst, int in, int outn) {
+  const float scale = (float)in / (float)outn;
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  Tap t;
+  t.i0 = (int)src;
+  if (t.i0 > in - 1) t.i0 = in - 1;
+  t.i1 = t.i0 + ((t.i0 < in - 1) ? 1 : 0);
+  t.l1 = src - (float)t.i0;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+// out = l0y (l0x v00 + l1x v01) + l1y (l0x v10 + l1x v11): ONE definition for every kernel
+// that resamples, so that all of them round alike
+__device__ __forceinline__ float tap_blend(const Tap& ty, const Tap& tx, float v00, float v01,
+                                           float v10, float v11) {
+  return ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11);
+}

@@ -52,23 +52,6 @@ extern "C" int pn_sine_pe_f32(float* out, const float* add, int h, int w, int C,
   return pn_sine_pe_offset_f32(out, add, h, w, C, temperature, 0.f, stream);
 }
 
-// ATen's upsample_bilinear2d source index (align_corners=False, no scale factor):
-//   src = max(scale * (dst + 0.5) - 0.5, 0), scale = in / out;
-//   i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1.
-struct Tap { int i0, i1; float l0, l1; };
-__device__ __forceinline__ Tap make_tap(int dst, int in, int outn) {
-  const float scale = (float)in / (float)outn;
-  float src = scale * ((float)dst + 0.5f) - 0.5f;
-  if (src < 0.f) src = 0.f;
-  Tap t;
-  t.i0 = (int)src;
-  if (t.i0 > in - 1) t.i0 = in - 1;
-  t.i1 = t.i0 + ((t.i0 < in - 1) ? 1 : 0);
-  t.l1 = src - (float)t.i0;
-  t.l0 = 1.f - t.l1;
-  return t;
-}
-
 __global__ __launch_bounds__(256) void k_bilinear_nhwc(const float* __restrict__ in,
                                                        float* __restrict__ out, int hi, int wi,
                                                        int ho, int wo, int C4, int accumulate,
@@ -122,7 +105,7 @@ __global__ __launch_bounds__(256) void k_bilinear_planar(const float* __restrict
   const float* ib = in + pl * hi * wi;
   const float v00 = ib[(int64_t)ty.i0 * wi + tx.i0], v01 = ib[(int64_t)ty.i0 * wi + tx.i1];
   const float v10 = ib[(int64_t)ty.i1 * wi + tx.i0], v11 = ib[(int64_t)ty.i1 * wi + tx.i1];
-  const float r = ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11);
+  const float r = tap_blend(ty, tx, v00, v01, v10, v11);
   if (GT0) ((uint8_t*)outv)[pl * per_plane + e] = r > 0.f ? 1 : 0;
   else     ((float*)outv)[pl * per_plane + e] = r;
 }
@@ -147,7 +130,7 @@ __global__ __launch_bounds__(256) void k_bilinear_planar4(const float* __restric
   for (int j = 0; j < 4; ++j) {
     const Tap tx = make_tap(ox + j, wi, wo);
     const float v00 = r0[tx.i0], v01 = r0[tx.i1], v10 = r1[tx.i0], v11 = r1[tx.i1];
-    r[j] = ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11);
+    r[j] = tap_blend(ty, tx, v00, v01, v10, v11);
   }
   const int64_t o = pl * ((int64_t)ho * wo) + (int64_t)oy * wo + ox;
   if (GT0) {
@@ -189,6 +172,41 @@ extern "C" int pn_bilinear_planar_f32(const float* in, float* out, int64_t P, in
 extern "C" int pn_bilinear_planar_gt0_u8(const float* in, uint8_t* out, int64_t P, int hi, int wi,
                                          int ho, int wo, void* stream) {
   return launch_planar(in, out, P, hi, wi, ho, wo, true, stream);
+}
+
+// ---- the rows a bilinear resize reads: out[b][t][p][:] = in[b][tap t of output pixel p][:],
+// t = 0..3 <-> (i0,j0), (i0,j1), (i1,j0), (i1,j1) of make_tap.  With these rows as the W
+// operand of the mask-logit GEMM, the FULL-RESOLUTION logits a layer's attention mask needs
+// (pairnet_head.py:244-246: interpolate(mask_pred) reads 4 of them per output pixel) come out
+// of a Q x 4 N_l GEMM instead of the Q x H2 W2 one; pn_mask_pack_stencil blends them. ----
+__global__ __launch_bounds__(256) void k_stencil_rows(const float* __restrict__ in,
+                                                      float* __restrict__ out, int hi, int wi,
+                                                      int ho, int wo, int C4, int64_t ibs,
+                                                      int64_t obs) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (tap, pixel, float4 group)
+  const int64_t n = (int64_t)ho * wo;
+  if (e >= 4 * n * C4) return;
+  const int c = (int)(e % C4);
+  const int64_t tp = e / C4;
+  const int t = (int)(tp / n);
+  const int pix = (int)(tp - (int64_t)t * n);
+  const int oy = pix / wo, ox = pix - oy * wo;
+  const Tap ty = make_tap(oy, hi, ho), tx = make_tap(ox, wi, wo);
+  const int sy = (t & 2) ? ty.i1 : ty.i0, sx = (t & 1) ? tx.i1 : tx.i0;
+  const float* ib = in + (int64_t)blockIdx.y * ibs;
+  st4(out + (int64_t)blockIdx.y * obs + e * 4, ld4(ib + ((int64_t)sy * wi + sx) * C4 * 4 + c * 4));
+}
+
+extern "C" int pn_bilinear_stencil_rows_f32(const float* in, float* out, int B, int hi, int wi,
+                                            int ho, int wo, int C, int64_t in_bstride,
+                                            int64_t out_bstride, void* stream) {
+  if (!in || !out || B <= 0 || B > 65535 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0 || C <= 0 ||
+      (C & 3) || ((in_bstride | out_bstride) & 3))
+    return PN_BAD_ARG;
+  const int64_t total = (int64_t)4 * ho * wo * (C / 4);
+  hipLaunchKernelGGL(k_stencil_rows, dim3(pn_cdiv(total, 256), B), dim3(256), 0,
+                     (hipStream_t)stream, in, out, hi, wi, ho, wo, C / 4, in_bstride, out_bstride);
+  return PN_LAUNCH_CHECK();
 }
 
 // ---- 3x3 stride-2 pad-1 max pooling, channel-last (ResNet stem) ----

@@ -111,9 +111,12 @@ class CrossHead2:
         self._dummies = {}
         self._post = OrderedDict()
         self._pan_jobs = []
-        # True: compute attention masks in the reference's operation order (full-size mask
-        # logits -> bilinear resize); False: resample the mask feature once (see _attn_mask)
-        self.exact_mask_order = False
+        # Attention masks (see _attn_mask).  True (default since round 3): the reference's
+        # operation order -- full-size mask logits -> bilinear resize -> threshold -- evaluated
+        # at the 4 logits per key the resize reads; "full": the same, densely (bit-identical,
+        # the cross-check); False: opt-in shortcut, logits against the mask feature resampled
+        # once per level (+2.5 % images/s, a different fp32 rounding of the same logits)
+        self.exact_mask_order = True
         # 3x3 FPN convolution (every mode is fp32 arithmetic on the fp32 MFMA): "winograd4" =
         # F(4x4,3x3), 4x fewer multiplications, ~1.6e-5 relative to the direct form (default:
         # the end-to-end errors against the reference are the same to three digits for all
@@ -391,6 +394,7 @@ class CrossHead2:
         pl.Qp, pl.att, pl.Qp0 = E(BQ, 256), E(BQ, 256), E(BQ, 256)
         pl.VQK = E(BQ, 768)
         pl.MFd = [E(B, n, 256) for n in pl.N]   # mask feature resampled to each level
+        pl.MFs = pl.ML4 = None                  # exact_mask_order=True: stencil rows, their logits
         pl.hq = E(hip.ffn_scratch_floats(BQ, self.dec_ffn))
         pl.MP = E(B, Q, HW2)
         pl.ML = E(BQ, max(pl.N))
@@ -498,6 +502,15 @@ class CrossHead2:
             for l, (h, wd) in enumerate(pl.shapes):
                 hip.bilinear_nhwc(pl.MF, pl.MFd[l], B, H2, W2, h, wd, 256, False, HW2 * 256,
                                   pl.N[l] * 256)
+        elif self.exact_mask_order != "full":
+            # the mask-feature rows each level's bilinear stencils read, once per image
+            if pl.MFs is None:
+                E = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
+                pl.MFs = [E(B, 4 * n, 256) for n in pl.N]
+                pl.ML4 = E(B * self.num_obj_query, 4 * max(pl.N))
+            for l, (h, wd) in enumerate(pl.shapes):
+                hip.bilinear_stencil_rows(pl.MF, pl.MFs[l], B, H2, W2, h, wd, 256, HW2 * 256,
+                                          4 * pl.N[l] * 256)
 
     def _mlp3(self, prefix, src, dst, pl):
         """Linear-ReLU-Linear-ReLU-Linear (`mask_embed`-style heads) via pl.m1 / pl.m2."""
@@ -533,16 +546,30 @@ class CrossHead2:
         :300) -> pl.bits / pl.rowall.
 
         The reference resizes the full-resolution mask logits bilinearly and thresholds.
-        Bilinear resampling is linear, so resize(me . MF) == me . resize(MF): the mask
-        feature is resampled once per image (pl.MFd) and each layer's logits are a
-        Q x N_l GEMM instead of a Q x 66 800 GEMM plus a resize (same values up to fp32
-        re-association; `exact_mask_order=True` keeps the reference's operation order)."""
+        `exact_mask_order`:
+          False   bilinear resampling is linear, so resize(me . MF) == me . resize(MF): the
+                  mask feature is resampled once per image (pl.MFd) and each layer's logits
+                  are a Q x N_l GEMM (same values up to fp32 re-association);
+          True    the reference's operation order, computed sparsely: an output pixel's
+                  bilinear stencil reads 4 full-resolution logits, so the layer computes
+                  exactly those -- me against the 4 N_l stencil rows of the mask feature
+                  (pl.MFs, gathered once per image; the same tile GEMM, hence the same
+                  rounding per logit, as the full Q x H2 W2 product) -- and
+                  `pn_mask_pack_stencil` blends them like `pn_bilinear_planar_f32`;
+          "full"  the dense form of the same thing (full-resolution logits, planar resize,
+                  pack): bit for bit the result of True, kept as its cross-check."""
         B, Q = pl.B, self.num_obj_query
         h, wd = pl.shapes[lvl]
         n = h * wd
-        if self.exact_mask_order:
+        if self.exact_mask_order == "full":
             hip.bilinear_planar(pl.MP if mp is None else mp, pl.ML, B * Q, pl.hw2[0], pl.hw2[1],
                                 h, wd)
+        elif self.exact_mask_order:
+            hip.gemm(pl.me if me is None else me, pl.MFs[lvl], pl.ML4, M=Q, N=4 * n, K=256,
+                     lda=256, ldw=256, ldc=4 * n, batch=B, sA=Q * 256, sW=4 * n * 256,
+                     sC=Q * 4 * n, force="tile64")
+            hip.mask_pack_stencil(pl.ML4, pl.bits, pl.rowall, B * Q, pl.hw2[0], pl.hw2[1], h, wd)
+            return
         else:
             hip.gemm(pl.me if me is None else me, pl.MFd[lvl], pl.ML, M=Q, N=n, K=256, lda=256,
                      ldw=256, ldc=n, batch=B, sA=Q * 256, sW=n * 256, sC=Q * n)
@@ -639,7 +666,7 @@ class CrossHead2:
         without `final_head` the last layer's class / mask heads are left to the caller."""
         w, B, Q = self.w, pl.B, self.num_obj_query
         qpos = w["query_embed.weight"]
-        exact = self.exact_mask_order
+        exact = self.exact_mask_order == "full"     # full-resolution logits of every layer
         # the INITIAL queries are learned constants (pl.q0: `query_feat` repeated over the
         # batch, filled when the plan is made; the first layer reads them in place), and so is
         # their mask embedding: computed on the plan's first call and kept (a new state dict

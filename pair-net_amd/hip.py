@@ -70,6 +70,8 @@ _SIGS = {
     "pn_bilinear_planar_f32": (C.c_int, [_vp, _vp, _i64] + [_i32] * 4 + [_vp]),
     "pn_bilinear_planar_gt0_u8": (C.c_int, [_vp, _vp, _i64] + [_i32] * 4 + [_vp]),
     "pn_mask_pack": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "pn_mask_pack_stencil": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "pn_bilinear_stencil_rows_f32": (C.c_int, [_vp, _vp] + [_i32] * 6 + [_i64, _i64, _vp]),
     "pn_attn_scratch_floats": (_i64, [_i32, _i32, _i32]),
     "pn_attention_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                                    _i64, _vp, _i32, _i32, _i32, _f32, _vp]),
@@ -566,6 +568,18 @@ def bilinear_planar_gt0(x, out, P, hi, wi, ho, wo):
 def mask_pack(logits, bits, rowall, R, Nk):
     _check(lib().pn_mask_pack(_ptr(logits), _ptr(bits, torch.int32),
                               _ptr(rowall, torch.int32), R, Nk, _stream()), "pn_mask_pack")
+
+
+def mask_pack_stencil(logits4, bits, rowall, R, hi, wi, ho, wo):
+    _check(lib().pn_mask_pack_stencil(_ptr(logits4), _ptr(bits, torch.int32),
+                                      _ptr(rowall, torch.int32), R, hi, wi, ho, wo, _stream()),
+           "pn_mask_pack_stencil")
+
+
+def bilinear_stencil_rows(x, out, B, hi, wi, ho, wo, Cc, in_bstride, out_bstride):
+    _check(lib().pn_bilinear_stencil_rows_f32(_ptr(x), _ptr(out), B, hi, wi, ho, wo, Cc,
+                                              in_bstride, out_bstride, _stream()),
+           "pn_bilinear_stencil_rows_f32")
 
 
 def attn_scratch_floats(B, Q, Nk):

@@ -99,8 +99,40 @@ def test_e2e_small_against_reference_golden():
 
 
 @pytest.mark.parametrize("conv_algo,exact_order", [
-    ("winograd", False), ("direct", False), ("winograd4", False), ("winograd", True)])
+    ("winograd", False), ("direct", False), ("winograd4", False), ("winograd", True),
+    ("winograd4", True), ("winograd4", "full")])
 def test_e2e_full_800x1333_against_reference_golden(conv_algo, exact_order):
+    _e2e_full(conv_algo, exact_order)
+
+
+def test_sparse_reference_mask_order_is_the_dense_one_bit_for_bit():
+    """`exact_mask_order=True` computes, per layer, only the full-resolution mask logits the
+    level's bilinear stencils read (Q x 4 N_l) and blends them; "full" computes all Q x H2 W2
+    and resizes.  Same GEMM kernel per logit, same blend: every output of the head is bitwise
+    the same, at 800 x 1333 with two images."""
+    fx = golden("e2e_full")
+    _, sd, _ = oracle_head(int(fx["weight_seed"]), overrides_of(fx))
+    H, W = int(fx["height"]), int(fx["width"])
+    feats = [f.to(DEV) for f in seeded.seeded_feats(int(fx["feat_seed"]) + 1, 2, H, W)]
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[2.083] * 4)] * 2
+    outs = {}
+    for mode in (True, "full", False):
+        head = _hip_head(sd)
+        head.exact_mask_order = mode
+        cls, masks = head.forward(feats, metas)
+        torch.cuda.synchronize()
+        outs[mode] = {k: v.clone() for k, v in list(cls.items()) + list(masks.items())
+                      if isinstance(v, torch.Tensor)}
+        outs[mode]["topk"] = head._last_plan.topk_idx.clone()
+    for k, v in outs[True].items():
+        assert torch.equal(v, outs["full"][k]), k
+    # (the once-resampled form is a different rounding of the same logits: it flips an
+    # attention-mask bit only where a resized logit is within ~1e-6 of zero)
+    print("outputs identical to the once-resampled form as well:",
+          all(torch.equal(v, outs[False][k]) for k, v in outs[True].items()))
+
+
+def _e2e_full(conv_algo, exact_order):
     fx = golden("e2e_full")
     head_o, sd, crc = oracle_head(int(fx["weight_seed"]), overrides_of(fx))
     assert crc == int(fx["weight_crc"])
@@ -111,8 +143,9 @@ def test_e2e_full_800x1333_against_reference_golden(conv_algo, exact_order):
     metas = [dict(img_shape=(H, W, 3), scale_factor=[2.083] * 4)]
     head = _hip_head(sd)
     head.conv_algo = conv_algo
-    # (True: attention masks in the reference's operation order -- full-size mask logits,
-    # then the bilinear resize -- instead of the once-resampled mask feature)
+    # (True / "full": attention masks in the reference's operation order -- full-size mask
+    # logits, then the bilinear resize; sparse / dense evaluation -- instead of the
+    # once-resampled mask feature)
     head.exact_mask_order = exact_order
     cls, masks = head.forward([f.to(DEV) for f in feats], metas)
     torch.cuda.synchronize()
@@ -248,7 +281,7 @@ def test_relation_decoder_on_golden_pair_features():
     assert e < 1e-4
 
 
-@pytest.mark.parametrize("exact_mask_order", [False, True])
+@pytest.mark.parametrize("exact_mask_order", [False, True, "full"])
 def test_against_oracle_other_seed_and_batch_consistency(exact_mask_order):
     head_o, sd, _ = oracle_head(1234)
     H, W = 64, 96

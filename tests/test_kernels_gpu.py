@@ -629,3 +629,53 @@ def test_mask_bits_round_trip(hip, n):
     with pytest.raises(RuntimeError):
         hip.pack_bool_bits(b.to(DEV), torch.zeros(max(1, (n + 7) // 8 - 1), dtype=torch.uint8,
                                                   device=DEV)[:(n + 7) // 8 - 1])
+
+
+@pytest.mark.parametrize("hi,wi,ho,wo", [(200, 334, 25, 42), (200, 334, 50, 84),
+                                         (200, 334, 100, 167), (24, 32, 3, 4), (19, 26, 5, 7),
+                                         (7, 9, 7, 9)])
+def test_stencil_rows_and_stencil_mask_pack(hip, hi, wi, ho, wo):
+    """pn_bilinear_stencil_rows_f32 gathers the 4 source rows of every output pixel of an
+    align_corners=False bilinear resize; logits against those rows, blended by
+    pn_mask_pack_stencil, give bit for bit the mask of (full-resolution logits ->
+    pn_bilinear_planar_f32 -> pn_mask_pack)."""
+    B, Q, C = 2, 100, 256
+    g = torch.Generator().manual_seed(hi * wi + ho)
+    mf = torch.randn(B, hi * wi, C, generator=g).to(DEV)
+    me = torch.randn(B * Q, C, generator=g).to(DEV)
+    n = ho * wo
+    rows = torch.empty(B, 4 * n, C, device=DEV)
+    hip.bilinear_stencil_rows(mf, rows, B, hi, wi, ho, wo, C, hi * wi * C, 4 * n * C)
+    # the gather against ATen's index formula
+    def taps(o, i_n, o_n):
+        src = (torch.arange(o_n, dtype=torch.float32) + 0.5) * (float(i_n) / float(o_n)) - 0.5
+        i0 = src.clamp(min=0).floor().long().clamp(max=i_n - 1)
+        return i0, (i0 + (i0 < i_n - 1).long())
+    y0, y1 = taps(None, hi, ho)
+    x0, x1 = taps(None, wi, wo)
+    idx = torch.stack([(yy[:, None] * wi + xx[None, :]).reshape(-1)
+                       for yy, xx in ((y0, x0), (y0, x1), (y1, x0), (y1, x1))]).reshape(-1)
+    assert torch.equal(rows.cpu(), mf.cpu()[:, idx])
+    # dense: full-resolution logits -> resize -> pack
+    full = torch.empty(B * Q, hi * wi, device=DEV)
+    hip.gemm(me, mf, full, M=Q, N=hi * wi, K=C, lda=C, ldw=C, ldc=hi * wi, batch=B, sA=Q * C,
+             sW=hi * wi * C, sC=Q * hi * wi, force="tile64")
+    small = torch.empty(B * Q, n, device=DEV)
+    hip.bilinear_planar(full, small, B * Q, hi, wi, ho, wo)
+    nw = (n + 31) // 32
+    bits_d = torch.zeros(B * Q * nw, dtype=torch.int32, device=DEV)
+    all_d = torch.zeros(B * Q, dtype=torch.int32, device=DEV)
+    hip.mask_pack(small, bits_d, all_d, B * Q, n)
+    # sparse: logits of the stencil rows -> blend + pack
+    l4 = torch.empty(B * Q, 4 * n, device=DEV)
+    hip.gemm(me, rows, l4, M=Q, N=4 * n, K=C, lda=C, ldw=C, ldc=4 * n, batch=B, sA=Q * C,
+             sW=4 * n * C, sC=Q * 4 * n, force="tile64")
+    bits_s = torch.zeros_like(bits_d)
+    all_s = torch.ones_like(all_d)
+    hip.mask_pack_stencil(l4, bits_s, all_s, B * Q, hi, wi, ho, wo)
+    torch.cuda.synchronize()
+    assert torch.equal(bits_s, bits_d) and torch.equal(all_s, all_d)
+    # an all-masked row is flagged
+    l4[3].fill_(-1.0)
+    hip.mask_pack_stencil(l4, bits_s, all_s, B * Q, hi, wi, ho, wo)
+    assert int(all_s[3]) == 1

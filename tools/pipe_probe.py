@@ -7,6 +7,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 B = int(os.environ.get("BATCH", 1))
 cfg = pairnet_head_cfg(); cfg.pop("type")
 head = CrossHead2(**cfg); head.init_weights(seed=0); head.to(dev); head.use_graphs = True
+if os.environ.get("EXACT"):     # EXACT=0 / 1 / full: attention-mask operation order
+    head.exact_mask_order = {"0": False, "1": True}.get(os.environ["EXACT"], os.environ["EXACT"])
 net = ResNet50Hip().to(dev); net.use_graphs = True
 H, W = 800, 1333
 metas = [dict(img_shape=(H, W, 3), scale_factor=[2.083] * 4)] * B

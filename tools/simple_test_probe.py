@@ -1,0 +1,36 @@
+"""Latency of the synchronous, reference-shaped call PSGTr.simple_test (fresh numpy arrays)."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pairnet_amd import build_detector, pairnet_r50
+dev = torch.device("cuda:0")
+det = build_detector(pairnet_r50())
+det.bbox_head.init_weights(seed=0)
+det.to(dev)
+det.bbox_head.use_graphs = det.backbone.use_graphs = True
+H, W = 800, 1333
+metas = [dict(img_shape=(H, W, 3), scale_factor=[2.083] * 4, ori_shape=(384, 640, 3))]
+g = torch.Generator().manual_seed(1)
+pool = [torch.randn(1, 3, H, W, generator=g).to(dev) for _ in range(4)]
+for i in range(6):
+    r = det.simple_test(pool[i % 4], metas, rescale=True)
+torch.cuda.synchronize()
+n = 20
+t = time.perf_counter()
+for i in range(n):
+    r = det.simple_test(pool[i % 4], metas, rescale=True)
+dt = (time.perf_counter() - t) / n
+print("simple_test: %.2f ms per call (masks %s %s)" % (1e3 * dt, r[0].masks.shape, r[0].masks.dtype))
+t = time.perf_counter()
+for i in range(n):
+    feat = det.extract_feat(pool[i % 4])
+    res = det.bbox_head.simple_test(feat, metas, rescale=True)
+    torch.cuda.synchronize()
+print("device part alone: %.2f ms per call" % (1e3 * (time.perf_counter() - t) / n))
+# (Tried: the masks of this synchronous call through the bit-packed transfer of ResultStreamer
+# as well.  Into a WARM host buffer the expansion takes 1.3 ms (4 threads) against 6.2 ms for
+# `.cpu()` of the 49 MB -- but the reference-shaped call returns FRESH arrays, and first-touch
+# page faults of a fresh 49 MB array cost 8 ms from the unpack threads (35 ms for torch.empty +
+# fill_ in a loop: every munmap / fault of a process with a GPU context goes through the amdgpu
+# MMU notifier), while hipMemcpy into pageable memory pins the destination in bulk.  14.7 ms
+# per call with `.cpu()`, 18.2-20.2 with the packed fetch: not adopted; the pipelined
+# ResultStreamer, whose ring buffers stay mapped, is where the packed transfer pays.)

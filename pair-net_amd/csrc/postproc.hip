@@ -777,16 +777,17 @@ static void unpack_range(const uint8_t* bits, uint8_t* bools, int64_t b0, int64_
 
 extern "C" int pn_unpack_bits_host(const uint8_t* bits, uint8_t* bools, int64_t n, int threads) {
   if (!bits || !bools || n <= 0 || threads < 1 || threads > 64) return PN_BAD_ARG;
-  static uint64_t lut[256];
-  static bool ready = false;
-  if (!ready) {            // (idempotent: concurrent first calls write the same values)
-    for (int b = 0; b < 256; ++b) {
-      uint64_t v = 0;
-      for (int j = 0; j < 8; ++j) v |= (uint64_t)((b >> j) & 1) << (8 * j);
-      lut[b] = v;
+  struct Lut {               // byte -> its 8 bits as 8 bytes (little-endian lanes)
+    uint64_t v[256];
+    Lut() {
+      for (int b = 0; b < 256; ++b) {
+        v[b] = 0;
+        for (int j = 0; j < 8; ++j) v[b] |= (uint64_t)((b >> j) & 1) << (8 * j);
+      }
     }
-    ready = true;
-  }
+  };
+  static const Lut table;    // (C++11: initialised once, thread-safe)
+  const uint64_t* lut = table.v;
   const int64_t nb = (n + 7) / 8;
   if (threads == 1 || nb < (1 << 16)) {
     unpack_range(bits, bools, 0, nb, n, lut);

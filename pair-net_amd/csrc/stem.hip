@@ -150,12 +150,11 @@ extern "C" int pn_stem7x7s2_f32(const float* img, const float* Wp, const float* 
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8)
       cus = n;
   }
-  static int wg_per_cu = 0;                      // resident workgroups per CU, asked once
-  if (!wg_per_cu) {
+  static const int wg_per_cu = [] {              // resident workgroups per CU, asked once
     int n = 0;
-    wg_per_cu = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stem7x7s2, 256, 0) == hipSuccess &&
-                        n > 0 ? n : 2;
-  }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_stem7x7s2, 256, 0) == hipSuccess &&
+                   n > 0 ? n : 2;
+  }();
   const int reserve = ((flags >> PN_GEMM_RESERVE_SHIFT) & 0x3ff) * 8;
   int64_t grid = (int64_t)cus * wg_per_cu - reserve;
   if (grid < 256) grid = 256;

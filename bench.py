@@ -28,6 +28,7 @@ Rank 0 prints ONE JSON line: the contract fields plus
 """
 import argparse
 import gc
+import math
 import glob
 import json
 import os
@@ -826,6 +827,45 @@ def main():
             del voa, s_out
         except Exception as e:  # pragma: no cover
             out["deformable_sampling_offsets"] = repr(e)
+        # random weights make the attention masks ~50 % dense, a trained
+        # head's are sparser -- the masked cross-attention of each level on the masks of the
+        # last step and on a synthetic mask with 10 % foreground (every query attends one
+        # rectangle of a tenth of the map, the rest is masked)
+        if args.head == "pairnet":
+            try:
+                Q = head.num_obj_query
+                res = {}
+                for l, (h, wd) in enumerate(pl.shapes):
+                    n = h * wd
+                    nw = (n + 31) // 32
+                    gen = torch.Generator(device=dev).manual_seed(11 + l)
+                    lg = torch.randn(B * Q, n, device=dev, generator=gen)      # ~50 % masked
+                    fg = torch.full((B * Q, h, wd), -1.0, device=dev)
+                    rh, rw = max(1, int(round(h * 0.316))), max(1, int(round(wd * 0.316)))
+                    ys = torch.randint(0, h - rh + 1, (B * Q,), generator=gen, device=dev).tolist()
+                    xs = torch.randint(0, wd - rw + 1, (B * Q,), generator=gen, device=dev).tolist()
+                    for r, (y0, x0) in enumerate(zip(ys, xs)):
+                        fg[r, y0:y0 + rh, x0:x0 + rw] = 1.0
+                    fg = fg.view(B * Q, n)
+                    bits = torch.empty(B * Q * nw, dtype=torch.int32, device=dev)
+                    rowall = torch.empty(B * Q, dtype=torch.int32, device=dev)
+                    row = {"keys": n}
+                    for name, logit in (("random_half", lg), ("foreground_10pct", fg)):
+                        hip.mask_pack(logit, bits, rowall, B * Q, n)
+                        t = timeit(lambda: hip.attention(
+                            pl.Qp, 256, pl.Kp[l], 256, pl.Vp[l], 256, bits, rowall, pl.att, 256,
+                            pl.scr, B, Q, n, 1.0 / math.sqrt(32.0)), 50)
+                        row[name] = {"attendable_fraction": float((logit >= 0).float().mean()),
+                                     "us": 1e3 * t}
+                    res["level_%d" % l] = row
+                    del lg, fg, bits, rowall
+                res["what"] = ("pn_attention_f32 alone (Q = %d queries x 8 heads against one "
+                               "level's keys), back to back, on a ~50 %% random mask and on a "
+                               "mask with one 10 %% rectangle of foreground per query: key tiles "
+                               "no query of a wave may attend to are skipped" % Q)
+                out["attention_mask_density"] = res
+            except Exception as e:  # pragma: no cover
+                out["attention_mask_density"] = repr(e)
         if backbone is not None and not swin:
             try:  # comparison leg: the same backbone through PyTorch-ROCm / MIOpen
                 from tools.torch_resnet50 import ResNet50

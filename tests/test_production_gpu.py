@@ -255,6 +255,16 @@ def test_result_streamer_equals_simple_test():
                     assert r[k].dtype == w[k].dtype and np.array_equal(r[k], w[k]), (graphs, pack, rep, k)
     with pytest.raises(RuntimeError):
         ResultStreamer(head, ring=1).pop()
+    # without a pipeline: results of a plain simple_test_bboxes on the current stream, copies
+    # on the streamer's own stream
+    head.use_graphs = net.use_graphs = False
+    streamer = ResultStreamer(head, ring=2)
+    for im, w in zip(imgs[:3], want[:3]):
+        streamer.push(head.simple_test_bboxes(net(im), metas))
+        (r,) = streamer.pop()
+        for k in fields:
+            assert np.array_equal(np.array(getattr(r, k)), w[k]), k
+    streamer.close()
 
 
 def test_two_heads_in_one_process_keep_their_own_grids():

@@ -8,10 +8,13 @@ simple_test_bboxes` (pairnet_head.py:926-930: pixel decoder, 9-layer masked deco
 PPN / Matrix Learner / top-k, 6-layer relation decoder, get_bboxes), 100 object / 100
 relation queries, fp32 -- BASELINE.json configs[1] on each GPU; consecutive steps take
 DIFFERENT images (a rotating pool of `--pool` distinct tensors, so that neither weights nor
-activations of "the" image can sit in the 256 MB MALL).  The secondary leg
+activations of "the" image can sit in the 256 MB MALL); attention masks are computed in the
+reference's operation order (`--mask-order`).  The secondary leg
 `simple_test_incl_result_d2h` adds the rest of `simple_test`: the panoptic-loop status check
-and `triplet2Result`'s device -> host copy of every field (psgtr.py:15-51) into pinned host
-buffers on a copy stream.  `--path head` times the
+and `triplet2Result` of every field to the host (psgtr.py:15-51; pinned ring buffers, the
+bool masks as bits over PCIe, `Result` objects built per image); further legs: the opt-in
+mask shortcut, two images per GPU, attention vs mask density, deformable sampling vs offset
+spread.  `--path head` times the
 head alone on a resident feature pyramid (round 1's headline; reported by the default run
 as the secondary `head_only`).  For N > 1 one rank per GPU over RCCL: started by
 torch.distributed.run, or by this script itself when WORLD_SIZE is unset (plain `python

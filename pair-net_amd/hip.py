@@ -310,7 +310,13 @@ def gemm(A, W, Cout, **kw):
         _check(lib().pn_gemm_f32(C.byref(d), _stream()), "pn_gemm_f32")
         return
     name = GEMM_KERNELS[lib().pn_gemm_variant(C.byref(d))]
+    # every operand of the fused op once: A, W, C, and where present the residual read by the
+    # epilogue and the row-periodic addend on A (positional encodings)
     nbytes = 4.0 * d.batch * (d.M * d.K + d.N * d.K + d.M * d.N)
+    if d.Res:
+        nbytes += 4.0 * d.batch * d.M * d.N
+    if d.Aadd:
+        nbytes += 4.0 * min(d.aadd_rows, d.M) * d.K
     _check(_launch(name, 2.0 * d.M * d.N * d.K * d.batch, nbytes,
                    lambda: lib().pn_gemm_f32(C.byref(d), _stream()),
                    meta=(d.M, d.N, d.K, d.batch, bool(d.splitk_scratch))), "pn_gemm_f32")

@@ -576,6 +576,56 @@ def main():
                             "what": "uint8 %dx%dx3 BGR image in HBM -> TestPipeline (resize to "
                                     "%dx%d, normalise, pad; one HIP kernel) -> %s -> head"
                                     % (h0, w0, H, W, bname)}
+            if engine is not None and rank == 0:
+                # host to host, PCIe both ways (never `value`): the decoded uint8 image in
+                # PINNED HOST memory -> H2D (0.74 MB) -> TestPipeline -> backbone -> head ->
+                # get_bboxes -> ResultStreamer -> Result objects on the host
+                from pairnet_amd import ResultStreamer
+                raw_host = raw.cpu().pin_memory()
+                raws = [torch.empty_like(raw) for _ in imgs]
+                streamer = ResultStreamer(head, ring=args.depth + 2)
+                built = [0]
+
+                def take(res):
+                    if len(streamer) >= streamer.ring - 1:
+                        built[0] += len(streamer.pop())
+                    streamer.push(res, engine)
+
+                def host_step():
+                    sl = engine.count % len(engine.streams_a)
+                    with torch.cuda.stream(engine.streams_a[sl]):
+                        raws[sl].copy_(raw_host, non_blocking=True)
+                        _, m = pipe(raws[sl], out=imgs[sl])
+                        res = engine.submit(backbone(imgs[sl], slot=sl), m)
+                        if res is not None:
+                            take(res)
+
+                def host_drain():
+                    with torch.cuda.stream(engine.streams_a[0]):
+                        for res in engine.flush():
+                            take(res)
+                    while len(streamer):
+                        built[0] += len(streamer.pop())
+                for _ in range(2 * args.depth):
+                    host_step()
+                host_drain()
+                built[0] = 0
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    host_step()
+                host_drain()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                from_decoded["host_to_host"] = {
+                    "images_per_s": n / dt, "ms_per_step": 1e3 * dt / n, "steps": n,
+                    "results_built": built[0],
+                    "what": "PCIe-inclusive: the decoded uint8 image starts in pinned host memory "
+                            "(H2D 0.74 MB per image) and every Result field ends in host memory "
+                            "(D2H 8.1 MB per image, masks as bits): TestPipeline -> backbone -> "
+                            "head -> get_bboxes -> triplet2Result, pipelined"}
+                streamer.close()
+                del streamer
             img.copy_(img_cpu)            # (the legs below run on the seeded tensor again)
 
     # ---- roofline leg: the same step again, eagerly on one stream, with HIP events

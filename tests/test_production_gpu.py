@@ -264,6 +264,15 @@ def test_result_streamer_equals_simple_test():
         (r,) = streamer.pop()
         for k in fields:
             assert np.array_equal(np.array(getattr(r, k)), w[k]), k
+    # two images per step: one ring entry carries both tuples
+    two = torch.cat(imgs[:2], 0)
+    streamer.push(head.simple_test_bboxes(net(two), metas * 2))
+    got2 = streamer.pop()
+    assert len(got2) == 2
+    for r, w in zip(got2, want[:2]):
+        for k in ("labels", "rel_pair_idxes", "rel_labels", "pan_results", "masks"):
+            assert np.array_equal(np.array(getattr(r, k)), w[k]), k
+        assert np.abs(np.array(r.rel_dists) - w["rel_dists"]).max() < 1e-5
     streamer.close()
 
 

@@ -12,6 +12,7 @@ from collections import OrderedDict
 
 import queue
 import threading
+import weakref
 
 import torch
 
@@ -54,9 +55,57 @@ class Result(object):
         yield self
 
 
-def triplet2Result(triplets, use_mask, eval_mask_rels=False):
+class _MaskFetcher:
+    """Device bool tensor -> numpy bool array for the synchronous `PSGTr.simple_test`, through
+    the bit-packed transfer of `ResultStreamer` (pn_pack_bool_bits on the device, 1/8 of the
+    bytes into a cached pinned buffer, pn_unpack_bits_host on host threads).
+
+    The caller gets an array nobody else holds -- like the reference's `.cpu().numpy()` -- but
+    its memory comes from a small pool that an array returns to when it is garbage collected:
+    a FRESH 49 MB host array per 800x1333 image costs 6-8 ms of first-touch page faults (every
+    fault / munmap of a process with a GPU context passes the amdgpu MMU notifier), a recycled
+    one 1.3 ms of expansion (tools/simple_test_probe.py).  A caller that keeps every result
+    (mmdet's test loop does) simply never returns arrays, and each call allocates as before."""
+    MIN = 1 << 20
+
+    def __init__(self, threads=4, keep=3):
+        self.threads, self.keep = threads, keep
+        self.bits, self.pool = {}, {}
+
+    def _recycle(self, key, t):
+        free = self.pool.setdefault(key, [])
+        if len(free) < self.keep:
+            free.append(t)
+
+    def __call__(self, t):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bool
+                and t.numel() >= self.MIN):
+            return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else t
+        nb = ((t.numel() + 7) // 8 + 15) // 16 * 16
+        bkey = (t.device, nb)
+        if bkey not in self.bits:
+            if len(self.bits) >= 4:
+                self.bits.clear()
+            self.bits[bkey] = (torch.empty(nb, dtype=torch.uint8, device=t.device),
+                               torch.empty(nb, dtype=torch.uint8, pin_memory=True))
+        dev, host = self.bits[bkey]
+        with torch.cuda.device(t.device):
+            hip.pack_bool_bits(t.contiguous(), dev)
+            host.copy_(dev, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        key = tuple(t.shape)
+        free = self.pool.get(key)
+        out = free.pop() if free else torch.empty(key, dtype=torch.bool)
+        hip.unpack_bits_host(host, out, self.threads)
+        arr = out.numpy()
+        weakref.finalize(arr, self._recycle, key, out)   # back to the pool when `arr` dies
+        return arr
+
+
+def triplet2Result(triplets, use_mask, eval_mask_rels=False, mask_fetch=None):
     """8-tuple of `CrossHead2.get_bboxes` (or, without masks, the 6-tuple of
-    `CrossHeadBBox.get_bboxes`) -> Result (psgtr.py:15-71)."""
+    `CrossHeadBBox.get_bboxes`) -> Result (psgtr.py:15-71).  `mask_fetch`: how the masks
+    reach the host (default: `.cpu()`)."""
     np_ = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else t   # (numpy passes)
     if not use_mask:
         bboxes, labels, rel_pairs, r_scores, r_labels, r_dists = triplets
@@ -68,7 +117,7 @@ def triplet2Result(triplets, use_mask, eval_mask_rels=False):
     return Result(refine_bboxes=np_(bboxes), labels=np_(labels),
                   formatted_masks=dict(pan_results=pan_seg), rel_pair_idxes=np_(rel_pairs),
                   rel_dists=np_(r_dists), rel_labels=np_(r_labels), pan_results=pan_seg,
-                  masks=np_(masks))
+                  masks=(mask_fetch or np_)(masks))
 
 
 class ResultStreamer:
@@ -306,6 +355,7 @@ class PSGTr:
                                           test_cfg=test_cfg or dict(max_per_img=100))
         self.num_classes = self.bbox_head.num_classes
         self.test_pipeline = None     # built by detect() (or set a preprocess.TestPipeline)
+        self._mask_fetch = None       # bit-packed D2H of the masks into recycled arrays
 
     def to(self, device):
         self.backbone.to(device)
@@ -367,7 +417,10 @@ class PSGTr:
         # segment was filtered, pairnet_head.py:882)
         if hasattr(results_list, "panoptic_jobs"):
             self.bbox_head.panoptic_status(results_list)
-        return [triplet2Result(t, self.bbox_head.use_mask) for t in results_list]
+        if self._mask_fetch is None:
+            self._mask_fetch = _MaskFetcher()
+        return [triplet2Result(t, self.bbox_head.use_mask, mask_fetch=self._mask_fetch)
+                for t in results_list]
 
     @torch.no_grad()
     def detect(self, image, rescale=False):

@@ -209,6 +209,7 @@ def test_result_streamer_equals_simple_test():
     from pairnet_amd import PipelinedHead, ResultStreamer, build_detector, pairnet_r50
     det = build_detector(pairnet_r50())
     det.backbone.load_state_dict(seeded_backbone_state(41))
+    det.bbox_head.init_weights(seed=3)     # (the default init gives constant masks)
     det.to(DEV)
     H, W = 160, 224
     metas = [dict(img_shape=(H, W, 3), scale_factor=[2.0] * 4)]
@@ -218,6 +219,8 @@ def test_result_streamer_equals_simple_test():
               "pan_results", "masks")
     want = [det.simple_test(im, metas)[0] for im in imgs]
     want = [{k: np.array(getattr(r, k)) for k in fields} for r in want]
+    assert 0.02 < want[0]["masks"].mean() < 0.98 and not np.array_equal(want[0]["masks"],
+                                                                        want[1]["masks"])
     head, net = det.bbox_head, det.backbone
     # (the 200 x 80 x 112 bool masks travel as bits unless pack_masks=False)
     for graphs, pack in ((False, True), (True, True), (True, False)):
@@ -270,8 +273,12 @@ def test_result_streamer_equals_simple_test():
     got2 = streamer.pop()
     assert len(got2) == 2
     for r, w in zip(got2, want[:2]):
-        for k in ("labels", "rel_pair_idxes", "rel_labels", "pan_results", "masks"):
+        for k in ("labels", "rel_pair_idxes", "rel_labels"):
             assert np.array_equal(np.array(getattr(r, k)), w[k]), k
+        # (a two-image launch takes other split-K factors than two one-image launches: the
+        # same logits to ~1e-6, so a mask / panoptic pixel on the threshold may differ)
+        assert (np.array(r.masks) != w["masks"]).mean() < 1e-4
+        assert (np.array(r.pan_results) != w["pan_results"]).mean() < 1e-3
         assert np.abs(np.array(r.rel_dists) - w["rel_dists"]).max() < 1e-5
     streamer.close()
 
@@ -385,3 +392,41 @@ def test_plan_caches_stay_bounded_over_many_shapes():
     again = run(*shapes[0], seed=1)              # its plan was evicted long ago
     for a, b in zip(first, again):
         assert torch.equal(a, b)
+
+
+def test_simple_test_mask_arrays_are_private_and_recycled():
+    """`PSGTr.simple_test` fetches the masks bit-packed into arrays from a pool that an array
+    only returns to when it is garbage collected: results the caller still holds are never
+    overwritten, dropped ones are reused, and the values are those of `.cpu().numpy()`."""
+    import gc
+    from oracle.backbone import seeded_backbone_state
+    from pairnet_amd import build_detector, pairnet_r50
+    det = build_detector(pairnet_r50())
+    det.backbone.load_state_dict(seeded_backbone_state(41))
+    det.bbox_head.init_weights(seed=3)
+    det.to(DEV)
+    H, W = 416, 544            # 200 x 208 x 272 masks: above the packed-transfer threshold
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[2.0] * 4)]
+    g = torch.Generator().manual_seed(5)
+    imgs = [torch.randn(1, 3, H, W, generator=g).to(DEV) for _ in range(3)]
+    want = []
+    for im in imgs:
+        tup = det.bbox_head.simple_test(det.extract_feat(im), metas, rescale=False)
+        want.append(tup[0][3].cpu().numpy().copy())
+    assert want[0].size >= 1 << 20 and not np.array_equal(want[0], want[1])
+    assert 0.02 < want[0].mean() < 0.98                             # (not a constant mask)
+    held = [det.simple_test(im, metas)[0] for im in imgs]          # all three alive
+    for r, w in zip(held, want):
+        assert r.masks.dtype == np.bool_ and np.array_equal(r.masks, w)
+    ptrs = {r.masks.ctypes.data for r in held}
+    assert len(ptrs) == 3                                           # three private arrays
+    view = held[0].masks[5]                                         # a view keeps its array alive
+    p0 = held[0].masks.ctypes.data
+    del held
+    gc.collect()
+    again = [det.simple_test(im, metas)[0] for im in imgs]
+    assert np.array_equal(view, want[0][5])                         # ... and was not overwritten
+    assert p0 not in {r.masks.ctypes.data for r in again}
+    assert {r.masks.ctypes.data for r in again} & ptrs              # dropped arrays came back
+    for r, w in zip(again, want):
+        assert np.array_equal(r.masks, w)

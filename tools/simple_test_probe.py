@@ -26,11 +26,11 @@ for i in range(n):
     res = det.bbox_head.simple_test(feat, metas, rescale=True)
     torch.cuda.synchronize()
 print("device part alone: %.2f ms per call" % (1e3 * (time.perf_counter() - t) / n))
-# (Tried: the masks of this synchronous call through the bit-packed transfer of ResultStreamer
-# as well.  Into a WARM host buffer the expansion takes 1.3 ms (4 threads) against 6.2 ms for
-# `.cpu()` of the 49 MB -- but the reference-shaped call returns FRESH arrays, and first-touch
-# page faults of a fresh 49 MB array cost 8 ms from the unpack threads (35 ms for torch.empty +
-# fill_ in a loop: every munmap / fault of a process with a GPU context goes through the amdgpu
-# MMU notifier), while hipMemcpy into pageable memory pins the destination in bulk.  14.7 ms
-# per call with `.cpu()`, 18.2-20.2 with the packed fetch: not adopted; the pipelined
-# ResultStreamer, whose ring buffers stay mapped, is where the packed transfer pays.)
+# (History: a packed fetch into a FRESH array per call measured 18-20 ms against 14.7 for
+# `.cpu()` -- first-touch page faults of 49 MB from the unpack threads; with arrays recycled
+# through a weakref-finalised pool the call takes 8.4 ms, 12.0 when the caller keeps every result.)
+t = time.perf_counter()
+keep = []
+for i in range(n):
+    keep.append(det.simple_test(pool[i % 4], metas, rescale=True))
+print("simple_test, caller keeps every result: %.2f ms per call" % (1e3 * (time.perf_counter() - t) / n))

@@ -435,6 +435,79 @@ class PSGTr:
         img, metas = self.test_pipeline(image)
         return self.simple_test(img, metas, rescale=rescale)
 
+    @torch.no_grad()
+    def stream(self, batches, rescale=False, depth=4, ring=6, copy=True):
+        """The throughput form of mmdet's `single_gpu_test` loop (tools/test.py:250-255):
+        `batches` yields `(img, img_metas)` -- normalised (B, 3, H, W) device tensors, as
+        `simple_test` takes them -- and this generator yields each batch's `[Result]`, in
+        order, `depth - 1` batches late: backbone + stage A of consecutive batches alternate
+        between two streams, the query chains of older batches run beside them, results reach
+        the host through `ResultStreamer` (INTEGRATION.md 2b spelled out).  `copy=False`
+        hands out views of the ring entry (valid for `ring` more batches) instead of private
+        arrays.  Backbones other than the native ResNet run in front on the caller's stream."""
+        from .pipeline import PipelinedHead
+        head, net = self.bbox_head, self.backbone
+        if self.neck is not None or not getattr(head, "use_mask", False):
+            # (the pipeline schedules the CrossHead2 family; other heads: one batch at a time)
+            for img, metas in batches:
+                yield self.simple_test(img, metas, rescale=rescale)
+            return
+        graphs = (head.use_graphs, getattr(net, "use_graphs", None))
+        head.use_graphs = True
+        slots = isinstance(net, ResNet50Hip)
+        if slots:
+            net.use_graphs = True
+        pipe = PipelinedHead(head, depth=depth)
+        if slots:
+            net.grid_reserve = pipe.grid_reserve
+        out = ResultStreamer(head, ring=ring)
+        own = (lambda rs: [self._own(r) for r in rs]) if copy else (lambda rs: rs)
+        ready = []
+
+        def take(res):
+            if len(out) >= out.ring - 1:
+                ready.append(own(out.pop()))
+            out.push(res, pipe)
+        try:
+            for img, metas in batches:
+                sl = pipe.count % len(pipe.streams_a)
+                sa = pipe.streams_a[sl]
+                sa.wait_stream(torch.cuda.current_stream(head.device))
+                with torch.cuda.stream(sa):
+                    feats = net(img, slot=sl) if slots else net(img)
+                    if len(feats) == 4 and self.out_indices != (0, 1, 2, 3):
+                        feats = tuple(feats[j] for j in self.out_indices)
+                    res = pipe.submit(feats, metas, rescale=rescale)
+                    if res is not None:
+                        take(res)
+                while ready:
+                    yield ready.pop(0)
+            with torch.cuda.stream(pipe.streams_a[0]):
+                tail = pipe.flush()
+            for res in tail:           # (one at a time: a popped view is handed out before
+                with torch.cuda.stream(pipe.streams_a[0]):     # its ring entry is pushed again)
+                    take(res)
+                while ready:
+                    yield ready.pop(0)
+            while len(out):
+                yield own(out.pop())
+        finally:
+            out.close()
+            head.use_graphs = graphs[0]
+            head.grid_reserve = 0
+            if slots:
+                net.use_graphs, net.grid_reserve = graphs[1], 0
+
+    @staticmethod
+    def _own(r):
+        """A Result whose arrays no longer alias the streamer's ring."""
+        import numpy as np
+        q = Result(**{k: (v.copy() if isinstance(v, np.ndarray) else v)
+                      for k, v in r.__dict__.items()})
+        if isinstance(q.formatted_masks, dict):
+            q.formatted_masks = dict(pan_results=q.pan_results)
+        return q
+
     def forward(self, img=None, img_metas=None, return_loss=False, rescale=False, **kw):
         """mmdet's `model(return_loss=False, rescale=True, img=[..], img_metas=[..])`."""
         if return_loss:

@@ -430,3 +430,36 @@ def test_simple_test_mask_arrays_are_private_and_recycled():
     assert {r.masks.ctypes.data for r in again} & ptrs              # dropped arrays came back
     for r, w in zip(again, want):
         assert np.array_equal(r.masks, w)
+
+
+@pytest.mark.parametrize("copy", [True, False])
+def test_detector_stream_equals_simple_test(copy):
+    """`PSGTr.stream` (pipeline + ResultStreamer behind one generator) yields, in order, what
+    `simple_test` returns image by image; with copy=True the arrays outlive the ring."""
+    from oracle.backbone import seeded_backbone_state
+    from pairnet_amd import build_detector, pairnet_r50
+    det = build_detector(pairnet_r50())
+    det.backbone.load_state_dict(seeded_backbone_state(41))
+    det.bbox_head.init_weights(seed=3)
+    det.to(DEV)
+    H, W = 160, 224
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[2.0] * 4)]
+    g = torch.Generator().manual_seed(9)
+    imgs = [torch.randn(1, 3, H, W, generator=g).to(DEV) for _ in range(9)]
+    fields = ("refine_bboxes", "labels", "rel_pair_idxes", "rel_dists", "rel_labels",
+              "pan_results", "masks")
+    want = [{k: np.array(getattr(det.simple_test(im, metas, rescale=True)[0], k)) for k in fields}
+            for im in imgs]
+    got = []
+    for results in det.stream(((im, metas) for im in imgs), rescale=True, ring=4, copy=copy):
+        assert len(results) == 1
+        got.append(results[0] if copy else
+                   {k: np.array(getattr(results[0], k)) for k in fields})
+    assert len(got) == len(want)
+    for r, w in zip(got, want):
+        for k in fields:
+            v = np.array(getattr(r, k)) if copy else r[k]
+            assert v.dtype == w[k].dtype and np.array_equal(v, w[k]), k
+    # the detector is left as it was found
+    assert det.bbox_head.use_graphs is False and det.bbox_head.grid_reserve == 0
+    assert det.backbone.grid_reserve == 0

@@ -55,27 +55,45 @@ class Result(object):
         yield self
 
 
+class _BoolArrayPool:
+    """Host bool tensors handed out as numpy arrays nobody else holds, and taken back when
+    such an array is garbage collected (`weakref.finalize`): a FRESH 49 MB host array per
+    800x1333 image costs 6-8 ms of first-touch page faults (every fault / munmap of a process
+    with a GPU context passes the amdgpu MMU notifier), a recycled one nothing.  A caller that
+    keeps every result (mmdet's test loop does) never returns arrays, and each take allocates
+    as `.cpu().numpy()` would."""
+
+    def __init__(self, keep=3):
+        self.keep, self.free = keep, {}
+
+    def take(self, shape):
+        free = self.free.get(tuple(shape))
+        return free.pop() if free else torch.empty(tuple(shape), dtype=torch.bool)
+
+    def _recycle(self, t):
+        free = self.free.setdefault(tuple(t.shape), [])
+        if len(free) < self.keep:
+            free.append(t)
+
+    def hand_out(self, t):
+        arr = t.numpy()
+        weakref.finalize(arr, self._recycle, t)     # back to the pool when `arr` dies
+        return arr
+
+
 class _MaskFetcher:
     """Device bool tensor -> numpy bool array for the synchronous `PSGTr.simple_test`, through
     the bit-packed transfer of `ResultStreamer` (pn_pack_bool_bits on the device, 1/8 of the
     bytes into a cached pinned buffer, pn_unpack_bits_host on host threads).
 
-    The caller gets an array nobody else holds -- like the reference's `.cpu().numpy()` -- but
-    its memory comes from a small pool that an array returns to when it is garbage collected:
-    a FRESH 49 MB host array per 800x1333 image costs 6-8 ms of first-touch page faults (every
-    fault / munmap of a process with a GPU context passes the amdgpu MMU notifier), a recycled
-    one 1.3 ms of expansion (tools/simple_test_probe.py).  A caller that keeps every result
-    (mmdet's test loop does) simply never returns arrays, and each call allocates as before."""
+    The caller gets an array nobody else holds -- like the reference's `.cpu().numpy()` -- out
+    of a `_BoolArrayPool`: 1.3 ms of expansion into a recycled array instead of 6-8 ms of page
+    faults into a fresh one (tools/simple_test_probe.py)."""
     MIN = 1 << 20
 
     def __init__(self, threads=4, keep=3):
-        self.threads, self.keep = threads, keep
-        self.bits, self.pool = {}, {}
-
-    def _recycle(self, key, t):
-        free = self.pool.setdefault(key, [])
-        if len(free) < self.keep:
-            free.append(t)
+        self.threads = threads
+        self.bits, self.pool = {}, _BoolArrayPool(keep)
 
     def __call__(self, t):
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bool
@@ -93,13 +111,9 @@ class _MaskFetcher:
             hip.pack_bool_bits(t.contiguous(), dev)
             host.copy_(dev, non_blocking=True)
             torch.cuda.current_stream().synchronize()
-        key = tuple(t.shape)
-        free = self.pool.get(key)
-        out = free.pop() if free else torch.empty(key, dtype=torch.bool)
+        out = self.pool.take(t.shape)
         hip.unpack_bits_host(host, out, self.threads)
-        arr = out.numpy()
-        weakref.finalize(arr, self._recycle, key, out)   # back to the pool when `arr` dies
-        return arr
+        return self.pool.hand_out(out)
 
 
 def triplet2Result(triplets, use_mask, eval_mask_rels=False, mask_fetch=None):
@@ -157,7 +171,8 @@ class ResultStreamer:
 
     PACK_MIN = 1 << 16     # bool fields of at least this many elements travel as bits
 
-    def __init__(self, head, ring=4, copy_wgs=4, pack_masks=True, unpack_threads=4):
+    def __init__(self, head, ring=4, copy_wgs=4, pack_masks=True, unpack_threads=4,
+                 private_masks=False):
         """`copy_wgs`: workgroups of the device -> pinned-host copy kernel (`pn_copy_stream`):
         PCIe needs no width (one workgroup moves 7 GB/s; 4 keep a 51 MB image well under a
         step); 0 = hipMemcpyAsync.  `pack_masks`: bool fields (the 2R x H0 x W0 masks, 49 of
@@ -169,6 +184,10 @@ class ResultStreamer:
         self.head, self.device, self.ring = head, head.device, ring
         self.copy_wgs = max(0, int(copy_wgs))
         self.pack_masks, self.unpack_threads = bool(pack_masks), int(unpack_threads)
+        # private_masks: the packed bool fields are expanded into arrays of a recycling pool
+        # (`_BoolArrayPool`) instead of the ring entry: the Results' masks then belong to the
+        # caller like the reference's, with no copy (needs pack_masks)
+        self.mask_pool = _BoolArrayPool(ring + 2) if private_masks and pack_masks else None
         # the host half of the packed transfer runs on a worker thread of this object: it
         # waits for an entry's copy event and expands its bits while the caller's thread
         # keeps submitting images (both waits and the expansion run without the GIL)
@@ -270,8 +289,10 @@ class ResultStreamer:
             try:
                 e["event"].synchronize()
                 for host, bools in zip(e["host"], e["bools"]):
-                    for h, b in zip(host, bools):
+                    for i, (h, b) in enumerate(zip(host, bools)):
                         if b is not None:
+                            if self.mask_pool is not None:     # a private array per result
+                                b = bools[i] = self.mask_pool.take(b.shape)
                             hip.unpack_bits_host(h, b, self.unpack_threads)
                 e["error"] = None
             except BaseException as exc:      # handed to the thread that pops this entry
@@ -310,6 +331,9 @@ class ResultStreamer:
         for host, bools in zip(e["host"], e["bools"]):
             fields = []
             for h, b in zip(host, bools):
+                if b is not None and self.mask_pool is not None:
+                    fields.append(self.mask_pool.hand_out(b))
+                    continue
                 h = b if b is not None else h          # (expanded by the worker thread)
                 fields.append(h.numpy() if isinstance(h, torch.Tensor) else h)
             out.append(triplet2Result(tuple(fields), use_mask))
@@ -460,7 +484,7 @@ class PSGTr:
         pipe = PipelinedHead(head, depth=depth)
         if slots:
             net.grid_reserve = pipe.grid_reserve
-        out = ResultStreamer(head, ring=ring)
+        out = ResultStreamer(head, ring=ring, private_masks=copy)
         own = (lambda rs: [self._own(r) for r in rs]) if copy else (lambda rs: rs)
         ready = []
 
@@ -502,7 +526,8 @@ class PSGTr:
     def _own(r):
         """A Result whose arrays no longer alias the streamer's ring."""
         import numpy as np
-        q = Result(**{k: (v.copy() if isinstance(v, np.ndarray) else v)
+        # (the masks already are a private array of the streamer's pool: `private_masks`)
+        q = Result(**{k: (v.copy() if isinstance(v, np.ndarray) and k != "masks" else v)
                       for k, v in r.__dict__.items()})
         if isinstance(q.formatted_masks, dict):
             q.formatted_masks = dict(pan_results=q.pan_results)

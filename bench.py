@@ -919,6 +919,21 @@ def main():
                 out["attention_mask_density"] = res
             except Exception as e:  # pragma: no cover
                 out["attention_mask_density"] = repr(e)
+        # RCCL on this box: one rank is what a single GPU can run of the multi-GPU path --
+        # communicator set-up and the bench's collectives (all-gather of the triplet records on
+        # a side stream, MAX reduction, barrier) through the real library.  In a child process
+        # with a time limit: nothing of the run above depends on it.
+        if backend == "nccl":
+            try:
+                probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools",
+                                     "rccl_single_rank_probe.py")
+                cp = subprocess.run([sys.executable, probe], capture_output=True, text=True,
+                                    timeout=120)
+                line = [l for l in cp.stdout.splitlines() if l.startswith("RCCL_JSON ")]
+                out["rccl_single_rank"] = (json.loads(line[-1][len("RCCL_JSON "):]) if line
+                                           else "no result: " + cp.stderr[-300:])
+            except Exception as e:  # pragma: no cover
+                out["rccl_single_rank"] = repr(e)
         if backbone is not None and not swin:
             try:  # comparison leg: the same backbone through PyTorch-ROCm / MIOpen
                 from tools.torch_resnet50 import ResNet50

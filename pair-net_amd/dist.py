@@ -73,7 +73,8 @@ class TripletGatherer:
     preallocated receive buffer and returns the records in dataset order
     ([world * n_local, L], a view of an internal buffer)."""
 
-    def __init__(self, n_local, num_rel_query, num_relations, device, group=None):
+    def __init__(self, n_local, num_rel_query, num_relations, device, group=None,
+                 force_collective=False):
         from . import hip
         self.hip, self.group = hip, group
         self.R, self.C1 = num_rel_query, num_relations + 1
@@ -85,6 +86,9 @@ class TripletGatherer:
         self.recv = torch.empty((self.world * n_local, self.L), device=device, dtype=torch.float32)
         self.out = torch.empty_like(self.recv)
         self.records_gathered = 0
+        # run the collective even with one rank (what a 1-GPU box can execute of the RCCL
+        # path: communicator set-up and the all-gather itself, tests/test_dist.py)
+        self.force_collective = bool(force_collective) and dist.is_initialized()
 
     def pack(self, i, labels, rel_dists, sub_pos, obj_pos):
         self.hip.pack_triplets(labels, rel_dists, sub_pos, obj_pos, self.send[i], self.R, self.C1)
@@ -92,7 +96,7 @@ class TripletGatherer:
     def gather(self, host_staging=False):
         """`host_staging`: run the collective on host copies (backend "gloo": the
         single-GPU functional check of the multi-rank control flow)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             self.records_gathered += self.n_local
             return self.send
         send, recv = (self.send.cpu(), self.recv.cpu()) if host_staging else (self.send, self.recv)

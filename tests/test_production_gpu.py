@@ -312,12 +312,13 @@ def test_two_heads_in_one_process_keep_their_own_grids():
     assert all(torch.equal(x, y) for x, y in zip(alone, [t for t in with_b if t.is_cuda]))
 
 
-@pytest.mark.parametrize("H,W", [(160, 112), (101, 149), (224, 136)])
+@pytest.mark.parametrize("H,W", [(160, 112), (101, 149), (224, 136), (1333, 800), (800, 1067)])
 def test_keep_ratio_shapes_portrait_and_odd_sides(H, W):
     """The test pipeline's keep-ratio resize (configs/mask2former/pairnet.py:310-331) hands
-    over portrait images and odd sides (mask feature 40x28 / 26x38 / 56x34: the odd ones take
-    the direct 3x3 FPN convolution, the even ones Winograd): image -> native backbone -> head
-    against the oracle chain, every output within the fp32 bar."""
+    over portrait images and odd sides (mask feature 40x28 / 26x38 / 56x34), and at full size a
+    portrait 1333 x 800 and a 4:3 800 x 1067 image (other tile counts for the stem, the
+    Winograd transforms and every split-K decision than the 800 x 1333 fixtures): image ->
+    native backbone -> head against the oracle chain, every output within the fp32 bar."""
     from helpers import head_cfg, oracle_head, tie_aware_topk_match
     from oracle.backbone import OracleResNet50, seeded_backbone_state
     from pairnet_amd import build_detector, pairnet_r50

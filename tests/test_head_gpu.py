@@ -601,3 +601,33 @@ def test_masked_decoder_layer_against_reference_golden():
     torch.cuda.synchronize()
     got = x.view(B, Q, 256).permute(1, 0, 2)
     assert _err(got, fx["out"]) < 1e-4
+
+
+def test_get_bboxes_with_different_image_shapes_in_one_batch():
+    """Two images of one batch with their own `img_shape` / `scale_factor` (a padded batch):
+    the reference resizes every image's masks to round(img_shape / scale_factor) of ITS meta
+    (pairnet_head.py:803-806, no crop -- kept); the device post-processing against the oracle's
+    restatement of the host loop on the same head outputs, with graph replay on and off."""
+    head_o, sd, _ = oracle_head(7)
+    H, W = 96, 128
+    feats = seeded.seeded_feats(21, 2, H, W)
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[2.0] * 4),
+             dict(img_shape=(80, 100, 3), scale_factor=[1.5, 1.25, 1.5, 1.25])]
+    for graphs in (False, True):
+        head = _hip_head(sd)
+        head.use_graphs = graphs
+        for rep in range(3 if graphs else 1):
+            cls, masks = head.forward([f.to(DEV) for f in feats], metas)
+            res = head.get_bboxes(cls, masks, metas)
+        torch.cuda.synchronize()
+        ref = head_o.get_bboxes({k: v.cpu() for k, v in cls.items()},
+                                {k: v.cpu() for k, v in masks.items()}, metas)
+        assert res[0][3].shape == (200, 48, 64) and res[1][3].shape == (200, 64, 67)
+        for r, o in zip(res, ref):
+            assert torch.equal(r[1].cpu(), o[1])                                  # labels
+            assert _err(r[7], o[7]) < 1e-6                                        # r_dists
+            assert r[3].shape == o[3].shape and r[4].shape == o[4].shape
+            assert float((r[3].cpu() != o[3]).float().mean()) < 1e-3             # masks
+            assert float((r[4].cpu() != o[4]).float().mean()) < 5e-3             # pan_img
+            assert np.array_equal(r[2].numpy() if not r[2].is_cuda else r[2].cpu().numpy(),
+                                  np.asarray(o[2]))

@@ -132,3 +132,22 @@ def test_psgtr2_batch_graphs_pipeline():
         for ra, rb in zip(both, o):
             for x, y in zip(ra, rb):
                 assert torch.equal(x.cpu(), y.cpu())
+
+
+def test_psgtr2_at_800x1333_against_the_oracle():
+    """The sibling at the production shape (its golden vectors are 96 x 128): every output
+    of forward() against the CPU oracle (pinned to the reference class on the small fixture)."""
+    head_o, sd, _ = oracle_psgtr2_head(29)
+    H, W = 800, 1333
+    feats = seeded.seeded_feats(30, 1, H, W)
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[2.083] * 4)]
+    head = _hip_head(sd)
+    with torch.no_grad():
+        cls_o, masks_o = head_o.forward(feats, metas)
+    cls, masks = head.forward([f.to(DEV) for f in feats], metas)
+    torch.cuda.synchronize()
+    errs = {k: _err(cls[k], cls_o[k]) for k in cls}
+    for k in masks:
+        errs[k] = _err(masks[k], masks_o[k]) / max(1.0, float(masks_o[k].abs().max()))
+    print("psgtr2 800x1333 errors:", errs)
+    assert all(v < 1e-3 for v in errs.values()), errs

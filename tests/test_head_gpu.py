@@ -391,9 +391,11 @@ def test_graph_reads_reused_feature_buffers_in_place():
     assert torch.equal(cls["rel"], eager[2])
 
 
-def test_swin_l_200_query_configuration():
+@pytest.mark.parametrize("B,H,W", [(2, 64, 80), (1, 800, 1333)])
+def test_swin_l_200_query_configuration(B, H, W):
     """BASELINE.json configs[3]: Swin-L channel widths, 200 object queries (200x200
-    importance matrix, top-k over 40 000), batch 2 -- against the CPU oracle."""
+    importance matrix, top-k over 40 000), batch 2 at a small size and one image at the
+    production size -- against the CPU oracle."""
     from collections import OrderedDict
     from oracle.head import OracleCrossHead2
     from pairnet_amd import CrossHead2, pairnet_head_cfg
@@ -406,24 +408,29 @@ def test_swin_l_200_query_configuration():
     head = CrossHead2(**cfg)
     head.load_state_dict(sd)
     head.to(DEV)
-    H, W = 64, 80
-    feats = seeded.seeded_feats(17, 2, H, W, channels=(192, 384, 768, 1536))
-    metas = [dict(img_shape=(H, W, 3), scale_factor=[1.0] * 4)] * 2
+    full = H >= 800
+    feats = seeded.seeded_feats(17, B, H, W, channels=(192, 384, 768, 1536))
+    sf = 2.083 if full else 1.0
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[sf] * 4)] * B
     trace = {}
-    ref_cls, ref_masks = head_o.forward(feats, metas, trace=trace)
+    with torch.no_grad():
+        ref_cls, ref_masks = head_o.forward(feats, metas, trace=trace)
     cls, masks = head.forward([f.to(DEV) for f in feats], metas)
-    assert cls["importance"].shape == (2, 200, 200) and cls["rel"].shape == (2, 100, 56)
-    assert _err(cls["cls"], ref_cls["cls"]) < 1e-3
-    assert _err(cls["importance"], ref_cls["importance"]) < 1e-3
+    assert cls["importance"].shape == (B, 200, 200) and cls["rel"].shape == (B, 100, 56)
+    e_cls, e_imp = _err(cls["cls"], ref_cls["cls"]), _err(cls["importance"], ref_cls["importance"])
     e, same = _rel_err(head_o, head, cls, ref_cls["rel"], trace["topk_idx"], trace["query_feat"])
-    assert e < 1e-3
-    for b in range(2):
+    print("Swin-L widths, Q = 200, %dx%d: cls %.2e importance %.2e rel %.2e" % (H, W, e_cls, e_imp, e))
+    assert e_cls < 1e-3 and e_imp < 1e-3 and e < 1e-3
+    for b in range(B):
         ok, exact = tie_aware_topk_match(ref_cls["importance"][b].numpy(),
                                          trace["topk_idx"][b].numpy(),
-                                         head._last_plan.topk_idx[b].cpu().numpy(), TIE_TOL_SMALL)
+                                         head._last_plan.topk_idx[b].cpu().numpy(),
+                                         TIE_TOL_FULL if full else TIE_TOL_SMALL)
+        print("image %d: %d/100 top-k positions identical" % (b, exact))
         assert ok
     res = head.get_bboxes(cls, masks, metas)
-    assert res[0][3].shape == (200, H, W) and res[0][1].shape == (200,)
+    h0, w0 = round(H / sf), round(W / sf)
+    assert res[0][3].shape == (200, h0, w0) and res[0][1].shape == (200,)
 
 
 def _crafted_postproc_inputs(seed, Q=100, h=24, w=32, empty=False):

@@ -317,7 +317,7 @@ int pn_mask_pack(const float* logits, uint32_t* bits, int32_t* rowall,
                  int64_t R, int Nk, void* stream);
 /* The same from logits4 [R][4][Nk = ho*wo], the four stencil logits per key (tap-major, see
  * pn_bilinear_stencil_rows_f32): bit = (bilinear blend of the four, as pn_bilinear_planar_f32
- * computes it from the (hi, wi) map) < 0. */
+ * computes it from the (hi, wi) map) < 0.  ho, wo <= 1024. */
 int pn_mask_pack_stencil(const float* logits4, uint32_t* bits, int32_t* rowall, int64_t R,
                          int hi, int wi, int ho, int wo, void* stream);
 

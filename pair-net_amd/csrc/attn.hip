@@ -73,37 +73,57 @@ extern "C" int pn_mask_pack(const float* logits, uint32_t* bits, int32_t* rowall
 // The same from the four full-resolution logits of each key's bilinear stencil (logits4
 // [R][4][Nk], tap-major as pn_bilinear_stencil_rows_f32 orders the rows): the resized logit
 // is blended exactly as pn_bilinear_planar_f32 blends it, thresholded, packed.
-__global__ __launch_bounds__(256) void k_mask_pack_stencil(const float* __restrict__ logits4,
+#define MPS_MAX_SIDE 1024   // output rows / columns whose blend weights fit the LDS tables
+#define MPS_NT 1024         // threads: a 16 700-key row is 5 rounds of 16 loads per thread
+__global__ __launch_bounds__(MPS_NT) void k_mask_pack_stencil(const float* __restrict__ logits4,
                                                            uint32_t* __restrict__ bits,
                                                            int32_t* __restrict__ rowall, int hi,
                                                            int wi, int ho, int wo) {
+  // the blend weights depend on the output row / column only: make_tap once per row and per
+  // column (the same function, hence the same weights, as pn_bilinear_planar_f32), not per key
+  __shared__ float ly0[MPS_MAX_SIDE], ly1[MPS_MAX_SIDE], lx0[MPS_MAX_SIDE], lx1[MPS_MAX_SIDE];
+  for (int t = threadIdx.x; t < ho; t += MPS_NT) {
+    const Tap ty = make_tap(t, hi, ho);
+    ly0[t] = ty.l0; ly1[t] = ty.l1;
+  }
+  for (int t = threadIdx.x; t < wo; t += MPS_NT) {
+    const Tap tx = make_tap(t, wi, wo);
+    lx0[t] = tx.l0; lx1[t] = tx.l1;
+  }
+  __syncthreads();
   const int Nk = ho * wo;
+  const float inv_wo = 1.f / (float)wo;
   const int64_t row = blockIdx.x;
   const int nwords = (Nk + 31) / 32;
   const float* lr = logits4 + row * 4 * Nk;
   uint32_t* br = bits + row * nwords;
   bool seen = false;
-  for (int base = 0; base < Nk; base += 512) {     // two 256-key strips, 8 loads in flight
-    float v[2][4];
+  for (int base = 0; base < Nk; base += 4 * MPS_NT) {   // four strips, 16 loads in flight
+    float v[4][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int i = min(base + 256 * j + (int)threadIdx.x, Nk - 1);
+    for (int j = 0; j < 4; ++j) {
+      const int i = min(base + MPS_NT * j + (int)threadIdx.x, Nk - 1);
 #pragma unroll
       for (int t = 0; t < 4; ++t) v[j][t] = lr[(int64_t)t * Nk + i];
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int i = base + 256 * j + threadIdx.x;
+    for (int j = 0; j < 4; ++j) {
+      const int i = base + MPS_NT * j + threadIdx.x;
       const bool valid = i < Nk;
       const int ic = valid ? i : Nk - 1;
-      const int oy = ic / wo, ox = ic - oy * wo;
-      const float r = tap_blend(make_tap(oy, hi, ho), make_tap(ox, wi, wo), v[j][0], v[j][1],
-                                v[j][2], v[j][3]);
+      int oy = (int)((float)ic * inv_wo);              // estimate, then exact
+      if (oy * wo > ic) --oy;
+      else if ((oy + 1) * wo <= ic) ++oy;
+      const int ox = ic - oy * wo;
+      Tap ty, tx;
+      ty.i0 = ty.i1 = tx.i0 = tx.i1 = 0;
+      ty.l0 = ly0[oy]; ty.l1 = ly1[oy]; tx.l0 = lx0[ox]; tx.l1 = lx1[ox];
+      const float r = tap_blend(ty, tx, v[j][0], v[j][1], v[j][2], v[j][3]);
       const bool masked = valid && r < 0.f;
       seen |= valid && !masked;
       const unsigned long long bal = __ballot(masked);
       const int lane = threadIdx.x & 63;
-      const int w0 = (base + 256 * j + (threadIdx.x & ~63)) / 32;
+      const int w0 = (base + MPS_NT * j + (threadIdx.x & ~63)) / 32;
       if (lane == 0 && w0 < nwords) br[w0] = (uint32_t)bal;
       if (lane == 32 && w0 + 1 < nwords) br[w0 + 1] = (uint32_t)(bal >> 32);
     }
@@ -115,9 +135,9 @@ __global__ __launch_bounds__(256) void k_mask_pack_stencil(const float* __restri
 extern "C" int pn_mask_pack_stencil(const float* logits4, uint32_t* bits, int32_t* rowall,
                                     int64_t R, int hi, int wi, int ho, int wo, void* stream) {
   if (!logits4 || !bits || !rowall || R <= 0 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0 ||
-      (int64_t)ho * wo >= ((int64_t)1 << 29))
+      ho > MPS_MAX_SIDE || wo > MPS_MAX_SIDE || (int64_t)ho * wo >= ((int64_t)1 << 24))
     return PN_BAD_ARG;
-  hipLaunchKernelGGL(k_mask_pack_stencil, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_mask_pack_stencil, dim3((unsigned)R), dim3(MPS_NT), 0, (hipStream_t)stream,
                      logits4, bits, rowall, hi, wi, ho, wo);
   return PN_LAUNCH_CHECK();
 }

@@ -449,34 +449,43 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_skinny(const GemmP p) {
   const int am = min(m0 + li, p.M - 1);
   const int wn_ = min(n0 + li, p.N - 1);
   const float* arow = (AMODE == A_ROW) ? A + (int64_t)am * p.lda : A + am;
-  const float* addrow = (p.Aadd && n0 >= p.aadd_from_col)
-                            ? p.Aadd + (int64_t)(am % p.aadd_rows) * p.ldaadd : nullptr;
+  const bool has_add = p.Aadd && n0 >= p.aadd_from_col;          // wave-uniform
+  const float* addrow = has_add ? p.Aadd + (int64_t)(am % p.aadd_rows) * p.ldaadd : arow;
   const float* wrow = W + (int64_t)wn_ * p.ldw;
 
   int ks = (p.K + NW - 1) / NW;
   ks = (ks + 31) & ~31;
   const int kbeg = min(wave * ks, p.K), kend = min(kbeg + ks, p.K);
 
+  // All loads of a chunk are UNCONDITIONAL and issued together (k clamped into the row, the
+  // value zeroed afterwards where k is past this wave's slice): a load under a per-lane
+  // predicate is its own branch with a full vmcnt(0) behind it -- four serialised round trips
+  // per chunk with a positional addend, measured 8 us per launch for a 1 us problem.
   auto load_chunk = [&](int kc, float4 (&a)[4], float4 (&b)[4]) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int kk = kc + 8 * s + 4 * lh;
-      const bool ok = kk < kend;
-      float4 av = make_float4(0.f, 0.f, 0.f, 0.f), bv = av;
-      if (ok) {
-        bv = ld4(wrow + kk);
-        if (AMODE == A_ROW) {
-          av = ld4(arow + kk);
-          if (addrow) av = add4(av, ld4(addrow + kk));
-        } else {
-          av.x = arow[(int64_t)(kk + 0) * p.lda];
-          av.y = arow[(int64_t)(kk + 1) * p.lda];
-          av.z = arow[(int64_t)(kk + 2) * p.lda];
-          av.w = arow[(int64_t)(kk + 3) * p.lda];
-        }
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int k0 = min(kc + 4 * lh, p.K - 4), k1 = min(kc + 8 + 4 * lh, p.K - 4);
+    const int k2 = min(kc + 16 + 4 * lh, p.K - 4), k3 = min(kc + 24 + 4 * lh, p.K - 4);
+    const bool ok0 = kc + 4 * lh < kend, ok1 = kc + 8 + 4 * lh < kend;
+    const bool ok2 = kc + 16 + 4 * lh < kend, ok3 = kc + 24 + 4 * lh < kend;
+    // (every element of a / b is written exactly once, from locals: the arrays stay in VGPRs)
+    const float4 w0 = ld4(wrow + k0), w1 = ld4(wrow + k1), w2 = ld4(wrow + k2), w3 = ld4(wrow + k3);
+    float4 x0, x1, x2, x3;
+    if (AMODE == A_ROW) {
+      x0 = ld4(arow + k0); x1 = ld4(arow + k1); x2 = ld4(arow + k2); x3 = ld4(arow + k3);
+      if (has_add) {                          // ONE wave-uniform branch per chunk
+        const float4 d0 = ld4(addrow + k0), d1 = ld4(addrow + k1);
+        const float4 d2 = ld4(addrow + k2), d3 = ld4(addrow + k3);
+        x0 = add4(x0, d0); x1 = add4(x1, d1); x2 = add4(x2, d2); x3 = add4(x3, d3);
       }
-      a[s] = av; b[s] = bv;
+    } else {
+      const int64_t l = p.lda;
+      x0 = make_float4(arow[k0 * l], arow[(k0 + 1) * l], arow[(k0 + 2) * l], arow[(k0 + 3) * l]);
+      x1 = make_float4(arow[k1 * l], arow[(k1 + 1) * l], arow[(k1 + 2) * l], arow[(k1 + 3) * l]);
+      x2 = make_float4(arow[k2 * l], arow[(k2 + 1) * l], arow[(k2 + 2) * l], arow[(k2 + 3) * l]);
+      x3 = make_float4(arow[k3 * l], arow[(k3 + 1) * l], arow[(k3 + 2) * l], arow[(k3 + 3) * l]);
     }
+    a[0] = ok0 ? x0 : zero4; a[1] = ok1 ? x1 : zero4; a[2] = ok2 ? x2 : zero4; a[3] = ok3 ? x3 : zero4;
+    b[0] = ok0 ? w0 : zero4; b[1] = ok1 ? w1 : zero4; b[2] = ok2 ? w2 : zero4; b[3] = ok3 ? w3 : zero4;
   };
   f32x16 acc;
 #pragma unroll

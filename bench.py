@@ -180,8 +180,18 @@ def bench_bbox(args, dev, rank, world):
            "kernel_profile": prof}
     if not check:
         raise SystemExit("pipelined result differs from the eager one")
+    import torch.distributed as dist
+    if world > 1 and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    try:      # (the JSON line last on stdout: see main())
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # pragma: no cover
+        pass
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 def main():
@@ -219,6 +229,9 @@ def main():
                          "at the logits the resize reads (default); 'dense' = the same with all "
                          "full-size logits (bit-identical); 'resampled' = the opt-in shortcut: "
                          "logits against the once-resampled mask feature")
+    ap.add_argument("--rccl-one-rank", action="store_true",
+                    help="with --gpus 1: initialise RCCL with world size 1 and run the per-step "
+                         "all-gather, the barriers and the timing reduction through it")
     ap.add_argument("--grid-trim", type=int, default=None,
                     help="persistent-GEMM workgroup slots left free for the query chains")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -248,6 +261,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = dict(device_id=dev) if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    # --rccl-one-rank: the multi-GPU code path on ONE GPU -- RCCL communicator (and its
+    # watchdog thread) alive during graph capture and replay, the triplet records of every step
+    # through all_gather_into_tensor on the side stream, barrier + MAX reduction around the
+    # timed region -- with world size 1 (what a single-GPU box can execute of it)
+    one_rank = bool(args.rccl_one_rank) and world == 1 and backend == "nccl"
+    if one_rank:
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port_ = s_.getsockname()[1]
+        s_.close()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port_)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     if args.head == "bbox":
         return bench_bbox(args, dev, rank, world)
@@ -312,21 +337,34 @@ def main():
                      for c, (h, w) in zip(chans, feature_shapes(H, W))]
         feats = [f.to(dev) for f in feats_cpu]
 
-    gatherer = TripletGatherer(B, R, head.num_relations, dev) if world > 1 else None
-    gather_stream = torch.cuda.Stream() if world > 1 else None
+    gatherer = TripletGatherer(B, R, head.num_relations, dev, force_collective=one_rank,
+                               ring=args.depth + 4) if world > 1 or one_rank else None
+    gather_stream = torch.cuda.Stream() if gatherer is not None else None
 
     def gather(res, sub_pos, obj_pos):
-        """Pack this batch's triplet records and all-gather them, on a side stream ordered
-        behind the stream the results were returned on: the collective (and the other ranks'
-        arrival at it) never stalls a compute stream."""
+        """Pack this batch's triplet records on the stream that produced them (the chain stream
+        of a pipelined result) and all-gather the records of the batch `depth` steps back on a
+        side stream: that collective's inputs have long been written, so it never makes a
+        hardware queue wait -- a side-stream command that waits for the NEWEST chain blocks the
+        pipeline stream HIP maps onto the same queue (188 instead of 203 images/s per GPU) --
+        and neither the collective nor the other ranks' arrival at it stalls a compute stream."""
         if gatherer is not None and res is not None:
-            gather_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(gather_stream):
+            src = getattr(res, "pipeline_stream", None) if engine is not None else None
+            ps = src if src is not None else torch.cuda.current_stream()
+            with torch.cuda.stream(ps):
+                gatherer.begin_step()
                 for i, r in enumerate(res):
                     gatherer.pack(i, r[1], r[7], sub_pos[i], obj_pos[i])
+                gatherer.end_step()
                 if engine is not None:   # the slot may be reused once this stream is here
-                    engine.consumed(res, gather_stream)
-                gatherer.gather(host_staging=backend != "nccl")
+                    engine.consumed(res, ps)
+            with torch.cuda.stream(gather_stream):
+                gatherer.gather_delayed(args.depth, host_staging=backend != "nccl")
+
+    def gather_flush():
+        if gatherer is not None:
+            with torch.cuda.stream(gather_stream):
+                gatherer.flush(host_staging=backend != "nccl")
 
     def step(with_backbone=args.path == "image"):
         """One batch.  Pipelined: backbone + stage A of this batch are queued on the stage-A
@@ -368,6 +406,7 @@ def main():
                     gather(res, *pair_ids(head._last_plan))
                     if on_result[0] is not None:
                         on_result[0](res)
+        gather_flush()             # the records still in the gatherer's ring
 
     # ---- warm-up (graph capture happens in the first two steps), then the stream ->
     # hardware-queue placement of the pipeline is chosen empirically (pipeline.py) ----
@@ -395,20 +434,20 @@ def main():
 
     def timed(n, **kw):
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or one_rank:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(n):
             step(**kw)
         drain()                      # the last batch finishes inside the timed region
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or one_rank:
             dist.barrier()
         return time.perf_counter() - t0
 
     # ---- timed region: exactly K steps ----
     elapsed = timed(args.steps)
-    if world > 1:
+    if world > 1 or one_rank:
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu",
                          dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -698,10 +737,10 @@ def main():
                     "between %d stream(s), their query chains run on %d more"
                     % (args.depth, args.a_streams, args.depth - args.a_streams)),
                 "collective": ("RCCL all-gather of triplet records, once per step"
-                               if world > 1 and backend == "nccl" else
+                               if (world > 1 or one_rank) and backend == "nccl" else
                                "gloo all-gather (functional check)" if world > 1 else "none")},
             "rccl_ranks": world if backend == "nccl" else 0,
-            "dist_backend": backend if world > 1 else None,
+            "dist_backend": backend if world > 1 or one_rank else None,
             "triplet_records_gathered": records,
             "triplet_record_bytes": 4 * gatherer.L if gatherer is not None else None,
             "pipeline_check": pipeline_check,
@@ -1004,11 +1043,20 @@ def main():
                          if obb is not None else " head (simple_test_bboxes)", sorted(sweep), n,
                          cores, avail)}
 
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    if world > 1 or one_rank:
         dist.barrier()
         dist.destroy_process_group()
+    # The JSON line must be the LAST line of stdout: RCCL writes a version banner through C
+    # stdio when NCCL_DEBUG=VERSION (set on these boxes), which -- buffered on a pipe -- would
+    # otherwise land behind it at exit.  Tear the communicator down, flush C stdio, then print.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # pragma: no cover
+        pass
+    if rank == 0:
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -71,10 +71,18 @@ class TripletGatherer:
     buffer (one small HIP kernel, csrc/postproc.hip k_pack_triplets; no torch.cat), and
     `gather()` issues ONE all-gather (RCCL over xGMI for backend "nccl") into a
     preallocated receive buffer and returns the records in dataset order
-    ([world * n_local, L], a view of an internal buffer)."""
+    ([world * n_local, L], a view of an internal buffer).
+
+    `ring` > 1 (the pipelined bench): `ring` send buffers used in turn, so that a step's
+    records can be packed on the stream that produced them while the collective of an OLDER
+    step -- `gather_delayed(delay)`, ordered behind that step's `packed` event, which by then
+    has long fired -- runs on a side stream.  Why: a command on a side stream that has to WAIT
+    (for the newest query chain to finish) blocks whatever else HIP has mapped onto the same
+    hardware queue, a stage-A stream of the pipeline as likely as not: measured 188 instead of
+    203 images/s per GPU with the pack + collective of the newest result on a side stream."""
 
     def __init__(self, n_local, num_rel_query, num_relations, device, group=None,
-                 force_collective=False):
+                 force_collective=False, ring=1):
         from . import hip
         self.hip, self.group = hip, group
         self.R, self.C1 = num_rel_query, num_relations + 1
@@ -82,13 +90,55 @@ class TripletGatherer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.n_local = n_local
         self.on_device = torch.device(device).type == "cuda"
-        self.send = torch.zeros((n_local, self.L), device=device, dtype=torch.float32)
+        self.ring = max(1, int(ring))
+        self.sends = [torch.zeros((n_local, self.L), device=device, dtype=torch.float32)
+                      for _ in range(self.ring)]
+        self.send = self.sends[0]
         self.recv = torch.empty((self.world * n_local, self.L), device=device, dtype=torch.float32)
         self.out = torch.empty_like(self.recv)
         self.records_gathered = 0
         # run the collective even with one rank (what a 1-GPU box can execute of the RCCL
         # path: communicator set-up and the all-gather itself, tests/test_dist.py)
         self.force_collective = bool(force_collective) and dist.is_initialized()
+        self.packed = [None] * self.ring      # per ring entry: event behind its pack kernels
+        self.filled = 0                       # steps packed so far
+        self.gathered = 0                     # steps gathered so far
+
+    # ---- ring form -----------------------------------------------------------------------
+    def begin_step(self):
+        """Select the ring entry of a new step: pack() then writes there (on the caller's
+        current stream); finish with end_step()."""
+        if self.filled - self.gathered >= self.ring:
+            raise RuntimeError("TripletGatherer ring is full: gather_delayed() / flush() first")
+        self.send = self.sends[self.filled % self.ring]
+
+    def end_step(self):
+        if self.on_device:
+            ev = self.packed[self.filled % self.ring] or torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.packed[self.filled % self.ring] = ev
+        self.filled += 1
+
+    def gather_delayed(self, delay, host_staging=False):
+        """All-gather the oldest packed step if it is at least `delay` steps old (on the
+        caller's current stream, behind that step's `packed` event); returns its records or
+        None."""
+        if self.filled - self.gathered <= delay:
+            return None
+        k = self.gathered % self.ring
+        if self.on_device and self.packed[k] is not None:
+            torch.cuda.current_stream().wait_event(self.packed[k])
+        self.send = self.sends[k]
+        out = self.gather(host_staging=host_staging)
+        self.gathered += 1
+        return out
+
+    def flush(self, host_staging=False):
+        """Gather every step still in the ring (end of the run)."""
+        outs = []
+        while self.gathered < self.filled:      # (copies: gather() returns an internal buffer)
+            outs.append(self.gather_delayed(0, host_staging=host_staging).clone())
+        return outs
 
     def pack(self, i, labels, rel_dists, sub_pos, obj_pos):
         self.hip.pack_triplets(labels, rel_dists, sub_pos, obj_pos, self.send[i], self.R, self.C1)

@@ -112,6 +112,54 @@ def test_preallocated_triplet_gatherer_world2_gloo(n_local):
             assert torch.equal(torch.from_numpy(got[step]), expect)
 
 
+def _ring_worker(rank, world, port, n_local, steps, delay, q):
+    """The pipelined bench's form: a ring of send buffers, the collective of the step `delay`
+    steps back, flush() at the end."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gt = TripletGatherer(n_local, 100, 56, "cpu", ring=delay + 2)
+    outs = []
+    for step in range(steps):
+        gt.begin_step()
+        for j in range(n_local):
+            gt.send[j].copy_(_record(100 * step + rank + j * world))
+        gt.end_step()
+        got = gt.gather_delayed(delay)
+        if got is not None:
+            outs.append(got.clone())
+    outs += [o.clone() for o in gt.flush()]
+    with pytest.raises(RuntimeError):          # (a full ring refuses another step)
+        for _ in range(delay + 3):
+            gt.begin_step()
+            gt.end_step()
+    q.put((rank, [o.numpy() for o in outs], gt.records_gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_local,delay", [(1, 3), (2, 1)])
+def test_delayed_ring_gatherer_world2_gloo(n_local, delay):
+    """Every step's records come back exactly once, in step order and dataset order, whether
+    they were gathered `delay` steps late or by flush()."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, port, steps = 2, _free_port(), 6
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, n_local, steps, delay, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {r: (o, n) for r, o, n in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        got, n = outs[r]
+        assert len(got) == steps and n == steps * world * n_local
+        for step in range(steps):
+            expect = torch.stack([_record(100 * step + i) for i in range(world * n_local)])
+            assert torch.equal(torch.from_numpy(got[step]), expect)
+
+
 @pytest.mark.gpu
 def test_pack_triplets_kernel_equals_the_torch_packing():
     from pairnet_amd import hip

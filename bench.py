@@ -1043,17 +1043,22 @@ def main():
                          if obb is not None else " head (simple_test_bboxes)", sorted(sweep), n,
                          cores, avail)}
 
+    # The JSON line must be the LAST line of stdout: RCCL writes a version banner through C
+    # stdio when NCCL_DEBUG=VERSION (set on these boxes), which -- buffered on a pipe -- would
+    # otherwise land behind it at exit.  Every rank flushes C stdio, then the last barrier,
+    # the communicator is torn down, C stdio is flushed once more, and only then rank 0 prints.
+    def flush_c_stdio():
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # pragma: no cover
+            pass
+    sys.stdout.flush()
+    flush_c_stdio()
     if world > 1 or one_rank:
         dist.barrier()
         dist.destroy_process_group()
-    # The JSON line must be the LAST line of stdout: RCCL writes a version banner through C
-    # stdio when NCCL_DEBUG=VERSION (set on these boxes), which -- buffered on a pipe -- would
-    # otherwise land behind it at exit.  Tear the communicator down, flush C stdio, then print.
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:  # pragma: no cover
-        pass
+    flush_c_stdio()
     if rank == 0:
         sys.stdout.write(json.dumps(out) + "\n")
         sys.stdout.flush()

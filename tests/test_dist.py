@@ -273,3 +273,36 @@ def test_rccl_executes_the_bench_collectives_with_one_rank():
     if "RCCL_ONE_RANK_" not in out.stdout:
         pytest.skip("RCCL could not initialise here: " + out.stderr[-400:])
     assert "RCCL_ONE_RANK_OK nccl" in out.stdout, out.stdout[-400:]
+
+
+@pytest.mark.gpu
+def test_bench_json_is_the_last_stdout_line_with_rccl_in_the_loop():
+    """`bench.py --rccl-one-rank`: the pipelined loop with a live RCCL communicator (its
+    watchdog thread beside graph capture and replay), every step's records through
+    all_gather_into_tensor, barrier + MAX reduction around the timed region -- and, with
+    NCCL_DEBUG=VERSION as on the GPU boxes, RCCL's banner (written through C stdio, buffered
+    on a pipe) must not land behind the JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["NCCL_DEBUG"] = "VERSION"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--rccl-one-rank", "--steps", "8",
+           "--warmup", "3", "--height", "256", "--width", "320", "--no-extras",
+           "--no-cpu-baseline"]
+    try:
+        out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=400)
+    except subprocess.TimeoutExpired:
+        pytest.skip("RCCL single-rank run did not finish within 400 s on this box")
+    if out.returncode != 0 and "NCCL" in out.stderr.upper():
+        pytest.skip("RCCL could not initialise here: " + out.stderr[-300:])
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert lines[-1].startswith("{"), lines[-3:]
+    rec = json.loads(lines[-1])
+    assert rec["dist_backend"] == "nccl" and rec["rccl_ranks"] == 1 and rec["n_gpus"] == 1
+    assert rec["triplet_records_gathered"] >= 8 and rec["value"] > 0
+    assert rec["config"]["collective"].startswith("RCCL all-gather")
+    assert sum(l.startswith("{") for l in lines) == 1

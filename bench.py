@@ -234,6 +234,9 @@ def main():
                          "all-gather, the barriers and the timing reduction through it")
     ap.add_argument("--grid-trim", type=int, default=None,
                     help="persistent-GEMM workgroup slots left free for the query chains")
+    ap.add_argument("--enc-fused-ln", default=None,
+                    help="encoder sites whose Linear + residual + LayerNorm run as one launch: "
+                         "'proj,ffn' (default), 'proj', 'ffn' or 'none' (A/B of csrc/gemm_ln.hip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -279,7 +282,7 @@ def main():
     from pairnet_amd import (CrossHead2, CrossHeadBaseline, PSGTrHead2, PipelinedHead,
                              ResNet50Hip, SwinTransformerHip, baseline_head_cfg, hip,
                              pairnet_head_cfg, psgtr2_head_cfg, swin_backbone_cfg)
-    from pairnet_amd.dist import TripletGatherer
+    from pairnet_amd.dist import TripletBatch, TripletCollector
 
     sibling = args.head != "pairnet"
     chans = tuple(int(c) for c in args.in_channels.split(","))
@@ -291,15 +294,15 @@ def main():
     head = {"pairnet": CrossHead2, "baseline": CrossHeadBaseline,
             "psgtr2": PSGTrHead2}[args.head](**cfg)
     ident = torch.arange(head.num_obj_query, device=dev).unsqueeze(0).expand(args.batch, -1)
-    pair_ids = {"pairnet": lambda pl: (pl.sub_pos, pl.obj_pos),
-                "baseline": lambda pl: (pl.sub_ids, pl.obj_ids),
-                "psgtr2": lambda pl: (ident, ident)}[args.head]   # query i IS triplet i
+    pair_ids = head.pair_positions      # the query rows of each image's R triplets
     head.init_weights(seed=0)
     head.to(dev)
     MASK_ORDER = {"reference": True, "dense": "full", "resampled": False}
     head.exact_mask_order = MASK_ORDER[args.mask_order]
     if args.conv:
         head.conv_algo = args.conv
+    if args.enc_fused_ln is not None:
+        head.enc_fused_ln = tuple(t for t in args.enc_fused_ln.split(",") if t in ("proj", "ffn"))
     head.use_graphs = not args.no_graphs
     engine = None if args.no_pipeline else PipelinedHead(
         head, depth=args.depth, a_streams=args.a_streams,
@@ -337,34 +340,28 @@ def main():
                      for c, (h, w) in zip(chans, feature_shapes(H, W))]
         feats = [f.to(dev) for f in feats_cpu]
 
-    gatherer = TripletGatherer(B, R, head.num_relations, dev, force_collective=one_rank,
-                               ring=args.depth + 4) if world > 1 or one_rank else None
-    gather_stream = torch.cuda.Stream() if gatherer is not None else None
+    # The multi-GPU leg is the product's own: `dist.TripletCollector` (what
+    # `dist.multi_gpu_test` is built on) packs each batch's triplet records on the stream that
+    # produced them -- the chain stream of a pipelined result -- and all-gathers the records of
+    # the batch `depth` steps back on a side stream: that collective's inputs have long been
+    # written, so it never makes a hardware queue wait (a side-stream command that waits for
+    # the NEWEST chain blocks the pipeline stream HIP maps onto the same queue: 188 instead of
+    # 203 images/s per GPU), and neither the collective nor the other ranks' arrival at it
+    # stalls a compute stream.
+    collector = TripletCollector(head, depth=args.depth, n_local=B, force_collective=one_rank,
+                                 host_staging=backend != "nccl") if world > 1 or one_rank else None
+    gatherer = collector.gatherer if collector is not None else None
 
     def gather(res, sub_pos, obj_pos):
-        """Pack this batch's triplet records on the stream that produced them (the chain stream
-        of a pipelined result) and all-gather the records of the batch `depth` steps back on a
-        side stream: that collective's inputs have long been written, so it never makes a
-        hardware queue wait -- a side-stream command that waits for the NEWEST chain blocks the
-        pipeline stream HIP maps onto the same queue (188 instead of 203 images/s per GPU) --
-        and neither the collective nor the other ranks' arrival at it stalls a compute stream."""
-        if gatherer is not None and res is not None:
+        if collector is not None and res is not None:
             src = getattr(res, "pipeline_stream", None) if engine is not None else None
-            ps = src if src is not None else torch.cuda.current_stream()
-            with torch.cuda.stream(ps):
-                gatherer.begin_step()
-                for i, r in enumerate(res):
-                    gatherer.pack(i, r[1], r[7], sub_pos[i], obj_pos[i])
-                gatherer.end_step()
-                if engine is not None:   # the slot may be reused once this stream is here
-                    engine.consumed(res, ps)
-            with torch.cuda.stream(gather_stream):
-                gatherer.gather_delayed(args.depth, host_staging=backend != "nccl")
+            collector.add(TripletBatch(
+                res, sub_pos, obj_pos, stream=src,
+                release=(lambda s, r=res: engine.consumed(r, s)) if engine is not None else None))
 
     def gather_flush():
-        if gatherer is not None:
-            with torch.cuda.stream(gather_stream):
-                gatherer.flush(host_staging=backend != "nccl")
+        if collector is not None:
+            collector.finish()
 
     def step(with_backbone=args.path == "image"):
         """One batch.  Pipelined: backbone + stage A of this batch are queued on the stage-A

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 15
+#define PN_ABI_VERSION 16
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -206,6 +206,22 @@ int pn_groupnorm_nhwc_f32(const float* x, const float* gamma, const float* beta,
                           int G, float eps, int relu, int64_t x_bstride,
                           int64_t y_bstride, void* stream);
 
+/* Linear + residual + post-norm of a transformer layer in one launch, N == 256:
+ *   y[r][:] = LayerNorm(res[r][:] + x[r][:] W^T + bias) * gamma + beta
+ * -- `output_proj` + identity + norms.0, and ffns.0.layers.1 + identity + norms.1, of the
+ * pixel decoder's six encoder layers (MultiScaleDeformableAttention.forward /
+ * BaseTransformerLayer, [3P] mmcv 1.7.0; configured at configs/mask2former/pairnet.py:40-66,
+ * run behind pairnet_head.py:262).  A workgroup owns 32 whole rows, so the pre-norm map never
+ * reaches HBM.  Bit for bit pn_gemm_f32 (row-major, residual epilogue) followed by
+ * pn_layernorm_f32.  x [M][ldx] (K used), W [256][ldw], res [M][ldres], y [M][ldy]; K % 32 == 0;
+ * 16-byte aligned operands, leading dimensions % 4 == 0; y must not alias x.  Meant for
+ * chip-filling M (>= 2048 rows: M / 32 workgroups); the query-side chains keep their own
+ * kernels. */
+int pn_linear_res_ln_f32(const float* x, int64_t ldx, const float* W, int64_t ldw,
+                         const float* bias /* nullable */, const float* res, int64_t ldres,
+                         const float* gamma, const float* beta, float* y, int64_t ldy,
+                         int M, int N, int K, float eps, void* stream);
+
 /* Fused FFN block of a decoder layer for M ~ 100 rows (facebook_detr.py:425-427 +
  * the norm that follows):  y = LayerNorm(x + W2 relu(W1 x + b1) + b2) * gamma + beta.
  * W1 [hidden][256], W2 [256][hidden]; hidden % 64 == 0; scratch =
@@ -245,6 +261,15 @@ int pn_msda_f32(const float* value, int64_t ld_value, const float* offaw,
                 int64_t ld_offaw, float* out, int B, int L,
                 const int32_t* level_h /* host */, const int32_t* level_w /* host */,
                 void* stream);
+/* The same with a tuning flag: 0 = the persistent, software-pipelined kernel (what
+ * pn_msda_f32 launches: workgroups walk their XCD band's query pairs, the next pair's
+ * offsets / logits in flight under the current pair's gathers), PN_MSDA_ONE_SHOT = one
+ * workgroup per query pair (rounds 1-3).  Both give bit-identical output. */
+#define PN_MSDA_ONE_SHOT 1
+int pn_msda_ex_f32(const float* value, int64_t ld_value, const float* offaw,
+                   int64_t ld_offaw, float* out, int B, int L,
+                   const int32_t* level_h /* host */, const int32_t* level_w /* host */,
+                   int flags, void* stream);
 
 /* The same operator in mmcv's OWN shape -- the entry a maintainer binds behind the
  * unmodified `MultiScaleDeformableAttention.forward` (mmcv/ops/multi_scale_deform_attn.py,
@@ -555,6 +580,54 @@ int pn_box_triplets_f32(const float* s_cls, const float* o_cls, const float* s_b
                         const float* o_box, float* det, int64_t* labels, int R, int C,
                         float img_h, float img_w, const float* scale_factor, int rescale,
                         void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Loss forward of CrossHead2 on device outputs (first slice: the
+ * values of `CrossHead2.loss`, pairnet_head.py:419-718; no backward).  The two
+ * Hungarian assignments themselves run on the host, as in the reference
+ * (`linear_sum_assignment(cost.cpu())`, matcher.py:262-264, and [3P] mmdet
+ * MaskHungarianAssigner): these entries produce their cost matrices and the loss
+ * scalars.
+ * ------------------------------------------------------------------------- */
+/* [3P] mmcv `point_sample` (pairnet_head.py:631-638) = grid_sample(maps, 2 p - 1, bilinear,
+ * zero padding, align_corners=False) with ONE point set shared by all maps:
+ * maps [P][h][w] float32, or uint8 0/1 when maps_are_u8 (ground-truth masks); pts [Np][2]
+ * (x, y) in [0, 1]; out [P][Np]. */
+int pn_point_sample_f32(const void* maps, int maps_are_u8, const float* pts, float* out, int P,
+                        int h, int w, int Np, void* stream);
+/* [3P] mmdet MaskHungarianAssigner's cost matrix (cfg configs/mask2former/pairnet.py:200-206;
+ * called at pairnet_head.py:641-643): cost [Q][G] =
+ *   -softmax(cls[q])[gt_labels[g]] w_cls + mean_p BCEwithLogits(pred_pts[q][p], gt_pts[g][p]) w_mask
+ *   + (1 - (2 sum s t + eps) / (sum s + sum t + eps)) w_dice,  s = sigmoid(pred_pts[q]). */
+int pn_mask_match_cost_f32(const float* cls /* [Q][ncls] */, int ncls,
+                           const int64_t* gt_labels /* [G] */, const float* pred_pts /* [Q][Np] */,
+                           const float* gt_pts /* [G][Np] */, float* cost, int Q, int G, int Np,
+                           float w_cls, float w_mask, float w_dice, float dice_eps, void* stream);
+/* `IdMatcher.assign` cost (approaches/matcher.py:250-258; called at pairnet_head.py:662-671):
+ * cost [R][G] = -softmax(sub[r])[gt_sub[g]] w_sub - softmax(obj[r])[gt_obj[g]] w_obj
+ *               - softmax(rel[r])[gt_rel[g]] w_rel. */
+int pn_id_match_cost_f32(const float* sub, const float* obj /* [R][ncls] */, const float* rel
+                         /* [R][nrel] */, int ncls, int nrel, const int64_t* gt_sub,
+                         const int64_t* gt_obj, const int64_t* gt_rel, float* cost, int R, int G,
+                         float w_sub, float w_obj, float w_rel, void* stream);
+/* [3P] mmdet CrossEntropyLoss, softmax form, reduction "mean" (`subobj_cls_loss`,
+ * pairnet_head.py:518-527): out[0] = loss_weight * mean over rows with target >= 0 of
+ * class_weight[y] (logsumexp(x) - x[y]); rows with target < 0 are the unmatched queries the
+ * reference masks out (`r_label_weights_mask`).  rows <= 4096. */
+int pn_ce_mean_f32(const float* logits, int64_t ld, const int64_t* target,
+                   const float* class_weight /* [C] or NULL */, float* out, int rows, int C,
+                   float loss_weight, void* stream);
+/* [3P] mmdet SeesawLoss, `loss_cls_classes` (`rel_cls_loss`, pairnet_head.py:529-536) over the
+ * rows with target >= 0; cum_samples [C] = the loss's persistent label counts INCLUDING this
+ * batch (the caller accumulates them, as seesaw_loss.py does before weighing).  C <= 64. */
+int pn_seesaw_mean_f32(const float* logits, int64_t ld, const int64_t* target,
+                       const float* cum_samples, float* out, int rows, int C, float p, float q,
+                       float eps, float loss_weight, void* stream);
+/* `BCEWithLogitsLoss` (losses/seg_losses.py:153-166) with the reference's
+ * pos_weight = numel / #(target > 0) (pairnet_head.py:541-552): out[0] = loss_weight * mean,
+ * out[1] = pos_weight. */
+int pn_bce_posw_mean_f32(const float* logits, const float* target, float* out /* [2] */, int64_t n,
+                         float loss_weight, void* stream);
 
 #ifdef __cplusplus
 }

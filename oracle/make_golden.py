@@ -895,6 +895,12 @@ def main():
         gen_e2e_image("e2e_image_full", "r50", 800, 1333, 2, 163, 31, 2.083)
     if want("e2e_image_swinl"):     # BASELINE configs[3]: Swin-L (true dims), 200 queries
         gen_e2e_image("e2e_image_swinl", "swinL", 256, 320, 2, 173, 41, 1.0, num_obj_query=200)
+    if want("e2e_image_swinl_full"):   # configs[3] at the production size, one image
+        # (SEP_XATTN=0.03 for this one: at 21 950 keys x 200 queries x 9 layers a few attention-
+        # mask bits differ between the fp32 and the fp64 evaluation, and with the default 0.1
+        # the margin of the recorded list is 3 instead of >= 10; image seed: SWINL_FULL_SEED)
+        gen_e2e_image("e2e_image_swinl_full", "swinL", 800, 1333, 1,
+                      int(os.environ.get("SWINL_FULL_SEED", 183)), 41, 2.083, num_obj_query=200)
     if want("baseline_small"):
         gen_baseline_small()
     if want("psgtr2_small"):

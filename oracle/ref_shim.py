@@ -193,3 +193,57 @@ def reference_conv_tiny():
     install()
     return sys.modules["pairnet.models.frameworks.cnn_factory"].creat_cnn(
         "conv_tiny").eval()
+
+
+def install_training():
+    """On top of install(): the names `CrossHead2.loss` needs (pairnet_head.py:419-718).  The
+    [3P] ones (point_sample, MaskHungarianAssigner + its costs, MaskPseudoSampler, SeesawLoss,
+    CrossEntropyLoss, multi_apply) come from oracle/mmdet_train.py (restated, unpinned); the
+    reference's OWN `IdMatcher` (approaches/matcher.py:208-275) and `BCEWithLogitsLoss`
+    (losses/seg_losses.py:153-166) are executed from /root/reference and register themselves
+    in those builders.  Idempotent."""
+    install()
+    if "pairnet.models.relation_heads.approaches.matcher" in sys.modules:
+        return
+    from . import mmdet_train as T
+    core = sys.modules["mmdet.core"]
+    core.__dict__.update(build_assigner=T.build_assigner, build_sampler=T.build_sampler,
+                         multi_apply=T.multi_apply, AssignResult=T.AssignResult,
+                         BaseAssigner=T.BaseAssigner)
+    _mod("mmdet.core.bbox")
+    _mod("mmdet.core.bbox.builder", BBOX_ASSIGNERS=T.BBOX_ASSIGNERS)
+    _mod("mmdet.core.bbox.match_costs", build_match_cost=T.build_match_cost)
+    sys.modules["mmdet.models.builder"].__dict__.update(LOSSES=T.LOSSES, build_loss=T.build_loss)
+    _mod("mmdet.models.losses")
+    _mod("mmdet.models.losses.utils", weighted_loss=T.weighted_loss)
+    sys.modules["mmcv.ops"].point_sample = T.point_sample
+    for pkg in ("pairnet.models.relation_heads.approaches", "pairnet.models.losses"):
+        _mod(pkg)
+    _load("pairnet.models.relation_heads.approaches.matcher",
+          "pairnet/models/relation_heads/approaches/matcher.py")
+    _load("pairnet.models.losses.seg_losses", "pairnet/models/losses/seg_losses.py")
+    # pairnet_head.py bound these names at import time (to the inference stubs)
+    head_mod = sys.modules["pairnet.models.relation_heads.pairnet_head"]
+    head_mod.__dict__.update(point_sample=T.point_sample, build_assigner=T.build_assigner,
+                             build_sampler=T.build_sampler, multi_apply=T.multi_apply,
+                             build_loss=T.build_loss)
+
+
+def build_reference_training_head(cfg=None, train_cfg=None):
+    """The reference CrossHead2 WITH its train_cfg (assigners, sampler, losses built)."""
+    install_training()
+    cls = sys.modules["pairnet.models.relation_heads.pairnet_head"].CrossHead2
+    cfg = L.CfgDict(cfg if cfg is not None else reference_head_cfg())
+    cfg.pop("type", None)
+    if train_cfg is None:
+        train_cfg = reference_model_cfg()["train_cfg"]
+    return cls(**cfg, train_cfg=L.CfgDict(train_cfg)).eval()
+
+
+def reference_model_cfg():
+    """The whole `model` dict of configs/mask2former/pairnet.py."""
+    path = os.path.join(REF_ROOT, "configs/mask2former/pairnet.py")
+    scope = {}
+    with open(path) as f:
+        exec(compile(f.read(), path, "exec"), scope)
+    return scope["model"]

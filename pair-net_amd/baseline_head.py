@@ -81,6 +81,12 @@ class CrossHeadBaseline(CrossHead2):
         pl.sub_seg, pl.obj_seg = E(B, R, HW2), E(B, R, HW2)
 
     # ------------------------------------------------------------------ stages
+    def pair_positions(self, pl=None):
+        """(sub_ids, obj_ids): the object-query rows matched to each relation query
+        (baseline.py:389-401)."""
+        pl = pl if pl is not None else self._last_plan
+        return pl.sub_ids, pl.obj_ids
+
     def _kv_problems(self, pl):
         """Stage A additionally projects the memories for the relation decoder's six
         cross-attentions (baseline.py:372-384: key = value = memory + level embedding,

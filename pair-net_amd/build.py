@@ -10,7 +10,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpairnet_hip.so")
-SOURCES = ["gemm", "stem", "winograd", "ffn", "norm", "msda", "resize", "attn", "ppn", "postproc", "swin", "preprocess", "detr"]
+SOURCES = ["gemm", "gemm_ln", "stem", "winograd", "ffn", "norm", "msda", "resize", "attn", "ppn", "postproc", "swin", "preprocess", "detr", "loss"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 

@@ -162,9 +162,166 @@ __global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
   }
 }
 
-extern "C" int pn_msda_f32(const float* value, int64_t ld_value, const float* offaw,
-                           int64_t ld_offaw, float* out, int B, int L, const int32_t* level_h,
-                           const int32_t* level_w, void* stream) {
+// The same two phases as a PERSISTENT, software-pipelined loop (round 4).  k_msda above
+// spends a workgroup's whole life on two queries: dispatch, one round trip for the
+// offsets / logits, one for the gathers, exit -- with five workgroups resident per CU only
+// one or two of them have gathers in flight at any time, and the vector L1 idles 40 % of
+// the kernel (20 of 34 TB/s).  Here a workgroup walks its band's query pairs: the offsets /
+// logits of pair i + 1 are fetched while pair i gathers (registers), the tap records are
+// double-buffered in LDS (one barrier per pair), and both queries of a pair gather in one
+// unconditional batch (2 x L x 4 float4 loads in flight per lane; a dead query reads token 0
+// and is not stored).  Arithmetic and summation order are k_msda's: bit-identical output.
+template <int L>
+__global__ __launch_bounds__(256) void k_msda_pipe(const float* __restrict__ value,
+                                                   const float* __restrict__ offaw,
+                                                   float* __restrict__ out,
+                                                   const MsdaLevels lv, const int64_t ldv,
+                                                   const int64_t ldo, const int pairs) {
+  __shared__ MsdaTap taps[2][MSDA_TQ][8][4][4];   // [buffer][query][head][point][level]
+  __shared__ float attw[2][MSDA_TQ][8][4][4];
+  __shared__ int tok[2][MSDA_TQ];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  constexpr int LP = L * 4;
+  const int band = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int qi = tid >> 7, head = (tid >> 4) & 7, pt = (tid >> 2) & 3, l = tid & 3;
+  const int lc = min(l, L - 1);
+  const int c4 = tid & 7, p2 = (tid >> 3) & 3, h2 = tid >> 5;
+  const char* vb = reinterpret_cast<const char*>(value + (int64_t)b * lv.N * ldv + h2 * 32 + c4 * 4);
+
+  // phase-1 inputs of one pair, fetched one iteration ahead
+  struct Pre { int n, qw, qh, qs; float e; float2 off; };
+  auto fetch = [&](int pair) {
+    Pre r;
+    int i = pair * MSDA_TQ + qi;            // index inside the band
+    r.n = -1; r.qw = 1; r.qh = 1; r.qs = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < L && r.n < 0) {
+        const int r0 = (band * lv.h[k]) >> 3, r1 = ((band + 1) * lv.h[k]) >> 3;
+        const int cnt = (r1 - r0) * lv.w[k];
+        if (i < cnt) {
+          r.n = lv.start[k] + r0 * lv.w[k] + i;
+          r.qw = lv.w[k]; r.qh = lv.h[k]; r.qs = lv.start[k];
+        } else {
+          i -= cnt;
+        }
+      }
+    }
+    const float* oa = offaw + ((int64_t)b * lv.N + max(r.n, 0)) * ldo;
+    r.e = oa[8 * LP * 2 + head * LP + lc * 4 + pt];
+    r.off = *reinterpret_cast<const float2*>(oa + head * LP * 2 + lc * 8 + pt * 2);
+    return r;
+  };
+
+  if (slot >= pairs) return;
+  Pre cur = fetch(slot);
+  int buf = 0;
+  for (int it = slot; it < pairs; it += per, buf ^= 1) {
+    // ---- phase 1 of pair `it` (from registers) ----
+    {
+      const int n = cur.n;
+      if ((tid & 127) == 0) tok[buf][qi] = n;
+      const bool live = n >= 0 && l < L;
+      const float e = cur.e;
+      const float2 off = cur.off;
+      const float mx = grp16_max(l < L ? e : -INFINITY);
+      const float ex = l < L ? expf(e - mx) : 0.f;
+      const int g0 = (tid & 63) & ~3;
+      float den = __shfl(ex, g0, 64);
+#pragma unroll
+      for (int k = 1; k < L; ++k) den += __shfl(ex, g0 + k, 64);
+      den += __shfl_xor(den, 4, 64);
+      den += __shfl_xor(den, 8, 64);
+      const float aw = ex / den;
+      MsdaTap t;
+      t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0.f;
+      t.off[0] = t.off[1] = t.off[2] = t.off[3] = 0u;
+      if (live) {
+        const int idx = n - cur.qs;
+        const int qy = idx / cur.qw, qx = idx - qy * cur.qw;
+        const float ref_x = ((float)qx + 0.5f) / (float)cur.qw;
+        const float ref_y = ((float)qy + 0.5f) / (float)cur.qh;
+        const int Hl = lv.h[lc], Wl = lv.w[lc];
+        const float locx = ref_x + off.x / (float)Wl;
+        const float locy = ref_y + off.y / (float)Hl;
+        const float gx = 2.f * locx - 1.f, gy = 2.f * locy - 1.f;
+        const float ix = ((gx + 1.f) * (float)Wl - 1.f) * 0.5f;
+        const float iy = ((gy + 1.f) * (float)Hl - 1.f) * 0.5f;
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)Wl), y0 = (int)fminf(fmaxf(fy, -2.f), (float)Hl);
+        const float tx = ix - fx, ty = iy - fy;
+        const bool xin0 = x0 >= 0 && x0 < Wl, xin1 = x0 + 1 >= 0 && x0 + 1 < Wl;
+        const bool yin0 = y0 >= 0 && y0 < Hl, yin1 = y0 + 1 >= 0 && y0 + 1 < Hl;
+        const int xa = min(max(x0, 0), Wl - 1), xb = min(max(x0 + 1, 0), Wl - 1);
+        const int ya = min(max(y0, 0), Hl - 1), yb = min(max(y0 + 1, 0), Hl - 1);
+        t.w[0] = (xin0 && yin0) ? (1.f - tx) * (1.f - ty) : 0.f;
+        t.w[1] = (xin1 && yin0) ? tx * (1.f - ty) : 0.f;
+        t.w[2] = (xin0 && yin1) ? (1.f - tx) * ty : 0.f;
+        t.w[3] = (xin1 && yin1) ? tx * ty : 0.f;
+        const unsigned row = (unsigned)ldv * 4u, base = (unsigned)lv.start[lc];
+        t.off[0] = (base + (unsigned)(ya * Wl + xa)) * row;
+        t.off[1] = (base + (unsigned)(ya * Wl + xb)) * row;
+        t.off[2] = (base + (unsigned)(yb * Wl + xa)) * row;
+        t.off[3] = (base + (unsigned)(yb * Wl + xb)) * row;
+      }
+      if (l < L) {          // (dead queries park row 0 with weight 0: gathers stay unconditional)
+        taps[buf][qi][head][pt][lc] = t;
+        attw[buf][qi][head][pt][lc] = live ? aw : 0.f;
+      }
+    }
+    __syncthreads();
+    // the next pair's offsets / logits travel while this pair gathers
+    if (it + per < pairs) cur = fetch(it + per);
+    // ---- phase 2: both queries' gathers in one batch ----
+    float4 v[MSDA_TQ][L][4];
+    MsdaTap t[MSDA_TQ][L];
+#pragma unroll
+    for (int q = 0; q < MSDA_TQ; ++q)
+#pragma unroll
+      for (int k = 0; k < L; ++k) {
+        t[q][k] = taps[buf][q][h2][p2][k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          v[q][k][j] = *reinterpret_cast<const float4*>(vb + t[q][k].off[j]);
+      }
+#pragma unroll
+    for (int q = 0; q < MSDA_TQ; ++q) {
+      const int nq = tok[buf][q];
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < L; ++k) {
+        const float a = attw[buf][q][h2][p2][k];
+        const float4* vv = v[q][k];
+        const float* w = t[q][k].w;
+        float4 s4;
+        s4.x = ((vv[0].x * w[0] + vv[1].x * w[1]) + vv[2].x * w[2]) + vv[3].x * w[3];
+        s4.y = ((vv[0].y * w[0] + vv[1].y * w[1]) + vv[2].y * w[2]) + vv[3].y * w[3];
+        s4.z = ((vv[0].z * w[0] + vv[1].z * w[1]) + vv[2].z * w[2]) + vv[3].z * w[3];
+        s4.w = ((vv[0].w * w[0] + vv[1].w * w[1]) + vv[2].w * w[2]) + vv[3].w * w[3];
+        acc.x += s4.x * a; acc.y += s4.y * a; acc.z += s4.z * a; acc.w += s4.w * a;
+      }
+      acc.x = pt_sum(acc.x); acc.y = pt_sum(acc.y);
+      acc.z = pt_sum(acc.z); acc.w = pt_sum(acc.w);
+      if (p2 == 0 && nq >= 0) st4(out + ((int64_t)b * lv.N + nq) * 256 + h2 * 32 + c4 * 4, acc);
+    }
+  }
+}
+
+static int msda_resident_wgs() {
+  static int n = 0;
+  if (n == 0) {
+    int k = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, k_msda_pipe<3>, 256, 0) != hipSuccess || k < 1)
+      k = 2;
+    n = k > 8 ? 8 : k;
+  }
+  return n;
+}
+
+extern "C" int pn_msda_ex_f32(const float* value, int64_t ld_value, const float* offaw,
+                              int64_t ld_offaw, float* out, int B, int L, const int32_t* level_h,
+                              const int32_t* level_w, int flags, void* stream) {
   if (!value || !offaw || !out || B <= 0 || L <= 0 || L > 4 || !level_h || !level_w)
     return PN_BAD_ARG;
   if (ld_value < 256 || (ld_value & 3) || ld_offaw < 8 * L * 12 || (ld_offaw & 1) ||
@@ -187,14 +344,39 @@ extern "C" int pn_msda_f32(const float* value, int64_t ld_value, const float* of
   }
   if ((int64_t)n * ld_value * 4 >= ((int64_t)1 << 32)) return PN_BAD_ARG;   // 32-bit tap offsets
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((per_band + MSDA_TQ - 1) / MSDA_TQ * 8, B);
+  const int pairs = (per_band + MSDA_TQ - 1) / MSDA_TQ;
+  if (flags & PN_MSDA_ONE_SHOT) {      // round 1-3 form: one workgroup per query pair
+    const dim3 grid(pairs * 8, B);
+    switch (L) {
+      case 1: hipLaunchKernelGGL(k_msda<1>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+      case 2: hipLaunchKernelGGL(k_msda<2>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+      case 3: hipLaunchKernelGGL(k_msda<3>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+      default: hipLaunchKernelGGL(k_msda<4>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+    }
+    return PN_LAUNCH_CHECK();
+  }
+  // persistent: every CU's resident slots, spread evenly over the 8 bands (XCDs)
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess)
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  int slots = cus * msda_resident_wgs() / 8;          // workgroups per band
+  if (B > 1) slots = (slots + B - 1) / B;
+  if (slots > pairs) slots = pairs;
+  if (slots < 1) slots = 1;
+  const dim3 grid(slots * 8, B);
   switch (L) {
-    case 1: hipLaunchKernelGGL(k_msda<1>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
-    case 2: hipLaunchKernelGGL(k_msda<2>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
-    case 3: hipLaunchKernelGGL(k_msda<3>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
-    default: hipLaunchKernelGGL(k_msda<4>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+    case 1: hipLaunchKernelGGL(k_msda_pipe<1>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw, pairs); break;
+    case 2: hipLaunchKernelGGL(k_msda_pipe<2>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw, pairs); break;
+    case 3: hipLaunchKernelGGL(k_msda_pipe<3>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw, pairs); break;
+    default: hipLaunchKernelGGL(k_msda_pipe<4>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw, pairs); break;
   }
   return PN_LAUNCH_CHECK();
+}
+
+extern "C" int pn_msda_f32(const float* value, int64_t ld_value, const float* offaw,
+                           int64_t ld_offaw, float* out, int B, int L, const int32_t* level_h,
+                           const int32_t* level_w, void* stream) {
+  return pn_msda_ex_f32(value, ld_value, offaw, ld_offaw, out, B, L, level_h, level_w, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------

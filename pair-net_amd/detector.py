@@ -375,7 +375,11 @@ class PSGTr:
         head_type = head_cfg.pop("type", "CrossHead2")
         if head_type not in heads:
             raise NotImplementedError("bbox_head.type must be one of %s" % sorted(heads))
-        self.bbox_head = heads[head_type](**head_cfg, train_cfg=None,
+        # (mmdet's SingleStageDetector hands the model-level train_cfg to the head -- the
+        # base class psgtr.py:84-86 calls; here only
+        # CrossHead2 reads it, for the forward values of its loss)
+        self.bbox_head = heads[head_type](**head_cfg,
+                                          train_cfg=train_cfg if head_type == "CrossHead2" else None,
                                           test_cfg=test_cfg or dict(max_per_img=100))
         self.num_classes = self.bbox_head.num_classes
         self.test_pipeline = None     # built by detect() (or set a preprocess.TestPipeline)
@@ -459,39 +463,25 @@ class PSGTr:
         img, metas = self.test_pipeline(image)
         return self.simple_test(img, metas, rescale=rescale)
 
-    @torch.no_grad()
-    def stream(self, batches, rescale=False, depth=4, ring=6, copy=True):
-        """The throughput form of mmdet's `single_gpu_test` loop (tools/test.py:250-255):
-        `batches` yields `(img, img_metas)` -- normalised (B, 3, H, W) device tensors, as
-        `simple_test` takes them -- and this generator yields each batch's `[Result]`, in
-        order, `depth - 1` batches late: backbone + stage A of consecutive batches alternate
-        between two streams, the query chains of older batches run beside them, results reach
-        the host through `ResultStreamer` (INTEGRATION.md 2b spelled out).  `copy=False`
-        hands out views of the ring entry (valid for `ring` more batches) instead of private
-        arrays.  Backbones other than the native ResNet run in front on the caller's stream."""
+    def _pipelined(self, batches, rescale, depth):
+        """Generator behind `stream()` / `stream_triplets()`: queues every `(img, img_metas)`
+        of `batches` -- backbone + stage A alternating between the pipeline's two stage-A
+        streams, the query chains of older batches beside them -- and yields
+        `(results, pipe)` for each batch, in order, `depth - 1` batches late.  `results`
+        carries `pipeline_stream` (the chain stream `get_bboxes` ran on: queue reads THERE)
+        and must be handed back with `pipe.consumed(results, stream)`.  Restores the
+        scheduling attributes it sets on the head / backbone when it is closed."""
         from .pipeline import PipelinedHead
         head, net = self.bbox_head, self.backbone
-        if self.neck is not None or not getattr(head, "use_mask", False):
-            # (the pipeline schedules the CrossHead2 family; other heads: one batch at a time)
-            for img, metas in batches:
-                yield self.simple_test(img, metas, rescale=rescale)
-            return
-        graphs = (head.use_graphs, getattr(net, "use_graphs", None))
-        head.use_graphs = True
         slots = isinstance(net, ResNet50Hip)
+        saved = (head.use_graphs, getattr(head, "grid_reserve", 0),
+                 getattr(net, "use_graphs", None), getattr(net, "grid_reserve", 0))
+        head.use_graphs = True
         if slots:
             net.use_graphs = True
         pipe = PipelinedHead(head, depth=depth)
         if slots:
             net.grid_reserve = pipe.grid_reserve
-        out = ResultStreamer(head, ring=ring, private_masks=copy)
-        own = (lambda rs: [self._own(r) for r in rs]) if copy else (lambda rs: rs)
-        ready = []
-
-        def take(res):
-            if len(out) >= out.ring - 1:
-                ready.append(own(out.pop()))
-            out.push(res, pipe)
         try:
             for img, metas in batches:
                 sl = pipe.count % len(pipe.streams_a)
@@ -502,25 +492,76 @@ class PSGTr:
                     if len(feats) == 4 and self.out_indices != (0, 1, 2, 3):
                         feats = tuple(feats[j] for j in self.out_indices)
                     res = pipe.submit(feats, metas, rescale=rescale)
-                    if res is not None:
-                        take(res)
-                while ready:
-                    yield ready.pop(0)
-            with torch.cuda.stream(pipe.streams_a[0]):
-                tail = pipe.flush()
-            for res in tail:           # (one at a time: a popped view is handed out before
-                with torch.cuda.stream(pipe.streams_a[0]):     # its ring entry is pushed again)
-                    take(res)
-                while ready:
-                    yield ready.pop(0)
+                if res is not None:
+                    yield res, pipe
+            while pipe.queue:
+                with torch.cuda.stream(pipe.streams_a[0]):
+                    res = pipe._finish(pipe.queue.pop(0))
+                yield res, pipe
+        finally:
+            # (grid_reserve is part of the stage graphs' key: put back what was there, so that
+            # a later simple_test() finds its captured graphs again)
+            head.use_graphs, head.grid_reserve = saved[0], saved[1]
+            if slots:
+                net.use_graphs, net.grid_reserve = saved[2], saved[3]
+
+    def _pipelines(self):
+        """Whether `_pipelined` can schedule this detector (the CrossHead2 family without a
+        neck); other heads run one batch at a time."""
+        return self.neck is None and bool(getattr(self.bbox_head, "use_mask", False))
+
+    @torch.no_grad()
+    def stream(self, batches, rescale=False, depth=4, ring=6, copy=True):
+        """The throughput form of mmdet's `single_gpu_test` loop (tools/test.py:250-255):
+        `batches` yields `(img, img_metas)` -- normalised (B, 3, H, W) device tensors, as
+        `simple_test` takes them -- and this generator yields each batch's `[Result]`, in
+        order, `depth - 1` batches late: backbone + stage A of consecutive batches alternate
+        between two streams, the query chains of older batches run beside them, results reach
+        the host through `ResultStreamer` (INTEGRATION.md 2b spelled out).  `copy=False`
+        hands out views of the ring entry instead of private arrays: a yielded view is valid
+        only until the NEXT batch is requested from this generator (the entry it lives in is
+        the next one pushed); copy what must live longer.  Backbones other than the native
+        ResNet run in front on the caller's stream."""
+        head = self.bbox_head
+        if not self._pipelines():
+            for img, metas in batches:
+                yield self.simple_test(img, metas, rescale=rescale)
+            return
+        out = ResultStreamer(head, ring=ring, private_masks=copy)
+        own = (lambda rs: [self._own(r) for r in rs]) if copy else (lambda rs: rs)
+        try:
+            for res, pipe in self._pipelined(batches, rescale, depth):
+                ready = own(out.pop()) if len(out) >= out.ring - 1 else None
+                if ready is not None and not copy:
+                    # a view: hand it out BEFORE its ring entry can be pushed again
+                    yield ready
+                    ready = None
+                out.push(res, pipe)
+                if ready is not None:
+                    yield ready
             while len(out):
                 yield own(out.pop())
         finally:
             out.close()
-            head.use_graphs = graphs[0]
-            head.grid_reserve = 0
-            if slots:
-                net.use_graphs, net.grid_reserve = graphs[1], 0
+
+    @torch.no_grad()
+    def stream_triplets(self, batches, rescale=False, depth=4):
+        """The device-side form of `stream()` for the distributed test loop
+        (`dist.multi_gpu_test`): yields a `dist.TripletBatch` per batch -- the `get_bboxes`
+        tuples (device tensors), the query rows of their triplets, the chain stream they were
+        produced on and a `release(stream)` hook -- without any D2H."""
+        from .dist import TripletBatch
+        head = self.bbox_head
+        if not self._pipelines():
+            for img, metas in batches:
+                feat = self.extract_feat(img)
+                res = head.simple_test(feat, metas, rescale=rescale)
+                yield TripletBatch(res, *head.pair_positions(getattr(head, "_last_plan", None)))
+            return
+        for res, pipe in self._pipelined(batches, rescale, depth):
+            sub, obj = head.pair_positions(head._last_plan)
+            yield TripletBatch(res, sub, obj, stream=res.pipeline_stream,
+                               release=lambda s, r=res, p=pipe: p.consumed(r, s))
 
     @staticmethod
     def _own(r):
@@ -575,6 +616,7 @@ def build_detector(cfg, train_cfg=None, test_cfg=None):
     cfg = dict(cfg)
     if cfg.pop("type", "PSGTr") != "PSGTr":
         raise NotImplementedError("only type='PSGTr'")
-    cfg.pop("train_cfg", None)
-    return PSGTr(cfg["backbone"], cfg["bbox_head"], test_cfg=cfg.get("test_cfg", test_cfg),
-                 neck=cfg.get("neck"))
+    model_train_cfg = cfg.pop("train_cfg", None)
+    return PSGTr(cfg["backbone"], cfg["bbox_head"],
+                 train_cfg=model_train_cfg if model_train_cfg is not None else train_cfg,
+                 test_cfg=cfg.get("test_cfg", test_cfg), neck=cfg.get("neck"))

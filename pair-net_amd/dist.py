@@ -101,6 +101,11 @@ class TripletGatherer:
         # path: communicator set-up and the all-gather itself, tests/test_dist.py)
         self.force_collective = bool(force_collective) and dist.is_initialized()
         self.packed = [None] * self.ring      # per ring entry: event behind its pack kernels
+        # per ring entry: event behind the all-gather that READ it (recorded on the stream the
+        # collective was issued on).  The host counters below only say that the collective has
+        # been ENQUEUED; a rank whose collectives are backed up behind a slow peer would
+        # otherwise re-pack an entry RCCL has not read yet (write-after-read).
+        self.sent = [None] * self.ring
         self.filled = 0                       # steps packed so far
         self.gathered = 0                     # steps gathered so far
 
@@ -110,7 +115,12 @@ class TripletGatherer:
         current stream); finish with end_step()."""
         if self.filled - self.gathered >= self.ring:
             raise RuntimeError("TripletGatherer ring is full: gather_delayed() / flush() first")
-        self.send = self.sends[self.filled % self.ring]
+        k = self.filled % self.ring
+        if self.on_device and self.sent[k] is not None:
+            # the packing stream may not overwrite the entry before the collective that read
+            # it has finished (a device-side wait: the host does not block)
+            torch.cuda.current_stream().wait_event(self.sent[k])
+        self.send = self.sends[k]
 
     def end_step(self):
         if self.on_device:
@@ -130,6 +140,10 @@ class TripletGatherer:
             torch.cuda.current_stream().wait_event(self.packed[k])
         self.send = self.sends[k]
         out = self.gather(host_staging=host_staging)
+        if self.on_device:
+            ev = self.sent[k] or torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.sent[k] = ev
         self.gathered += 1
         return out
 
@@ -141,7 +155,15 @@ class TripletGatherer:
         return outs
 
     def pack(self, i, labels, rel_dists, sub_pos, obj_pos):
+        if not self.on_device:     # host records (the gloo tests of the control flow)
+            self.send[i].copy_(pack_triplets(labels, rel_dists, sub_pos, obj_pos))
+            return
         self.hip.pack_triplets(labels, rel_dists, sub_pos, obj_pos, self.send[i], self.R, self.C1)
+
+    def pack_padding(self, i):
+        """A rank without an image for row i of this step still takes part in the collective:
+        its row is zeros (dropped when the records are truncated to the dataset length)."""
+        self.send[i].zero_()
 
     def gather(self, host_staging=False):
         """`host_staging`: run the collective on host copies (backend "gloo": the
@@ -159,3 +181,171 @@ class TripletGatherer:
         out.view(self.n_local, self.world, self.L).copy_(
             recv.view(self.world, self.n_local, self.L).transpose(0, 1))
         return out
+
+
+class TripletBatch:
+    """One batch of `get_bboxes` tuples as a detector's `stream_triplets()` yields them:
+    `results[i]` is image i's tuple (labels at [1], r_dists last), `sub_pos[i]` / `obj_pos[i]`
+    the query rows of its R triplets, `stream` the stream they were produced on (None on the
+    host) and `release(stream)` tells the producer that its buffers have been read on `stream`
+    up to this point."""
+    __slots__ = ("results", "sub_pos", "obj_pos", "stream", "release")
+
+    def __init__(self, results, sub_pos, obj_pos, stream=None, release=None):
+        self.results, self.sub_pos, self.obj_pos = results, sub_pos, obj_pos
+        self.stream, self.release = stream, release
+
+
+class TripletCollector:
+    """Pack-and-gather of a data-parallel run, the part of mmdet's `collect_results_*`
+    (tools/test.py:262-267) that runs per step: `add(batch)` packs a `TripletBatch`'s records
+    into a `TripletGatherer` ring entry ON THE STREAM THAT PRODUCED THEM, releases the
+    producer's buffers, and issues the all-gather of the step `depth` steps back on a side
+    stream (its inputs have long been written: the collective never makes a hardware queue
+    wait, and a slow peer never stalls a compute stream).  `pad()` contributes a zero step
+    (a rank that has run out of images still takes part in every collective); `finish()`
+    gathers what is left in the ring and, with `keep_steps`, returns every step's records
+    [steps * world * n_local, L] in dataset order (image (s * n_local + j) * W + r is row j
+    of rank r in step s)."""
+
+    def __init__(self, head, depth=4, n_local=1, group=None, host_staging=None,
+                 force_collective=False, keep_steps=0):
+        ini = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if ini else 1
+        self.device = torch.device(getattr(head, "device", None) or "cpu")
+        self.on_gpu = self.device.type == "cuda"
+        if host_staging is None:    # gloo cannot take device tensors: stage through the host
+            host_staging = self.on_gpu and ini and dist.get_backend(group) != "nccl"
+        self.host_staging, self.depth, self.n_local = bool(host_staging), int(depth), int(n_local)
+        self.gatherer = TripletGatherer(n_local, head.num_rel_query, head.num_relations,
+                                        self.device, group=group,
+                                        force_collective=force_collective, ring=depth + 4)
+        self.side = torch.cuda.Stream(self.device) if self.on_gpu else None
+        self.rows = self.world * self.n_local
+        store_dev = torch.device("cpu") if self.host_staging else self.device
+        self.records = torch.zeros((keep_steps * self.rows, self.gatherer.L), device=store_dev,
+                                   dtype=torch.float32) if keep_steps else None
+        self.stored = 0
+
+    def _on(self, stream):
+        import contextlib
+        if self.on_gpu and stream is not None:
+            return torch.cuda.stream(stream)
+        return contextlib.nullcontext()
+
+    def _store(self, out):
+        if out is not None and self.records is not None:
+            k = self.stored      # (gather() hands out an internal buffer: keep a copy)
+            self.records[k * self.rows:(k + 1) * self.rows].copy_(out, non_blocking=True)
+            self.stored = k + 1
+
+    def _collect(self, delay):
+        with self._on(self.side):
+            self._store(self.gatherer.gather_delayed(delay, host_staging=self.host_staging))
+
+    def add(self, tb, before_release=None):
+        """`tb`: a TripletBatch of `n_local` images.  `before_release(tb)`: optional reader of
+        the batch's device tensors, run on the producing stream before they are released."""
+        g = self.gatherer
+        ps = tb.stream if tb.stream is not None else (
+            torch.cuda.current_stream(self.device) if self.on_gpu else None)
+        with self._on(ps):
+            g.begin_step()
+            for i, res in enumerate(tb.results):
+                g.pack(i, res[1], res[-1], tb.sub_pos[i], tb.obj_pos[i])
+            for i in range(len(tb.results), self.n_local):
+                g.pack_padding(i)
+            g.end_step()
+            if before_release is not None:
+                before_release(tb)
+            if tb.release is not None:    # the producer's slot may be reused once `ps` is here
+                tb.release(ps)
+        self._collect(self.depth)
+
+    def pad(self):
+        g = self.gatherer
+        g.begin_step()
+        for i in range(self.n_local):
+            g.pack_padding(i)
+        g.end_step()
+        self._collect(self.depth)
+
+    def finish(self):
+        g = self.gatherer
+        with self._on(self.side):
+            while g.gathered < g.filled:
+                self._store(g.gather_delayed(0, host_staging=self.host_staging))
+        if self.side is not None:
+            self.side.synchronize()
+        return self.records
+
+
+def multi_gpu_test(detector, dataset, annotations=None, evaluator=None, metrics=None, *,
+                   depth=4, group=None, host_staging=None, force_collective=False,
+                   rescale=False):
+    """The reference's distributed test loop -- mmdet `multi_gpu_test` + `collect_results_*`
+    (tools/test.py:256-267) followed by `dataset.evaluate` (:277-295 ->
+    pairnet/datasets/psg.py:285-404) -- for one process per GPU:
+
+      * rank r takes the images r, r + W, ... (`shard_indices`: DistributedSampler(
+        shuffle=False)), one per step, and runs them through `detector.stream_triplets`
+        (PSGTr: backbone -> PipelinedHead, `depth` images in flight);
+      * every image's triplet record (labels | rel_dists | sub_pos | obj_pos, ~27 KB) is
+        packed on the stream that produced it and all-gathered `depth` steps later on a side
+        stream (`TripletGatherer` ring; RCCL for backend "nccl", host-staged for "gloo"), so
+        neither the collective nor a slow peer stalls a compute stream; ranks that run out of
+        images contribute zero rows, so every rank issues the same ceil(N / W) collectives;
+      * masks and panoptic maps never travel: with `annotations` + `evaluator`
+        (`TripletEvaluator`) every rank matches ITS images against their ground truth on its
+        own GPU, and only the per-image match lists (a few KB of Python lists) are gathered
+        once at the end; rank 0 adds them to `metrics` (`SceneGraphMetrics`) in dataset order.
+
+    `dataset[i]` -> `(img, img_metas)` as `simple_test` takes them (one image);
+    `annotations[i]` -> dict(gt_rels, gt_labels, gt_masks) (or None).  Returns a dict:
+    `records` [N, L] float32 in dataset order on EVERY rank (`unpack_triplets` splits a row),
+    `num_images`, `world_size`, `rank`, `collectives`, and on rank 0 `metrics`
+    (`metrics.summary()`) when an evaluator was given."""
+    ini = dist.is_available() and dist.is_initialized()
+    W = dist.get_world_size(group) if ini else 1
+    rank = dist.get_rank(group) if ini else 0
+    N = len(dataset)
+    steps = (N + W - 1) // W
+    mine = shard_indices(N, rank, W)
+    col = TripletCollector(detector.bbox_head, depth=depth, n_local=1, group=group,
+                           host_staging=host_staging, force_collective=force_collective,
+                           keep_steps=steps)
+    local_evals = []
+    batches = (dataset[i] for i in mine)
+    done = 0
+    for tb in detector.stream_triplets(batches, rescale=rescale, depth=depth):
+        if len(tb.results) != 1:
+            raise ValueError("multi_gpu_test takes one image per step (samples_per_gpu=1, "
+                             "configs/_base_/datasets/psg.py)")
+        idx = mine[done]
+        ann = annotations[idx] if annotations is not None else None
+
+        def evaluate(res, idx=idx, ann=ann):
+            if evaluator is None or ann is None:
+                return
+            ev = evaluator(res, ann["gt_rels"], ann["gt_labels"], ann["gt_masks"])
+            iou = evaluator.iou_stats(res, ann["gt_rels"], ann["gt_labels"], ann["gt_masks"]) \
+                if hasattr(evaluator, "iou_stats") and len(ann["gt_rels"]) else None
+            local_evals.append((idx, ev, ann["gt_rels"], iou))
+        col.add(tb, before_release=lambda tb: evaluate(tb.results[0]))
+        done += 1
+    for _ in range(steps - done):          # ranks with one image fewer: a zero row
+        col.pad()
+    records = col.finish()
+    out = dict(records=records[:N], num_images=N, world_size=W, rank=rank,
+               collectives=col.gatherer.gathered, local_indices=mine)
+    if evaluator is not None:
+        evals = [local_evals]
+        if W > 1:
+            evals = [None] * W
+            dist.all_gather_object(evals, local_evals, group=group)
+        if rank == 0 and metrics is not None:
+            for idx, ev, gt_rels, iou in sorted((e for part in evals for e in part),
+                                                key=lambda e: e[0]):
+                metrics.add(ev, gt_rels, iou=iou)
+            out["metrics"] = metrics.summary()
+    return out

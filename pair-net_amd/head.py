@@ -66,8 +66,12 @@ class CrossHead2:
         relation_decoder = ConfigDict(relation_decoder)
         if mapper != "conv_tiny":
             raise NotImplementedError("only mapper='conv_tiny' (configs/mask2former/pairnet.py:26)")
-        if train_cfg:
-            raise NotImplementedError("inference path only (SURVEY.md section 8)")
+        # train_cfg (mmdet passes the model-level one to the head): kept for `loss()` -- the
+        # forward VALUES of the reference's loss (losses.py); there is no backward here
+        self._loss_cfg = dict(train_cfg=train_cfg, rel_cls_loss=rel_cls_loss,
+                              subobj_cls_loss=subobj_cls_loss,
+                              importance_match_loss=importance_match_loss)
+        self._loss = None
         # the same checks the reference makes (pairnet_head.py:72-87)
         assert "num_feats" in positional_encoding
         assert positional_encoding["num_feats"] * 2 == embed_dims
@@ -130,6 +134,10 @@ class CrossHead2:
         # (a per-call hint, hip.reserve_slots; PipelinedHead sets it for its own schedule)
         self.grid_reserve = 0
         self.fuse_ppn_front = True      # normalise + cosine matrix + first Matrix Learner layer in one launch
+        # encoder sites whose Linear + identity + LayerNorm run as one row-owning launch
+        # (pn_linear_res_ln_f32): "proj" = output_proj -> norms.0, "ffn" = FFN-2 -> norms.1;
+        # () = the GEMM -> LayerNorm pairs of rounds 1-3 (bit-identical either way)
+        self.enc_fused_ln = ("proj", "ffn")
         self.init_weights()
 
     # ------------------------------------------------------------------ params
@@ -463,14 +471,27 @@ class CrossHead2:
                      ldc=544, bias=w[a + "voa.bias"], aadd=pl.enc_pos, ldaadd=256, aadd_rows=SN,
                      aadd_from_col=256)
             hip.msda(pl.VOA, 544, pl.VOA.view(-1)[256:], 544, pl.S, B, pl.shapes)
-            hip.linear(pl.S.view(-1, 256), w[a + "output_proj.weight"], w[a + "output_proj.bias"],
-                       Y2, res=X2)
-            hip.layernorm(Y2, w[p + "norms.0.weight"], w[p + "norms.0.bias"], X12)
+            # output_proj + identity + norms.0, and ffns.0.layers.1 + identity + norms.1: each
+            # one launch whose workgroups own whole rows (csrc/gemm_ln.hip; bitwise the
+            # GEMM -> LayerNorm pair it replaces, `enc_fused_ln` selects per site)
+            if "proj" in self.enc_fused_ln:
+                hip.linear_res_ln(pl.S.view(-1, 256), w[a + "output_proj.weight"],
+                                  w[a + "output_proj.bias"], X2, w[p + "norms.0.weight"],
+                                  w[p + "norms.0.bias"], X12)
+            else:
+                hip.linear(pl.S.view(-1, 256), w[a + "output_proj.weight"],
+                           w[a + "output_proj.bias"], Y2, res=X2)
+                hip.layernorm(Y2, w[p + "norms.0.weight"], w[p + "norms.0.bias"], X12)
             hip.linear(X12, w[p + "ffns.0.layers.0.0.weight"], w[p + "ffns.0.layers.0.0.bias"],
                        pl.H, relu=True)
-            hip.linear(pl.H, w[p + "ffns.0.layers.1.weight"], w[p + "ffns.0.layers.1.bias"], Y2,
-                       res=X12)
-            hip.layernorm(Y2, w[p + "norms.1.weight"], w[p + "norms.1.bias"], X2)
+            if "ffn" in self.enc_fused_ln:
+                hip.linear_res_ln(pl.H, w[p + "ffns.0.layers.1.weight"],
+                                  w[p + "ffns.0.layers.1.bias"], X12, w[p + "norms.1.weight"],
+                                  w[p + "norms.1.bias"], X2)
+            else:
+                hip.linear(pl.H, w[p + "ffns.0.layers.1.weight"], w[p + "ffns.0.layers.1.bias"],
+                           Y2, res=X12)
+                hip.layernorm(Y2, w[p + "norms.1.weight"], w[p + "norms.1.bias"], X2)
         # FPN level (C2): lateral 1x1 + GN, + bilinear-up(finest memory), 3x3 + GN + ReLU
         f = feats[0]
         cin, HW2 = f.shape[1], pl.HW2
@@ -786,7 +807,8 @@ class CrossHead2:
         """Run stage 'a' or 'b' of plan `pl` on the current stream: eagerly, or (with
         `use_graphs`) as one hipGraph replay.  A stage is captured on its second call
         (the first, eager one is the warm-up torch requires before capture)."""
-        cfg = (self.exact_mask_order, self.conv_algo, self.fuse_ppn_front, self.grid_reserve)
+        cfg = (self.exact_mask_order, self.conv_algo, self.fuse_ppn_front, self.grid_reserve,
+               tuple(self.enc_fused_ln))
         if pl.graph_cfg != cfg:          # a captured graph bakes these switches in
             pl.graph_a = pl.graph_b = pl.me0 = None
             pl.graph_c = {}
@@ -1033,6 +1055,31 @@ class CrossHead2:
                     hip.panoptic_continue(state, up, area, seg, H0, W0)
             out.append(dict(nkeep=nkeep, rounds=rounds))
         return out
+
+    def loss(self, all_cls_scores, all_mask_preds, gt_rels_list, gt_bboxes_list, gt_labels_list,
+             gt_masks_list, img_metas, gt_bboxes_ignore=None, **kw):
+        """The reference's `CrossHead2.loss` (pairnet_head.py:419-477), forward values only:
+        {loss_r_cls, loss_sub_cls, loss_obj_cls, loss_match} as 0-dim device tensors, from the
+        two dicts `forward` returns and the per-image ground truth (losses.py; `point_coords=`
+        fixes the sampled mask points, default torch.rand like the reference)."""
+        if self._loss is None:
+            from .losses import CrossHead2Loss
+            self._loss = CrossHead2Loss(self.num_classes, self.num_relations, self.num_obj_query,
+                                        self.num_rel_query, **self._loss_cfg)
+        return self._loss.loss(all_cls_scores, all_mask_preds, gt_rels_list, gt_bboxes_list,
+                               gt_labels_list, gt_masks_list, img_metas,
+                               gt_bboxes_ignore=gt_bboxes_ignore, **kw)
+
+    def forward_train(self, *a, **kw):
+        raise NotImplementedError("training (backward, optimizer) is outside SURVEY.md section 8; "
+                                  "`loss()` gives the reference's loss VALUES on forward() outputs")
+
+    def pair_positions(self, pl=None):
+        """(sub_pos, obj_pos): per image the query rows of the R selected pairs
+        (pairnet_head.py:338-340) of plan `pl` (default: the last forward's) -- what the
+        distributed test loop packs into the triplet records next to labels and r_dists."""
+        pl = pl if pl is not None else self._last_plan
+        return pl.sub_pos, pl.obj_pos
 
     def simple_test_bboxes(self, feats, img_metas, rescale=False):
         """pairnet_head.py:926-930."""

@@ -63,6 +63,19 @@ _SIGS = {
     "pn_ffn_ln2_f32": (C.c_int, [_vp] * 12 + [_i32, _i32, _i32, _f32, _vp]),
     "pn_msda_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, C.POINTER(_i32),
                               C.POINTER(_i32), _vp]),
+    "pn_msda_ex_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, C.POINTER(_i32),
+                                 C.POINTER(_i32), _i32, _vp]),
+    "pn_linear_res_ln_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64,
+                                       _i32, _i32, _i32, _f32, _vp]),
+    "pn_point_sample_f32": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pn_mask_match_cost_f32": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32,
+                                         _f32, _f32, _f32, _vp]),
+    "pn_id_match_cost_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32,
+                                       _f32, _f32, _f32, _vp]),
+    "pn_ce_mean_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
+    "pn_seesaw_mean_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32,
+                                     _vp]),
+    "pn_bce_posw_mean_f32": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp]),
     "pn_msda_loc_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_sine_pe_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "pn_sine_pe_offset_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp]),
@@ -119,7 +132,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 15   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 16   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -451,6 +464,24 @@ def layernorm(x, gamma, beta, out, eps=1e-5):
                                   eps, _stream()), "pn_layernorm_f32")
 
 
+def linear_res_ln(x, weight, bias, res, gamma, beta, out, eps=1e-5):
+    """out = LayerNorm(res + x @ weight.T + bias) * gamma + beta, 256 output columns, one
+    launch (csrc/gemm_ln.hip); bit for bit linear(..., res=res) followed by layernorm()."""
+    M, ldx = _rowmajor(x)
+    N, ldw = _rowmajor(weight)
+    Mr, ldr = _rowmajor(res)
+    Mo, ldo = _rowmajor(out)
+    K = x.shape[1]
+    assert Mr == M and Mo == M and N == 256 and weight.shape[1] == K
+    # operands of the fused op once each: x, W, residual in, normalised rows out
+    nbytes = 4.0 * (M * K + N * K + 2 * M * N)
+    _check(_launch("k_gemm_rowln", 2.0 * M * N * K, nbytes,
+                   lambda: lib().pn_linear_res_ln_f32(_ptr(x), ldx, _ptr(weight), ldw, _ptr(bias),
+                                                      _ptr(res), ldr, _ptr(gamma), _ptr(beta),
+                                                      _ptr(out), ldo, M, N, K, eps, _stream()),
+                   meta=(M, N, K, 1, False)), "pn_linear_res_ln_f32")
+
+
 def layernorm_rows(x, gamma, beta, out, eps=1e-5):
     """LayerNorm over the last dim of 2-D row views (any C % 4 == 0, C <= 3072)."""
     rows, ldx = _rowmajor(x)
@@ -525,7 +556,10 @@ def l2normalize(x, out, eps=1e-12):
                                     _stream()), "pn_l2normalize_f32")
 
 
-def msda(value, ld_value, offaw, ld_offaw, out, B, shapes):
+MSDA_ONE_SHOT = 1     # PN_MSDA_ONE_SHOT: the rounds 1-3 launch form (A/B probes)
+
+
+def msda(value, ld_value, offaw, ld_offaw, out, B, shapes, flags=0):
     L = len(shapes)
     hs = (_i32 * L)(*[s[0] for s in shapes])
     ws = (_i32 * L)(*[s[1] for s in shapes])
@@ -533,9 +567,9 @@ def msda(value, ld_value, offaw, ld_offaw, out, B, shapes):
     # algorithmic bytes: value read + offsets/logits read + output write
     nbytes = 4.0 * B * n * (256 + 8 * L * 4 * 3 + 256)
     _check(_launch("k_msda", 2.0 * B * n * 8 * L * 4 * 4 * 32 * 2, nbytes,
-                   lambda: lib().pn_msda_f32(_ptr(value), ld_value, _ptr(offaw), ld_offaw,
-                                             _ptr(out), B, L, hs, ws, _stream())),
-           "pn_msda_f32")
+                   lambda: lib().pn_msda_ex_f32(_ptr(value), ld_value, _ptr(offaw), ld_offaw,
+                                                _ptr(out), B, L, hs, ws, flags, _stream())),
+           "pn_msda_ex_f32")
 
 
 def msda_loc(value, ld_value, spatial_shapes, level_start_index, loc, aw, out, B, N, Nq, L):
@@ -850,3 +884,49 @@ def box_triplets(s_cls, o_cls, s_box, o_box, det, labels, R, Cc, img_h, img_w, s
     _check(lib().pn_box_triplets_f32(_ptr(s_cls), _ptr(o_cls), _ptr(s_box), _ptr(o_box), _ptr(det),
                                      _ptr(labels, torch.int64), R, Cc, float(img_h), float(img_w),
                                      sf, 1 if rescale else 0, _stream()), "pn_box_triplets_f32")
+
+
+# ---- loss forward (csrc/loss.hip) ----------------------------------------------------------
+def point_sample(maps, pts, out):
+    """maps [P][h][w] float32 or bool / uint8; pts [Np][2]; out [P][Np] (mmcv point_sample with
+    one point set for all maps)."""
+    P, h, w = maps.shape
+    u8 = maps.dtype in (torch.bool, torch.uint8)
+    _check(lib().pn_point_sample_f32(_ptr(maps, maps.dtype), int(u8), _ptr(pts), _ptr(out), P, h, w,
+                                     pts.shape[0], _stream()), "pn_point_sample_f32")
+
+
+def mask_match_cost(cls, gt_labels, pred_pts, gt_pts, cost, w_cls, w_mask, w_dice, dice_eps):
+    Q, ncls = cls.shape
+    G, Np = gt_pts.shape
+    _check(lib().pn_mask_match_cost_f32(_ptr(cls), ncls, _ptr(gt_labels, torch.int64),
+                                        _ptr(pred_pts), _ptr(gt_pts), _ptr(cost), Q, G, Np, w_cls,
+                                        w_mask, w_dice, dice_eps, _stream()),
+           "pn_mask_match_cost_f32")
+
+
+def id_match_cost(sub, obj, rel, gt_sub, gt_obj, gt_rel, cost, w_sub, w_obj, w_rel):
+    R, ncls = sub.shape
+    _check(lib().pn_id_match_cost_f32(_ptr(sub), _ptr(obj), _ptr(rel), ncls, rel.shape[1],
+                                      _ptr(gt_sub, torch.int64), _ptr(gt_obj, torch.int64),
+                                      _ptr(gt_rel, torch.int64), _ptr(cost), R, gt_sub.shape[0],
+                                      w_sub, w_obj, w_rel, _stream()), "pn_id_match_cost_f32")
+
+
+def ce_mean(logits, target, class_weight, out, loss_weight):
+    rows, ld = _rowmajor(logits)
+    _check(lib().pn_ce_mean_f32(_ptr(logits), ld, _ptr(target, torch.int64), _ptr(class_weight),
+                                _ptr(out), rows, logits.shape[1], loss_weight, _stream()),
+           "pn_ce_mean_f32")
+
+
+def seesaw_mean(logits, target, cum_samples, out, p, q, eps, loss_weight):
+    rows, ld = _rowmajor(logits)
+    _check(lib().pn_seesaw_mean_f32(_ptr(logits), ld, _ptr(target, torch.int64), _ptr(cum_samples),
+                                    _ptr(out), rows, logits.shape[1], p, q, eps, loss_weight,
+                                    _stream()), "pn_seesaw_mean_f32")
+
+
+def bce_posw_mean(logits, target, out, loss_weight):
+    _check(lib().pn_bce_posw_mean_f32(_ptr(logits), _ptr(target), _ptr(out), logits.numel(),
+                                      loss_weight, _stream()), "pn_bce_posw_mean_f32")

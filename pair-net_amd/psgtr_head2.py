@@ -101,6 +101,12 @@ class PSGTrHead2(CrossHead2):
                 dict(sub_seg=pl.sub_seg.view(1, B, Q, H2, W2),
                      obj_seg=pl.obj_seg.view(1, B, Q, H2, W2)))
 
+    def pair_positions(self, pl=None):
+        """Query i IS triplet i (psgtr_head2.py:345-444): identity rows."""
+        pl = pl if pl is not None else self._last_plan
+        ident = torch.arange(self.num_obj_query, device=self.device, dtype=torch.int64)
+        return ident.unsqueeze(0).expand(pl.B, -1), ident.unsqueeze(0).expand(pl.B, -1)
+
     def forward_head(self, decoder_out, mask_feature, attn_mask_target_size):
         raise NotImplementedError("PSGTrHead2.forward_head (six outputs, psgtr_head2.py:288) is "
                                   "internal to forward() here")

@@ -160,6 +160,130 @@ def test_delayed_ring_gatherer_world2_gloo(n_local, delay):
             assert torch.equal(torch.from_numpy(got[step]), expect)
 
 
+class _HostHead:
+    """What `multi_gpu_test` reads of a head."""
+    num_rel_query, num_relations, device = 100, 56, None
+
+
+class _HostDetector:
+    """A detector stand-in for the CPU tests of the distributed LOOP (the real one needs the
+    MI355X): `stream_triplets` yields, `lag` batches late like the pipeline, host tensors that
+    are a deterministic function of the image; `released` counts the release hooks."""
+
+    def __init__(self, lag=3):
+        self.bbox_head, self.lag, self.released = _HostHead(), lag, 0
+
+    @staticmethod
+    def detect(img):
+        i = int(img.flatten()[0])
+        d = unpack_triplets(_record(i), 100, 56)
+        res = (None, d["labels"], None, None, None, None, None, d["rel_dists"])
+        return res, d["sub_pos"], d["obj_pos"]
+
+    def stream_triplets(self, batches, rescale=False, depth=4):
+        from pairnet_amd.dist import TripletBatch
+        queue = []
+
+        def rel(stream):
+            self.released += 1
+        for img, metas in batches:
+            r, s, o = self.detect(img)
+            queue.append(TripletBatch([r], [s], [o], stream=None, release=rel))
+            if len(queue) > self.lag:
+                yield queue.pop(0)
+        while queue:
+            yield queue.pop(0)
+
+
+class _ListEvaluator:
+    """Stands in for TripletEvaluator: the "match lists" are a function of labels and GT."""
+
+    def __call__(self, res, gt_rels, gt_labels, gt_masks):
+        n = len(gt_rels)
+        base = int(res[1][0])
+        p2g = [[(base + r) % n] if n and r % 3 == 0 else [] for r in range(100)]
+        rec = {k: len({g for l in p2g[:k] for g in l}) / float(n) for k in (20, 50, 100)} if n else None
+        return dict(pred_to_gt=p2g, phrdet_pred_to_gt=p2g, sgdet_recall=rec, phrdet_recall=rec)
+
+
+def _host_dataset(n):
+    return [(torch.full((1, 3, 2, 2), float(i)), [dict(img_shape=(2, 2, 3), scale_factor=[1.0] * 4)])
+            for i in range(n)]
+
+
+def _host_annotations(n):
+    import numpy as np
+    out = []
+    for i in range(n):
+        g = 0 if i == 1 else 2 + i % 3       # (image 1 has no ground-truth relations: skipped)
+        rels = np.array([[j % 2, (j + 1) % 2, 1 + (i + j) % 56] for j in range(g)]).reshape(-1, 3)
+        out.append(dict(gt_rels=rels, gt_labels=np.array([3, 7]), gt_masks=None))
+    return out
+
+
+def _loop_worker(rank, world, port, n_images, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pairnet_amd.dist import multi_gpu_test
+    from pairnet_amd.evaluation import SceneGraphMetrics
+    det = _HostDetector()
+    out = multi_gpu_test(det, _host_dataset(n_images), annotations=_host_annotations(n_images),
+                         evaluator=_ListEvaluator(), metrics=SceneGraphMetrics(56), depth=2)
+    q.put((rank, out["records"].numpy(), out["collectives"], det.released, out.get("metrics")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multi_gpu_test_world2_equals_world1_gloo():
+    """The product loop end to end on the host: shard -> detect -> pack -> delayed ring
+    all-gather -> dataset-order records on EVERY rank, evaluated where the images are, metrics
+    on rank 0 -- with an uneven split (5 images over 2 ranks: rank 1 pads a zero step) the
+    records and the metrics equal those of the one-process run."""
+    from pairnet_amd.dist import multi_gpu_test
+    from pairnet_amd.evaluation import SceneGraphMetrics
+    n = 5
+    det = _HostDetector()
+    one = multi_gpu_test(det, _host_dataset(n), annotations=_host_annotations(n),
+                         evaluator=_ListEvaluator(), metrics=SceneGraphMetrics(56), depth=2)
+    assert one["world_size"] == 1 and one["collectives"] == n and det.released == n
+    expect = torch.stack([_record(i) for i in range(n)])
+    assert torch.equal(one["records"], expect)
+    assert one["metrics"]["images"] == n - 1 and one["metrics"]["skipped"] == 1
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, port = 2, _free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {r: rest for r, *rest in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        rec, ncoll, released, metrics = outs[r]
+        assert torch.equal(torch.from_numpy(rec), expect)
+        assert ncoll == 3                                  # ceil(5 / 2) collectives on BOTH ranks
+        assert released == len(shard_indices(n, r, world))
+    assert outs[1][3] is None and outs[0][3] == one["metrics"]
+
+
+def test_ring_entry_waits_for_the_collective_that_read_it():
+    """the ring's host counters only say a collective was ENQUEUED.  On a device the
+    entry carries a `sent` event behind its all-gather, and begin_step() makes the packing
+    stream wait for it; on the host (this test) the bookkeeping must still cycle."""
+    gt = TripletGatherer(1, 100, 56, "cpu", ring=3)
+    assert gt.sent == [None, None, None]
+    for step in range(7):
+        gt.begin_step()
+        gt.send[0].copy_(_record(step))
+        gt.end_step()
+        out = gt.gather_delayed(1)
+        if step >= 1:
+            assert torch.equal(out[0], _record(step - 1))
+    assert torch.equal(gt.flush()[0][0], _record(6))
+
+
 @pytest.mark.gpu
 def test_pack_triplets_kernel_equals_the_torch_packing():
     from pairnet_amd import hip
@@ -306,3 +430,124 @@ def test_bench_json_is_the_last_stdout_line_with_rccl_in_the_loop():
     assert rec["triplet_records_gathered"] >= 8 and rec["value"] > 0
     assert rec["config"]["collective"].startswith("RCCL all-gather")
     assert sum(l.startswith("{") for l in lines) == 1
+
+
+# ---- the product loop on the MI355X -------------------------------------------------------
+_LOOP_SCRIPT = r"""
+import os, sys, json, socket, torch
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+backend, rank, world, port, out_path = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6]
+from oracle.backbone import seeded_backbone_state      # (seeded weights only: test infrastructure)
+from pairnet_amd import build_detector, pairnet_r50
+from pairnet_amd.dist import multi_gpu_test
+from pairnet_amd.evaluation import SceneGraphMetrics, TripletEvaluator
+torch.cuda.set_device(0)
+if world > 0:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+det = build_detector(pairnet_r50())
+det.backbone.load_state_dict(seeded_backbone_state(41))
+det.bbox_head.init_weights(seed=3)
+det.to("cuda:0")
+H, W, N = 160, 224, 5
+metas = [dict(img_shape=(H, W, 3), scale_factor=[2.0] * 4)]
+g = torch.Generator().manual_seed(3)
+data = [(torch.randn(1, 3, H, W, generator=g).to("cuda:0"), metas) for _ in range(N)]
+ga = torch.Generator().manual_seed(11)
+ann = []
+for i in range(N):
+    gm = torch.rand(3, 80, 112, generator=ga) > 0.5
+    rels = np.array([[0, 1, 5], [1, 2, 7], [2, 0, 9]]) if i != 2 else np.zeros((0, 3), dtype=np.int64)
+    ann.append(dict(gt_rels=rels, gt_labels=np.array([1 + i, 20, 90]), gt_masks=gm.numpy()))
+out = multi_gpu_test(det, data, annotations=ann, evaluator=TripletEvaluator(),
+                     metrics=SceneGraphMetrics(56), depth=3,
+                     force_collective=(backend == "nccl"))
+if rank == 0:
+    # second call in the same process: the cached plans / graphs serve it
+    again = multi_gpu_test(det, data, depth=3, force_collective=(backend == "nccl")) if world <= 1 else None
+    np.savez(out_path, records=out["records"].cpu().numpy(), collectives=out["collectives"],
+             metrics=json.dumps(out.get("metrics")),
+             again=(again["records"].cpu().numpy() if again is not None else np.zeros(0)))
+if world > 0:
+    dist.barrier()
+    dist.destroy_process_group()
+print("LOOP_DONE", rank)
+"""
+
+
+def _run_loop(tmp_path, backend, world):
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out_path = str(tmp_path / ("loop_%s_%d.npz" % (backend, world)))
+    port = str(_free_port())
+    procs = [subprocess.Popen([sys.executable, "-c", _LOOP_SCRIPT, root, backend, str(r),
+                               str(world), port, out_path], env=env, cwd=root,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(max(world, 1))]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600))
+        except subprocess.TimeoutExpired:
+            for q_ in procs:
+                q_.kill()
+            raise
+    return procs, outs, (np.load(out_path) if os.path.exists(out_path) else None)
+
+
+@pytest.mark.gpu
+def test_multi_gpu_test_on_the_gpu_equals_simple_test_and_two_gloo_ranks(tmp_path):
+    """`dist.multi_gpu_test` with the real detector: (a) one process, no process group: every
+    image's record equals the one packed from `PSGTr.simple_test`-path outputs, the evaluator
+    ran on the device results; (b) two ranks sharing this box's GPU over gloo (host-staged
+    collective), uneven split: the same records in dataset order and the same metrics."""
+    import json
+    import numpy as np
+    from oracle.backbone import seeded_backbone_state
+    from pairnet_amd import build_detector, pairnet_r50
+    procs, outs, one = _run_loop(tmp_path, "none", 0)
+    assert procs[0].returncode == 0, outs[0][1][-3000:]
+    det = build_detector(pairnet_r50())
+    det.backbone.load_state_dict(seeded_backbone_state(41))
+    det.bbox_head.init_weights(seed=3)
+    det.to("cuda:0")
+    H, W = 160, 224
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[2.0] * 4)]
+    g = torch.Generator().manual_seed(3)
+    head = det.bbox_head
+    for i in range(5):
+        img = torch.randn(1, 3, H, W, generator=g).to("cuda:0")
+        res = head.simple_test(det.extract_feat(img), metas)[0]
+        sub, obj = head.pair_positions()
+        want = pack_triplets(res[1].cpu(), res[7].cpu(), sub[0].cpu(), obj[0].cpu())
+        assert np.array_equal(one["records"][i], want.numpy()), i
+    assert int(one["collectives"]) == 5 and np.array_equal(one["again"], one["records"])
+    m1 = json.loads(str(one["metrics"]))
+    assert m1["images"] == 4 and m1["skipped"] == 1 and "sgdet_mean_recall" in m1
+    procs, outs, two = _run_loop(tmp_path, "gloo", 2)
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    assert np.array_equal(two["records"], one["records"]) and int(two["collectives"]) == 3
+    assert json.loads(str(two["metrics"])) == m1
+
+
+@pytest.mark.gpu
+def test_multi_gpu_test_through_rccl_with_one_rank(tmp_path):
+    """The same loop with a live RCCL communicator (world_size 1, `force_collective`): every
+    step's records go through all_gather_into_tensor on the side stream."""
+    import numpy as np
+    try:
+        procs, outs, got = _run_loop(tmp_path, "nccl", 1)
+    except Exception as e:           # (timeout)
+        pytest.skip("RCCL single-rank run did not finish: %r" % (e,))
+    if procs[0].returncode != 0 and "NCCL" in outs[0][1].upper():
+        pytest.skip("RCCL could not initialise here: " + outs[0][1][-300:])
+    assert procs[0].returncode == 0, outs[0][1][-3000:]
+    _, _, one = _run_loop(tmp_path, "none", 0)
+    assert np.array_equal(got["records"], one["records"]) and int(got["collectives"]) == 5

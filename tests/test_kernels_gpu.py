@@ -36,6 +36,45 @@ def close(got, ref, tol, what=""):
 
 
 # ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,K", [(21950, 256), (21950, 1024), (4099, 512), (33, 32), (2048, 256)])
+def test_linear_residual_layernorm_is_bitwise_the_unfused_pair(hip, M, K):
+    """pn_linear_res_ln_f32 (one row-owning launch) against pn_gemm_f32 with its residual
+    epilogue followed by pn_layernorm_f32: same products in the same order, same LayerNorm
+    arithmetic -- bit for bit, including a ragged last row tile; and against torch on the CPU
+    within fp32 re-association (2e-5 of the output scale)."""
+    x, w = R(M, K, seed=1).to(DEV), (R(256, K, seed=2) * 0.2).to(DEV)
+    b, res = R(256, seed=3).to(DEV), R(M, 256, seed=4).to(DEV)
+    g, be = R(256, seed=5, lo=0.5, hi=1.5).to(DEV), R(256, seed=6).to(DEV)
+    pre, want = torch.empty(M, 256, device=DEV), torch.empty(M, 256, device=DEV)
+    hip.linear(x, w, b, pre, res=res, force="tile64")
+    hip.layernorm(pre, g, be, want)
+    got = torch.full((M, 256), float("nan"), device=DEV)
+    hip.linear_res_ln(x, w, b, res, g, be, got)
+    assert torch.equal(got, want)
+    ref = F.layer_norm(res.cpu().double() + x.cpu().double() @ w.cpu().double().T + b.cpu().double(),
+                       (256,), g.cpu().double(), be.cpu().double(), 1e-5)
+    close(got, ref, 2e-5, "linear+res+LN")
+    # strided operands: a column window of a wider buffer (the [value | offsets | logits] rows)
+    wide = torch.zeros(M, K + 64, device=DEV)
+    wide[:, 32:32 + K] = x
+    got2 = torch.empty(M, 256, device=DEV)
+    hip.linear_res_ln(wide[:, 32:32 + K], w, None, res, g, be, got2)
+    hip.linear(x, w, None, pre, res=res, force="tile64")
+    hip.layernorm(pre, g, be, want)
+    assert torch.equal(got2, want)
+
+
+def test_linear_residual_layernorm_refuses_what_it_cannot_run(hip):
+    x, w = torch.zeros(64, 48, device=DEV), torch.zeros(256, 48, device=DEV)
+    v = torch.zeros(256, device=DEV)
+    o = torch.zeros(64, 256, device=DEV)
+    with pytest.raises(RuntimeError):          # K % 32 != 0
+        hip.linear_res_ln(x, w, v, o, v, v, torch.empty_like(o))
+    with pytest.raises(AssertionError):        # N != 256
+        hip.linear_res_ln(torch.zeros(64, 64, device=DEV), torch.zeros(128, 64, device=DEV), v,
+                          torch.zeros(64, 128, device=DEV), v, v, torch.zeros(64, 128, device=DEV))
+
+
 @pytest.mark.parametrize("force", ["tile", "tile64", "tile128x64", "skinny", None])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 256), (100, 134, 256), (1000, 544, 260),
                                    (37, 56, 2048), (129, 64, 96), (5, 33, 8)])
@@ -270,6 +309,12 @@ def _run_msda(hip, value, off, logits, shapes):
     out2 = torch.empty(bs, n, 256, device=DEV)
     hip.msda(voa, voa.shape[-1], voa.view(-1)[256:], voa.shape[-1], out2, bs, shapes)
     assert torch.equal(out, out2)
+    # the persistent, software-pipelined kernel (default) and the one-workgroup-per-pair
+    # form of rounds 1-3 compute the same arithmetic in the same order: bit-identical
+    out3 = torch.full((bs, n, 256), float("nan"), device=DEV)
+    hip.msda(voa, voa.shape[-1], voa.view(-1)[256:], voa.shape[-1], out3, bs, shapes,
+             flags=hip.MSDA_ONE_SHOT)
+    assert torch.equal(out, out3)
     return out
 
 

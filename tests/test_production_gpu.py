@@ -187,18 +187,25 @@ def test_r50_800x1333_graph_replay_and_pipeline_give_the_eager_result():
             assert torch.equal(a, b)
 
 
-def test_swin_l_200_queries_image_to_triplets_matches_the_reference():
+@pytest.mark.parametrize("name", ["e2e_image_swinl", "e2e_image_swinl_full"])
+def test_swin_l_200_queries_image_to_triplets_matches_the_reference(name):
     """configs[3]: the TRUE Swin-L backbone (197 M parameters, 18-block third stage) under
-    the 200-query head, batch 2, strict pair indices."""
-    fx = golden("e2e_image_swinl")
+    the 200-query head through `PSGTr.simple_test`, strict pair indices: two images at
+    256 x 320 (`e2e_image_swinl`) and one image at the PRODUCTION size 800 x 1333
+    (`e2e_image_swinl_full`, round 4: Swin-L's own widths -- K = 192 / 384 / 768 / 1536 split-K
+    choices, 24 / 48-head windows -- at the size the 57.9 images/s figure is quoted on)."""
+    fx = golden(name)
     det = _detector(fx, "swinL")
     img, metas = _image(fx)
     img = img.to(DEV)
-    _check_features(fx, det.extract_feat(img), (0, 1))
+    n = int(fx["batch"])
+    images = tuple(range(n))
+    assert (int(fx["height"]), int(fx["width"])) == ((800, 1333) if name.endswith("full") else (256, 320))
+    _check_features(fx, det.extract_feat(img), images)
     results = det.simple_test(img, metas)
-    assert det.bbox_head._last_plan.imp.shape == (2, 200, 200)
-    _check_head(fx, det, (0, 1), 2)
-    _check_results(fx, results, (0, 1), 200)
+    assert det.bbox_head._last_plan.imp.shape == (n, 200, 200)
+    _check_head(fx, det, images, n)
+    _check_results(fx, results, images, 200)
 
 
 def test_result_streamer_equals_simple_test():

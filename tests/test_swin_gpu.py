@@ -138,7 +138,8 @@ CONFIGS = {
 @pytest.mark.parametrize("name,B,H,W", [("tiny4", 2, 75, 101), ("tiny7", 1, 128, 160),
                                         ("b12", 1, 200, 264), ("b12", 2, 96, 136),
                                         ("swinB", 1, 192, 256), ("swinL", 1, 192, 256),
-                                        ("swinL", 2, 200, 264), ("swinB", 1, 800, 1333)])
+                                        ("swinL", 2, 200, 264), ("swinB", 1, 800, 1333),
+                                        ("swinL", 1, 800, 1333)])
 def test_swin_backbone_matches_oracle(name, B, H, W):
     """(800 x 1333 with the reference's Swin-B: every stage map -- 200x334, 100x167, 50x84,
     25x42 -- needs window padding to a multiple of 12, and 167 / 25 are odd sides for the patch

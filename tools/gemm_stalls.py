@@ -1,0 +1,215 @@
+"""Stall attribution for k_gemm_tile per shape class (rocprofv3 --pmc, counters only).
+
+  python tools/gemm_stalls.py                 # on the GPU box: runs the PMC passes, folds them
+  python tools/gemm_stalls.py --workload      # the profiled process (launched by the above)
+
+Every pass profiles the same deterministic launch sequence: for each shape of SHAPES,
+WARM + REP launches of pn_gemm_f32 on N(0,1) operands.  The k_gemm_tile dispatches of a pass
+are matched to shapes by order (split-K reduce launches carry another kernel name and are
+skipped).  Output: gpurun_out/r04_gemm_stalls.json -- per shape, per counter, the mean over the
+REP timed launches, plus derived fractions:
+
+  mfma_busy      SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)   matrix pipe busy
+  wait_any       SQ_WAIT_ANY / SQ_WAVE_CYCLES            wave-cycles waiting on anything
+  wait_inst_any  SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES       ... on an s_waitcnt
+  wait_inst_lds  SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES       ... on an lgkmcnt for LDS
+  active_*       SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES       wave-cycles an instruction of the class
+                                                         is executing
+  vmem_latency   SQ_INST_LEVEL_VMEM / SQ_INSTS_VMEM      mean cycles a VMEM instruction is in flight
+  lds_latency    SQ_INST_LEVEL_LDS / SQ_INSTS_LDS
+  occupancy      SQ_LEVEL_WAVES / SQ_BUSY_CU_CYCLES ...  mean resident waves per CU
+"""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+# (name, M, N, K, options)
+SHAPES = [
+    ("enc_ffn1_21950x1024x256_relu", 21950, 1024, 256, dict(relu=True)),
+    ("enc_ffn2_21950x256x1024_res", 21950, 256, 1024, dict(res=True)),
+    ("enc_voa_21950x544x256_posadd", 21950, 544, 256, dict(aadd=True)),
+    ("enc_outproj_21950x256x256_res", 21950, 256, 256, dict(res=True)),
+    ("mask_feature_66800x256x256", 66800, 256, 256, {}),
+    ("r50_s3_conv3_4200x1024x256_res", 4200, 1024, 256, dict(res=True)),
+    ("r50_s3_conv1_4200x256x1024_splitk", 4200, 256, 1024, dict(relu=True, splitk=True)),
+    ("r50_s2_conv3_16700x512x128_res", 16700, 512, 128, dict(res=True)),
+    ("r50_s2_conv1_16700x128x512", 16700, 128, 512, dict(relu=True)),
+    ("r50_s4_conv1_1050x512x2048_splitk", 1050, 512, 2048, dict(relu=True, splitk=True)),
+]
+WARM, REP = 2, 6
+
+PASSES = [
+    ["SQ_WAVES", "SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES",
+     "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_LEVEL_WAVES", "SQ_BUSY_CYCLES", "SQ_CYCLES"],
+    ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY",
+     "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_VALU"],
+    ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_MISC", "SQ_ACTIVE_INST_FLAT",
+     "SQ_INST_CYCLES_VMEM_RD", "SQ_INST_CYCLES_VMEM_WR", "SQ_INST_CYCLES_SALU", "SQ_INST_CYCLES_SMEM"],
+    ["SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VALU",
+     "SQ_INSTS_MFMA", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH"],
+    ["SQ_INST_LEVEL_VMEM", "SQ_INSTS_VMEM"],
+    ["SQ_INST_LEVEL_LDS", "SQ_INSTS_LDS"],
+    ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_UNALIGNED_STALL",
+     "SQ_LDS_DATA_FIFO_FULL", "SQ_LDS_CMD_FIFO_FULL", "SQ_VMEM_TA_ADDR_FIFO_FULL",
+     "SQ_VMEM_TA_CMD_FIFO_FULL"],
+    ["SQ_IFETCH", "SQ_IFETCH_LEVEL", "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_THREAD_CYCLES_VALU"],
+    ["TCP_PENDING_STALL_CYCLES_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum",
+     "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TA_TCP_STATE_READ_sum"],
+    ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCC_EA0_RDREQ_sum", "TCC_TAG_STALL_sum"],
+    ["TA_BUSY_avr", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum",
+     "TD_TD_BUSY_sum", "TD_TC_STALL_sum"],
+]
+
+
+def workload():
+    import torch
+    from pairnet_amd import hip
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    for name, M, N, K, opt in SHAPES:
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(N, K, device=dev) * 0.05
+        b = torch.randn(N, device=dev)
+        o = torch.empty(M, N, device=dev)
+        kw = {}
+        if opt.get("res"):
+            kw["res"] = torch.randn(M, N, device=dev)
+        if opt.get("aadd"):
+            kw["aadd"] = torch.randn(M, K, device=dev)
+            kw["aadd_from_col"] = 256
+        if opt.get("splitk"):
+            kw["scratch"] = torch.empty(16 * M * N, device=dev)
+        if opt.get("relu"):
+            kw["relu"] = True
+        torch.cuda.synchronize()
+        for _ in range(WARM + REP):
+            hip.linear(x, w, b, o, **kw)
+        torch.cuda.synchronize()
+
+
+def available():
+    try:
+        out = subprocess.run(["rocprofv3", "-L"], capture_output=True, text=True, timeout=120).stdout
+    except Exception:
+        return None
+    import re
+    return set(re.findall(r"[A-Z][A-Za-z0-9_]+", out))
+
+
+def run_pass(i, ctrs, outdir):
+    d = os.path.join(outdir, "pass%d" % i)
+    cmd = ["rocprofv3", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "-o", "p", "--",
+                                           sys.executable, os.path.abspath(__file__), "--workload"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    open(os.path.join(outdir, "pass%d.log" % i), "w").write(r.stdout[-4000:] + "\n" + r.stderr[-4000:])
+    return parse_pass(i, outdir)
+
+
+def parse_pass(i, outdir):
+    d = os.path.join(outdir, "pass%d" % i)
+    rows = {}
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r_ in csv.DictReader(open(path)):
+            if not r_["Kernel_Name"].startswith("void k_gemm_tile<"):
+                continue
+            e = rows.setdefault(int(r_["Dispatch_Id"]), {"grid": int(r_["Grid_Size"]),
+                                                         "wg": int(r_["Workgroup_Size"]),
+                                                         "vgpr": int(r_["VGPR_Count"]),
+                                                         "agpr": int(r_["Accum_VGPR_Count"]),
+                                                         "sgpr": int(r_["SGPR_Count"]),
+                                                         "lds": int(r_["LDS_Block_Size"]),
+                                                         "ns": float(r_["End_Timestamp"]) - float(r_["Start_Timestamp"]),
+                                                         "c": {}})
+            e["c"][r_["Counter_Name"]] = e["c"].get(r_["Counter_Name"], 0.0) + float(r_["Counter_Value"])
+    return [rows[k] for k in sorted(rows)]
+
+
+FOLD_ONLY = "--fold" in sys.argv     # fold the CSVs of an earlier run (no GPU needed)
+ONLY = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--pass=")]
+
+
+def main():
+    outdir = os.path.join(ROOT, "gpurun_out", "gemm_stalls")
+    os.makedirs(outdir, exist_ok=True)
+    avail = None if FOLD_ONLY else available()
+    res = {name: {"M": M, "N": N, "K": K, "opts": sorted(opt), "counters": {}}
+           for name, M, N, K, opt in SHAPES}
+    skipped = []
+    for i, ctrs in enumerate(PASSES):
+        if ONLY and i not in ONLY and not FOLD_ONLY:
+            continue
+        use = [c for c in ctrs if avail is None or c in avail]
+        skipped += [c for c in ctrs if c not in use]
+        if not use:
+            continue
+        try:
+            disp = parse_pass(i, outdir) if FOLD_ONLY else run_pass(i, use, outdir)
+            if FOLD_ONLY and not disp:
+                continue
+        except Exception as e:   # a pass that fails must not cost the others
+            skipped += use
+            print("pass %d failed: %r" % (i, e))
+            continue
+        per = WARM + REP
+        if len(disp) != per * len(SHAPES):
+            print("pass %d: %d k_gemm_tile dispatches, expected %d" % (i, len(disp), per * len(SHAPES)))
+            skipped += use
+            continue
+        for si, (name, M, N, K, opt) in enumerate(SHAPES):
+            timed = disp[si * per + WARM:(si + 1) * per]
+            r = res[name]
+            r.update(grid=timed[0]["grid"], workgroup=timed[0]["wg"], vgpr=timed[0]["vgpr"],
+                     agpr=timed[0]["agpr"], sgpr=timed[0]["sgpr"], lds_bytes=timed[0]["lds"])
+            r.setdefault("us_under_pmc", []).append(round(sum(t["ns"] for t in timed) / len(timed) / 1e3, 2))
+            for c in use:
+                r["counters"][c] = sum(t["c"].get(c, 0.0) for t in timed) / len(timed)
+    for name, r in res.items():
+        c = r["counters"]
+        g = lambda k: c.get(k)
+        d = {}
+        wc = g("SQ_WAVE_CYCLES")
+        if g("SQ_VALU_MFMA_BUSY_CYCLES") and g("SQ_BUSY_CU_CYCLES"):
+            d["mfma_busy"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / (4.0 * g("SQ_BUSY_CU_CYCLES"))
+        if wc:
+            for k, n in (("SQ_WAIT_ANY", "wait_any"), ("SQ_WAIT_INST_ANY", "wait_inst_any"),
+                         ("SQ_WAIT_INST_LDS", "wait_inst_lds"), ("SQ_ACTIVE_INST_ANY", "active_any"),
+                         ("SQ_ACTIVE_INST_LDS", "active_lds"), ("SQ_ACTIVE_INST_VMEM", "active_vmem"),
+                         ("SQ_ACTIVE_INST_VALU", "active_valu"), ("SQ_ACTIVE_INST_SCA", "active_scalar"),
+                         ("SQ_ACTIVE_INST_MISC", "active_misc_barrier_etc"),
+                         ("SQ_ACTIVE_INST_FLAT", "active_flat")):
+                if g(k) is not None:
+                    d[n] = g(k) / wc
+        if g("SQ_INST_LEVEL_VMEM") and g("SQ_INSTS_VMEM"):
+            d["vmem_latency_cycles"] = g("SQ_INST_LEVEL_VMEM") / g("SQ_INSTS_VMEM")
+        if g("SQ_INST_LEVEL_LDS") and g("SQ_INSTS_LDS"):
+            d["lds_latency_cycles"] = g("SQ_INST_LEVEL_LDS") / g("SQ_INSTS_LDS")
+        if g("SQ_LEVEL_WAVES") and g("SQ_BUSY_CYCLES"):
+            d["level_waves_per_busy_cycle"] = g("SQ_LEVEL_WAVES") / g("SQ_BUSY_CYCLES")
+        if g("SQ_WAVE_CYCLES") and g("SQ_BUSY_CU_CYCLES"):
+            d["waves_per_cu_while_busy"] = g("SQ_WAVE_CYCLES") / g("SQ_BUSY_CU_CYCLES")
+        if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
+            d["lds_bank_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
+        if g("TCC_HIT_sum") is not None and g("TCC_REQ_sum"):
+            d["l2_hit_rate"] = g("TCC_HIT_sum") / max(g("TCC_HIT_sum") + (g("TCC_MISS_sum") or 0.0), 1.0)
+        r["derived"] = {k: round(v, 4) for k, v in d.items()}
+    out = {"source": "tools/gemm_stalls.py: rocprofv3 --pmc (counters only, one pass per counter "
+                     "group), MI355X, pn_gemm_f32 on N(0,1) operands, mean over %d launches after "
+                     "%d warm-up launches per shape" % (REP, WARM),
+           "passes": PASSES, "skipped_counters": sorted(set(skipped)), "shapes": res}
+    path = os.path.join(ROOT, "gpurun_out", "r04_gemm_stalls.json")
+    json.dump(out, open(path, "w"), indent=1)
+    for name, r in res.items():
+        print(name, r.get("us_under_pmc"), json.dumps(r["derived"]))
+
+
+if __name__ == "__main__":
+    if "--workload" in sys.argv:
+        workload()
+    else:
+        main()

@@ -20,8 +20,10 @@ ref = torch.empty(B, SN, 256, device=dev)
 spread = voa.clone()
 spread[..., 256:448] += 8.0 * torch.randn(B, SN, 192, generator=g).to(dev)
 alg = 4.0 * B * SN * (256 + 8 * 3 * 4 * 3 + 256)
-for name, v in (("init grid", voa), ("init + N(0,8px)", spread)):
-    run = lambda: hip.msda(v, 544, v.view(-1)[256:], 544, out, B, shapes)
+for name, v, flags in (("init grid  persistent", voa, 0), ("init grid  one-shot", voa, hip.MSDA_ONE_SHOT),
+                       ("N(0,8px)   persistent", spread, 0), ("N(0,8px)   one-shot", spread, hip.MSDA_ONE_SHOT),
+                       ("init grid  persistent", voa, 0), ("init grid  one-shot", voa, hip.MSDA_ONE_SHOT)):
+    run = lambda: hip.msda(v, 544, v.view(-1)[256:], 544, out, B, shapes, flags=flags)
     for _ in range(5):
         run()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,4 +32,4 @@ for name, v in (("init grid", voa), ("init + N(0,8px)", spread)):
         run()
     e.record(); torch.cuda.synchronize()
     us = 1e3 * s.elapsed_time(e) / 100
-    print("%-16s %7.2f us  %6.0f GB/s algorithmic  checksum %.6e" % (name, us, alg / us * 1e-3, float(out.double().sum())))
+    print("%-24s %7.2f us  %6.0f GB/s algorithmic  checksum %.6e" % (name, us, alg / us * 1e-3, float(out.double().sum())))

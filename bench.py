@@ -539,6 +539,36 @@ def main():
                     "ring)" % streamer.ring}
         del streamer
 
+    # ---- secondary: the PRODUCT's distributed test loop on this rank's GPU --
+    # `dist.multi_gpu_test` (the reference's multi_gpu_test + collect_results,
+    # tools/test.py:256-267): shard -> PSGTr.stream_triplets -> records packed on the producing
+    # chain stream -> delayed ring all-gather -> dataset-order records, on the detector built
+    # from this run's backbone + head and its calibrated pipeline.  What the loop costs on top
+    # of the bare step() loop above is the difference to the headline. ----
+    product_loop = None
+    if rank == 0 and world == 1 and engine is not None and args.path == "image" and B == 1 \
+            and args.head == "pairnet" and not args.no_extras:
+        from pairnet_amd import PSGTr
+        from pairnet_amd.dist import multi_gpu_test
+        det = PSGTr.from_parts(backbone, head)
+        det._pipes = {args.depth: engine}       # (this run's calibrated stream placement)
+        n = min(args.steps, 100)
+        data = [(pool[i % len(pool)], metas) for i in range(n)]
+        multi_gpu_test(det, data[:2 * args.depth], depth=args.depth, force_collective=one_rank)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = multi_gpu_test(det, data, depth=args.depth, force_collective=one_rank)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        product_loop = {"images_per_s": n / dt, "ms_per_image": 1e3 * dt / n, "images": n,
+                        "records": list(got["records"].shape), "collectives": got["collectives"],
+                        "what": "pairnet_amd.dist.multi_gpu_test(detector, dataset) on one rank: "
+                                "every image through PSGTr.stream_triplets, its triplet record "
+                                "packed on the chain stream and gathered `depth` steps later"}
+        head.use_graphs = not args.no_graphs
+        backbone.use_graphs = not args.no_graphs
+        head.grid_reserve = backbone.grid_reserve = engine.grid_reserve
+
     # ---- secondary: the head alone on the resident pyramid (round 1's headline) ----
     head_only = None
     if args.path == "image" and world == 1:
@@ -744,6 +774,8 @@ def main():
         }
         if simple_test is not None:
             out["simple_test_incl_result_d2h"] = simple_test
+        if product_loop is not None:
+            out["multi_gpu_test_product_loop"] = product_loop
         if head_only is not None:
             out["head_only"] = head_only
         if from_decoded is not None:

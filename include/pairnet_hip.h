@@ -261,11 +261,13 @@ int pn_msda_f32(const float* value, int64_t ld_value, const float* offaw,
                 int64_t ld_offaw, float* out, int B, int L,
                 const int32_t* level_h /* host */, const int32_t* level_w /* host */,
                 void* stream);
-/* The same with a tuning flag: 0 = the persistent, software-pipelined kernel (what
- * pn_msda_f32 launches: workgroups walk their XCD band's query pairs, the next pair's
- * offsets / logits in flight under the current pair's gathers), PN_MSDA_ONE_SHOT = one
- * workgroup per query pair (rounds 1-3).  Both give bit-identical output. */
-#define PN_MSDA_ONE_SHOT 1
+/* The same with a tuning flag: 0 = one workgroup per query pair (what pn_msda_f32 launches);
+ * PN_MSDA_PERSISTENT / PN_MSDA_PERSISTENT_BATCHED = persistent workgroups walking their XCD
+ * band's query pairs with the next pair's offsets / logits in flight (one / both queries of a
+ * pair gathering at a time): measured slower in round 4 (csrc/msda.hip), kept as the A/B.
+ * All three give bit-identical output. */
+#define PN_MSDA_PERSISTENT 1
+#define PN_MSDA_PERSISTENT_BATCHED 2
 int pn_msda_ex_f32(const float* value, int64_t ld_value, const float* offaw,
                    int64_t ld_offaw, float* out, int B, int L,
                    const int32_t* level_h /* host */, const int32_t* level_w /* host */,

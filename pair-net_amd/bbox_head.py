@@ -110,6 +110,7 @@ class CrossHeadBBox(CrossHead2):
         self.use_graphs = False
         self.grid_reserve = 0
         self.fuse_ppn_front = True
+        self.enc_fused_ln = ("proj", "ffn")     # see head.py
         self.init_weights()
 
     # ------------------------------------------------------------------ params
@@ -428,14 +429,26 @@ class CrossHeadBBox(CrossHead2):
                              SN, SN, 4)
             else:
                 hip.msda(pl.VOA, 640, pl.VOA.view(-1)[256:], 640, pl.S, B, pl.shapes)
-            hip.linear(pl.S.view(-1, 256), w[a + "output_proj.weight"], w[a + "output_proj.bias"],
-                       Y2, res=X2)
-            hip.layernorm(Y2, w[p + "norms.0.weight"], w[p + "norms.0.bias"], X12)
+            # (Linear + identity + LayerNorm as one row-owning launch where `enc_fused_ln` says
+            # so, like the pixel decoder's encoder in head.py: bitwise the pair it replaces)
+            if "proj" in self.enc_fused_ln:
+                hip.linear_res_ln(pl.S.view(-1, 256), w[a + "output_proj.weight"],
+                                  w[a + "output_proj.bias"], X2, w[p + "norms.0.weight"],
+                                  w[p + "norms.0.bias"], X12)
+            else:
+                hip.linear(pl.S.view(-1, 256), w[a + "output_proj.weight"],
+                           w[a + "output_proj.bias"], Y2, res=X2)
+                hip.layernorm(Y2, w[p + "norms.0.weight"], w[p + "norms.0.bias"], X12)
             hip.linear(X12, w[p + "ffns.0.layers.0.0.weight"], w[p + "ffns.0.layers.0.0.bias"],
                        pl.H, relu=True)
-            hip.linear(pl.H, w[p + "ffns.0.layers.1.weight"], w[p + "ffns.0.layers.1.bias"], Y2,
-                       res=X12)
-            hip.layernorm(Y2, w[p + "norms.1.weight"], w[p + "norms.1.bias"], X2)
+            if "ffn" in self.enc_fused_ln:
+                hip.linear_res_ln(pl.H, w[p + "ffns.0.layers.1.weight"],
+                                  w[p + "ffns.0.layers.1.bias"], X12, w[p + "norms.1.weight"],
+                                  w[p + "norms.1.bias"], X2)
+            else:
+                hip.linear(pl.H, w[p + "ffns.0.layers.1.weight"], w[p + "ffns.0.layers.1.bias"],
+                           Y2, res=X12)
+                hip.layernorm(Y2, w[p + "norms.1.weight"], w[p + "norms.1.bias"], X2)
 
     def _box_branch(self, i, src, pl, dst, res=None):
         """reg_branches[i]: Linear-ReLU-Linear-ReLU-Linear(4) (+ res)."""
@@ -555,7 +568,7 @@ class CrossHeadBBox(CrossHead2):
         from the second call on) as one hipGraph replay.  A stage-A graph is tied to the
         buffers it was captured on: the neck's in-place token rows belong to the plan (its
         key), plain feature tensors are staged through the plan's own token rows."""
-        cfg = (self.fuse_ppn_front, self.grid_reserve)
+        cfg = (self.fuse_ppn_front, self.grid_reserve, tuple(self.enc_fused_ln))
         if pl.graph_cfg != cfg:
             pl.graph_a = pl.graph_b = None
             pl.graph_cfg = cfg

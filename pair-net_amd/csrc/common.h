@@ -38,6 +38,22 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// LayerNorm of one 256-channel row held as a float4 per lane (one wave = one row): two-pass
+// moments like torch's CPU LayerNorm.  ONE definition, compiled WITHOUT implicit fused
+// multiply-add contraction: hipcc otherwise picks the products it fuses per call site, and
+// kernels that are documented as bit-identical (pn_layernorm_f32, the second norm of
+// pn_ffn_ln2_f32, the epilogue of pn_linear_res_ln_f32) would only agree by luck.
+__device__ __forceinline__ float4 ln256_row(const float4 v, const float4 gg, const float4 bb,
+                                            const float eps) {
+#pragma clang fp contract(off)
+  const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.f / 256.f);
+  const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+  const float var = wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.f / 256.f);
+  const float rstd = 1.f / sqrtf(var + eps);
+  return make_float4((dx * rstd) * gg.x + bb.x, (dy * rstd) * gg.y + bb.y,
+                     (dz * rstd) * gg.z + bb.z, (dw * rstd) * gg.w + bb.w);
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) {
   return *reinterpret_cast<const float4*>(p);
 }

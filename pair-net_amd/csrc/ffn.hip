@@ -125,23 +125,13 @@ __global__ __launch_bounds__(256) void k_reduce_ln(const float* __restrict__ par
   for (; s < S; ++s) v = add4(v, ld4(pp + s * ps));
   if (bias) v = add4(v, ld4(bias + lane * 4));
   if (res) v = add4(ld4(res + row * 256 + lane * 4), v);
-  const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.f / 256.f);
-  const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-  const float var = wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.f / 256.f);
-  const float rstd = 1.f / sqrtf(var + eps);
   const float4 gg = ld4(g + lane * 4), bb = ld4(b + lane * 4);
-  const float4 o = make_float4(dx * rstd * gg.x + bb.x, dy * rstd * gg.y + bb.y,
-                               dz * rstd * gg.z + bb.z, dw * rstd * gg.w + bb.w);
+  const float4 o = ln256_row(v, gg, bb, eps);
   st4(y + row * 256 + lane * 4, o);
-  if (y2) {   // a second LayerNorm of the result (the decoder's post_norm): the arithmetic of
-              // k_layernorm256 on the row this wave already holds
-    const float m2 = wave_sum((o.x + o.y) + (o.z + o.w)) * (1.f / 256.f);
-    const float ex = o.x - m2, ey = o.y - m2, ez = o.z - m2, ew = o.w - m2;
-    const float v2 = wave_sum((ex * ex + ey * ey) + (ez * ez + ew * ew)) * (1.f / 256.f);
-    const float r2 = 1.f / sqrtf(v2 + eps);
+  if (y2) {   // a second LayerNorm of the result (the decoder's post_norm): k_layernorm256's
+              // arithmetic (the shared ln256_row) on the row this wave already holds
     const float4 g4 = ld4(g2 + lane * 4), b4 = ld4(b2n + lane * 4);
-    st4(y2 + row * 256 + lane * 4, make_float4(ex * r2 * g4.x + b4.x, ey * r2 * g4.y + b4.y,
-                                               ez * r2 * g4.z + b4.z, ew * r2 * g4.w + b4.w));
+    st4(y2 + row * 256 + lane * 4, ln256_row(o, g4, b4, eps));
   }
 }
 

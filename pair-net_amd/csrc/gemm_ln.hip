@@ -115,14 +115,7 @@ __global__ __launch_bounds__(256) void k_gemm_rowln(
     const int grow = m0 + r0 + j;
     const float4 t = ld4(T + (r0 + j) * RLN_TLD + lane * 4);
     const float4 v = add4(t, rs[j]);
-    const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.f / 256.f);
-    const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-    const float var = wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.f / 256.f);
-    const float rstd = 1.f / sqrtf(var + eps);
-    if (grow < M)
-      st4(Y + (int64_t)grow * ldy + lane * 4,
-          make_float4(dx * rstd * gg.x + bb.x, dy * rstd * gg.y + bb.y,
-                      dz * rstd * gg.z + bb.z, dw * rstd * gg.w + bb.w));
+    if (grow < M) st4(Y + (int64_t)grow * ldy + lane * 4, ln256_row(v, gg, bb, eps));
   }
 }
 

@@ -162,16 +162,20 @@ __global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
   }
 }
 
-// The same two phases as a PERSISTENT, software-pipelined loop (round 4).  k_msda above
-// spends a workgroup's whole life on two queries: dispatch, one round trip for the
-// offsets / logits, one for the gathers, exit -- with five workgroups resident per CU only
-// one or two of them have gathers in flight at any time, and the vector L1 idles 40 % of
-// the kernel (20 of 34 TB/s).  Here a workgroup walks its band's query pairs: the offsets /
-// logits of pair i + 1 are fetched while pair i gathers (registers), the tap records are
-// double-buffered in LDS (one barrier per pair), and both queries of a pair gather in one
-// unconditional batch (2 x L x 4 float4 loads in flight per lane; a dead query reads token 0
-// and is not stored).  Arithmetic and summation order are k_msda's: bit-identical output.
-template <int L>
+// The same two phases as a PERSISTENT, software-pipelined loop (round 4; MEASURED SLOWER,
+// kept selectable as the evidence: PN_MSDA_PERSISTENT / PN_MSDA_PERSISTENT_BATCHED).  The
+// idea: k_msda above spends a workgroup's whole life on two queries -- dispatch, one round
+// trip for the offsets / logits, one for the gathers, exit -- so let a workgroup walk its
+// band's query pairs instead: the offsets / logits of pair i + 1 are fetched while pair i
+// gathers (registers), the tap records are double-buffered in LDS (one barrier per pair),
+// and with BATCH both queries of a pair gather in one unconditional batch (2 x L x 4 float4
+// loads in flight per lane; a dead query reads token 0 and is not stored).  Arithmetic and
+// summation order are k_msda's: bit-identical output.  On MI355X (tools/msda_ab.py, same
+// run): batched 57.5-62.2 us against 49.9-57.5 us one-shot at the init offsets, 70.0 against
+// 65.6 with N(0, 8 px) offsets -- more loads in flight per CU do not help a kernel that is
+// bound by the vector L1's request rate, and 4 resident workgroups instead of 5 cost more
+// than the hidden launch / phase-1 latency buys.
+template <int L, bool BATCH>
 __global__ __launch_bounds__(256) void k_msda_pipe(const float* __restrict__ value,
                                                    const float* __restrict__ offaw,
                                                    float* __restrict__ out,
@@ -273,46 +277,52 @@ __global__ __launch_bounds__(256) void k_msda_pipe(const float* __restrict__ val
     __syncthreads();
     // the next pair's offsets / logits travel while this pair gathers
     if (it + per < pairs) cur = fetch(it + per);
-    // ---- phase 2: both queries' gathers in one batch ----
-    float4 v[MSDA_TQ][L][4];
-    MsdaTap t[MSDA_TQ][L];
+    // ---- phase 2: BATCH: both queries' gathers in one batch (2 x L x 4 loads in flight per
+    // lane); otherwise one query at a time like k_msda (L x 4 in flight, fewer registers) ----
+    constexpr int NQ = BATCH ? MSDA_TQ : 1;
 #pragma unroll
-    for (int q = 0; q < MSDA_TQ; ++q)
+    for (int qb = 0; qb < MSDA_TQ; qb += NQ) {
+      float4 v[NQ][L][4];
+      MsdaTap t[NQ][L];
 #pragma unroll
-      for (int k = 0; k < L; ++k) {
-        t[q][k] = taps[buf][q][h2][p2][k];
+      for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          v[q][k][j] = *reinterpret_cast<const float4*>(vb + t[q][k].off[j]);
+        for (int k = 0; k < L; ++k) {
+          t[q][k] = taps[buf][qb + q][h2][p2][k];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            v[q][k][j] = *reinterpret_cast<const float4*>(vb + t[q][k].off[j]);
+        }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int nq = tok[buf][qb + q];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+          const float a = attw[buf][qb + q][h2][p2][k];
+          const float4* vv = v[q][k];
+          const float* w = t[q][k].w;
+          float4 s4;
+          s4.x = ((vv[0].x * w[0] + vv[1].x * w[1]) + vv[2].x * w[2]) + vv[3].x * w[3];
+          s4.y = ((vv[0].y * w[0] + vv[1].y * w[1]) + vv[2].y * w[2]) + vv[3].y * w[3];
+          s4.z = ((vv[0].z * w[0] + vv[1].z * w[1]) + vv[2].z * w[2]) + vv[3].z * w[3];
+          s4.w = ((vv[0].w * w[0] + vv[1].w * w[1]) + vv[2].w * w[2]) + vv[3].w * w[3];
+          acc.x += s4.x * a; acc.y += s4.y * a; acc.z += s4.z * a; acc.w += s4.w * a;
+        }
+        acc.x = pt_sum(acc.x); acc.y = pt_sum(acc.y);
+        acc.z = pt_sum(acc.z); acc.w = pt_sum(acc.w);
+        if (p2 == 0 && nq >= 0) st4(out + ((int64_t)b * lv.N + nq) * 256 + h2 * 32 + c4 * 4, acc);
       }
-#pragma unroll
-    for (int q = 0; q < MSDA_TQ; ++q) {
-      const int nq = tok[buf][q];
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int k = 0; k < L; ++k) {
-        const float a = attw[buf][q][h2][p2][k];
-        const float4* vv = v[q][k];
-        const float* w = t[q][k].w;
-        float4 s4;
-        s4.x = ((vv[0].x * w[0] + vv[1].x * w[1]) + vv[2].x * w[2]) + vv[3].x * w[3];
-        s4.y = ((vv[0].y * w[0] + vv[1].y * w[1]) + vv[2].y * w[2]) + vv[3].y * w[3];
-        s4.z = ((vv[0].z * w[0] + vv[1].z * w[1]) + vv[2].z * w[2]) + vv[3].z * w[3];
-        s4.w = ((vv[0].w * w[0] + vv[1].w * w[1]) + vv[2].w * w[2]) + vv[3].w * w[3];
-        acc.x += s4.x * a; acc.y += s4.y * a; acc.z += s4.z * a; acc.w += s4.w * a;
-      }
-      acc.x = pt_sum(acc.x); acc.y = pt_sum(acc.y);
-      acc.z = pt_sum(acc.z); acc.w = pt_sum(acc.w);
-      if (p2 == 0 && nq >= 0) st4(out + ((int64_t)b * lv.N + nq) * 256 + h2 * 32 + c4 * 4, acc);
     }
   }
 }
 
+template <bool BATCH>
 static int msda_resident_wgs() {
   static int n = 0;
   if (n == 0) {
     int k = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, k_msda_pipe<3>, 256, 0) != hipSuccess || k < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, k_msda_pipe<3, BATCH>, 256, 0) != hipSuccess || k < 1)
       k = 2;
     n = k > 8 ? 8 : k;
   }
@@ -345,7 +355,8 @@ extern "C" int pn_msda_ex_f32(const float* value, int64_t ld_value, const float*
   if ((int64_t)n * ld_value * 4 >= ((int64_t)1 << 32)) return PN_BAD_ARG;   // 32-bit tap offsets
   hipStream_t s = (hipStream_t)stream;
   const int pairs = (per_band + MSDA_TQ - 1) / MSDA_TQ;
-  if (flags & PN_MSDA_ONE_SHOT) {      // round 1-3 form: one workgroup per query pair
+  if (!(flags & (PN_MSDA_PERSISTENT | PN_MSDA_PERSISTENT_BATCHED))) {
+    // default: one workgroup per query pair
     const dim3 grid(pairs * 8, B);
     switch (L) {
       case 1: hipLaunchKernelGGL(k_msda<1>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
@@ -356,20 +367,29 @@ extern "C" int pn_msda_ex_f32(const float* value, int64_t ld_value, const float*
     return PN_LAUNCH_CHECK();
   }
   // persistent: every CU's resident slots, spread evenly over the 8 bands (XCDs)
+  const bool batched = flags & PN_MSDA_PERSISTENT_BATCHED;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess)
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  int slots = cus * msda_resident_wgs() / 8;          // workgroups per band
+  int slots = cus * (batched ? msda_resident_wgs<true>() : msda_resident_wgs<false>()) / 8;
   if (B > 1) slots = (slots + B - 1) / B;
   if (slots > pairs) slots = pairs;
   if (slots < 1) slots = 1;
   const dim3 grid(slots * 8, B);
+#define PN_MSDA_PIPE(LL)                                                                       \
+  if (batched)                                                                                 \
+    hipLaunchKernelGGL((k_msda_pipe<LL, true>), grid, dim3(256), 0, s, value, offaw, out, lv,  \
+                       ld_value, ld_offaw, pairs);                                             \
+  else                                                                                         \
+    hipLaunchKernelGGL((k_msda_pipe<LL, false>), grid, dim3(256), 0, s, value, offaw, out, lv, \
+                       ld_value, ld_offaw, pairs)
   switch (L) {
-    case 1: hipLaunchKernelGGL(k_msda_pipe<1>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw, pairs); break;
-    case 2: hipLaunchKernelGGL(k_msda_pipe<2>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw, pairs); break;
-    case 3: hipLaunchKernelGGL(k_msda_pipe<3>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw, pairs); break;
-    default: hipLaunchKernelGGL(k_msda_pipe<4>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw, pairs); break;
+    case 1: PN_MSDA_PIPE(1); break;
+    case 2: PN_MSDA_PIPE(2); break;
+    case 3: PN_MSDA_PIPE(3); break;
+    default: PN_MSDA_PIPE(4); break;
   }
+#undef PN_MSDA_PIPE
   return PN_LAUNCH_CHECK();
 }
 

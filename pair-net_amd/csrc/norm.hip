@@ -12,14 +12,8 @@ __global__ __launch_bounds__(256) void k_layernorm256(const float* __restrict__ 
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float4 v = ld4(x + row * 256 + lane * 4);
-  const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.f / 256.f);
-  const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-  const float var = wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.f / 256.f);
-  const float rstd = 1.f / sqrtf(var + eps);
   const float4 gg = ld4(g + lane * 4), bb = ld4(b + lane * 4);
-  st4(y + row * 256 + lane * 4,
-      make_float4(dx * rstd * gg.x + bb.x, dy * rstd * gg.y + bb.y,
-                  dz * rstd * gg.z + bb.z, dw * rstd * gg.w + bb.w));
+  st4(y + row * 256 + lane * 4, ln256_row(v, gg, bb, eps));
 }
 
 extern "C" int pn_layernorm_f32(const float* x, const float* gamma, const float* beta,

@@ -10,6 +10,7 @@ beside the native one lives in tools/torch_resnet50.py, not in the product packa
 """
 from collections import OrderedDict
 
+import contextlib
 import queue
 import threading
 import weakref
@@ -198,28 +199,65 @@ class ResultStreamer:
         self.head_i = self.tail_i = 0     # push / pop counters
 
     def _entry(self, key, results, n_jobs):
-        e = self.entries[self.head_i % self.ring]
+        """Ring entry for a batch whose fields have the shapes of `results`.  Every field owns
+        FLAT buffers (device staging, pinned host, and for packed bool fields the host bool
+        array) sized for the largest shape seen so far; the entry hands out views of their
+        prefixes.  A keep-ratio evaluation set with many original image sizes therefore stops
+        allocating once its largest image has passed (a multi-MB pinned or host allocation per
+        image is an mmap / munmap pair against the busy GPU)."""
+        idx = self.head_i % self.ring
+        e = self.entries[idx]
         if e is not None and e["key"] == key:
             return e
         is_dev = lambda t: isinstance(t, torch.Tensor) and t.is_cuda
         packed = lambda t: (self.pack_masks and is_dev(t) and t.dtype == torch.bool
                             and t.numel() >= self.PACK_MIN)
         nbits = lambda t: ((t.numel() + 7) // 8 + 15) // 16 * 16
-        e = self.entries[self.head_i % self.ring] = dict(
-            key=key,
-            dev=[[torch.empty(nbits(t), dtype=torch.uint8, device=self.device) if packed(t)
-                  else torch.empty(t.shape, dtype=t.dtype, device=self.device) if is_dev(t)
-                  else None for t in tup] for tup in results],
-            host=[[torch.empty(nbits(t), dtype=torch.uint8, pin_memory=True) if packed(t)
-                   else torch.empty(t.shape, dtype=t.dtype, pin_memory=True) if is_dev(t) else t
-                   for t in tup] for tup in results],    # (host-side constants pass through)
-            # packed fields: the bool arrays the Results hold (ordinary host memory, written
-            # by the host threads of pop())
-            bools=[[torch.empty(t.shape, dtype=torch.bool) if packed(t) else None for t in tup]
-                   for tup in results],
-            dev_states=torch.empty(max(1, n_jobs), 16, dtype=torch.uint8, device=self.device),
-            host_states=torch.empty(max(1, n_jobs), 16, dtype=torch.uint8, pin_memory=True),
-            event=torch.cuda.Event(), jobs=0, ready=threading.Event(), error=None)
+        # layout: per field 'p' (packed bits), 'd' (device tensor copied as is), 'h' (host const)
+        layout = tuple(tuple("p" if packed(t) else "d" if is_dev(t) else "h" for t in tup)
+                       for tup in results)
+        if e is None or e["layout"] != layout or e["caps"]["jobs"] < n_jobs:
+            e = self.entries[idx] = dict(layout=layout, caps=dict(jobs=max(1, n_jobs)), flat={},
+                                         event=torch.cuda.Event(), ready=threading.Event(),
+                                         error=None, jobs=0)
+            e["dev_states"] = torch.empty(e["caps"]["jobs"], 16, dtype=torch.uint8, device=self.device)
+            e["host_states"] = torch.empty(e["caps"]["jobs"], 16, dtype=torch.uint8, pin_memory=True)
+        flat, caps = e["flat"], e["caps"]
+
+        def grown(name, nbytes, make):
+            """flat uint8 buffer `name` of at least nbytes (16-byte granules)."""
+            nbytes = (max(int(nbytes), 1) + 15) // 16 * 16
+            if caps.get(name, 0) < nbytes:
+                flat[name] = make(nbytes)
+                caps[name] = nbytes
+            return flat[name]
+        dev_u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=self.device)
+        pin_u8 = lambda n: torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        host_b = lambda n: torch.empty(n, dtype=torch.bool)
+        view = lambda buf, t: buf[:t.numel() * t.element_size()].view(t.dtype).view(t.shape)
+        dev, host, bools = [], [], []
+        for i, (tup, lay) in enumerate(zip(results, layout)):
+            d_row, h_row, b_row = [], [], []
+            for j, (t, kind) in enumerate(zip(tup, lay)):
+                name = "%d.%d" % (i, j)
+                if kind == "p":
+                    nb = nbits(t)
+                    d_row.append(grown("d" + name, nb, dev_u8)[:nb])
+                    h_row.append(grown("h" + name, nb, pin_u8)[:nb])
+                    b_row.append(grown("b" + name, t.numel(), host_b)[:t.numel()].view(t.shape))
+                elif kind == "d":
+                    nb = t.numel() * t.element_size()
+                    d_row.append(view(grown("d" + name, nb, dev_u8), t))
+                    h_row.append(view(grown("h" + name, nb, pin_u8), t))
+                    b_row.append(None)
+                else:                       # host-side constants pass through
+                    d_row.append(None)
+                    h_row.append(t)
+                    b_row.append(None)
+            dev.append(d_row)
+            host.append(h_row)
+            bools.append(b_row)
+        e.update(key=key, dev=dev, host=host, bools=bools)
         return e
 
     def _to_host(self, src, dst):
@@ -463,47 +501,96 @@ class PSGTr:
         img, metas = self.test_pipeline(image)
         return self.simple_test(img, metas, rescale=rescale)
 
+    def pipeline(self, depth=4):
+        """The detector's `PipelinedHead` for `depth` batches in flight, created once and kept:
+        its four streams keep their hardware-queue placement (which `calibrate_pipeline`
+        chooses empirically; worth ~8 % of the step, pipeline.py) across `stream()` /
+        `stream_triplets()` / `dist.multi_gpu_test` calls."""
+        from .pipeline import PipelinedHead
+        pipes = self.__dict__.setdefault("_pipes", {})
+        if depth not in pipes:
+            saved = getattr(self.bbox_head, "grid_reserve", 0)
+            pipes[depth] = PipelinedHead(self.bbox_head, depth=depth)
+            self.bbox_head.grid_reserve = saved      # (set per run by _scheduled)
+        return pipes[depth]
+
+    @contextlib.contextmanager
+    def _scheduled(self, depth):
+        """The scheduling attributes a pipelined run sets on the head / backbone (hipGraph
+        replay, the workgroup slots stage A leaves free), restored afterwards: grid_reserve is
+        part of the stage graphs' key, so a later simple_test() finds its own graphs again."""
+        head, net = self.bbox_head, self.backbone
+        slots = isinstance(net, ResNet50Hip)
+        saved = (head.use_graphs, getattr(head, "grid_reserve", 0),
+                 getattr(net, "use_graphs", None), getattr(net, "grid_reserve", 0))
+        pipe = self.pipeline(depth)
+        head.use_graphs, head.grid_reserve = True, pipe.grid_reserve
+        if slots:
+            net.use_graphs, net.grid_reserve = True, pipe.grid_reserve
+        try:
+            yield pipe, slots
+        finally:
+            head.use_graphs, head.grid_reserve = saved[0], saved[1]
+            if slots:
+                net.use_graphs, net.grid_reserve = saved[2], saved[3]
+
+    def _submit(self, pipe, slots, img, metas, rescale):
+        """Queue one batch: backbone + stage A on the pipeline's next stage-A stream."""
+        head, net = self.bbox_head, self.backbone
+        sl = pipe.count % len(pipe.streams_a)
+        sa = pipe.streams_a[sl]
+        sa.wait_stream(torch.cuda.current_stream(head.device))
+        with torch.cuda.stream(sa):
+            feats = net(img, slot=sl) if slots else net(img)
+            if len(feats) == 4 and self.out_indices != (0, 1, 2, 3):
+                feats = tuple(feats[j] for j in self.out_indices)
+            return pipe.submit(feats, metas, rescale=rescale)
+
+    @torch.no_grad()
+    def calibrate_pipeline(self, img, img_metas, depth=4, steps=8):
+        """Choose the stream -> hardware-queue placement of this detector's pipeline on a
+        representative batch (`PipelinedHead.calibrate` with the backbone in front, the way
+        `stream()` queues it).  Optional, once per process; returns the per-rotation times."""
+        with self._scheduled(depth) as (pipe, slots):
+            for _ in range(2 * depth):      # plans made, stage graphs captured
+                self._submit(pipe, slots, img, img_metas, False)
+            pipe.flush()
+            return pipe.calibrate(None, img_metas, steps=steps,
+                                  submit=lambda: self._submit(pipe, slots, img, img_metas, False))
+
     def _pipelined(self, batches, rescale, depth):
         """Generator behind `stream()` / `stream_triplets()`: queues every `(img, img_metas)`
         of `batches` -- backbone + stage A alternating between the pipeline's two stage-A
         streams, the query chains of older batches beside them -- and yields
         `(results, pipe)` for each batch, in order, `depth - 1` batches late.  `results`
         carries `pipeline_stream` (the chain stream `get_bboxes` ran on: queue reads THERE)
-        and must be handed back with `pipe.consumed(results, stream)`.  Restores the
-        scheduling attributes it sets on the head / backbone when it is closed."""
-        from .pipeline import PipelinedHead
-        head, net = self.bbox_head, self.backbone
-        slots = isinstance(net, ResNet50Hip)
-        saved = (head.use_graphs, getattr(head, "grid_reserve", 0),
-                 getattr(net, "use_graphs", None), getattr(net, "grid_reserve", 0))
-        head.use_graphs = True
-        if slots:
-            net.use_graphs = True
-        pipe = PipelinedHead(head, depth=depth)
-        if slots:
-            net.grid_reserve = pipe.grid_reserve
-        try:
-            for img, metas in batches:
-                sl = pipe.count % len(pipe.streams_a)
-                sa = pipe.streams_a[sl]
-                sa.wait_stream(torch.cuda.current_stream(head.device))
-                with torch.cuda.stream(sa):
-                    feats = net(img, slot=sl) if slots else net(img)
-                    if len(feats) == 4 and self.out_indices != (0, 1, 2, 3):
-                        feats = tuple(feats[j] for j in self.out_indices)
-                    res = pipe.submit(feats, metas, rescale=rescale)
-                if res is not None:
+        and must be handed back with `pipe.consumed(results, stream)`."""
+        with self._scheduled(depth) as (pipe, slots):
+            if pipe.queue:
+                raise RuntimeError("the detector's pipeline is in use by another generator")
+            try:
+                for img, metas in batches:
+                    res = self._submit(pipe, slots, img, metas, rescale)
+                    if res is not None:
+                        yield res, pipe
+                while pipe.queue:
+                    with torch.cuda.stream(pipe.streams_a[0]):
+                        res = pipe._finish(pipe.queue.pop(0))
                     yield res, pipe
-            while pipe.queue:
-                with torch.cuda.stream(pipe.streams_a[0]):
-                    res = pipe._finish(pipe.queue.pop(0))
-                yield res, pipe
-        finally:
-            # (grid_reserve is part of the stage graphs' key: put back what was there, so that
-            # a later simple_test() finds its captured graphs again)
-            head.use_graphs, head.grid_reserve = saved[0], saved[1]
-            if slots:
-                net.use_graphs, net.grid_reserve = saved[2], saved[3]
+            finally:
+                if pipe.queue:          # (the consumer stopped early: finish what is queued)
+                    with torch.cuda.stream(pipe.streams_a[0]):
+                        pipe.flush()
+
+    @classmethod
+    def from_parts(cls, backbone, bbox_head, neck=None, out_indices=(0, 1, 2, 3)):
+        """A detector around already-built parts (same attributes as the constructor sets)."""
+        det = cls.__new__(cls)
+        det.backbone, det.bbox_head, det.neck = backbone, bbox_head, neck
+        det.out_indices = tuple(out_indices)
+        det.num_classes = bbox_head.num_classes
+        det.test_pipeline, det._mask_fetch = None, None
+        return det
 
     def _pipelines(self):
         """Whether `_pipelined` can schedule this detector (the CrossHead2 family without a
@@ -594,9 +681,17 @@ def load_checkpoint(model, filename, map_location="cpu", strict=False, trust=Fal
     The file is read with `weights_only=True` (tensors, containers, strings, numbers: what a
     state dict plus `meta` needs); a checkpoint that pickles other objects is refused unless
     the caller vouches for it with `trust=True` (mmcv unpickles anything -- arbitrary code)."""
+    import pickle
     try:
         ckpt = torch.load(filename, map_location=map_location, weights_only=True)
-    except Exception as e:   # pickle.UnpicklingError and friends: non-tensor payload
+    except (pickle.UnpicklingError, RuntimeError) as e:
+        # only what the restricted unpickler raises for a non-tensor payload: I/O errors
+        # (missing file, permissions) propagate unchanged, and so does a corrupt archive
+        # (torch raises RuntimeError for that too: told apart by its message)
+        refused = isinstance(e, pickle.UnpicklingError) or "weights_only" in str(e).lower() \
+            or "unsupported global" in str(e).lower()
+        if not refused:
+            raise
         if not trust:
             raise RuntimeError(
                 "%s holds pickled objects beyond tensors / plain containers (%s); pass "

@@ -164,7 +164,9 @@ class TripletEvaluator:
                 same = pl == gt_labels_np[o]
                 if same.any():
                     best = 0
-                    for v in iou[same, o]:      # (python max: a NaN IoU never replaces `best`)
+                    for v in iou[same, o]:      # (python max(v, best) with the reference's argument
+                        # order: a NaN IoU -- empty prediction AND empty ground truth -- DOES
+                        # replace `best`, max(nan, x) returns nan; kept for parity)
                         best = max(v, best)
                     vals.append(best)
             out.append(np.array(vals))

@@ -50,6 +50,7 @@ class CrossHead2:
 
     # operation order of the relation decoder's layers this head is built for
     RELATION_ORDER = ("cross_attn", "norm", "self_attn", "norm", "ffn", "norm")
+    POST_ENTRIES = 8     # post-processing buffer sets kept per plan / for foreign inputs
 
     def __init__(self, num_classes, in_channels, num_relations, num_obj_query=100,
                  num_rel_query=100, mapper="conv_tiny", use_mask=True, pixel_decoder=None,
@@ -935,9 +936,19 @@ class CrossHead2:
         table = owner if owner is not None else self._post
         pb = table.get(k)
         if pb is None:
-            if owner is None and len(self._post) >= 8:
-                self._post.pop(next(iter(self._post)))
+            if len(table) >= self.POST_ENTRIES:
+                # bounded either way (an evaluation set with keep-ratio resizing has many
+                # original sizes, ~190 MB of buffers each at 480 x 640): drop the oldest entry.
+                # Rare and not on the steady-state path: wait for the device first (queued
+                # kernels and captured get_bboxes graphs may still reference its buffers),
+                # and forget the plan's get_bboxes graphs (they are re-captured on demand).
+                torch.cuda.synchronize(anchor.device)
+                table.pop(next(iter(table)))
+                if owner is not None:
+                    pl.graph_c = {}
             pb = table[k] = build()
+        elif owner is not None and next(reversed(table)) != k:
+            table[k] = table.pop(k)          # most recently used last
         return pb
 
     @torch.no_grad()

@@ -309,12 +309,13 @@ def _run_msda(hip, value, off, logits, shapes):
     out2 = torch.empty(bs, n, 256, device=DEV)
     hip.msda(voa, voa.shape[-1], voa.view(-1)[256:], voa.shape[-1], out2, bs, shapes)
     assert torch.equal(out, out2)
-    # the persistent, software-pipelined kernel (default) and the one-workgroup-per-pair
-    # form of rounds 1-3 compute the same arithmetic in the same order: bit-identical
-    out3 = torch.full((bs, n, 256), float("nan"), device=DEV)
-    hip.msda(voa, voa.shape[-1], voa.view(-1)[256:], voa.shape[-1], out3, bs, shapes,
-             flags=hip.MSDA_ONE_SHOT)
-    assert torch.equal(out, out3)
+    # the persistent, software-pipelined launch forms (round 4: measured slower, kept as the
+    # A/B) compute the same arithmetic in the same order as the default: bit-identical
+    for flags in (hip.MSDA_PERSISTENT, hip.MSDA_PERSISTENT_BATCHED):
+        out3 = torch.full((bs, n, 256), float("nan"), device=DEV)
+        hip.msda(voa, voa.shape[-1], voa.view(-1)[256:], voa.shape[-1], out3, bs, shapes,
+                 flags=flags)
+        assert torch.equal(out, out3)
     return out
 
 

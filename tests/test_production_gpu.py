@@ -110,6 +110,18 @@ def _check_head(fx, det, images, n_img):
     assert all(e < 1e-3 for e in errs.values()), errs
 
 
+# Mask / panoptic tolerances: 3-4 x what was MEASURED on MI355X in round 4 (gpurun_out/c2_prod.log
+# and the round's final test run; printed by every run).  A mask bit differs where the upsampled
+# logit lies within fp32 rounding of 0: measured 0.6e-6 ... 1.3e-6 of the mask bits
+# at 800 x 1333 (R50: both images, one- and two-image launches; Swin-L / 200 queries) and
+# 1.8e-6 / 2.1e-6 on the 256 x 320 Swin-L fixture (fewer bits per mask); the panoptic maps were
+# identical everywhere (0 pixels) -- one flipped threshold can move one pixel, so a handful are
+# allowed.  (Rounds 1-3 accepted 1e-3
+# and 5e-3, derived from nothing.)
+MASK_BIT_TOL = 7e-6
+PAN_PIXEL_TOL = 2e-5
+
+
 def _check_results(fx, results, images, Q):
     """`triplet2Result` fields (psgtr.py:15-51) against the reference's get_bboxes tuple."""
     H0 = round(int(fx["height"]) / float(fx["img_scale"]))
@@ -128,7 +140,7 @@ def _check_results(fx, results, images, Q):
         mism = float((got != ref_masks.astype(bool)).mean())
         pan = float((r.pan_results != fx["res%d_pan_img" % i]).mean())
         print("image %d: mask bit mismatch %.2e, panoptic map mismatch %.2e" % (i, mism, pan))
-        assert mism < 1e-3 and pan < 5e-3
+        assert mism <= MASK_BIT_TOL and pan <= PAN_PIXEL_TOL, (mism, pan)
         assert r.formatted_masks["pan_results"] is r.pan_results
         assert r.pan_results.shape == (H0, W0)
 
@@ -287,6 +299,26 @@ def test_result_streamer_equals_simple_test():
         assert (np.array(r.masks) != w["masks"]).mean() < 1e-4
         assert (np.array(r.pan_results) != w["pan_results"]).mean() < 1e-3
         assert np.abs(np.array(r.rel_dists) - w["rel_dists"]).max() < 1e-5
+    streamer.close()
+    # images of different ORIGINAL sizes (keep-ratio evaluation sets): a ring entry's buffers
+    # are sized by the largest shape seen and handed out as views -- after the largest image no
+    # entry allocates again, and every image's fields still equal simple_test's
+    streamer = ResultStreamer(head, ring=2)
+    sfs = (1.0, 2.0, 1.6, 1.0, 2.0, 1.25)
+    ptrs = []
+    for j, sf in enumerate(sfs):
+        m = [dict(img_shape=(H, W, 3), scale_factor=[sf] * 4)]
+        w_ = det.simple_test(imgs[j % 3], m)[0]
+        w_ = {k: np.array(getattr(w_, k)) for k in fields}
+        streamer.push(head.simple_test_bboxes(net(imgs[j % 3]), m))
+        (r,) = streamer.pop()
+        assert r.masks.shape == (200, round(H / sf), round(W / sf))
+        for k in fields:
+            assert np.array_equal(np.array(getattr(r, k)), w_[k]), (sf, k)
+        e = streamer.entries[j % 2]
+        ptrs.append({n: b.data_ptr() for n, b in e["flat"].items()})
+    # entry 0 saw its largest image first; entry 1 grew once (scale 2.0 -> 1.0), then stayed
+    assert ptrs[2] == ptrs[0] and ptrs[4] == ptrs[0] and ptrs[3] != ptrs[1] and ptrs[5] == ptrs[3]
     streamer.close()
 
 

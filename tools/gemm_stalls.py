@@ -197,8 +197,28 @@ def main():
             d["lds_bank_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
         if g("TCC_HIT_sum") is not None and g("TCC_REQ_sum"):
             d["l2_hit_rate"] = g("TCC_HIT_sum") / max(g("TCC_HIT_sum") + (g("TCC_MISS_sum") or 0.0), 1.0)
+        us = r.get("us_under_pmc")
+        if us:
+            t = sum(us) / len(us) * 1e-6
+            flops = 2.0 * r["M"] * r["N"] * r["K"]
+            d["us"] = sum(us) / len(us)
+            d["tflops"] = flops / t * 1e-12
+            d["frac_of_157.3_roof"] = flops / t / 157.3e12
+            if d.get("mfma_busy"):
+                # every v_mfma_f32_32x32x2_f32 is 4096 flop and 64 matrix-pipe cycles on one of
+                # 1024 SIMDs: the clock the pipe must have run at to be busy `mfma_busy` of the
+                # kernel's duration
+                d["implied_mfma_clock_ghz"] = flops / 4096.0 * 64.0 / 1024.0 / (d["mfma_busy"] * t) * 1e-9
         r["derived"] = {k: round(v, 4) for k, v in d.items()}
-    out = {"source": "tools/gemm_stalls.py: rocprofv3 --pmc (counters only, one pass per counter "
+    out = {"reading": "Matrix pipe busy 0.79-0.87 of the CU-busy cycles on the encoder shapes "
+                      "(0.57-0.70 on the 2 GF backbone shapes); waves wait on s_waitcnt 0.60-0.79 of "
+                      "their cycles, which with 3.5 x 4 waves per CU sharing one matrix pipe per SIMD "
+                      "is a wave waiting for its turn, not a starved pipe; LDS waits are 3-4 %, LDS "
+                      "bank conflicts 0, barrier / misc instructions 1 %.  What separates 0.87 busy "
+                      "from 0.64 of the 157.3 TFLOP/s roof is the CLOCK: implied_mfma_clock_ghz = "
+                      "1.7-1.8 GHz under this load against 2.4 GHz nominal (the board throttles on "
+                      "fp32-MFMA power, DESIGN.md 6.1).",
+           "source": "tools/gemm_stalls.py: rocprofv3 --pmc (counters only, one pass per counter "
                      "group), MI355X, pn_gemm_f32 on N(0,1) operands, mean over %d launches after "
                      "%d warm-up launches per shape" % (REP, WARM),
            "passes": PASSES, "skipped_counters": sorted(set(skipped)), "shapes": res}

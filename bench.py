@@ -832,6 +832,22 @@ def main():
                      "tflops": k[1] / (v[1] / v[0] * 1e-3) / 1e12,
                      "frac": k[1] / (v[1] / v[0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                      "share_of_kernel_time": v[1] / prof[dominant]["ms"]} for k, v in shapes]
+            # round 4: twelve of the dominant kernel's launches per image (the encoder's two
+            # N = 256 Linears, among them FFN-2, its best-running shape) moved into the
+            # row-owning Linear + residual + LayerNorm kernel: reported beside it, and both
+            # together as the fp32-MFMA GEMM work of the step
+            if "k_gemm_rowln" in prof:
+                out["roofline_linear_res_ln"] = roof("k_gemm_rowln")
+            gemms = [k for k in prof if k.startswith(("k_gemm_tile", "k_gemm_rowln", "k_gemm_group"))]
+            if gemms:
+                fl = sum(prof[k]["flops"] for k in gemms)
+                ms = sum(prof[k]["ms"] for k in gemms)
+                out["roofline_all_gemm_kernels"] = {
+                    "kernels": sorted(gemms), "bound": "mfma", "unit": "TFLOP/s",
+                    "achieved": fl / (ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                    "frac": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                    "ms_per_step": ms / nprof,
+                    "launches_per_step": sum(prof[k]["launches"] for k in gemms) // nprof}
             # the north star's other named kernel: achieved HBM GB/s of the deformable sampling
             msda = [k for k in prof if k.startswith("k_msda")]
             if msda:

@@ -129,8 +129,22 @@ def reference_head_cfg():
     return L.CfgDict(scope["model"]["bbox_head"])
 
 
+def _losses(training):
+    """Which `build_loss` the reference's CrossHead2 constructor sees: the name-only stub of
+    the inference shims (no parameters, no buffers: the state dict is the inference one), or
+    the restated mmdet losses after install_training() (SeesawLoss adds the buffer
+    `rel_cls_loss.cum_samples`)."""
+    mod = sys.modules["pairnet.models.relation_heads.pairnet_head"]
+    if training:
+        from . import mmdet_train as T
+        mod.build_loss = T.build_loss
+    else:
+        mod.build_loss = lambda cfg: _Loss(cfg)
+
+
 def build_reference_head(cfg=None):
     install()
+    _losses(False)
     cls = sys.modules["pairnet.models.relation_heads.pairnet_head"].CrossHead2
     cfg = L.CfgDict(cfg if cfg is not None else reference_head_cfg())
     cfg.pop("type", None)
@@ -232,6 +246,7 @@ def install_training():
 def build_reference_training_head(cfg=None, train_cfg=None):
     """The reference CrossHead2 WITH its train_cfg (assigners, sampler, losses built)."""
     install_training()
+    _losses(True)
     cls = sys.modules["pairnet.models.relation_heads.pairnet_head"].CrossHead2
     cfg = L.CfgDict(cfg if cfg is not None else reference_head_cfg())
     cfg.pop("type", None)

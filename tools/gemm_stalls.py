@@ -59,11 +59,9 @@ PASSES = [
      "SQ_LDS_DATA_FIFO_FULL", "SQ_LDS_CMD_FIFO_FULL", "SQ_VMEM_TA_ADDR_FIFO_FULL",
      "SQ_VMEM_TA_CMD_FIFO_FULL"],
     ["SQ_IFETCH", "SQ_IFETCH_LEVEL", "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_THREAD_CYCLES_VALU"],
-    ["TCP_PENDING_STALL_CYCLES_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum",
-     "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TA_TCP_STATE_READ_sum"],
-    ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCC_EA0_RDREQ_sum", "TCC_TAG_STALL_sum"],
-    ["TA_BUSY_avr", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum",
-     "TD_TD_BUSY_sum", "TD_TC_STALL_sum"],
+    # (TCP_* / TCC_* / TA_* groups were tried twice in round 4: rocprofv3 did not finish ONE pass
+    # of them over this workload within 600 s -- per-dispatch collection of the per-channel
+    # cache counters serialises every launch -- so the cache side is not in the evidence file)
 ]
 
 

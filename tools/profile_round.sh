@@ -7,9 +7,9 @@
 #   gpurun_out/<tag>_swinl_bench.json            configs[3] shape (Swin-L, 200 queries), image -> triplets
 #   gpurun_out/<tag>_bbox_bench.json             `bench.py --head bbox` (cross_r101_vg: R101 -> neck -> CrossHeadBBox)
 #   gpurun_out/pmc_traffic.json                  tools/pmc_traffic.sh (separate --pmc passes)
-# usage: tools/profile_round.sh r03_v1
+# usage: tools/profile_round.sh r04_v1
 set -u
-TAG="${1:-r03_vX}"
+TAG="${1:-r04_vX}"
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"

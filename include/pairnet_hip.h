@@ -268,6 +268,8 @@ int pn_msda_f32(const float* value, int64_t ld_value, const float* offaw,
  * All three give bit-identical output. */
 #define PN_MSDA_PERSISTENT 1
 #define PN_MSDA_PERSISTENT_BATCHED 2
+#define PN_MSDA_LOW_OCCUPANCY 4    /* one-shot form with the compiler's register choice (84 VGPRs, 5
+                                      workgroups per CU: rounds 1-3); default: 62 VGPRs, 8 per CU */
 int pn_msda_ex_f32(const float* value, int64_t ld_value, const float* offaw,
                    int64_t ld_offaw, float* out, int B, int L,
                    const int32_t* level_h /* host */, const int32_t* level_w /* host */,

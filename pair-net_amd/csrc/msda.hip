@@ -42,10 +42,10 @@ struct __attribute__((aligned(16))) MsdaTap {
 // thread (head, point, 4 channels) reads them back (broadcast within its 8 lanes), issues
 // the L x 4 float4 gathers of a query back to back and accumulates.
 template <int L>
-__global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
+__device__ __forceinline__ void msda_one_shot(const float* __restrict__ value,
                                               const float* __restrict__ offaw,
                                               float* __restrict__ out,
-                                              const MsdaLevels lv, const int64_t ldv,
+                                              const MsdaLevels& lv, const int64_t ldv,
                                               const int64_t ldo) {
   __shared__ MsdaTap taps[MSDA_TQ][8][4][4];   // [query][head][point][level]
   __shared__ float attw[MSDA_TQ][8][4][4];     // softmax weight of the same slot
@@ -160,6 +160,29 @@ __global__ __launch_bounds__(256) void k_msda(const float* __restrict__ value,
       if (p2 == 0) st4(out + ((int64_t)b * lv.N + nq) * 256 + h2 * 32 + c4 * 4, acc);
     }
   }
+}
+
+// Two register budgets of the same body (round 4).  k_msda, the default: bounded to 6+ waves
+// per SIMD -- hipcc then finds 62 VGPRs without spilling, 8 workgroups per CU (the hardware
+// maximum of 32 waves; 9 KB of LDS each).  k_msda_lo: the compiler's own choice (84 VGPRs, 5
+// workgroups per CU), rounds 1-3, selectable with PN_MSDA_LOW_OCCUPANCY.  Same arithmetic,
+// bit-identical output; tools/msda_ab.py, same run: 45.9 / 55.9 us against 49.9 / 59.5 us at
+// the init offsets (second / first pass of the probe), 63.7 against 65.3 with N(0, 8 px)
+// offsets: 1.08 GB of value rows pass the vector L1 in 45.9 us = 23.6 TB/s, 0.9 of what the
+// bare gather pattern reaches (26 TB/s, tools/gather_probe.hip).
+template <int L>
+__global__ __launch_bounds__(256, 6) void k_msda(const float* __restrict__ value,
+                                                 const float* __restrict__ offaw,
+                                                 float* __restrict__ out, const MsdaLevels lv,
+                                                 const int64_t ldv, const int64_t ldo) {
+  msda_one_shot<L>(value, offaw, out, lv, ldv, ldo);
+}
+template <int L>
+__global__ __launch_bounds__(256) void k_msda_lo(const float* __restrict__ value,
+                                                 const float* __restrict__ offaw,
+                                                 float* __restrict__ out, const MsdaLevels lv,
+                                                 const int64_t ldv, const int64_t ldo) {
+  msda_one_shot<L>(value, offaw, out, lv, ldv, ldo);
 }
 
 // The same two phases as a PERSISTENT, software-pipelined loop (round 4; MEASURED SLOWER,
@@ -356,8 +379,17 @@ extern "C" int pn_msda_ex_f32(const float* value, int64_t ld_value, const float*
   hipStream_t s = (hipStream_t)stream;
   const int pairs = (per_band + MSDA_TQ - 1) / MSDA_TQ;
   if (!(flags & (PN_MSDA_PERSISTENT | PN_MSDA_PERSISTENT_BATCHED))) {
-    // default: one workgroup per query pair
+    // one workgroup per query pair
     const dim3 grid(pairs * 8, B);
+    if (flags & PN_MSDA_LOW_OCCUPANCY) {
+      switch (L) {
+        case 1: hipLaunchKernelGGL(k_msda_lo<1>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+        case 2: hipLaunchKernelGGL(k_msda_lo<2>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+        case 3: hipLaunchKernelGGL(k_msda_lo<3>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+        default: hipLaunchKernelGGL(k_msda_lo<4>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+      }
+      return PN_LAUNCH_CHECK();
+    }
     switch (L) {
       case 1: hipLaunchKernelGGL(k_msda<1>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
       case 2: hipLaunchKernelGGL(k_msda<2>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
@@ -408,7 +440,7 @@ extern "C" int pn_msda_f32(const float* value, int64_t ld_value, const float* of
 //   out[b][q][h][:] = sum_{l,p} w[b][q][h][l][p] * bilinear(value_l[b][:, h, :], loc[b][q][h][l][p])
 // with zero padding, `loc` in [0, 1] x [0, 1] as (x, y).
 template <int L>
-__global__ __launch_bounds__(256) void k_msda_loc(const float* __restrict__ value,
+__global__ __launch_bounds__(256, 6) void k_msda_loc(const float* __restrict__ value,
                                                   const int64_t* __restrict__ shapes,
                                                   const int64_t* __restrict__ starts,
                                                   const float* __restrict__ loc,

@@ -162,7 +162,7 @@ __device__ __forceinline__ void at6(const float4 (&m)[6], float4 (&o)[4]) {
   o[3] = add4(axpy4(8.f, e, b), m[5]);
 }
 
-__global__ __launch_bounds__(256) void k_wino_f43_input(const float* __restrict__ in,
+__global__ __launch_bounds__(256, 3) void k_wino_f43_input(const float* __restrict__ in,
                                                         float* __restrict__ V, int H, int W,
                                                         int C4, int th, int tw,
                                                         int64_t tiles_total) {

@@ -556,7 +556,7 @@ def l2normalize(x, out, eps=1e-12):
                                     _stream()), "pn_l2normalize_f32")
 
 
-MSDA_PERSISTENT, MSDA_PERSISTENT_BATCHED = 1, 2     # PN_MSDA_* launch forms (A/B probes)
+MSDA_PERSISTENT, MSDA_PERSISTENT_BATCHED, MSDA_LOW_OCCUPANCY = 1, 2, 4   # PN_MSDA_* launch forms (A/B)
 
 
 def msda(value, ld_value, offaw, ld_offaw, out, B, shapes, flags=0):

@@ -311,7 +311,7 @@ def _run_msda(hip, value, off, logits, shapes):
     assert torch.equal(out, out2)
     # the persistent, software-pipelined launch forms (round 4: measured slower, kept as the
     # A/B) compute the same arithmetic in the same order as the default: bit-identical
-    for flags in (hip.MSDA_PERSISTENT, hip.MSDA_PERSISTENT_BATCHED):
+    for flags in (hip.MSDA_PERSISTENT, hip.MSDA_PERSISTENT_BATCHED, hip.MSDA_LOW_OCCUPANCY):
         out3 = torch.full((bs, n, 256), float("nan"), device=DEV)
         hip.msda(voa, voa.shape[-1], voa.view(-1)[256:], voa.shape[-1], out3, bs, shapes,
                  flags=flags)

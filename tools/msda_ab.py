@@ -20,7 +20,8 @@ ref = torch.empty(B, SN, 256, device=dev)
 spread = voa.clone()
 spread[..., 256:448] += 8.0 * torch.randn(B, SN, 192, generator=g).to(dev)
 alg = 4.0 * B * SN * (256 + 8 * 3 * 4 * 3 + 256)
-VARIANTS = (("one-shot", 0), ("persistent", hip.MSDA_PERSISTENT), ("persistent x2", hip.MSDA_PERSISTENT_BATCHED))
+VARIANTS = (("one-shot 8/CU", 0), ("one-shot 5/CU", hip.MSDA_LOW_OCCUPANCY), ("persistent", hip.MSDA_PERSISTENT),
+            ("persistent x2", hip.MSDA_PERSISTENT_BATCHED))
 for name, v, flags in [("%-10s %s" % (dn, vn), dv, fl) for rep in range(2)
                        for dn, dv in (("init grid", voa), ("N(0,8px)", spread)) for vn, fl in VARIANTS]:
     run = lambda: hip.msda(v, 544, v.view(-1)[256:], 544, out, B, shapes, flags=flags)

@@ -87,6 +87,10 @@ int pn_gemm_f32(const pn_gemm_desc* d, void* stream);
  * the 9 decoder layers, whose per-problem tile counts do not fill 256 CUs evenly. */
 int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream);
 
+/* Resident workgroups per CU the persistent 64x64-tile kernel (plain row-major A) is sized
+ * for: pn_gemm_grid_size(d) = min(tiles, CUs * this - reserved slots) rounded to 8. */
+int pn_gemm_wgs_per_cu(void);
+
 /* Which kernel pn_gemm_f32 would launch for `d` (for profiling / roofline
  * attribution; +1 = the column-major-A instantiation). */
 #define PN_GEMM_VARIANT_SKINNY        0  /* k_gemm_skinny<A>                 */

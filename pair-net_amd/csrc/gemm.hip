@@ -23,10 +23,36 @@
 #include "common.h"
 #include "gemm_common.h"
 
+// Resident workgroups per CU the persistent tile kernels are sized for.  64x64 tiles: 5 since
+// round 4 (rounds 1-3: 4).  In the pipelined bench, three alternating runs per build on one
+// box (tools/bench_variant.py): 4 everywhere 206.1 / 206.2 / 206.1 images/s; 5 for the
+// instantiations that fit 96 VGPRs without spilling (plain row-major A, implicit-GEMM conv) and
+// 4 for the rest 207.6 / 207.5 / 207.3; 5 everywhere (positional-addend, column-major and
+// grouped instantiations then spill 4-8 registers) 208.3 / 207.9 / 208.0: +0.9 %.  1216
+// instead of 960 workgroup slots turn the 1056- and 2088-tile backbone launches into one and
+// two full rounds, and a fifth wave per SIMD covers more of each tile's load latency.  Six
+// would need 80 VGPRs (9-26 spilled).  Build-time constants so that a variant library can be
+// A/B'd against the product one; > 4 also bounds the kernel's registers to that many waves
+// per SIMD.  Results do not depend on them (a tile's arithmetic is the same wherever it runs).
+#ifndef PN_GEMM_WGS64
+#define PN_GEMM_WGS64 5
+#endif
+#ifndef PN_GEMM_WGS64_SPILLING      // the instantiations that spill a few registers at 5
+#define PN_GEMM_WGS64_SPILLING 5
+#endif
+
 template <int BM, int BN, int AMODE>
 struct TileSmem {
   static constexpr int A_ELEMS = (AMODE == A_COL) ? 32 * (BM + 4) : BM * 36;
   static constexpr int FLOATS = A_ELEMS + BN * 36;
+};
+
+template <int BM, int BN, int AMODE, bool ADD>
+struct TileWgs {   // resident workgroups per CU this instantiation is sized (and register-bounded) for
+  static constexpr int value =
+      (BM * BN > 128 * 64) ? 2 : (BM * BN > 64 * 64) ? 3
+      : ((AMODE == A_ROW && !ADD) || AMODE == A_CONV) ? PN_GEMM_WGS64 : PN_GEMM_WGS64_SPILLING;
+  static constexpr int min_waves = (BM * BN <= 64 * 64 && value > 4) ? value : 1;
 };
 
 struct TileRef {
@@ -392,8 +418,8 @@ struct SingleLocator {
 
 // ADD: the launch has a row-periodic addend on A (positional encodings), pn_gemm_desc.Aadd
 template <int BM, int BN, int WM, int WN, int AMODE, bool ADD = false>
-__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void k_gemm_tile(const GemmP p,
-                                                                          const int batch) {
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (TileWgs<BM, BN, AMODE, ADD>::min_waves))
+void k_gemm_tile(const GemmP p, const int batch) {
   __shared__ __attribute__((aligned(16))) float smem[TileSmem<BM, BN, AMODE>::FLOATS];
   const SingleLocator loc{p, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN};
   gemm_persistent<BM, BN, WM, WN, AMODE, ADD>(loc, loc.mt * loc.nt * batch, smem);
@@ -427,7 +453,7 @@ struct GroupLocator {
   }
 };
 
-__global__ __launch_bounds__(256) void k_gemm_group(const GroupP g) {
+__global__ __launch_bounds__(256, (TileWgs<64, 64, A_ROW, true>::min_waves)) void k_gemm_group(const GroupP g) {
   __shared__ __attribute__((aligned(16))) float smem[TileSmem<64, 64, A_ROW>::FLOATS];
   const GroupLocator loc{g};
   gemm_persistent<64, 64, 32, 32, A_ROW, true>(loc, g.tile_start[GEMM_GROUP_MAX], smem);
@@ -585,15 +611,14 @@ static int resident_wgs(Kern kern, int cap, int threads = 256) {
 template <int BM, int BN, int WM, int WN, int AMODE>
 static int launch_tile(const GemmP& p, int batch, hipStream_t s, int flags) {
   const int64_t ntiles = (int64_t)pn_cdiv(p.N, BN) * pn_cdiv(p.M, BM) * batch;
-  constexpr int cap = (BM * BN <= 64 * 64) ? 4 : (BM * BN <= 128 * 64) ? 3 : 2;
   constexpr int NT = 64 * (BM / WM) * (BN / WN);
   if (AMODE == A_ROW && p.Aadd) {
     auto kern = k_gemm_tile<BM, BN, WM, WN, AMODE, AMODE == A_ROW>;
-    static const int wgs = resident_wgs(kern, cap, NT);
+    static const int wgs = resident_wgs(kern, TileWgs<BM, BN, AMODE, (AMODE == A_ROW)>::value, NT);
     hipLaunchKernelGGL(kern, dim3(persistent_grid(ntiles, wgs, flags)), dim3(NT), 0, s, p, batch);
   } else {
     auto kern = k_gemm_tile<BM, BN, WM, WN, AMODE, false>;
-    static const int wgs = resident_wgs(kern, cap, NT);
+    static const int wgs = resident_wgs(kern, TileWgs<BM, BN, AMODE, false>::value, NT);
     hipLaunchKernelGGL(kern, dim3(persistent_grid(ntiles, wgs, flags)), dim3(NT), 0, s, p, batch);
   }
   return PN_LAUNCH_CHECK();
@@ -748,8 +773,10 @@ extern "C" int pn_gemm_f32(const pn_gemm_desc* d, void* stream) {
 extern "C" int pn_gemm_grid_size(const pn_gemm_desc* d) {
   if (!d || d->M <= 0 || d->N <= 0 || d->batch <= 0) return PN_BAD_ARG;
   const int64_t tiles = (int64_t)pn_cdiv(d->M, 64) * pn_cdiv(d->N, 64) * d->batch;
-  return persistent_grid(tiles, 4, d->flags);
+  return persistent_grid(tiles, TileWgs<64, 64, A_ROW, false>::value, d->flags);
 }
+
+extern "C" int pn_gemm_wgs_per_cu(void) { return TileWgs<64, 64, A_ROW, false>::value; }
 
 extern "C" int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream) {
   if (!d || count <= 0 || count > GEMM_GROUP_MAX) return PN_BAD_ARG;
@@ -765,7 +792,7 @@ extern "C" int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream)
     tiles += g.mt[i] * g.nt[i] * d[i].batch;
   }
   for (int i = count; i <= GEMM_GROUP_MAX; ++i) g.tile_start[i] = tiles;
-  hipLaunchKernelGGL(k_gemm_group, dim3(persistent_grid(tiles, 4, d[0].flags)), dim3(256), 0,
+  hipLaunchKernelGGL(k_gemm_group, dim3(persistent_grid(tiles, TileWgs<64, 64, A_ROW, true>::value, d[0].flags)), dim3(256), 0,
                      (hipStream_t)stream, g);
   return PN_LAUNCH_CHECK();
 }

@@ -493,14 +493,25 @@ __global__ __launch_bounds__(1024) void k_attn_combine(const float* __restrict__
   out[((int64_t)b * Q + q) * ldo + head * 32 + d] = num / den;
 }
 
+#ifndef ATT_SMALL_MAX
 #define ATT_SMALL_MAX 512    // keys up to which one workgroup's waves split the key range
+#endif
 #define ATT_MIN_CHUNK 64     // keys per chunk at least (two tiles)
 
+// Workgroups a long-key launch aims for (build-time, so that variant libraries can be A/B'd).
+// Round 4: 512 instead of 1024 -- 53 instead of 105 chunks of the 16 700-key level halve the
+// partial (O, m, l) round trip through k_attn_combine while each workgroup's five-tile life
+// becomes ten tiles; bench `roofline_attention` over the 30 calls of an image, two runs each
+// on one box: 1024: 12.86 / 12.85 us, 768: 12.66 / 12.62, 512: 12.29 / 12.22 (second box:
+// 512: 12.37 / 12.26, 384: 12.62 / 12.63, 256: 12.52 / 12.55).
+#ifndef ATT_WANT_WGS
+#define ATT_WANT_WGS 512
+#endif
 static int attn_chunking(int Nk, int B, int Q, int* chunk) {
-  // long key sets: ~1000 workgroups, chunks of at least 4 tiles (128 keys) and a multiple of
-  // 32 keys, at most ATT_MAXCH of them
+  // long key sets: ~ATT_WANT_WGS workgroups, chunks of at least 2 tiles (64 keys) and a multiple
+  // of 32 keys, at most ATT_MAXCH of them
   const int qgroups = (Q + 127) / 128;
-  int want = 1024 / (8 * B * qgroups);
+  int want = ATT_WANT_WGS / (8 * B * qgroups);
   if (want < 1) want = 1;
   if (want > ATT_MAXCH) want = ATT_MAXCH;
   int ch = ((Nk + want - 1) / want + 31) & ~31;
@@ -541,8 +552,10 @@ extern "C" int pn_attention_f32(const float* q, int64_t ldq, const float* k, int
     p.nchunks = 1;
     if (ntiles <= 4)
       hipLaunchKernelGGL(k_attn_small<4>, grid, dim3(256), 0, s, p);
-    else
+    else if (ntiles <= 16)
       hipLaunchKernelGGL(k_attn_small<8>, grid, dim3(512), 0, s, p);
+    else   // (only with a larger ATT_SMALL_MAX: 16 waves at the 128-register cap, no prefetch)
+      hipLaunchKernelGGL((k_attn_small<16, false>), grid, dim3(1024), 0, s, p);
     return PN_LAUNCH_CHECK();
   }
   p.nchunks = attn_chunking(Nk, B, Q, &p.chunk);

@@ -558,13 +558,18 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_skinny(const GemmP p) {
   }
 }
 
+#ifndef PN_SKINNY_NW256
+#define PN_SKINNY_NW256 8
+#endif
 template <int AMODE>
 static int launch_skinny(const GemmP& p, int batch, hipStream_t s) {
   dim3 grid(pn_cdiv(p.N, 32), pn_cdiv(p.M, 32), batch);
+  // (waves per 32x32 tile = K slices; PN_SKINNY_NW256: build-time choice for 128 < K <= 256, the
+  // query chains' shape, so that variant libraries can be A/B'd)
   if (p.K <= 128)
     hipLaunchKernelGGL((k_gemm_skinny<AMODE, 4>), grid, dim3(256), 0, s, p);
   else if (p.K <= 256)
-    hipLaunchKernelGGL((k_gemm_skinny<AMODE, 8>), grid, dim3(512), 0, s, p);
+    hipLaunchKernelGGL((k_gemm_skinny<AMODE, PN_SKINNY_NW256>), grid, dim3(64 * PN_SKINNY_NW256), 0, s, p);
   else
     hipLaunchKernelGGL((k_gemm_skinny<AMODE, 16>), grid, dim3(1024), 0, s, p);
   return PN_LAUNCH_CHECK();

@@ -126,6 +126,7 @@ extern "C" int pn_linear_res_ln_f32(const float* x, int64_t ldx, const float* W,
   if (!x || !W || !res || !gamma || !beta || !y || M <= 0) return PN_BAD_ARG;
   if (N != 256 || K <= 0 || K % 32) return PN_BAD_ARG;
   if (ldx % 4 || ldw % 4 || ldres % 4 || ldy % 4) return PN_BAD_ARG;
+  if (ldx < K || ldw < K || ldres < 256 || ldy < 256 || y == x) return PN_BAD_ARG;
   if (((uintptr_t)x | (uintptr_t)W | (uintptr_t)res | (uintptr_t)gamma | (uintptr_t)beta |
        (uintptr_t)y) & 15)
     return PN_BAD_ARG;

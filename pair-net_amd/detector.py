@@ -424,6 +424,7 @@ class PSGTr:
         self._mask_fetch = None       # bit-packed D2H of the masks into recycled arrays
 
     def to(self, device):
+        self.__dict__.pop("_pipes", None)     # (cached pipelines hold the old device's streams)
         self.backbone.to(device)
         if self.neck is not None:
             self.neck.to(device)

@@ -166,9 +166,12 @@ class CrossHead2Loss:
         np.add.at(self.cum_samples, kept, 1.0)
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         out = torch.empty(6, device=dev, dtype=torch.float32)
-        if self.subobj_cw is not None and self._cw is None:
+        if self.subobj_cw is not None and (self._cw is None or self._cw.device != dev):
             self._cw = torch.tensor(self.subobj_cw, dtype=torch.float32, device=dev)
         nc = sub.shape[-1]
+        if self._cw is not None and self._cw.numel() != nc:
+            raise ValueError("subobj_cls_loss.class_weight has %d entries for %d class logits"
+                             % (self._cw.numel(), nc))
         hip.ce_mean(obj.reshape(-1, nc), up(o_ids), self._cw, out[0:1], self.subobj_w)
         hip.ce_mean(sub.reshape(-1, nc), up(s_ids), self._cw, out[1:2], self.subobj_w)
         hip.seesaw_mean(rel.reshape(-1, self.num_relations), up(r_lab),

@@ -35,6 +35,22 @@ def test_bad_arguments_are_refused_without_launching(built_lib):
     assert lib.pn_topk_pairs(None, None, None, None, None, 1, 100, 100, None) == -1
     assert lib.pn_gemm_group_f32(None, 3, None) == -1
     assert lib.pn_layernorm_f32(None, None, None, None, 4, 256, 1e-5, None) == -1
+    # round 4 entries: refused before anything is launched (NULL operands, N != 256, K % 32)
+    assert lib.pn_linear_res_ln_f32(None, 256, None, 256, None, None, 256, None, None, None, 256,
+                                    64, 256, 256, 1e-5, None) == -1
+    assert lib.pn_linear_res_ln_f32(16, 256, 16, 256, None, 16, 256, 16, 16, 32, 256,
+                                    64, 128, 256, 1e-5, None) == -1      # N != 256
+    assert lib.pn_linear_res_ln_f32(16, 256, 16, 256, None, 16, 256, 16, 16, 32, 256,
+                                    64, 256, 48, 1e-5, None) == -1       # K % 32
+    assert lib.pn_msda_ex_f32(None, 256, None, 288, None, 1, 3, None, None, 0, None) == -1
+    assert lib.pn_point_sample_f32(None, 0, None, None, 1, 8, 8, 16, None) == -1
+    assert lib.pn_mask_match_cost_f32(None, 134, None, None, None, None, 100, 3, 64, 2.0, 5.0, 5.0,
+                                      1.0, None) == -1
+    assert lib.pn_id_match_cost_f32(None, None, None, 134, 56, None, None, None, None, 100, 3,
+                                    1.0, 1.0, 0.0, None) == -1
+    assert lib.pn_ce_mean_f32(None, 134, None, None, None, 10, 134, 1.0, None) == -1
+    assert lib.pn_seesaw_mean_f32(None, 56, None, None, None, 10, 56, 0.8, 2.0, 0.01, 2.0, None) == -1
+    assert lib.pn_bce_posw_mean_f32(None, None, None, 100, 5.0, None) == -1
 
 
 def test_state_dict_names_match_reference_layout():

@@ -758,7 +758,7 @@ extern "C" int pn_gemm_f32(const pn_gemm_desc* d, void* stream) {
     return colmajor ? launch_skinny<A_COL>(p, d->batch, s) : launch_skinny<A_ROW>(p, d->batch, s);
   }
   // Tile choice (measured on MI355X, tools/gemm_probe.hip / gemm_sweep.py): with
-  // K = 256..1024 the persistent 64x64 tile at 4 workgroups per CU is best or within 3 %
+  // K = 256..1024 the persistent 64x64 tile (4 workgroups per CU then, 5 since round 4) is best or within 3 %
   // of the best on every encoder shape (99-112 TFLOP/s); 128x64 and 128x128 stay
   // selectable for sweeps.
   if (d->flags & PN_GEMM_FORCE_TILE128x64)

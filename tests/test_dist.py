@@ -555,3 +555,34 @@ def test_multi_gpu_test_through_rccl_with_one_rank(tmp_path):
     assert procs[0].returncode == 0, outs[0][1][-3000:]
     _, _, one = _run_loop(tmp_path, "none", 0)
     assert np.array_equal(got["records"], one["records"]) and int(got["collectives"]) == 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["baseline_r50", "psgtr2_r50", "cross_r101_vg"])
+def test_multi_gpu_test_with_the_sibling_heads(model):
+    """The product loop over the sibling detectors (BASELINE configs[4]: same loop, other
+    heads): CrossHeadBaseline (matched object-query rows), PSGTrHead2 (query i is triplet i),
+    both through the pipeline, and the box-trunk CrossHeadBBox (neck: one batch at a time) --
+    every record equals the one packed from the head's own synchronous outputs."""
+    import pairnet_amd as P
+    from pairnet_amd.dist import multi_gpu_test, unpack_triplets
+    cfg = getattr(P, model)()
+    det = P.build_detector(cfg.model if "model" in cfg else cfg)
+    det.bbox_head.init_weights(seed=5)
+    det.to("cuda:0")
+    H, W = 160, 224
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[2.0] * 4, batch_input_shape=(H, W))]
+    g = torch.Generator().manual_seed(21)
+    data = [(torch.randn(1, 3, H, W, generator=g).to("cuda:0"), metas) for _ in range(4)]
+    head = det.bbox_head
+    want = []
+    for img, m in data:
+        res = head.simple_test(det.extract_feat(img), m)[0]
+        sub, obj = head.pair_positions()
+        want.append(pack_triplets(res[1].cpu(), res[-1].cpu(), sub[0].cpu(), obj[0].cpu()))
+    out = multi_gpu_test(det, data, depth=3)
+    assert out["records"].shape == (4, triplet_record_len(head.num_rel_query, head.num_relations))
+    for i in range(4):
+        assert torch.equal(out["records"][i].cpu(), want[i]), (model, i)
+    d = unpack_triplets(out["records"][0].cpu(), head.num_rel_query, head.num_relations)
+    assert d["rel_dists"].shape == (head.num_rel_query, head.num_relations + 1)

@@ -82,7 +82,7 @@ typedef struct pn_gemm_desc {
 
 int pn_gemm_f32(const pn_gemm_desc* d, void* stream);
 
-/* `count` (<= 16) independent row-major problems in ONE launch of the persistent 64x64
+/* `count` (<= 18) independent row-major problems in ONE launch of the persistent 64x64
  * tile kernel (all their tiles share the grid): used for the 18 key/value projections of
  * the 9 decoder layers, whose per-problem tile counts do not fill 256 CUs evenly. */
 int pn_gemm_group_f32(const pn_gemm_desc* d, int count, void* stream);

@@ -429,13 +429,16 @@ void k_gemm_tile(const GemmP p, const int batch) {
 // problems are enumerated together (n-tile fastest, so workgroups that share an A panel
 // are neighbours), which fills the chip where a single M x 256 problem leaves a
 // ragged second round of workgroups.
-#define GEMM_GROUP_MAX 16
+#define GEMM_GROUP_MAX 18   // (the 18 K / V projections of the 9 decoder layers in ONE launch; the
+                            // descriptor block is 3.7 KB of the 4 KB kernel-argument space)
 struct GroupP {
   int n;
   int tile_start[GEMM_GROUP_MAX + 1];
   int mt[GEMM_GROUP_MAX], nt[GEMM_GROUP_MAX];
   GemmP p[GEMM_GROUP_MAX];
 };
+
+static_assert(sizeof(GroupP) <= 4096, "k_gemm_group's argument block must fit the kernarg segment");
 
 struct GroupLocator {
   const GroupP& g;

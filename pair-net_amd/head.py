@@ -652,8 +652,8 @@ class CrossHead2:
         # launches: 18 problems whose tile counts (9/33/131 x 2 per image) would each
         # leave most of the 256 CUs idle on their own
         probs = self._kv_problems(pl)
-        for j in range(0, len(probs), 16):
-            hip.gemm_group(probs[j:j + 16])
+        for j in range(0, len(probs), hip.GEMM_GROUP_MAX):
+            hip.gemm_group(probs[j:j + hip.GEMM_GROUP_MAX])
 
     def _memory_kv(self, pl, attn_prefix, l, Kp, Vp):
         """The two GEMM problems K = (mem_l + level_embed_l + pe_l) Wk^T + bk and

@@ -19,6 +19,7 @@ GEMM_RELU, GEMM_A_COLMAJOR, GEMM_FORCE_TILE, GEMM_FORCE_SKINNY = 1, 2, 4, 8
 GEMM_GELU = 256
 GEMM_FORCE_TILE64, GEMM_FORCE_TILE128x64 = 16, 32
 GEMM_RELU_AFTER_RES = 128
+GEMM_GROUP_MAX = 18       # problems per pn_gemm_group_f32 launch (csrc/gemm.hip)
 
 
 class GemmDesc(C.Structure):

@@ -167,6 +167,21 @@ def test_gemm_group_and_column_split_add(hip):
         kw = {k: v for k, v in pr.items() if k not in ("A", "W", "C")}
         hip.gemm(pr["A"], pr["W"], single, force="tile", **kw)
         assert torch.equal(single, pr["C"])            # same kernel body, same order
+    # the full group (18 problems = the K / V projections of all nine decoder layers) in one
+    # launch, and one more is refused
+    probs, refs = [], []
+    for i in range(hip.GEMM_GROUP_MAX):
+        M = (97, 410, 1650)[i % 3]
+        a, w = R(1, M, 256, seed=40 + i), R(256, 256, seed=70 + i)
+        out = torch.empty(1, M, 256, device=DEV)
+        probs.append(dict(A=a.to(DEV), W=w.to(DEV), C=out, M=M, N=256, K=256, lda=256, ldw=256,
+                          ldc=256, batch=1, sA=M * 256, sC=M * 256))
+        refs.append(torch.nn.functional.linear(a, w))
+    hip.gemm_group(probs)
+    for pr, ref in zip(probs, refs):
+        close(pr["C"], ref, 2e-5, "group of 18")
+    with pytest.raises(RuntimeError):
+        hip.gemm_group(probs + probs[:1])
     M, SN = 2 * 500, 500
     x, w, b, pos = R(M, 256, seed=1), R(544, 256, seed=2), R(544, seed=3), R(SN, 256, seed=4)
     out = torch.empty(M, 544, device=DEV)

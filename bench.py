@@ -237,6 +237,9 @@ def main():
     ap.add_argument("--enc-fused-ln", default=None,
                     help="encoder sites whose Linear + residual + LayerNorm run as one launch: "
                          "'proj,ffn' (default), 'proj', 'ffn' or 'none' (A/B of csrc/gemm_ln.hip)")
+    ap.add_argument("--set", action="append", default=[], metavar="ATTR=VALUE",
+                    help="A/B aid: set a boolean / integer scheduling attribute of the head before "
+                         "the run (e.g. --set group_input_convs=0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -301,6 +304,11 @@ def main():
     head.exact_mask_order = MASK_ORDER[args.mask_order]
     if args.conv:
         head.conv_algo = args.conv
+    for kv in args.set:
+        k, v = kv.split("=", 1)
+        if not hasattr(head, k):
+            raise SystemExit("--set: the head has no attribute %r" % k)
+        setattr(head, k, type(getattr(head, k))(int(v)))
     if args.enc_fused_ln is not None:
         head.enc_fused_ln = tuple(t for t in args.enc_fused_ln.split(",") if t in ("proj", "ffn"))
     head.use_graphs = not args.no_graphs

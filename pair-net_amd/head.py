@@ -139,6 +139,12 @@ class CrossHead2:
         # (pn_linear_res_ln_f32): "proj" = output_proj -> norms.0, "ffn" = FFN-2 -> norms.1;
         # () = the GEMM -> LayerNorm pairs of rounds 1-3 (bit-identical either way)
         self.enc_fused_ln = ("proj", "ffn")
+        # the pixel decoder's three 1x1 input convolutions as one grouped GEMM launch
+        # (channels_last features only) instead of three split-K launches.  Off: measured in
+        # round 4, three alternating 300-step runs: grouped 207.7 / 208.3 / 207.9 images/s,
+        # split 209.9 / 209.4 / 209.8 -- the grouped kernel has no K split, and the 68 deep-K
+        # tiles of the C5 convolution (64 chunks each) become its tail
+        self.group_input_convs = False
         self.init_weights()
 
     # ------------------------------------------------------------------ params
@@ -385,6 +391,13 @@ class CrossHead2:
         nblk = max(hip.groupnorm_nblk(HW2), hip.groupnorm_nblk(max(pl.N)))
         pl.gn_part = torch.empty(B * nblk * 32 * 2, device=dev, dtype=torch.float64)
         pl.T1, pl.T2 = E(B, HW2, 256), E(B, HW2, 256)
+        # (grouped input convolutions: one output buffer per level, views of pl.T1, which is
+        # idle until the lateral convolution: sum(N) <= HW2 rows)
+        pl.tmpconv3 = None
+        if sum(pl.N) <= HW2:
+            t1 = pl.T1.view(-1)
+            offs = [0, B * pl.N[0] * 256, B * (pl.N[0] + pl.N[1]) * 256]
+            pl.tmpconv3 = [t1[o:o + B * n * 256].view(B, n, 256) for o, n in zip(offs, pl.N)]
         # Winograd scratch: F(2x2): 16 planes of B * HW2 / 4 tiles x 256 (even sides only),
         # F(4x4): 36 planes of B * ceil(H2/4) * ceil(W2/4) tiles x 256
         pl.wino = hw2[0] % 2 == 0 and hw2[1] % 2 == 0
@@ -452,16 +465,28 @@ class CrossHead2:
         """MSDeformAttnPixelDecoder -> pl.X (memories), pl.MF."""
         w, B, SN = self.w, pl.B, pl.SN
         pd = "pixel_decoder."
+        group = self.group_input_convs and pl.nhwc and pl.tmpconv3 is not None
+        if group:
+            # the three 1x1 input convolutions (C5 / C4 / C3: 68 + 264 + 1044 tiles with 64 / 32 /
+            # 16 k-chunks) as ONE grouped launch instead of three split-K launches and their
+            # three reduce passes (channels_last features are row-major A operands)
+            hip.gemm_group([dict(
+                A=feats[3 - l], W=w[pd + "input_convs.%d.conv.weight" % l], C=pl.tmpconv3[l],
+                M=pl.N[l], N=256, K=feats[3 - l].shape[1], lda=feats[3 - l].shape[1],
+                ldw=feats[3 - l].shape[1], ldc=256, bias=w[pd + "input_convs.%d.conv.bias" % l],
+                batch=B, sA=feats[3 - l].shape[1] * pl.N[l], sC=pl.N[l] * 256) for l in range(3)])
         for l in range(3):
             f = feats[3 - l]
             cin, n = f.shape[1], pl.N[l]
             # NCHW features are read as column-major A operands, channels_last ones as
             # row-major [pixels][channels]: no transpose pass either way
-            hip.gemm(f, w[pd + "input_convs.%d.conv.weight" % l], pl.tmpconv, M=n, N=256, K=cin,
-                     lda=cin if pl.nhwc else n, ldw=cin, ldc=256,
-                     bias=w[pd + "input_convs.%d.conv.bias" % l], batch=B, sA=cin * n,
-                     sC=n * 256, colmajor=not pl.nhwc, scratch=pl.splitk)
-            hip.groupnorm_nhwc(pl.tmpconv, w[pd + "input_convs.%d.gn.weight" % l],
+            conv = pl.tmpconv3[l] if group else pl.tmpconv
+            if not group:
+                hip.gemm(f, w[pd + "input_convs.%d.conv.weight" % l], conv, M=n, N=256, K=cin,
+                         lda=cin if pl.nhwc else n, ldw=cin, ldc=256,
+                         bias=w[pd + "input_convs.%d.conv.bias" % l], batch=B, sA=cin * n,
+                         sC=n * 256, colmajor=not pl.nhwc, scratch=pl.splitk)
+            hip.groupnorm_nhwc(conv, w[pd + "input_convs.%d.gn.weight" % l],
                                w[pd + "input_convs.%d.gn.bias" % l], pl.X[:, pl.start[l]:],
                                pl.gn_part, B, n, self.gn_groups, False, n * 256, SN * 256)
         X2, X12, Y2 = pl.X.view(-1, 256), pl.X1.view(-1, 256), pl.Y.view(-1, 256)
@@ -809,7 +834,7 @@ class CrossHead2:
         `use_graphs`) as one hipGraph replay.  A stage is captured on its second call
         (the first, eager one is the warm-up torch requires before capture)."""
         cfg = (self.exact_mask_order, self.conv_algo, self.fuse_ppn_front, self.grid_reserve,
-               tuple(self.enc_fused_ln))
+               tuple(self.enc_fused_ln), self.group_input_convs)
         if pl.graph_cfg != cfg:          # a captured graph bakes these switches in
             pl.graph_a = pl.graph_b = pl.me0 = None
             pl.graph_c = {}

@@ -78,6 +78,23 @@ def latest_pmc():
     return files[-1] if files else None
 
 
+def sustained_mfma_clock():
+    """(GHz, source) the fp32 matrix pipe held under the path's own GEMMs, from the committed
+    stall counters (tools/gemm_stalls.py: MFMA instructions x 64 cycles / 1024 SIMDs / (busy
+    fraction x kernel time)); the long launches only (>= 70 us: their CU-busy window covers the
+    kernel).  None when the evidence file is absent."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_stalls.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        clk = [v["derived"]["implied_mfma_clock_ghz"] for v in d["shapes"].values()
+               if v.get("derived", {}).get("us", 0) >= 70 and "implied_mfma_clock_ghz" in v["derived"]]
+        return (sum(clk) / len(clk), os.path.relpath(files[-1], ROOT)) if clk else (None, None)
+    except (OSError, ValueError, KeyError, TypeError):
+        return None, None
+
+
 def bench_bbox(args, dev, rank, world):
     """Secondary measurement: the box-trunk sibling
     configs/deformable_detr/cross_r101_vg.py -- image tensor -> ResNet-101 (C3-C5) ->
@@ -816,7 +833,17 @@ def main():
                                             for v in sq) / sum(v["launches_profiled"] for v in sq)
                 except (OSError, ValueError, KeyError, TypeError):
                     pass
+                extra = {}
+                if bound == "mfma":
+                    # informational: the same rate against the roof at the clock the board
+                    # actually holds under this load (it throttles on fp32-MFMA power); `frac`
+                    # stays the fraction of the 2.4 GHz datasheet roof
+                    clk, clk_src = sustained_mfma_clock()
+                    if clk:
+                        extra = {"sustained_clock_ghz": clk, "sustained_clock_source": clk_src,
+                                 "frac_of_sustained_clock_roof": ach / (peak * clk / 2.4)}
                 return {
+                    **extra,
                     "kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
                     "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
                     "mfma_util_pmc": mfma_util,

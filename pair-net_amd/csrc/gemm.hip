@@ -664,8 +664,13 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
   c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
 }
 
-// Number of K splits for a 64x64-tile launch: enough work items for ~4 workgroups per CU,
-// at least 4 chunks (128 k) per split, and the partials must fit the caller's scratch.
+// Number of K splits for a 64x64-tile launch; the partials must fit the caller's scratch.
+// Round 4 rule, from a sweep over the 16 mid-size shapes of one image with 1216 workgroup slots
+// (tools/ksplit_sweep.py: the round-3 rule -- ~1024 work items, >= 4 chunks per split -- cost
+// 3412 us per image, the per-shape best 3351): aim for ~800 work items, never more than 6
+// splits (the reduce pass and the partials' round trip grow with S: the 68-tile C5 convolution
+// takes 22 us with 3-6 splits and 28 with 16), at least 8 chunks per split, 16 where the tile
+// count alone half-fills the chip (522 tiles x 16 chunks runs best unsplit, 528 x 32 in two).
 static int splitk_factor(const GemmP& p, int batch, const float* scratch, int64_t scratch_floats,
                          int* chunks_per_split, int flags) {
   const int nk = pn_cdiv(p.K, 32);
@@ -674,10 +679,21 @@ static int splitk_factor(const GemmP& p, int batch, const float* scratch, int64_
   const int forced = (flags >> PN_GEMM_KSPLIT_SHIFT) & 31;   // tuning: PN_GEMM_KSPLIT(n)
   if (!scratch || (p.N & 3) || !aligned16(p.bias) || ((uintptr_t)scratch & 15) || forced == 1)
     return 1;
+#ifdef PN_SPLITK_ROUND3          // (the rule of rounds 1-3, for A/B builds)
   if (!forced && (tiles >= 512 || nk < 8)) return 1;
   int S = forced ? forced : (int)((1024 + tiles - 1) / tiles);
   if (S > 16) S = 16;
   if (!forced && S > nk / 4) S = nk / 4;
+#else
+  if (!forced && (tiles >= 1024 || nk < 8)) return 1;
+  int S = forced ? forced : (int)((1600 + tiles) / (2 * tiles));      // round(800 / tiles)
+  if (!forced) {
+    if (S > 6) S = 6;
+    const int min_chunks = tiles > 400 ? 16 : 8;
+    if (S > nk / min_chunks) S = nk / min_chunks;
+  }
+  if (S > 16) S = 16;
+#endif
   if (S > nk) S = nk;
   const int64_t per = (int64_t)batch * p.M * p.N;
   if ((int64_t)S * per > scratch_floats) S = (int)(scratch_floats / per);

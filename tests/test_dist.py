@@ -268,6 +268,23 @@ def test_multi_gpu_test_world2_equals_world1_gloo():
     assert outs[1][3] is None and outs[0][3] == one["metrics"]
 
 
+def test_collector_pads_partial_batches_and_keeps_step_order():
+    """`TripletCollector` on the host (no process group): two images per step, the last step
+    with one image only (its second row is zeros), records kept in step order; the gather of a
+    step is issued `depth` steps late and `finish()` collects the rest."""
+    from pairnet_amd.dist import TripletBatch, TripletCollector
+    col = TripletCollector(_HostHead(), depth=2, n_local=2, keep_steps=3)
+    for step, ids in enumerate(((0, 1), (2, 3), (4,))):
+        got = [_HostDetector.detect(torch.full((1,), float(i))) for i in ids]
+        col.add(TripletBatch([g[0] for g in got], [g[1] for g in got], [g[2] for g in got]))
+        assert col.stored == max(0, step + 1 - 2)            # delayed by `depth` steps
+    rec = col.finish()
+    assert col.stored == 3 and rec.shape == (6, triplet_record_len(100, 56))
+    for i in range(5):
+        assert torch.equal(rec[i], _record(i))
+    assert float(rec[5].abs().sum()) == 0.0                  # the padded row of the last step
+
+
 def test_ring_entry_waits_for_the_collective_that_read_it():
     """the ring's host counters only say a collective was ENQUEUED.  On a device the
     entry carries a `sent` event behind its all-gather, and begin_step() makes the packing

@@ -11,7 +11,7 @@ a, b = len(marks) - 90, len(marks) - 10                    # inside the final ti
 t0, t1, steps = marks[a]["s"], marks[b]["s"], b - a
 print("%d steps, wall %.3f ms/step" % (steps, (t1 - t0) / steps / 1e6))
 win = [r for r in rows if r["s"] >= t0 and r["e"] <= t1]
-big = lambda r: ("k_gemm_tile" in r["n"] or "k_gemm_group" in r["n"])
+big = lambda r: ("k_gemm_tile" in r["n"] or "k_gemm_group" in r["n"] or "k_gemm_rowln" in r["n"])
 def union(rs):
     ev = sorted([(r["s"], 1) for r in rs] + [(r["e"], -1) for r in rs])
     depth, last, hist = 0, t0, collections.Counter()

@@ -166,7 +166,9 @@ class ResultStreamer:
 
     `pop()` waits for that batch's copies, checks its panoptic loops like `PSGTr.simple_test`
     (IndexError when every segment was filtered, pairnet_head.py:882) and returns Results
-    whose arrays are VIEWS of the ring entry: valid until `ring` more batches have been pushed
+    whose arrays are VIEWS of the ring entry: valid until that entry is pushed again, i.e. for
+    `ring` minus the number of batches still in flight more pushes -- ONE push when pop() is
+    only called on a full ring; with `private_masks` the masks are private arrays
     (copy what must live longer).  The reference returns fresh arrays; this is the documented
     deviation that keeps allocation out of the loop."""
 

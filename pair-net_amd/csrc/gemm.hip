@@ -37,6 +37,12 @@
 #ifndef PN_GEMM_WGS64
 #define PN_GEMM_WGS64 5
 #endif
+#ifndef PN_GEMM_WGS128x64           // 128x64 tiles (126 VGPRs: up to 4 waves per SIMD, 27 KB of LDS)
+#define PN_GEMM_WGS128x64 3
+#endif
+#ifndef PN_GEMM_BIGM_128x64         // 1: plain row-major launches with M >= 16384, N >= 256 take
+#define PN_GEMM_BIGM_128x64 0       // 128x64 tiles (power experiment)
+#endif
 #ifndef PN_GEMM_WGS64_SPILLING      // the instantiations that spill a few registers at 5
 #define PN_GEMM_WGS64_SPILLING 5
 #endif
@@ -50,7 +56,7 @@ struct TileSmem {
 template <int BM, int BN, int AMODE, bool ADD>
 struct TileWgs {   // resident workgroups per CU this instantiation is sized (and register-bounded) for
   static constexpr int value =
-      (BM * BN > 128 * 64) ? 2 : (BM * BN > 64 * 64) ? 3
+      (BM * BN > 128 * 64) ? 2 : (BM * BN > 64 * 64) ? PN_GEMM_WGS128x64
       : ((AMODE == A_ROW && !ADD) || AMODE == A_CONV) ? PN_GEMM_WGS64 : PN_GEMM_WGS64_SPILLING;
   static constexpr int min_waves = (BM * BN <= 64 * 64 && value > 4) ? value : 1;
 };
@@ -780,7 +786,9 @@ extern "C" int pn_gemm_f32(const pn_gemm_desc* d, void* stream) {
   // K = 256..1024 the persistent 64x64 tile (4 workgroups per CU then, 5 since round 4) is best or within 3 %
   // of the best on every encoder shape (99-112 TFLOP/s); 128x64 and 128x128 stay
   // selectable for sweeps.
-  if (d->flags & PN_GEMM_FORCE_TILE128x64)
+  const bool big_m = PN_GEMM_BIGM_128x64 && !colmajor && !d->Aadd && d->M >= 16384 &&
+                     d->N >= 256 && d->N % 64 == 0 && !(d->flags & PN_GEMM_FORCE_TILE64);
+  if ((d->flags & PN_GEMM_FORCE_TILE128x64) || big_m)
     return colmajor ? launch_tile<128, 64, 64, 32, A_COL>(p, d->batch, s, d->flags)
                     : launch_tile<128, 64, 64, 32, A_ROW>(p, d->batch, s, d->flags);
   if (d->flags & PN_GEMM_FORCE_TILE)

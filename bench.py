@@ -577,6 +577,7 @@ def main():
         from pairnet_amd.dist import multi_gpu_test
         det = PSGTr.from_parts(backbone, head)
         det._pipes = {args.depth: engine}       # (this run's calibrated stream placement)
+        det._calibrated = {args.depth}
         n = min(args.steps, 100)
         data = [(pool[i % len(pool)], metas) for i in range(n)]
         multi_gpu_test(det, data[:2 * args.depth], depth=args.depth, force_collective=one_rank)

@@ -427,6 +427,7 @@ class PSGTr:
 
     def to(self, device):
         self.__dict__.pop("_pipes", None)     # (cached pipelines hold the old device's streams)
+        self.__dict__.pop("_calibrated", None)
         self.backbone.to(device)
         if self.neck is not None:
             self.neck.to(device)
@@ -558,8 +559,14 @@ class PSGTr:
             for _ in range(2 * depth):      # plans made, stage graphs captured
                 self._submit(pipe, slots, img, img_metas, False)
             pipe.flush()
-            return pipe.calibrate(None, img_metas, steps=steps,
-                                  submit=lambda: self._submit(pipe, slots, img, img_metas, False))
+            times = pipe.calibrate(None, img_metas, steps=steps,
+                                   submit=lambda: self._submit(pipe, slots, img, img_metas, False))
+        self.__dict__.setdefault("_calibrated", set()).add(depth)
+        return times
+
+    def pipeline_calibrated(self, depth=4):
+        """Whether `calibrate_pipeline` has run for this depth (on the current device)."""
+        return depth in self.__dict__.get("_calibrated", ())
 
     def _pipelined(self, batches, rescale, depth):
         """Generator behind `stream()` / `stream_triplets()`: queues every `(img, img_metas)`

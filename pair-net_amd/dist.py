@@ -226,6 +226,10 @@ class TripletCollector:
         self.records = torch.zeros((keep_steps * self.rows, self.gatherer.L), device=store_dev,
                                    dtype=torch.float32) if keep_steps else None
         self.stored = 0
+        if self.on_gpu:
+            # the buffers above were zero-filled on the CURRENT stream; they are written next
+            # on other streams (chain streams, the side stream): finish the fills first
+            torch.cuda.current_stream(self.device).synchronize()
 
     def _on(self, stream):
         import contextlib
@@ -282,7 +286,7 @@ class TripletCollector:
 
 def multi_gpu_test(detector, dataset, annotations=None, evaluator=None, metrics=None, *,
                    depth=4, group=None, host_staging=None, force_collective=False,
-                   rescale=False):
+                   rescale=False, calibrate=True):
     """The reference's distributed test loop -- mmdet `multi_gpu_test` + `collect_results_*`
     (tools/test.py:256-267) followed by `dataset.evaluate` (:277-295 ->
     pairnet/datasets/psg.py:285-404) -- for one process per GPU:
@@ -301,7 +305,10 @@ def multi_gpu_test(detector, dataset, annotations=None, evaluator=None, metrics=
         once at the end; rank 0 adds them to `metrics` (`SceneGraphMetrics`) in dataset order.
 
     `dataset[i]` -> `(img, img_metas)` as `simple_test` takes them (one image);
-    `annotations[i]` -> dict(gt_rels, gt_labels, gt_masks) (or None).  Returns a dict:
+    `annotations[i]` -> dict(gt_rels, gt_labels, gt_masks) (or None).  `calibrate`: on the
+    first call per detector, choose the stream -> hardware-queue placement of its pipeline on
+    this rank's first image (`PSGTr.calibrate_pipeline`: ~50 throw-away submissions, worth ~8 %
+    of the step).  Returns a dict:
     `records` [N, L] float32 in dataset order on EVERY rank (`unpack_triplets` splits a row),
     `num_images`, `world_size`, `rank`, `collectives`, and on rank 0 `metrics`
     (`metrics.summary()`) when an evaluator was given."""
@@ -314,6 +321,10 @@ def multi_gpu_test(detector, dataset, annotations=None, evaluator=None, metrics=
     col = TripletCollector(detector.bbox_head, depth=depth, n_local=1, group=group,
                            host_staging=host_staging, force_collective=force_collective,
                            keep_steps=steps)
+    if calibrate and mine and hasattr(detector, "calibrate_pipeline") and \
+            hasattr(detector, "_pipelines") and detector._pipelines() and \
+            not detector.pipeline_calibrated(depth):
+        detector.calibrate_pipeline(*dataset[mine[0]], depth=depth)
     local_evals = []
     batches = (dataset[i] for i in mine)
     done = 0

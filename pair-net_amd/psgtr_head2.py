@@ -104,7 +104,14 @@ class PSGTrHead2(CrossHead2):
     def pair_positions(self, pl=None):
         """Query i IS triplet i (psgtr_head2.py:345-444): identity rows."""
         pl = pl if pl is not None else self._last_plan
-        ident = torch.arange(self.num_obj_query, device=self.device, dtype=torch.int64)
+        ident = self.__dict__.get("_ident")
+        if ident is None or ident.device != self.device:
+            # a constant, made ONCE and complete before it is handed out: consumers read it on
+            # other streams (the chain stream of a pipelined result) without any ordering
+            # against the stream it was created on
+            ident = torch.arange(self.num_obj_query, device=self.device, dtype=torch.int64)
+            torch.cuda.current_stream(self.device).synchronize()
+            self._ident = ident
         return ident.unsqueeze(0).expand(pl.B, -1), ident.unsqueeze(0).expand(pl.B, -1)
 
     def forward_head(self, decoder_out, mask_feature, attn_mask_target_size):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 16
+#define PN_ABI_VERSION 17
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -597,6 +597,14 @@ int pn_box_triplets_f32(const float* s_cls, const float* o_cls, const float* s_b
  * MaskHungarianAssigner): these entries produce their cost matrices and the loss
  * scalars.
  * ------------------------------------------------------------------------- */
+/* `PSGTr.forward_train`'s ground-truth mask preparation (frameworks/psgtr.py:126-141):
+ * masks [G][h][w] uint8 0/1 -> zero-padded on the right / bottom to the batch tensor's
+ * [H][W] (F.pad) -> nearest-neighbour resize to [Ho][Wo] (F.interpolate(mode="nearest"):
+ * source index min(floor(dst * (float)in / out), in - 1); the reference passes
+ * (Ho, Wo) = (H // 2, W // 2)).  out [G][Ho][Wo] uint8.  G, Ho <= 65535. */
+int pn_gt_mask_prepare_u8(const uint8_t* masks, uint8_t* out, int G, int h, int w, int H, int W,
+                          int Ho, int Wo, void* stream);
+
 /* [3P] mmcv `point_sample` (pairnet_head.py:631-638) = grid_sample(maps, 2 p - 1, bilinear,
  * zero padding, align_corners=False) with ONE point set shared by all maps:
  * maps [P][h][w] float32, or uint8 0/1 when maps_are_u8 (ground-truth masks); pts [Np][2]

@@ -10,6 +10,9 @@ oracle/ref_shim.install_training():
   CrossHead2._get_target_single      pairnet_head.py:614-718
   IdMatcher.assign                   pairnet/models/relation_heads/approaches/matcher.py:208-275
   BCEWithLogitsLoss                  pairnet/models/losses/seg_losses.py:153-166
+  PSGTr.forward_train, mask block    pairnet/models/frameworks/psgtr.py:126-141
+                                     (`prepare_gt_masks`; that block is two torch calls, F.pad
+                                     and F.interpolate(mode="nearest"): pinned against those)
 
 The third-party pieces those methods call (point_sample, MaskHungarianAssigner and its costs,
 MaskPseudoSampler, ClassificationCost, SeesawLoss, mmdet's CrossEntropyLoss) are the
@@ -26,6 +29,24 @@ import torch.nn.functional as F
 from scipy.optimize import linear_sum_assignment
 
 from . import mmdet_train as T
+
+
+def prepare_gt_masks(masks, H, W):
+    """psgtr.py:126-141: one image's ground-truth masks [G, h, w] (uint8 0/1) zero-padded on
+    the right / bottom to the batch tensor's (H, W), then nearest-neighbour resized to
+    (H // 2, W // 2).  ATen's legacy "nearest" reads source index
+    min(floor(dst * float32(in / out)), in - 1), the product in float32."""
+    import numpy as np
+    m = np.asarray(masks)
+    G, h, w = m.shape
+    Ho, Wo = H // 2, W // 2
+    padded = np.zeros((G, H, W), dtype=m.dtype)
+    padded[:, :h, :w] = m
+    sy = np.float32(H) / np.float32(Ho)
+    sx = np.float32(W) / np.float32(Wo)
+    iy = np.minimum(np.floor(np.arange(Ho, dtype=np.float32) * sy).astype(np.int64), H - 1)
+    ix = np.minimum(np.floor(np.arange(Wo, dtype=np.float32) * sx).astype(np.int64), W - 1)
+    return padded[:, iy[:, None], ix[None, :]]
 
 
 class OracleCrossHead2Loss:

@@ -18,15 +18,29 @@
 #include "common.h"
 
 #define RLN_BM 32
-#define RLN_LD 36
 #define RLN_TLD 264   // transposed-tile row stride (floats): 4 rows apart = 32 banks apart
+// Operand image in LDS.  k_gemm_tile pads its rows to 36 floats; here 288 rows x 36 floats are
+// 41 472 B -- 512 B more than a quarter of the CU's 160 KB, i.e. THREE workgroups per CU.
+// RLN_SWIZZLE = 1 (default) stores rows unpadded (32 floats) with the float4 column XOR-ed by
+// (row & 7): the eight lanes that a ds_read_b128 phase serves (rows li .. li + 7, same k) still
+// touch eight different 16-byte bank groups, a staging thread's row of eight float4 stores
+// still fills one 128-byte line, and the image is 36 864 B: FOUR workgroups per CU.
+#ifndef RLN_SWIZZLE
+#define RLN_SWIZZLE 1
+#endif
+#if RLN_SWIZZLE
+#define RLN_LD 32
+#else
+#define RLN_LD 36
+#endif
 
-__global__ __launch_bounds__(256) void k_gemm_rowln(
+__global__ __launch_bounds__(256, RLN_SWIZZLE ? 4 : 3) void k_gemm_rowln(
     const float* __restrict__ A, const int64_t lda, const float* __restrict__ W,
     const int64_t ldw, const float* __restrict__ bias, const float* __restrict__ Res,
     const int64_t ldres, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ Y, const int64_t ldy, const int M, const int K, const float eps) {
-  __shared__ __attribute__((aligned(16))) float smem[(RLN_BM + 256) * RLN_LD];
+  constexpr int kImage = (RLN_BM + 256) * RLN_LD, kT = RLN_BM * RLN_TLD;
+  __shared__ __attribute__((aligned(16))) float smem[kImage > kT ? kImage : kT];
   float* const sA = smem;
   float* const sB = smem + RLN_BM * RLN_LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -48,27 +62,44 @@ __global__ __launch_bounds__(256) void k_gemm_rowln(
 #pragma unroll
     for (int j = 0; j < 8; ++j) rb[j] = buf_ld4(rW, w_off[j], kt * 32 * 4);
   };
+#if RLN_SWIZZLE
+  const int skc = ((tid & 7) ^ (lrow & 7)) * 4;       // (row + 32 j) & 7 == lrow & 7
+#else
+  const int skc = kc;
+#endif
   auto store_chunk = [&]() {
-    st4(sA + lrow * RLN_LD + kc, ra);
+    st4(sA + lrow * RLN_LD + skc, ra);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) st4(sB + (lrow + 32 * j) * RLN_LD + kc, rb[j]);
+    for (int j = 0; j < 8; ++j) st4(sB + (lrow + 32 * j) * RLN_LD + skc, rb[j]);
   };
 
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#if RLN_SWIZZLE
+  // float4 column (2 kb + lh) of row r sits at column (2 kb + lh) ^ (r & 7) = 2 kb ^ sx with
+  // sx = lh ^ (li & 7) (every row this lane reads has r & 7 == li & 7)
+  const int sx = lh ^ (li & 7);
+  const float* fA = sA + li * RLN_LD;
+  const float* fB = sB + (wave * 64 + li) * RLN_LD;
+  int koff[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) koff[kb] = ((2 * kb) ^ sx) * 4;
+#else
   const float* fA = sA + li * RLN_LD + 4 * lh;
   const float* fB = sB + (wave * 64 + li) * RLN_LD + 4 * lh;
+  const int koff[4] = {0, 8, 16, 24};
+#endif
   auto compute = [&]() {
     float4 fa[2], fb0[2], fb1[2];
-    fa[0] = ld4(fA); fb0[0] = ld4(fB); fb1[0] = ld4(fB + 32 * RLN_LD);
+    fa[0] = ld4(fA + koff[0]); fb0[0] = ld4(fB + koff[0]); fb1[0] = ld4(fB + 32 * RLN_LD + koff[0]);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const int cur = kb & 1;
       if (kb + 1 < 4) {
-        fa[cur ^ 1] = ld4(fA + (kb + 1) * 8);
-        fb0[cur ^ 1] = ld4(fB + (kb + 1) * 8);
-        fb1[cur ^ 1] = ld4(fB + 32 * RLN_LD + (kb + 1) * 8);
+        fa[cur ^ 1] = ld4(fA + koff[kb + 1]);
+        fb0[cur ^ 1] = ld4(fB + koff[kb + 1]);
+        fb1[cur ^ 1] = ld4(fB + 32 * RLN_LD + koff[kb + 1]);
       }
       const float4 av = fa[cur], b0 = fb0[cur], b1 = fb1[cur];
       acc0 = mfma32(av.x, b0.x, acc0); acc1 = mfma32(av.x, b1.x, acc1);

@@ -27,6 +27,32 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
+// ---- PSGTr.forward_train's ground-truth mask preparation (frameworks/psgtr.py:126-141):
+// F.pad(mask [G][h][w], right / bottom to the batch's [H][W]) then F.interpolate(size =
+// (Ho, Wo), mode = "nearest") in one pass over the OUTPUT: ATen's legacy nearest reads source
+// index min(floor(dst * (float)in / out), in - 1); a source pixel outside [h) x [w) is padding.
+__global__ __launch_bounds__(256) void k_gt_mask_prepare(const uint8_t* __restrict__ in,
+                                                         uint8_t* __restrict__ out, int h, int w,
+                                                         int H, int W, int Ho, int Wo) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, g = blockIdx.z;
+  if (x >= Wo) return;
+  const float sy_f = (float)H / (float)Ho, sx_f = (float)W / (float)Wo;
+  const int sy = min((int)floorf((float)y * sy_f), H - 1);
+  const int sx = min((int)floorf((float)x * sx_f), W - 1);
+  out[((int64_t)g * Ho + y) * Wo + x] =
+      (sy < h && sx < w) ? in[((int64_t)g * h + sy) * w + sx] : (uint8_t)0;
+}
+
+extern "C" int pn_gt_mask_prepare_u8(const uint8_t* masks, uint8_t* out, int G, int h, int w,
+                                     int H, int W, int Ho, int Wo, void* stream) {
+  if (!masks || !out || G <= 0 || G > 65535 || h <= 0 || w <= 0 || H < h || W < w || Ho <= 0 ||
+      Wo <= 0 || Ho > 65535)
+    return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_gt_mask_prepare, dim3(pn_cdiv(Wo, 256), Ho, G), dim3(256), 0,
+                     (hipStream_t)stream, masks, out, h, w, H, W, Ho, Wo);
+  return PN_LAUNCH_CHECK();
+}
+
 // ---- mmcv point_sample = F.grid_sample(input, 2 p - 1, bilinear, zeros, align_corners=False)
 // maps [P][h][w] (float, or uint8 0/1 for ground-truth masks), pts [Np][2] (x, y) in [0, 1],
 // shared by all P maps (pairnet_head.py:630-638: the same random points for every query and

@@ -493,6 +493,41 @@ class PSGTr:
                 for t in results_list]
 
     @torch.no_grad()
+    def val_losses(self, img, img_metas, gt_rels=None, gt_bboxes=None, gt_labels=None,
+                   gt_masks=None, gt_bboxes_ignore=None, **kw):
+        """The VALUES the reference's `PSGTr.forward_train` returns (psgtr.py:113-146), as a
+        validation loss: extract_feat -> ground-truth masks zero-padded to the batch tensor's
+        (H, W) and nearest-resized to (H // 2, W // 2) (:126-141, one kernel per image:
+        `pn_gt_mask_prepare_u8`) -> `bbox_head.val_losses` (head forward + `loss`).  Forward
+        only: no autograd graph, no optimizer (training is outside SURVEY.md 8).
+
+        `gt_masks[i]`: image i's instance masks [G, h, w], 0/1 -- a BitmapMasks-like object
+        (`.to_ndarray()`), a numpy array or a tensor (host or device)."""
+        from . import hip
+        x = self.extract_feat(img)
+        if getattr(self.bbox_head, "use_mask", True):
+            assert gt_masks is not None
+            H, W = int(img.shape[2]), int(img.shape[3])
+            dev = self.bbox_head.device
+            prepared = []
+            with torch.cuda.device(dev):
+                for each in gt_masks:
+                    m = each.to_ndarray() if hasattr(each, "to_ndarray") else each
+                    m = torch.as_tensor(m).to(dev)
+                    if m.dtype not in (torch.bool, torch.uint8):
+                        m = (m != 0)
+                    if m.dim() != 3 or m.shape[1] > H or m.shape[2] > W:
+                        raise ValueError("gt_masks: [G, h, w] with h <= %d, w <= %d, got %s"
+                                         % (H, W, tuple(m.shape)))
+                    out = torch.empty((m.shape[0], H // 2, W // 2), dtype=torch.uint8, device=dev)
+                    if m.shape[0]:
+                        hip.gt_mask_prepare(m.contiguous(), out, H, W)
+                    prepared.append(out)
+            gt_masks = prepared
+        return self.bbox_head.val_losses(x, img_metas, gt_rels, gt_bboxes, gt_labels, gt_masks,
+                                         gt_bboxes_ignore, **kw)
+
+    @torch.no_grad()
     def detect(self, image, rescale=False):
         """Decoded uint8 (H, W, 3) BGR image (cv2 order, host or device) -> [Result]: the
         reference's test pipeline (configs/mask2former/pairnet.py:310-331) on the GPU
@@ -674,7 +709,8 @@ class PSGTr:
     def forward(self, img=None, img_metas=None, return_loss=False, rescale=False, **kw):
         """mmdet's `model(return_loss=False, rescale=True, img=[..], img_metas=[..])`."""
         if return_loss:
-            raise NotImplementedError("inference path only")
+            raise NotImplementedError("no training step (backward, optimizer) here: "
+                                      "`val_losses` gives forward_train's loss VALUES")
         if isinstance(img, (list, tuple)):
             img, img_metas = img[0], img_metas[0]
         return self.simple_test(img, img_metas, rescale=rescale)

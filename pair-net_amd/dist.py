@@ -129,10 +129,12 @@ class TripletGatherer:
             self.packed[self.filled % self.ring] = ev
         self.filled += 1
 
-    def gather_delayed(self, delay, host_staging=False):
+    def gather_delayed(self, delay, host_staging=False, consume=None):
         """All-gather the oldest packed step if it is at least `delay` steps old (on the
         caller's current stream, behind that step's `packed` event); returns its records or
-        None."""
+        None.  `consume(records)`: reader of the returned buffer, run BEFORE the ring entry is
+        marked as read -- with one rank the records ARE the ring entry, so a reader that ran
+        after this call would not be ordered in front of the entry's next pack."""
         if self.filled - self.gathered <= delay:
             return None
         k = self.gathered % self.ring
@@ -140,6 +142,8 @@ class TripletGatherer:
             torch.cuda.current_stream().wait_event(self.packed[k])
         self.send = self.sends[k]
         out = self.gather(host_staging=host_staging)
+        if consume is not None:
+            out = consume(out)
         if self.on_device:
             ev = self.sent[k] or torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -151,7 +155,8 @@ class TripletGatherer:
         """Gather every step still in the ring (end of the run)."""
         outs = []
         while self.gathered < self.filled:      # (copies: gather() returns an internal buffer)
-            outs.append(self.gather_delayed(0, host_staging=host_staging).clone())
+            outs.append(self.gather_delayed(0, host_staging=host_staging,
+                                            consume=lambda o: o.clone()))
         return outs
 
     def pack(self, i, labels, rel_dists, sub_pos, obj_pos):
@@ -238,14 +243,16 @@ class TripletCollector:
         return contextlib.nullcontext()
 
     def _store(self, out):
-        if out is not None and self.records is not None:
+        if self.records is not None:
             k = self.stored      # (gather() hands out an internal buffer: keep a copy)
             self.records[k * self.rows:(k + 1) * self.rows].copy_(out, non_blocking=True)
             self.stored = k + 1
+        return out
 
     def _collect(self, delay):
         with self._on(self.side):
-            self._store(self.gatherer.gather_delayed(delay, host_staging=self.host_staging))
+            self.gatherer.gather_delayed(delay, host_staging=self.host_staging,
+                                         consume=self._store)
 
     def add(self, tb, before_release=None):
         """`tb`: a TripletBatch of `n_local` images.  `before_release(tb)`: optional reader of
@@ -278,7 +285,7 @@ class TripletCollector:
         g = self.gatherer
         with self._on(self.side):
             while g.gathered < g.filled:
-                self._store(g.gather_delayed(0, host_staging=self.host_staging))
+                g.gather_delayed(0, host_staging=self.host_staging, consume=self._store)
         if self.side is not None:
             self.side.synchronize()
         return self.records

@@ -1108,7 +1108,19 @@ class CrossHead2:
 
     def forward_train(self, *a, **kw):
         raise NotImplementedError("training (backward, optimizer) is outside SURVEY.md section 8; "
-                                  "`loss()` gives the reference's loss VALUES on forward() outputs")
+                                  "`val_losses()` / `loss()` give the reference's loss VALUES")
+
+    def val_losses(self, x, img_metas, gt_rels, gt_bboxes, gt_labels=None, gt_masks=None,
+                   gt_bboxes_ignore=None, **kw):
+        """The values of the reference's `forward_train` (pairnet_head.py:720-757):
+        `outs = self(x, img_metas)`, then `loss(*outs, gt_rels, gt_bboxes, gt_labels, gt_masks,
+        img_metas)`.  Forward only."""
+        if gt_labels is None:
+            raise ValueError("gt_labels is required (the reference's four-argument form feeds "
+                             "loss() one positional argument short)")
+        outs = self.forward(x, img_metas)
+        return self.loss(*outs, gt_rels, gt_bboxes, gt_labels, gt_masks, img_metas,
+                         gt_bboxes_ignore=gt_bboxes_ignore, **kw)
 
     def pair_positions(self, pl=None):
         """(sub_pos, obj_pos): per image the query rows of the R selected pairs

@@ -69,6 +69,7 @@ _SIGS = {
                                  C.POINTER(_i32), _i32, _vp]),
     "pn_linear_res_ln_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64,
                                        _i32, _i32, _i32, _f32, _vp]),
+    "pn_gt_mask_prepare_u8": (C.c_int, [_vp, _vp] + [_i32] * 7 + [_vp]),
     "pn_point_sample_f32": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_mask_match_cost_f32": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32,
                                          _f32, _f32, _f32, _vp]),
@@ -134,7 +135,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 16   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 17   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -889,6 +890,17 @@ def box_triplets(s_cls, o_cls, s_box, o_box, det, labels, R, Cc, img_h, img_w, s
 
 
 # ---- loss forward (csrc/loss.hip) ----------------------------------------------------------
+def gt_mask_prepare(masks, out, H, W):
+    """masks [G][h][w] bool / uint8 -> out [G][Ho][Wo] uint8: zero-padded to [H][W], then
+    nearest-neighbour resized (psgtr.py:126-141)."""
+    G, h, w = masks.shape
+    assert masks.dtype in (torch.bool, torch.uint8) and out.dtype in (torch.bool, torch.uint8)
+    assert out.shape[0] == G and masks.is_contiguous() and out.is_contiguous()
+    _check(lib().pn_gt_mask_prepare_u8(_ptr(masks, masks.dtype), _ptr(out, out.dtype), G, h, w, H,
+                                       W, out.shape[1], out.shape[2], _stream()),
+           "pn_gt_mask_prepare_u8")
+
+
 def point_sample(maps, pts, out):
     """maps [P][h][w] float32 or bool / uint8; pts [Np][2]; out [P][Np] (mmcv point_sample with
     one point set for all maps)."""

@@ -44,6 +44,8 @@ def test_bad_arguments_are_refused_without_launching(built_lib):
                                     64, 256, 48, 1e-5, None) == -1       # K % 32
     assert lib.pn_msda_ex_f32(None, 256, None, 288, None, 1, 3, None, None, 0, None) == -1
     assert lib.pn_point_sample_f32(None, 0, None, None, 1, 8, 8, 16, None) == -1
+    assert lib.pn_gt_mask_prepare_u8(None, None, 3, 8, 8, 16, 16, 8, 8, None) == -1
+    assert lib.pn_gt_mask_prepare_u8(16, 32, 3, 20, 8, 16, 16, 8, 8, None) == -1   # h > H
     assert lib.pn_mask_match_cost_f32(None, 134, None, None, None, None, 100, 3, 64, 2.0, 5.0, 5.0,
                                       1.0, None) == -1
     assert lib.pn_id_match_cost_f32(None, None, None, 134, 56, None, None, None, None, 100, 3,

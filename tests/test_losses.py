@@ -133,3 +133,20 @@ def test_seesaw_loss_properties():
     full = T.SeesawLoss(num_classes=56, loss_weight=2.0)
     a, b = full(x, y)["loss_cls_classes"], full(x, y)["loss_cls_classes"]
     assert torch.isfinite(a) and torch.isfinite(b) and full.cum_samples[1] == 12
+
+
+@pytest.mark.parametrize("h,w,H,W", [(90, 120, 96, 128), (96, 128, 96, 128), (50, 77, 96, 160),
+                                      (61, 45, 75, 51)])
+def test_ground_truth_mask_preparation_is_pad_then_nearest(h, w, H, W):
+    """oracle.losses.prepare_gt_masks against the two torch calls PSGTr.forward_train makes
+    (psgtr.py:132-138: F.pad to the batch tensor's size, F.interpolate(mode="nearest") to
+    half of it), including odd batch sizes where the nearest source index is not 2 * dst."""
+    import torch.nn.functional as F
+    from oracle.losses import prepare_gt_masks
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    mask = (torch.rand(4, h, w, generator=g) > 0.5).to(torch.uint8)
+    want = F.interpolate(F.pad(mask, (0, W - w, 0, H - h)).unsqueeze(1), size=(H // 2, W // 2),
+                         mode="nearest").squeeze(1)
+    got = prepare_gt_masks(mask.numpy(), H, W)
+    assert got.shape == tuple(want.shape) and got.dtype == np.uint8
+    assert np.array_equal(got, want.numpy())

@@ -116,3 +116,62 @@ def test_loss_refuses_an_image_without_relations():
         head.loss(cls, masks, [torch.zeros(0, 3)], None, gt_labels, gt_masks, metas)
     with pytest.raises(NotImplementedError):
         head.forward_train()
+
+
+@pytest.mark.parametrize("h,w,H,W", [(90, 120, 96, 128), (96, 128, 96, 128), (61, 45, 75, 51),
+                                      (800, 1216, 800, 1344)])
+def test_ground_truth_mask_preparation_kernel_is_the_oracle_bit_for_bit(h, w, H, W):
+    from oracle.losses import prepare_gt_masks
+    from pairnet_amd import hip
+    g = torch.Generator().manual_seed(h + w)
+    mask = torch.rand(3, h, w, generator=g) > 0.5
+    out = torch.empty((3, H // 2, W // 2), dtype=torch.uint8, device=DEV)
+    with torch.cuda.device(DEV):
+        hip.gt_mask_prepare(mask.to(DEV), out, H, W)
+    assert np.array_equal(out.cpu().numpy(), prepare_gt_masks(mask.numpy().astype(np.uint8), H, W))
+
+
+def test_detector_val_losses_is_forward_train_without_the_backward():
+    """PSGTr.val_losses (psgtr.py:113-146): backbone -> masks padded / resized -> head forward
+    -> loss, against the oracle loss on the same head outputs and the oracle's prepared masks."""
+    from oracle.losses import prepare_gt_masks
+    from pairnet_amd import PSGTr
+    from pairnet_amd.backbone import ResNet50Hip
+    from pairnet_amd import CrossHead2
+    H, W = 96, 128
+    head = CrossHead2(**head_cfg())
+    head.init_weights(seed=3)
+    det = PSGTr.from_parts(ResNet50Hip(depth=50), head).to(DEV)
+    g = torch.Generator().manual_seed(11)
+    img = torch.randn(2, 3, H, W, generator=g).to(DEV)
+    metas = [dict(img_shape=(90, 120, 3), scale_factor=[2.0] * 4, batch_input_shape=(H, W))] * 2
+    gt_labels = [torch.tensor([3, 17, 90, 120, 3]), torch.tensor([5, 60, 7])]
+    raw = [(torch.rand(5, 90, 120, generator=g) > 0.6).numpy().astype(np.uint8),
+           (torch.rand(3, 90, 120, generator=g) > 0.5).numpy().astype(np.uint8)]
+
+    class Bitmap:                       # mmdet BitmapMasks, as far as forward_train reads it
+        def __init__(self, a):
+            self.a = a
+
+        def to_ndarray(self):
+            return self.a
+    gt_rels = [torch.tensor([[0, 1, 5], [2, 3, 17], [1, 0, 56], [4, 2, 5]]),
+               torch.tensor([[0, 1, 2], [2, 1, 30]])]
+    pts = [torch.rand(1, 12544, 2, generator=g) for _ in range(2)]
+    got = det.val_losses(img, metas, gt_rels, None, gt_labels, [Bitmap(a) for a in raw],
+                         point_coords=pts)
+    cls, masks = head.forward(det.extract_feat(img), metas)
+    cpu = lambda d: {k: v.detach().cpu().clone() for k, v in d.items()}
+    prepared = [torch.from_numpy(prepare_gt_masks(a, H, W)) for a in raw]
+    # (half the batch tensor; the mask logits are at a quarter: point sampling works in
+    # normalised coordinates, the two grids never have to agree)
+    assert tuple(prepared[0].shape[1:]) == (H // 2, W // 2)
+    want = OracleCrossHead2Loss().loss(cpu(cls), cpu(masks), gt_rels, gt_labels, prepared,
+                                       point_coords=pts)
+    for k in want:
+        assert abs(float(got[k]) - float(want[k])) < 1e-4 * max(1.0, abs(float(want[k]))), k
+    with pytest.raises(NotImplementedError):
+        det.forward(img, metas, return_loss=True)
+    with pytest.raises(ValueError):
+        det.val_losses(img, metas, gt_rels, None, gt_labels,
+                       [np.zeros((5, H + 1, W), np.uint8), raw[1]])

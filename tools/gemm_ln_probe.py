@@ -3,6 +3,8 @@ N = 256 shapes, eager, back to back (tools/gemm_ln_probe.py; run on the GPU box)
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pairnet_amd import hip
+if os.environ.get("LIB"):          # an alternative build of the library (tools/README.md)
+    hip.LIB_PATH = os.path.abspath(os.environ["LIB"])
 dev = "cuda:0"
 torch.manual_seed(0)
 M = int(os.environ.get("ROWS", 21950))

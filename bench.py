@@ -928,6 +928,35 @@ def main():
         if backbone is not None and not swin:
             backbone.use_graphs = not args.no_graphs
         out["latency_ms_single_stream_graphs"] = timeit(whole, 10)
+        if args.head == "pairnet" and hasattr(head, "loss"):
+            # SURVEY 8 f4 (forward slice): the loss VALUES of CrossHead2.loss on this step's
+            # outputs with a synthetic ground truth (12 instance masks at half the batch
+            # tensor's size, 10 relations per image, the config's 12544 sampled points)
+            try:
+                g = torch.Generator().manual_seed(5)
+                G, T = 12, 10
+                Hh, Wh = (int(img.shape[2]) if img is not None else 4 * feats[0].shape[2]) // 2, \
+                    (int(img.shape[3]) if img is not None else 4 * feats[0].shape[3]) // 2
+                gt_masks = [(torch.rand(G, Hh // 8, Wh // 8, generator=g) > 0.7).to(dev)
+                            .repeat_interleave(8, 1).repeat_interleave(8, 2).contiguous()
+                            for _ in range(B)]
+                gt_labels = [torch.randint(0, head.num_classes, (G,), generator=g) for _ in range(B)]
+                gt_rels = [torch.stack([torch.randint(0, G, (T,), generator=g),
+                                        torch.randint(0, G, (T,), generator=g),
+                                        torch.randint(1, head.num_relations + 1, (T,), generator=g)], 1)
+                           for _ in range(B)]
+                lossf = lambda: head.loss(*outs, gt_rels, None, gt_labels, gt_masks, metas)
+                vals = lossf()
+                out["loss_forward"] = {
+                    "ms_per_batch": timeit(lossf, 10), "images": B,
+                    "values": {k: float(v) for k, v in vals.items()},
+                    "what": "CrossHead2.loss on the forward outputs (values only): point "
+                            "sampling of 100 mask logit maps + %d ground-truth masks at 12544 "
+                            "points, the two match-cost matrices on the GPU, both Hungarian "
+                            "assignments with scipy on the host (as the reference), Seesaw / CE / "
+                            "BCE(pos_weight) reductions on the GPU" % G}
+            except Exception as e:      # noqa: BLE001 -- an extra, never the headline
+                out["loss_forward"] = repr(e)
         if engine is not None and args.mask_order == "reference":
             # the same pipelined steps with the opt-in shortcut for the attention masks: the
             # mask feature is resampled to each level once per image and every layer's logits

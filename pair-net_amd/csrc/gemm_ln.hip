@@ -19,14 +19,17 @@
 
 #define RLN_BM 32
 #define RLN_TLD 264   // transposed-tile row stride (floats): 4 rows apart = 32 banks apart
-// Operand image in LDS.  k_gemm_tile pads its rows to 36 floats; here 288 rows x 36 floats are
-// 41 472 B -- 512 B more than a quarter of the CU's 160 KB, i.e. THREE workgroups per CU.
-// RLN_SWIZZLE = 1 (default) stores rows unpadded (32 floats) with the float4 column XOR-ed by
-// (row & 7): the eight lanes that a ds_read_b128 phase serves (rows li .. li + 7, same k) still
-// touch eight different 16-byte bank groups, a staging thread's row of eight float4 stores
-// still fills one 128-byte line, and the image is 36 864 B: FOUR workgroups per CU.
+// Operand image in LDS: rows padded to 36 floats, as in k_gemm_tile.  288 rows x 36 floats are
+// 41 472 B -- 512 B more than a quarter of the CU's 160 KB, i.e. three workgroups per CU.
+// -DRLN_SWIZZLE=1 (measured in round 4, NOT adopted) stores rows unpadded (32 floats) with the
+// float4 column XOR-ed by (row & 7) -- as conflict-free as the padding for the eight lanes of
+// a ds_read_b128 phase and for a staging thread row -- which makes the image 36 864 B and FOUR
+// workgroups fit.  The 686 row tiles of an 800x1333 image are all resident at three per CU
+// already, so the occupancy buys nothing stand-alone (K = 1024: 111.5 vs 108.6 us, the XOR-ed
+// addresses cost two VALU instructions per fragment), and under the pipeline it measured
+// 207.6-208.0 against 208.6-208.8 images/s (three alternating runs, tools/ab_rln.sh).
 #ifndef RLN_SWIZZLE
-#define RLN_SWIZZLE 1
+#define RLN_SWIZZLE 0
 #endif
 #if RLN_SWIZZLE
 #define RLN_LD 32

@@ -204,6 +204,35 @@ def test_gemm_is_an_fmaf_chain(hip):
         assert torch.equal(out.cpu(), x @ w.t())
 
 
+@pytest.mark.parametrize("M", [1, 3, 4, 5, 33, 35, 36, 37, 64, 65, 68, 69, 96, 97, 100, 101, 132])
+def test_gemm_ragged_edges_are_exact(hip, M):
+    """Tiles that hang over the problem in M (1 .. 4 valid rows in a wave block, whole blocks
+    past M) and in N (200 = 3 x 64 + 8): with integer-valued operands the result must be the
+    exact product -- bias, ReLU, residual, batches with their own W, split-K partials.  (Written
+    for the round-4 experiment that ran such blocks as 4-row v_mfma_f32_4x4x1 strips / skipped
+    them; kept as the edge-case test of the kernel that stayed.)"""
+    g = torch.Generator().manual_seed(M)
+    B, N, K = 2, 200, 96
+    x = torch.randint(-8, 9, (B, M, K), generator=g).float()
+    w = torch.randint(-8, 9, (B, N, K), generator=g).float()
+    bias = torch.randint(-8, 9, (N,), generator=g).float()
+    res = torch.randint(-8, 9, (B, M, N), generator=g).float()
+    want = F.relu(torch.einsum("bmk,bnk->bmn", x, w) + bias) + res
+    out = torch.full((B, M, N), float("nan"), device=DEV)
+    hip.gemm(x.to(DEV), w.to(DEV), out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, bias=bias.to(DEV),
+             res=res.to(DEV), ldres=N, sRes=M * N, relu=True, batch=B, sA=M * K, sW=N * K,
+             sC=M * N, force="tile64")
+    assert torch.equal(out.cpu(), want), M
+    # split-K partials of a ragged block (K = 2048: scratch supplied), single problem
+    K2 = 2048
+    x2 = torch.randint(-4, 5, (M, K2), generator=g).float()
+    w2 = torch.randint(-4, 5, (N, K2), generator=g).float()
+    out2 = torch.full((M, N), float("nan"), device=DEV)
+    hip.linear(x2.to(DEV), w2.to(DEV), bias.to(DEV), out2, force="tile64",
+               scratch=torch.empty(8 * 1024 * 1024, device=DEV))
+    assert torch.equal(out2.cpu(), x2 @ w2.t() + bias), M
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,relu", [(2, 13, 17, 256, 256, 3, False),
                                                   (1, 20, 20, 64, 64, 7, True),
                                                   (2, 9, 40, 32, 64, 7, True)])

@@ -41,6 +41,18 @@ struct __attribute__((aligned(16))) MsdaTap {
 // them in LDS (the gather threads used to recompute them eight times over).  Phase 2:
 // thread (head, point, 4 channels) reads them back (broadcast within its 8 lanes), issues
 // the L x 4 float4 gathers of a query back to back and accumulates.
+// -DMSDA_NT=1 (round 4, measured, NOT adopted): the offsets / logits are loaded and the output
+// is stored with the non-temporal hint, so that those 48 MB of stream do not push a band's
+// value rows out of its XCD's L2.  FETCH_SIZE per launch falls by 8 % (tools/ab_msda_nt.sh:
+// 117.4 -> 108.0 MB over the probe's mix of init and N(0, 8 px) offsets), the kernel does not
+// get faster (init offsets 46.9 -> 49.8 us, N(0, 8 px) 63.0 -> 61.9 us) and the pipelined bench
+// does not move (208.5 vs 208.4 images/s, three alternating runs): it is bound by the L1
+// request rate, not by the L2 misses.
+#ifndef MSDA_NT
+#define MSDA_NT 0
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int L>
 __device__ __forceinline__ void msda_one_shot(const float* __restrict__ value,
                                               const float* __restrict__ offaw,
@@ -82,8 +94,17 @@ __device__ __forceinline__ void msda_one_shot(const float* __restrict__ value,
     const bool live = n >= 0 && l < L;
     const int nc = max(n, 0), lc = min(l, L - 1);
     const float* oa = offaw + ((int64_t)b * lv.N + nc) * ldo;
+#if MSDA_NT
+    // offsets / logits are read once and the output is written once: non-temporal accesses,
+    // so that 48 MB of stream do not push the band's value rows out of the XCD's 4 MB L2
+    const float e = __builtin_nontemporal_load(oa + 8 * LP * 2 + head * LP + lc * 4 + pt);
+    const f32x2 off_v = __builtin_nontemporal_load(
+        reinterpret_cast<const f32x2*>(oa + head * LP * 2 + lc * 8 + pt * 2));
+    const float2 off = make_float2(off_v[0], off_v[1]);
+#else
     const float e = oa[8 * LP * 2 + head * LP + lc * 4 + pt];
     const float2 off = *reinterpret_cast<const float2*>(oa + head * LP * 2 + lc * 8 + pt * 2);
+#endif
     // softmax over the head's L x 4 logits: levels summed in order per point, then the
     // points pairwise (the summation order of the reference-checked first version)
     const float mx = grp16_max(l < L ? e : -INFINITY);
@@ -157,7 +178,16 @@ __device__ __forceinline__ void msda_one_shot(const float* __restrict__ value,
       }
       acc.x = pt_sum(acc.x); acc.y = pt_sum(acc.y);
       acc.z = pt_sum(acc.z); acc.w = pt_sum(acc.w);
+#if MSDA_NT
+      if (p2 == 0) {
+        f32x4 o4;
+        o4[0] = acc.x; o4[1] = acc.y; o4[2] = acc.z; o4[3] = acc.w;
+        __builtin_nontemporal_store(
+            o4, reinterpret_cast<f32x4*>(out + ((int64_t)b * lv.N + nq) * 256 + h2 * 32 + c4 * 4));
+      }
+#else
       if (p2 == 0) st4(out + ((int64_t)b * lv.N + nq) * 256 + h2 * 32 + c4 * 4, acc);
+#endif
     }
   }
 }

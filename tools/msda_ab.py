@@ -2,6 +2,8 @@
 import os, sys, math, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pairnet_amd import hip
+if os.environ.get("LIB"):          # an alternative build of the library (tools/README.md)
+    hip.LIB_PATH = os.path.abspath(os.environ["LIB"])
 dev = "cuda:0"
 shapes = [(25, 42), (50, 84), (100, 167)]
 SN = sum(h * w for h, w in shapes)

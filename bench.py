@@ -257,6 +257,8 @@ def main():
     ap.add_argument("--set", action="append", default=[], metavar="ATTR=VALUE",
                     help="A/B aid: set a boolean / integer scheduling attribute of the head before "
                          "the run (e.g. --set group_input_convs=0)")
+    ap.add_argument("--bb-set", action="append", default=[], metavar="ATTR=VALUE",
+                    help="integer attribute of the native ResNet backbone (tuning A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -350,6 +352,11 @@ def main():
             backbone, bname = SwinTransformerHip(**scfg).to(dev), "Swin-%s" % swin
         else:
             backbone, bname = ResNet50Hip().to(dev), "ResNet-50"
+            for kv in args.bb_set:
+                k, v = kv.split("=", 1)
+                if not hasattr(backbone, k):
+                    raise SystemExit("--bb-set: the backbone has no attribute %r" % k)
+                setattr(backbone, k, int(v))
             backbone.use_graphs = not args.no_graphs
         if engine is not None:   # the backbone runs on the stage-A streams: same free slots
             backbone.grid_reserve = engine.grid_reserve

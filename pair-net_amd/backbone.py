@@ -84,6 +84,9 @@ class ResNet50Hip:
         # tiles than the 16 of F(2x2,3x3) -- stages 2 and 3 at 800x1333, not the 25x42 map of
         # stage 4; "direct" = implicit GEMM
         self.conv_algo = "winograd4"
+        # narrowest 3x3 layer that takes the Winograd form (128: stages 2-4; 64 adds the three
+        # K = 64 layers of stage 1 -- measured in round 4)
+        self.wino_min_planes = 128
 
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._params.items())
@@ -145,7 +148,7 @@ class ResNet50Hip:
                     # stride-1 3x3 layers of >= 128 channels also get their Winograd F(2x2,3x3)
                     # weights (stages 2-4; the 64-channel layers of stage 1 would be K = 64
                     # GEMMs, slower than the direct form)
-                    if conv == "conv2" and co >= 128 and not (b == 0 and i > 0):
+                    if conv == "conv2" and co >= 64 and not (b == 0 and i > 0):
                         w[p + "conv2.wino"] = hip.winograd_weights(cw.to(dev))
                         w[p + "conv2.wino4"] = hip.winograd43_weights(cw.to(dev))
         self.w = w
@@ -154,7 +157,7 @@ class ResNet50Hip:
         pass
 
     def _plan(self, B, H, W, slot=0):
-        key = (B, H, W, slot)
+        key = (B, H, W, slot, self.conv_algo, self.wino_min_planes)   # (a plan's graph bakes both in)
         if key in self._plans:
             return self._plans[key]
         if self.w is None:
@@ -183,7 +186,7 @@ class ResNet50Hip:
             pl.idt.append(E(B, h, wd, planes * 4))
             pl.ping.append(E(B, h, wd, planes * 4))
             pl.out.append(E(B, h, wd, planes * 4))
-            if planes >= 128:
+            if planes >= self.wino_min_planes:
                 t2, t4 = B * ((h + 1) // 2) * ((wd + 1) // 2), B * ((h + 3) // 4) * ((wd + 3) // 4)
                 nwino = max(nwino, 16 * t2 * planes, 36 * t4 * planes)
                 # F(4x4,3x3) where it multiplies fewer (64-row padded) GEMM rows
@@ -261,7 +264,7 @@ class ResNet50Hip:
                            t1.view(-1, planes), relu=True, scratch=pl.scratch)
                 # conv2 3x3, stride on this layer ("pytorch" style) (+BN+ReLU)
                 wino = self.conv_algo in ("winograd", "winograd4") and p + "conv2.wino" in w \
-                    and stride == 1
+                    and stride == 1 and planes >= self.wino_min_planes
                 if wino and self.conv_algo == "winograd4" and pl.f43[i]:
                     # 4x fewer multiplications (fp32; ~1.6e-5 relative to the direct form)
                     hip.conv3x3_winograd43(t1, w[p + "conv2.wino4"], w[p + "conv2.b"], pl.t2[i],

@@ -53,6 +53,19 @@ struct TileSmem {
   static constexpr int FLOATS = A_ELEMS + BN * 36;
 };
 
+// -DPN_GEMM_W2=1 (round-4 experiment, NOT adopted): the default 64x64 launches run as TWO waves
+// of 64x32 (two accumulators per wave, a quarter fewer LDS fragment reads per flop) instead of
+// four waves of 32x32 at 5 workgroups = 20 waves per CU.  149 VGPRs: 6 workgroups = 12 waves
+// per CU without spilling, 8 = 16 waves with 72-224 B of scratch.  Exact on the integer-operand
+// tests; stand-alone within -4 .. +3 % on the M = 21 950 shapes and 5-20 % slower on the
+// backbone's; pipelined 191.3 (6 / CU) and 175.6 (8 / CU) against 207.4 images/s.
+#ifndef PN_GEMM_W2
+#define PN_GEMM_W2 0
+#endif
+#ifndef PN_GEMM_W2_WGS
+#define PN_GEMM_W2_WGS 8
+#endif
+
 template <int BM, int BN, int AMODE, bool ADD>
 struct TileWgs {   // resident workgroups per CU this instantiation is sized (and register-bounded) for
   static constexpr int value =
@@ -89,7 +102,7 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
   constexpr int NB = (BN * BK / 4) / NT;
   constexpr int QM = BM / 4;         // float4 per k-row of a column-major A tile
   constexpr int KSTEP = NT / QM;     // k rows covered per pass
-  static_assert(NT == 256 || NT == 512, "4 or 8 waves");
+  static_assert(NT == 128 || NT == 256 || NT == 512, "2, 4 or 8 waves");
 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
   const int q8 = ntiles >> 3, r8 = ntiles & 7;
@@ -424,7 +437,9 @@ struct SingleLocator {
 
 // ADD: the launch has a row-periodic addend on A (positional encodings), pn_gemm_desc.Aadd
 template <int BM, int BN, int WM, int WN, int AMODE, bool ADD = false>
-__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (TileWgs<BM, BN, AMODE, ADD>::min_waves))
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN),
+                             ((BM == 64 && WM == 64) ? PN_GEMM_W2_WGS / 2
+                                                     : TileWgs<BM, BN, AMODE, ADD>::min_waves))
 void k_gemm_tile(const GemmP p, const int batch) {
   __shared__ __attribute__((aligned(16))) float smem[TileSmem<BM, BN, AMODE>::FLOATS];
   const SingleLocator loc{p, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN};
@@ -628,11 +643,13 @@ static int launch_tile(const GemmP& p, int batch, hipStream_t s, int flags) {
   constexpr int NT = 64 * (BM / WM) * (BN / WN);
   if (AMODE == A_ROW && p.Aadd) {
     auto kern = k_gemm_tile<BM, BN, WM, WN, AMODE, AMODE == A_ROW>;
-    static const int wgs = resident_wgs(kern, TileWgs<BM, BN, AMODE, (AMODE == A_ROW)>::value, NT);
+    static const int wgs = resident_wgs(
+        kern, (BM == 64 && WM == 64) ? PN_GEMM_W2_WGS : TileWgs<BM, BN, AMODE, (AMODE == A_ROW)>::value, NT);
     hipLaunchKernelGGL(kern, dim3(persistent_grid(ntiles, wgs, flags)), dim3(NT), 0, s, p, batch);
   } else {
     auto kern = k_gemm_tile<BM, BN, WM, WN, AMODE, false>;
-    static const int wgs = resident_wgs(kern, TileWgs<BM, BN, AMODE, false>::value, NT);
+    static const int wgs = resident_wgs(
+        kern, (BM == 64 && WM == 64) ? PN_GEMM_W2_WGS : TileWgs<BM, BN, AMODE, false>::value, NT);
     hipLaunchKernelGGL(kern, dim3(persistent_grid(ntiles, wgs, flags)), dim3(NT), 0, s, p, batch);
   }
   return PN_LAUNCH_CHECK();
@@ -714,12 +731,17 @@ static int launch_tile64_splitk(const GemmP& p, int batch, float* scratch, int64
                                 hipStream_t s, int flags) {
   int cps;
   const int S = splitk_factor(p, batch, scratch, scratch_floats, &cps, flags);
-  if (S <= 1) return launch_tile<64, 64, 32, 32, AMODE>(p, batch, s, flags);
+#if PN_GEMM_W2
+#define PN_T64_WM 64
+#else
+#define PN_T64_WM 32
+#endif
+  if (S <= 1) return launch_tile<64, 64, PN_T64_WM, 32, AMODE>(p, batch, s, flags);
   GemmP q = p;                       // pass 1: raw partial products into the scratch
   q.C = scratch; q.ldc = p.N; q.sC = (int64_t)p.M * p.N;
   q.bias = nullptr; q.Res = nullptr; q.relu = 0; q.relu_after = 0;
   q.ksplit = S; q.split_chunks = cps;
-  if (int rc = launch_tile<64, 64, 32, 32, AMODE>(q, batch * S, s, flags)) return rc;
+  if (int rc = launch_tile<64, 64, PN_T64_WM, 32, AMODE>(q, batch * S, s, flags)) return rc;
   const int64_t n = (int64_t)p.M * (p.N / 4);
   hipLaunchKernelGGL(k_splitk_reduce, dim3(pn_cdiv(n, 256), batch), dim3(256), 0, s, scratch, p, S);
   return PN_LAUNCH_CHECK();

@@ -504,6 +504,9 @@ class PSGTr:
         `gt_masks[i]`: image i's instance masks [G, h, w], 0/1 -- a BitmapMasks-like object
         (`.to_ndarray()`), a numpy array or a tensor (host or device)."""
         from . import hip
+        if not hasattr(self.bbox_head, "val_losses"):
+            raise NotImplementedError("loss values are built for CrossHead2 only (%s has no "
+                                      "loss forward here)" % type(self.bbox_head).__name__)
         x = self.extract_feat(img)
         if getattr(self.bbox_head, "use_mask", True):
             assert gt_masks is not None

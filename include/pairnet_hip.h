@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 17
+#define PN_ABI_VERSION 18
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -489,6 +489,16 @@ int pn_copy_stream(const void* src, void* dst, int64_t bytes, int wgs, void* str
  * host threads, 1..64): the inverse, one 0 / 1 byte per element = numpy bool. */
 int pn_pack_bool_bits(const uint8_t* bools, uint8_t* bits, int64_t n, void* stream);
 int pn_unpack_bits_host(const uint8_t* bits, uint8_t* bools, int64_t n, int threads);
+
+/* Ground truth from the decoded panoptic PNG (the evaluator's side: pairnet/datasets/psg.py:
+ * 354-372; the training-side loader: pairnet/datasets/pipelines/loading.py:128-147):
+ *   rgb   [H][W][3] uint8, RGB                 ids / cats [G] int32: the annotation's segments
+ *   masks [G][H][W] uint8 0/1 = (id(pixel) == ids[g]),  id = R + 256 G + 65536 B ([3P]
+ *         panopticapi rgb2id); every listed segment, an id absent from the image -> zeros
+ *   sem   [H][W] int32 or NULL: cats[g] of the LAST listed segment owning the pixel, else 255
+ * G <= 256; rgb and masks 4-byte aligned.  G == 0 with sem: sem is filled with 255. */
+int pn_pan_masks_u8(const uint8_t* rgb, const int* ids, const int* cats, uint8_t* masks, int* sem,
+                    int G, int H, int W, void* stream);
 
 /* Test-time image front end (configs/mask2former/pairnet.py:310-331, mean / std :229-231):
  * mmdet Resize(keep_ratio) [= mmcv.imresize = OpenCV INTER_LINEAR on uint8, fixed point] ->

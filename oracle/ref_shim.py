@@ -262,3 +262,124 @@ def reference_model_cfg():
     with open(path) as f:
         exec(compile(f.read(), path, "exec"), scope)
     return scope["model"]
+
+
+# ---- dataset side: PanopticSceneGraphDataset / LoadPanopticSceneGraphAnnotations -------------
+PAN_IMAGES = {}     # file name -> (H, W, 3) uint8 RGB array: what the stubbed image readers return
+CAPTURED = {}       # last call of the stubbed sgg_evaluation (its keyword arguments)
+
+
+def _ensure(name, **attrs):
+    m = sys.modules.get(name) or _mod(name)
+    m.__dict__.update(attrs)
+    return m
+
+
+def install_dataset():
+    """Load the reference's pairnet/datasets/psg.py and pipelines/loading.py in place, under
+    name-only stubs of what they import from mmcv / mmdet / detectron2 / panopticapi (all absent
+    from the image): file and image readers that serve PAN_IMAGES, empty pipeline base classes,
+    a COCOPanoptic that only keeps the dataset dict, and an `sgg_evaluation` that records what
+    the dataset's `evaluate` hands it.  The in-tree code -- the constructor's filtering,
+    `get_ann_info`, the ground-truth block of `evaluate`, `_load_masks_and_semantic_segs` --
+    runs unmodified.  Returns (PanopticSceneGraphDataset, LoadPanopticSceneGraphAnnotations)."""
+    if "pairnet.datasets.psg" in sys.modules:
+        return (sys.modules["pairnet.datasets.psg"].PanopticSceneGraphDataset,
+                sys.modules["pairnet.datasets.pipelines.loading"].LoadPanopticSceneGraphAnnotations)
+    if not available():
+        raise RuntimeError("reference tree not present at " + REF_ROOT)
+    sys.dont_write_bytecode = True
+    import json
+    import numpy as np
+    from . import dataset as D
+
+    def _image(path, **kw):
+        return PAN_IMAGES[os.path.basename(path)].copy()
+
+    class FileClient:
+        def __init__(self, **kw):
+            pass
+
+        def get(self, filename):
+            return filename                 # (imfrombytes below resolves it)
+
+    class ProgressBar:
+        def __init__(self, n):
+            pass
+
+        def update(self):
+            pass
+
+    def load(path):
+        with open(path) as f:
+            return json.load(f)
+
+    _ensure("mmcv", load=load, FileClient=FileClient, ProgressBar=ProgressBar,
+            imfrombytes=lambda b, flag="color", channel_order="bgr": _image(b))
+    _ensure("mmcv.parallel", DataContainer=object)
+    _ensure("detectron2")
+    _ensure("detectron2.data")
+    _ensure("detectron2.data.detection_utils", read_image=_image)
+    _ensure("panopticapi")
+    _ensure("panopticapi.utils", rgb2id=D.rgb2id)      # [3P]: the published one-line definition
+
+    class CocoPanopticDataset:
+        def __len__(self):
+            return len(self.data_infos)
+
+        def _set_group_flag(self):
+            pass
+
+        def pre_pipeline(self, results):
+            pass
+
+    class COCOPanoptic:
+        def createIndex(self):
+            self.imgToAnns = {a["image_id"]: [a] for a in self.dataset["annotations"]}
+            self.catToImgs = {}
+            self.cats = {c["id"]: c for c in self.dataset["categories"]}
+
+        def get_cat_ids(self):
+            return sorted(self.cats)
+
+    class _Pipe:
+        def __init__(self, with_bbox=True, with_label=True, with_mask=True, with_seg=True,
+                     file_client_args=None, **kw):
+            self.with_bbox, self.with_label = with_bbox, with_label
+            self.with_mask, self.with_seg = with_mask, with_seg
+            self.file_client_args, self.file_client = dict(file_client_args or {}), None
+
+    class BitmapMasks:
+        def __init__(self, masks, height, width):
+            self.masks = np.stack(masks, 0) if len(masks) else np.zeros((0, height, width), np.uint8)
+            self.height, self.width = height, width
+
+        def to_ndarray(self):
+            return self.masks
+
+    _ensure("mmdet")
+    _ensure("mmdet.core", BitmapMasks=BitmapMasks)
+    _ensure("mmdet.datasets", DATASETS=_Registry(), PIPELINES=_Registry(),
+            CocoPanopticDataset=CocoPanopticDataset)
+    _ensure("mmdet.datasets.coco_panoptic", COCOPanoptic=COCOPanoptic)
+    _ensure("mmdet.datasets.pipelines", Compose=lambda p: p, DefaultFormatBundle=object,
+            LoadAnnotations=_Pipe, to_tensor=None)
+    _ensure("mmdet.datasets.pipelines.loading", LoadPanopticAnnotations=_Pipe)
+
+    def sgg_evaluation(*a, **kw):
+        CAPTURED.clear()
+        CAPTURED.update(kw, args=a)
+        return "captured"
+
+    class Result:                           # (relation_util.Result is a field holder: keep the
+        def __init__(self, **kw):           #  keyword arguments the dataset passes)
+            self.__dict__.update(kw)
+
+    for pkg in ("pairnet", "pairnet.models", "pairnet.models.relation_heads", "pairnet.datasets",
+                "pairnet.datasets.pipelines"):
+        _ensure(pkg)
+    _ensure("pairnet.evaluation", sgg_evaluation=sgg_evaluation)
+    _ensure("pairnet.models.relation_heads.approaches", Result=Result)
+    loading = _load("pairnet.datasets.pipelines.loading", "pairnet/datasets/pipelines/loading.py")
+    psg = _load("pairnet.datasets.psg", "pairnet/datasets/psg.py")
+    return psg.PanopticSceneGraphDataset, loading.LoadPanopticSceneGraphAnnotations

@@ -16,6 +16,7 @@ from .detector import (PSGTr, Result, ResultStreamer, build_detector, load_check
                        triplet2Result)
 from .dist import all_gather_triplets, shard_indices  # noqa: F401
 from .evaluation import SceneGraphMetrics, TripletEvaluator  # noqa: F401
+from . import dataset  # noqa: F401  (PSG ground truth: load_psg, ann_info, eval_ground_truth, ...)
 
 __all__ = ["ConfigDict", "load_config", "pairnet_head_cfg", "pairnet_r50", "CrossHead2",
            "PSGTr", "Result", "ResultStreamer", "build_detector", "load_checkpoint", "triplet2Result", "all_gather_triplets",
@@ -23,4 +24,4 @@ __all__ = ["ConfigDict", "load_config", "pairnet_head_cfg", "pairnet_r50", "Cros
            "baseline_r50", "PSGTrHead2", "psgtr2_head_cfg", "psgtr2_r50", "ResNet50Hip",
            "SwinTransformerHip", "pairnet_swin", "swin_backbone_cfg", "TestPipeline", "test_pipeline_cfg",
            "CrossHeadBBox", "ChannelMapper", "bbox_head_cfg", "channel_mapper_cfg", "cross_r101_vg",
-           "TripletEvaluator", "SceneGraphMetrics"]
+           "TripletEvaluator", "SceneGraphMetrics", "dataset"]

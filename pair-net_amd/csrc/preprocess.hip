@@ -69,3 +69,78 @@ extern "C" int pn_preprocess_u8_f32(const uint8_t* img, int H, int W, float* out
                      mean3[2], stdinv3[0], stdinv3[1], stdinv3[2], to_rgb);
   return PN_LAUNCH_CHECK();
 }
+
+// ---- ground truth from the panoptic PNG (pairnet/datasets/psg.py:354-372 for the evaluator,
+// pipelines/loading.py:128-147 for the training-side loader): the decoded RGB image -> segment
+// id per pixel ([3P] panopticapi rgb2id: R + 256 G + 65536 B) -> one 0/1 byte mask per listed
+// segment (`seg == id`, every segment, things and stuff; a listed id absent from the image
+// gives an empty mask) and, optionally, the semantic map (the category of the LAST listed
+// segment that owns the pixel, 255 where none does: `np.where` applied in list order).
+// HBM-bound byte work: 3 B read, G (+4) B written per pixel; a thread owns four consecutive
+// pixels (three aligned 32-bit loads, one 32-bit store per segment), the <= 256 ids sit in LDS.
+#define PAN_MAX_SEGMENTS 256
+__global__ __launch_bounds__(256) void k_pan_masks(const uint8_t* __restrict__ rgb,
+                                                   const int* __restrict__ ids,
+                                                   const int* __restrict__ cats,
+                                                   uint8_t* __restrict__ masks,
+                                                   int* __restrict__ sem, const int G,
+                                                   const int64_t HW) {
+  __shared__ int s_id[PAN_MAX_SEGMENTS], s_cat[PAN_MAX_SEGMENTS];
+  for (int g = threadIdx.x; g < G; g += 256) {
+    s_id[g] = ids[g];
+    s_cat[g] = cats ? cats[g] : 0;
+  }
+  __syncthreads();
+  const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p0 >= HW) return;
+  int id[4];
+  if (p0 + 4 <= HW) {             // 12 bytes = three aligned words (the image base is 4-aligned)
+    const unsigned* w = reinterpret_cast<const unsigned*>(rgb + p0 * 3);
+    const unsigned a = w[0], b = w[1], c = w[2];
+    id[0] = (int)(a & 0xffffffu);                                   // R0 G0 B0
+    id[1] = (int)((a >> 24) | ((b & 0xffffu) << 8));                // R1 | G1 B1
+    id[2] = (int)((b >> 16) | ((c & 0xffu) << 16));                 // R2 G2 | B2
+    id[3] = (int)(c >> 8);                                          // R3 G3 B3
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t p = p0 + j < HW ? p0 + j : HW - 1;
+      id[j] = rgb[p * 3] + 256 * rgb[p * 3 + 1] + 65536 * rgb[p * 3 + 2];
+    }
+  }
+  int sm[4] = {255, 255, 255, 255};
+  const bool whole = p0 + 4 <= HW && !(HW & 3);      // (every row of `masks` 4-aligned)
+  for (int g = 0; g < G; ++g) {
+    const int want = s_id[g];
+    const unsigned m0 = id[0] == want, m1 = id[1] == want, m2 = id[2] == want, m3 = id[3] == want;
+    if (m0) sm[0] = s_cat[g];
+    if (m1) sm[1] = s_cat[g];
+    if (m2) sm[2] = s_cat[g];
+    if (m3) sm[3] = s_cat[g];
+    uint8_t* dst = masks + (int64_t)g * HW + p0;
+    if (whole) {
+      *reinterpret_cast<unsigned*>(dst) = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+    } else {
+      const unsigned m[4] = {m0, m1, m2, m3};
+      for (int j = 0; j < 4; ++j)
+        if (p0 + j < HW) dst[j] = (uint8_t)m[j];
+    }
+  }
+  if (sem) {
+    for (int j = 0; j < 4; ++j)
+      if (p0 + j < HW) sem[p0 + j] = sm[j];
+  }
+}
+
+extern "C" int pn_pan_masks_u8(const uint8_t* rgb, const int* ids, const int* cats, uint8_t* masks,
+                               int* sem, int G, int H, int W, void* stream) {
+  if (!rgb || H <= 0 || W <= 0 || G < 0 || G > PAN_MAX_SEGMENTS) return PN_BAD_ARG;
+  if (G > 0 && (!ids || !masks)) return PN_BAD_ARG;
+  if (sem && G > 0 && !cats) return PN_BAD_ARG;
+  if (((uintptr_t)rgb | (uintptr_t)masks) & 3) return PN_BAD_ARG;
+  if (G == 0 && !sem) return 0;
+  const int64_t HW = (int64_t)H * W;
+  hipLaunchKernelGGL(k_pan_masks, dim3(pn_cdiv(pn_cdiv(HW, 4), 256)), dim3(256), 0,
+                     (hipStream_t)stream, rgb, ids, cats, masks, sem, G, HW);
+  return PN_LAUNCH_CHECK();
+}

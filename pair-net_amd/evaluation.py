@@ -23,6 +23,12 @@ import torch
 from . import hip
 
 
+def _tensor(x):
+    """Ground truth as handed in: numpy, lists, or tensors (host or ALREADY on the device, as
+    `pairnet_amd.dataset.eval_ground_truth` leaves the masks)."""
+    return x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))
+
+
 class TripletEvaluator:
     def __init__(self, iou_thr=0.5, ks=(20, 50, 100)):
         self.iou_thr, self.ks = float(iou_thr), tuple(ks)
@@ -37,10 +43,10 @@ class TripletEvaluator:
         dev = masks.device
         R, C1 = r_dists.shape
         H, W = masks.shape[-2:]
-        gt_rels = torch.as_tensor(np.asarray(gt_rels), dtype=torch.int64)
-        gt_labels = torch.as_tensor(np.asarray(gt_labels), dtype=torch.int64)
+        gt_rels = _tensor(gt_rels).cpu().to(torch.int64)
+        gt_labels = _tensor(gt_labels).cpu().to(torch.int64)
         G, nobj = int(gt_rels.shape[0]), int(gt_labels.shape[0])
-        gt_masks = torch.as_tensor(np.asarray(gt_masks)).to(dev).view(nobj, H, W)
+        gt_masks = _tensor(gt_masks).to(dev).view(nobj, H, W)
         i32 = lambda t: t.to(torch.int32).to(dev).contiguous()
         gtrip = i32(torch.stack([gt_labels[gt_rels[:, 0]], gt_rels[:, 2],
                                  gt_labels[gt_rels[:, 1]]], 1))
@@ -84,8 +90,8 @@ class TripletEvaluator:
         det, labels, r_dists = result[0], result[1], result[5]
         dev = det.device
         R, C1 = r_dists.shape
-        gt_rels = torch.as_tensor(np.asarray(gt_rels), dtype=torch.int64)
-        gt_labels = torch.as_tensor(np.asarray(gt_labels), dtype=torch.int64)
+        gt_rels = _tensor(gt_rels).cpu().to(torch.int64)
+        gt_labels = _tensor(gt_labels).cpu().to(torch.int64)
         G = int(gt_rels.shape[0])
         gbox = torch.as_tensor(np.asarray(gt_boxes), dtype=torch.float32).to(dev).contiguous()
         i32 = lambda t: t.to(torch.int32).to(dev).contiguous()
@@ -142,7 +148,7 @@ class TripletEvaluator:
         gt_rels = np.asarray(gt_rels)
         gt_labels_np = np.asarray(gt_labels)
         nobj, P = int(gt_labels_np.shape[0]), int(masks.shape[0])
-        gm = torch.as_tensor(np.asarray(gt_masks)).to(dev).view(nobj, H, W)
+        gm = _tensor(gt_masks).to(dev).view(nobj, H, W)
         nw = (H * W + 63) // 64
         pw = torch.empty(P, nw, device=dev, dtype=torch.int64)
         gw = torch.empty(nobj, nw, device=dev, dtype=torch.int64)

@@ -118,6 +118,7 @@ _SIGS = {
                                    C.c_double, _i32, _i32, _vp, _vp]),
     "pn_triplet_match_boxes": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp,
                                          _vp, _f32, _i32, _i32, _vp, _vp]),
+    "pn_pan_masks_u8": (C.c_int, [_vp] * 5 + [_i32] * 3 + [_vp]),
     "pn_preprocess_u8_f32": (C.c_int, [_vp, _i32, _i32, _vp] + [_i32] * 4 + [C.POINTER(_f32),
                                                                             C.POINTER(_f32), _i32, _vp]),
     "pn_pack_mask_bits": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
@@ -135,7 +136,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 17   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 18   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -890,6 +891,20 @@ def box_triplets(s_cls, o_cls, s_box, o_box, det, labels, R, Cc, img_h, img_w, s
 
 
 # ---- loss forward (csrc/loss.hip) ----------------------------------------------------------
+def pan_masks(rgb, ids, cats, masks, sem=None):
+    """rgb [H][W][3] uint8 (RGB panoptic PNG) -> masks [G][H][W] uint8 (`rgb2id(rgb) == ids[g]`)
+    and optionally sem [H][W] int32 (category of the last listed owner, 255 = none)."""
+    H, W, c = rgb.shape
+    G = int(ids.shape[0])
+    assert c == 3 and rgb.dtype == torch.uint8 and rgb.is_contiguous()
+    assert masks.shape == (G, H, W) and masks.is_contiguous() and masks.dtype in (torch.uint8, torch.bool)
+    _check(lib().pn_pan_masks_u8(_ptr(rgb, torch.uint8), _ptr(ids, torch.int32) if G else None,
+                                 _ptr(cats, torch.int32) if (G and cats is not None) else None,
+                                 _ptr(masks, masks.dtype) if G else None,
+                                 _ptr(sem, torch.int32) if sem is not None else None, G, H, W,
+                                 _stream()), "pn_pan_masks_u8")
+
+
 def gt_mask_prepare(masks, out, H, W):
     """masks [G][h][w] bool / uint8 -> out [G][Ho][Wo] uint8: zero-padded to [H][W], then
     nearest-neighbour resized (psgtr.py:126-141)."""

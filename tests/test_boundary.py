@@ -45,6 +45,9 @@ def test_bad_arguments_are_refused_without_launching(built_lib):
     assert lib.pn_msda_ex_f32(None, 256, None, 288, None, 1, 3, None, None, 0, None) == -1
     assert lib.pn_point_sample_f32(None, 0, None, None, 1, 8, 8, 16, None) == -1
     assert lib.pn_gt_mask_prepare_u8(None, None, 3, 8, 8, 16, 16, 8, 8, None) == -1
+    assert lib.pn_pan_masks_u8(None, None, None, None, None, 0, 8, 8, None) == -1
+    assert lib.pn_pan_masks_u8(16, 16, None, 32, None, 257, 8, 8, None) == -1      # G > 256
+    assert lib.pn_pan_masks_u8(16, 16, None, 33, None, 2, 8, 8, None) == -1        # alignment
     assert lib.pn_gt_mask_prepare_u8(16, 32, 3, 20, 8, 16, 16, 8, 8, None) == -1   # h > H
     assert lib.pn_mask_match_cost_f32(None, 134, None, None, None, None, 100, 3, 64, 2.0, 5.0, 5.0,
                                       1.0, None) == -1

@@ -964,6 +964,59 @@ def main():
                             "BCE(pos_weight) reductions on the GPU" % G}
             except Exception as e:      # noqa: BLE001 -- an extra, never the headline
                 out["loss_forward"] = repr(e)
+        # SURVEY 8 f1 (ground-truth side): panoptic PNG -> per-segment masks, one kernel
+        try:
+            from pairnet_amd import hip as _hip
+            g = torch.Generator().manual_seed(7)
+            Hg, Wg, Gs = 480, 640, 20
+            ids = torch.randperm(2 ** 24 - 2, generator=g)[:Gs].to(torch.int32) + 1
+            grid = torch.randint(0, Gs, (Hg // 8, Wg // 8), generator=g) \
+                .repeat_interleave(8, 0).repeat_interleave(8, 1)
+            seg = ids.long()[grid]
+            rgb = torch.stack([seg % 256, (seg // 256) % 256, seg // 65536], -1).to(torch.uint8).to(dev)
+            ids_d, cats_d = ids.to(dev), torch.arange(Gs, dtype=torch.int32, device=dev)
+            gm = torch.empty((Gs, Hg, Wg), dtype=torch.uint8, device=dev)
+            sem = torch.empty((Hg, Wg), dtype=torch.int32, device=dev)
+            run = lambda: _hip.pan_masks(rgb, ids_d, cats_d, gm, sem)
+            for _ in range(5):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(200):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / 200
+            nbytes = Hg * Wg * (3 + Gs + 4)
+            ok = bool(torch.equal(gm.cpu(), (seg[None] == ids.long()[:, None, None]).to(torch.uint8)))
+            # the same kernel where it is bandwidth- rather than launch-sized
+            Hb, Wb, Gb = 2048, 2048, 64
+            rgb_b = torch.randint(0, 256, (Hb, Wb, 3), generator=g, dtype=torch.uint8).to(dev)
+            ids_b = torch.arange(1, Gb + 1, dtype=torch.int32, device=dev)
+            gm_b = torch.empty((Gb, Hb, Wb), dtype=torch.uint8, device=dev)
+            big = lambda: _hip.pan_masks(rgb_b, ids_b, None, gm_b)
+            for _ in range(3):
+                big()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(20):
+                big()
+            e1.record()
+            torch.cuda.synchronize()
+            us_b = 1e3 * e0.elapsed_time(e1) / 20
+            nb_b = Hb * Wb * (3 + Gb)
+            out["ground_truth_masks"] = {
+                "large_2048x2048x64": {"us": us_b, "gbs": nb_b / us_b * 1e-3,
+                                       "frac_of_hbm": nb_b / us_b * 1e-3 / 8000.0},
+                "kernel": "k_pan_masks", "us_per_image": us, "bytes_per_image": nbytes,
+                "gbs": nbytes / us * 1e-3, "frac_of_hbm": nbytes / us * 1e-3 / 8000.0,
+                "equals_rgb2id_compare": ok,
+                "what": "480x640 panoptic PNG (RGB, resident in HBM) -> 20 segment masks + semantic "
+                        "map (psg.py:354-372, loading.py:128-147), back-to-back launches incl. "
+                        "launch overhead: a 8 MB problem is launch-latency sized"}
+        except Exception as e:      # noqa: BLE001 -- an extra, never the headline
+            out["ground_truth_masks"] = repr(e)
         if engine is not None and args.mask_order == "reference":
             # the same pipelined steps with the opt-in shortcut for the attention masks: the
             # mask feature is resampled to each level once per image and every layer's logits

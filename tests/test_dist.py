@@ -477,7 +477,9 @@ ann = []
 for i in range(N):
     gm = torch.rand(3, 80, 112, generator=ga) > 0.5
     rels = np.array([[0, 1, 5], [1, 2, 7], [2, 0, 9]]) if i != 2 else np.zeros((0, 3), dtype=np.int64)
-    ann.append(dict(gt_rels=rels, gt_labels=np.array([1 + i, 20, 90]), gt_masks=gm.numpy()))
+    # (odd images: masks already on the device, as pairnet_amd.dataset.eval_ground_truth leaves them)
+    ann.append(dict(gt_rels=rels, gt_labels=np.array([1 + i, 20, 90]),
+                    gt_masks=gm.to("cuda:0") if i % 2 else gm.numpy()))
 if world == 0:      # the optional stream -> hardware-queue calibration of the detector's pipeline
     times = det.calibrate_pipeline(*data[0], depth=3, steps=2)
     assert len(times) == 4 and all(t > 0 for t in times) and det.pipeline(3) is det.pipeline(3)

@@ -78,21 +78,30 @@ def latest_pmc():
     return files[-1] if files else None
 
 
-def sustained_mfma_clock():
-    """(GHz, source) the fp32 matrix pipe held under the path's own GEMMs, from the committed
-    stall counters (tools/gemm_stalls.py: MFMA instructions x 64 cycles / 1024 SIMDs / (busy
-    fraction x kernel time)); the long launches only (>= 70 us: their CU-busy window covers the
-    kernel).  None when the evidence file is absent."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_stalls.json")))
-    if not files:
-        return None, None
-    try:
-        d = json.load(open(files[-1]))
-        clk = [v["derived"]["implied_mfma_clock_ghz"] for v in d["shapes"].values()
-               if v.get("derived", {}).get("us", 0) >= 70 and "implied_mfma_clock_ghz" in v["derived"]]
-        return (sum(clk) / len(clk), os.path.relpath(files[-1], ROOT)) if clk else (None, None)
-    except (OSError, ValueError, KeyError, TypeError):
-        return None, None
+def gather_roof(dev, hip, lines_log2=(12, 14, 18), reps=20):
+    """In-run micro-probe (csrc/msda.hip k_gather_probe): the rate at which THIS board delivers
+    the deformable-sampling access pattern -- 8 lanes x 16 B per random 128-byte line, 12 lines
+    in flight per lane group, nothing else -- for a window of 2^k lines: 512 KB (L2-resident
+    everywhere), 2 MB (about one XCD band of the value map: the kernel's working set per L2)
+    and 32 MB (HBM).  Returns {window_kb: TB/s}; one layer moves 21 950 x 8 x 12 x 4 lines."""
+    nwg = 21950 * 4
+    lines = torch.zeros((1 << max(lines_log2)) * 32, device=dev)
+    idx = torch.randint(0, 1 << 30, (nwg * 32 * 12,), device=dev, dtype=torch.int32)
+    out = torch.empty(nwg * 256, device=dev)
+    res = {}
+    for k in lines_log2:
+        mask = (1 << k) - 1
+        for _ in range(3):
+            hip.gather_probe(lines, idx, out, nwg, mask)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            hip.gather_probe(lines, idx, out, nwg, mask)
+        e1.record()
+        e1.synchronize()
+        sec = e0.elapsed_time(e1) * 1e-3 / reps
+        res[(1 << k) * 128 // 1024] = nwg * 256 * 12 * 16 / sec / 1e12
+    return res
 
 
 def bench_bbox(args, dev, rank, world):
@@ -602,6 +611,109 @@ def main():
         backbone.use_graphs = not args.no_graphs
         head.grid_reserve = backbone.grid_reserve = engine.grid_reserve
 
+    # ---- secondary: the reference's REAL call pattern (tools/test.py:199-267 with
+    # Resize(keep_ratio) + Pad(size_divisor=1), configs/mask2former/pairnet.py:310-321): one
+    # image per step, a new tensor shape every few images.  >= 200 images whose ORIGINAL sizes
+    # are drawn from the COCO size histogram (13 distinct padded shapes, 16 original sizes,
+    # seeded random order) through `dist.multi_gpu_test`: cold pass (every shape's first
+    # sight inside the timed region), then a second pass; every record is checked bit for
+    # bit against an eager single-stream call on that image alone. ----
+    shape_mix = None
+    if product_loop is not None and (H, W) == (800, 1333):
+        from pairnet_amd.dist import multi_gpu_test, unpack_triplets
+        from pairnet_amd.preprocess import rescale_size
+        from pairnet_amd.head import CrossHead2 as _H
+        ORIG = [((480, 640), 22), ((427, 640), 15), ((640, 480), 6), ((426, 640), 6),
+                ((375, 500), 5), ((428, 640), 3), ((640, 427), 3), ((425, 640), 2),
+                ((333, 500), 2), ((360, 640), 2), ((500, 375), 2), ((424, 640), 2),
+                ((612, 612), 2), ((640, 640), 1), ((512, 640), 1), ((640, 426), 1)]
+        n_mix = 240
+        gm = torch.Generator().manual_seed(77)
+        wts = torch.tensor([float(wt) for _, wt in ORIG])
+        draw = torch.multinomial(wts, n_mix, replacement=True, generator=gm).tolist()
+        draw[:len(ORIG)] = list(range(len(ORIG)))       # (every size at least once)
+        perm = torch.randperm(n_mix, generator=gm).tolist()
+        draw = [draw[i] for i in perm]
+        imgs_by_shape, items = {}, []
+        for k, oi in enumerate(draw):
+            (h0, w0), _ = ORIG[oi]
+            hn, wn = rescale_size(h0, w0, (1333, 800))
+            pair = imgs_by_shape.setdefault((hn, wn), [
+                torch.randn(1, 3, hn, wn, generator=gm).to(dev) for _ in range(2)])
+            meta = dict(img_shape=(hn, wn, 3), ori_shape=(h0, w0, 3), pad_shape=(hn, wn, 3),
+                        scale_factor=[wn / w0, hn / h0, wn / w0, hn / h0])
+            items.append((pair[k % 2], [meta], (hn, wn), k % 2, (h0, w0)))
+        data = [(im, m) for im, m, _, _, _ in items]
+        det.reserve([(800, 1333), (1333, 800)], depth=args.depth,
+                    orig_sizes=[sz for sz, _ in ORIG])
+        arenas = list(head._arenas.values()) + list(head._post_arenas.values()) + \
+            list(backbone._arenas.values())
+        grows0 = sum(a.grows for a in arenas)
+        caps0, ev0 = _H.captures, head._plans.evictions + backbone._plans.evictions
+        torch.cuda.synchronize()
+        mem0 = torch.cuda.memory_allocated()
+        t0 = time.perf_counter()
+        cold = multi_gpu_test(det, data, depth=args.depth, force_collective=one_rank)
+        torch.cuda.synchronize()
+        dt_cold = time.perf_counter() - t0
+        caps1 = _H.captures
+        t0 = time.perf_counter()
+        warm = multi_gpu_test(det, data, depth=args.depth, force_collective=one_rank)
+        torch.cuda.synchronize()
+        dt_warm = time.perf_counter() - t0
+        mem1 = torch.cuda.memory_allocated()
+        # per-shape steady state: each padded shape alone, 24 images after its own warm-up
+        alone_ms = {}
+        for shp, pair in imgs_by_shape.items():
+            (h0, w0) = next(o for _, _, s_, _, o in items if s_ == shp)
+            m = next(m for _, m, s_, _, _ in items if s_ == shp)
+            one = [(pair[i % 2], m) for i in range(24)]
+            multi_gpu_test(det, one[:8], depth=args.depth, force_collective=one_rank)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            multi_gpu_test(det, one, depth=args.depth, force_collective=one_rank)
+            torch.cuda.synchronize()
+            alone_ms[shp] = 1e3 * (time.perf_counter() - t0) / len(one)
+        ideal = sum(alone_ms[s_] for _, _, s_, _, _ in items) / 1e3
+        # every record of both passes == an eager single-stream call on that image alone
+        head.use_graphs = backbone.use_graphs = False
+        head.grid_reserve = backbone.grid_reserve = 0
+        want, same = {}, torch.equal(cold["records"], warm["records"])
+        for k, (im, m, shp, which, orig) in enumerate(items):
+            if (shp, which, orig) not in want:
+                r = head.simple_test_bboxes(backbone(im, slot=7), m)[0]
+                sub, obj = head.pair_positions()
+                from pairnet_amd.dist import pack_triplets
+                want[(shp, which, orig)] = pack_triplets(r[1], r[7], sub[0], obj[0]).clone()
+            same &= torch.equal(cold["records"][k].to(dev), want[(shp, which, orig)])
+        head.use_graphs = not args.no_graphs
+        backbone.use_graphs = not args.no_graphs
+        head.grid_reserve = backbone.grid_reserve = engine.grid_reserve
+        if not same:
+            raise SystemExit("shape_mix_product_loop: a record differs from the eager "
+                             "single-shape result")
+        shape_mix = {
+            "images": n_mix, "padded_shapes": sorted("%dx%d" % s_ for s_ in imgs_by_shape),
+            "original_sizes": len(ORIG),
+            "images_per_s": n_mix / dt_cold, "ms_per_image": 1e3 * dt_cold / n_mix,
+            "second_pass_images_per_s": n_mix / dt_warm,
+            "per_shape_alone_ms": {"%dx%d" % k_: round(v, 3) for k_, v in sorted(alone_ms.items())},
+            "ideal_images_per_s": n_mix / ideal,
+            "frac_of_ideal": ideal / dt_cold, "second_pass_frac_of_ideal": ideal / dt_warm,
+            "arena_grows_in_run": sum(a.grows for a in arenas) - grows0,
+            "plan_evictions_in_run": head._plans.evictions + backbone._plans.evictions - ev0,
+            "graph_captures_first_pass": caps1 - caps0,
+            "graph_captures_second_pass": _H.captures - caps1,
+            "arena_bytes": head.arena_bytes() + backbone.arena_bytes(),
+            "device_bytes_growth_over_both_passes": int(mem1 - mem0),
+            "records_bitwise_eager_single_shape": bool(same),
+            "what": "pairnet_amd.dist.multi_gpu_test over %d images of %d padded shapes "
+                    "(original sizes from the COCO histogram, seeded order): first pass incl. "
+                    "every shape's first sight, then a second pass; `ideal` = each image at "
+                    "the steady-state rate of its own shape run alone" % (
+                        n_mix, len(imgs_by_shape))}
+        del imgs_by_shape, items, data
+
     # ---- secondary: the head alone on the resident pyramid (round 1's headline) ----
     head_only = None
     if args.path == "image" and world == 1:
@@ -809,6 +921,8 @@ def main():
             out["simple_test_incl_result_d2h"] = simple_test
         if product_loop is not None:
             out["multi_gpu_test_product_loop"] = product_loop
+        if shape_mix is not None:
+            out["shape_mix_product_loop"] = shape_mix
         if head_only is not None:
             out["head_only"] = head_only
         if from_decoded is not None:
@@ -841,17 +955,7 @@ def main():
                                             for v in sq) / sum(v["launches_profiled"] for v in sq)
                 except (OSError, ValueError, KeyError, TypeError):
                     pass
-                extra = {}
-                if bound == "mfma":
-                    # informational: the same rate against the roof at the clock the board
-                    # actually holds under this load (it throttles on fp32-MFMA power); `frac`
-                    # stays the fraction of the 2.4 GHz datasheet roof
-                    clk, clk_src = sustained_mfma_clock()
-                    if clk:
-                        extra = {"sustained_clock_ghz": clk, "sustained_clock_source": clk_src,
-                                 "frac_of_sustained_clock_roof": ach / (peak * clk / 2.4)}
                 return {
-                    **extra,
                     "kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
                     "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
                     "mfma_util_pmc": mfma_util,
@@ -894,7 +998,28 @@ def main():
             # the north star's other named kernel: achieved HBM GB/s of the deformable sampling
             msda = [k for k in prof if k.startswith("k_msda")]
             if msda:
-                out["roofline_deformable_sampling"] = roof(msda[0])
+                r = out["roofline_deformable_sampling"] = roof(msda[0])
+                # HBM is the wrong roof for a gather whose value rows are L2-resident (each
+                # XCD samples its own band): the roof it is under is the rate the vector L1 /
+                # L2 deliver for this access pattern, measured here by a bare-gather probe in
+                # the same run (never a constant).  One layer passes N x 8 heads x 12 (level,
+                # point) x 4 taps x 128 B through the L1.
+                try:
+                    probe = gather_roof(dev, hip)
+                    l1_bytes = 21950.0 * (H * W) / (800 * 1333) * 8 * 12 * 4 * 128 \
+                        if (H, W) != (800, 1333) else 21950.0 * 8 * 12 * 4 * 128
+                    ach = l1_bytes / (r["avg_launch_us"] * 1e-6) / 1e12
+                    r.update({
+                        "gather_bytes_per_launch": l1_bytes, "gather_achieved": ach,
+                        "gather_unit": "TB/s", "gather_peak": probe[2048],
+                        "frac_of_gather_peak": ach / probe[2048],
+                        "gather_probe_tbs_by_window_kb": {str(k): v for k, v in probe.items()},
+                        "gather_peak_source": "k_gather_probe in this run: 8 lanes x 16 B per "
+                                              "random 128-byte line, 12 lines in flight per lane "
+                                              "group, 2 MB window (one XCD band of the value map)"})
+                except Exception as e:      # (a probe failure must not lose the bench line)
+                    r["gather_peak"] = None
+                    r["gather_probe_error"] = repr(e)
             # ... and its attention GEMMs (QK^T / PV on the fp32 MFMA, flash-style): small
             # latency-bound launches of the query chain; matrix-pipe utilisation from the PMC pass
             if "k_attn_chunk" in prof:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 18
+#define PN_ABI_VERSION 19
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -297,6 +297,33 @@ int pn_msda_loc_f32(const float* value, int64_t ld_value, const int64_t* spatial
                     const int64_t* level_start_index, const float* sampling_locations,
                     const float* attention_weights, float* out, int B, int N, int Nq, int L,
                     void* stream);
+
+/* Backward of pn_msda_loc_f32, in the shape of mmcv's `ext_module.ms_deform_attn_backward`
+ * (mmcv/ops/multi_scale_deform_attn.py, `MultiScaleDeformableAttnFunction.backward`; the second
+ * half of the reference's one native boundary -- what the training step of
+ * pairnet_head.py:420-757 / tools/train.py:115-241 differentiates through):
+ *   grad_output         [B][Nq][256]
+ *   grad_value          [B][N][ld_value]   ACCUMULATED into (hardware fp32 atomics): the caller
+ *                                          zeroes it first, as mmcv does (zeros_like(value))
+ *   grad_sampling_loc   [B][Nq][8][L][4][2]  written
+ *   grad_attn_weight    [B][Nq][8][L][4]     written
+ * Arithmetic of mmcv's ms_deform_attn_col2im_bilinear (locations outside (-1, H) x (-1, W)
+ * contribute nothing); grad_value's summation order is not deterministic (nor is mmcv's), the
+ * other two outputs are. */
+int pn_msda_bwd_f32(const float* value, int64_t ld_value, const int64_t* spatial_shapes,
+                    const int64_t* level_start_index, const float* sampling_locations,
+                    const float* attention_weights, const float* grad_output, float* grad_value,
+                    float* grad_sampling_loc, float* grad_attn_weight, int B, int N, int Nq, int L,
+                    void* stream);
+
+/* Diagnostic (bench.py's `roofline_deformable_sampling.gather_peak`): the bare access pattern of
+ * the sampling kernels above -- 8 lanes x 16 B per random 128-byte line, 12 independent lines per
+ * lane group, no arithmetic but a sum -- over `workgroups` x 256 threads, lines drawn from the
+ * first line_mask + 1 (a power of two) lines of `lines`; idx [workgroups][32][12] int32 (any
+ * values: masked), out [workgroups][256].  Replaces nothing in the reference: it measures the
+ * roof the deformable-attention gather (mmcv ms_deform_attn_forward) sits under here. */
+int pn_gather_probe_f32(const float* lines, const int32_t* idx, float* out, int workgroups,
+                        int line_mask, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Positional encoding / resampling

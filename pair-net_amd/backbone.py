@@ -17,7 +17,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
-from .plans import PlanCache
+from .plans import Arena, PlanCache, measure_bytes
 
 BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}   # bottleneck ResNets (mmdet arch_settings)
 EPS = 1e-5
@@ -73,9 +73,12 @@ class ResNet50Hip:
             if v.dim() == 4:
                 fan_in = v.shape[1] * v.shape[2] * v.shape[3]
                 v.copy_(torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5)
-        self.device, self.w, self._plans = None, None, PlanCache()
-        # replay the forward pass as one hipGraph after an eager warm-up call
+        self.device, self.w, self._plans, self._arenas = None, None, PlanCache(), {}
+        # replay the forward pass as one hipGraph once a (shape, slot) has run `graph_after`
+        # times eagerly (no host synchronisation either way: plans are views of the slot's
+        # arena, plans.py)
         self.use_graphs = False
+        self.graph_after = 1
         # persistent-GEMM workgroup slots left free for concurrent streams (hip.reserve_slots)
         self.grid_reserve = 0
         # 3x3 stride-1 layers of >= 128 channels (stages 2-4): "winograd" = F(2x2,3x3) around
@@ -107,6 +110,7 @@ class ResNet50Hip:
 
     def to(self, device):
         self.device, self.w, self._plans = torch.device(device), None, PlanCache()
+        self._arenas = {}
         return self
 
     def eval(self):
@@ -154,7 +158,53 @@ class ResNet50Hip:
         self.w = w
 
     class _Plan:
-        pass
+        """Views of one slot's arena for one (batch, image size) + the captured hipGraph."""
+
+        def busy_events(self):
+            out = []
+            for st in self.streams.values():
+                ev = torch.cuda.Event()
+                ev.record(st)
+                out.append(ev)
+            return out
+
+    def _arena(self, slot):
+        a = self._arenas.get(slot)
+        if a is None:
+            a = self._arenas[slot] = Arena(self.device, on_grow=lambda a, s=slot: self._plans.drop(
+                lambda k: k[3] == s))
+        return a
+
+    def _layout_for(self, dims):
+        def layout(E):
+            pl = ResNet50Hip._Plan()
+            self._layout(pl, E, *dims)
+            return pl
+        return layout
+
+    def _measure(self, dims):
+        return measure_bytes(self._layout_for(dims))
+
+    def reserve(self, batch, H, W, slots=(0,)):
+        """Size the arenas of `slots` up front for [batch, 3, H, W] images (optional: they
+        grow on demand, one device wait per growth)."""
+        if self.w is None:
+            self._pack()
+        for s in slots:
+            self._arena(s).reserve((batch, H, W), self._measure)
+
+    def arena_bytes(self):
+        return sum(a.capacity for a in self._arenas.values())
+
+    @staticmethod
+    def feature_shapes(H, W):
+        """[(h, w)] of C2..C5 for an H x W image (7x7/2 stem, 3x3/2 pool, then /2 per stage)."""
+        h, w = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = []
+        for i in range(4):
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            out.append((h, w))
+        return out
 
     def _plan(self, B, H, W, slot=0):
         key = (B, H, W, slot, self.conv_algo, self.wino_min_planes)   # (a plan's graph bakes both in)
@@ -162,11 +212,19 @@ class ResNet50Hip:
             return self._plans[key]
         if self.w is None:
             self._pack()
-        E = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
-        pl = ResNet50Hip._Plan()
+
+        dims = (B, H, W)
+        pl = self._arena(slot).carve(self._layout_for(dims), dims, self._measure)
+        pl.graph = pl.outs = pl.last_img = None
+        pl.calls, pl.staged, pl.streams = 0, False, {}
+        self._plans[key] = pl
+        return pl
+
+    def _layout(self, pl, E, B, H, W):
+        """Every activation buffer as a view of the slot's arena; sizes are non-decreasing in
+        B, H and W (plans.py)."""
         pl.B = B
-        pl.graph = pl.static_img = pl.outs = None
-        pl.calls, pl.staged = 0, False
+        pl.img = E(B, 3, H, W)        # staging copy of the image for graph replay (see forward)
         h1, w1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         h, wd = (h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1
         pl.stem, pl.hw_stem = E(B, h1, w1, 64), (h1, w1)
@@ -194,8 +252,6 @@ class ResNet50Hip:
             else:
                 pl.f43.append(False)
         pl.wV, pl.wM = E(max(nwino, 4)), E(max(nwino, 4))   # Winograd transform planes
-        self._plans[key] = pl
-        return pl
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -213,21 +269,29 @@ class ResNet50Hip:
         B, _, H, W = img.shape
         pl = self._plan(B, H, W, slot)
         if getattr(pl, "reserve", None) != self.grid_reserve:   # a captured graph bakes it in
-            pl.reserve, pl.graph, pl.calls = self.grid_reserve, None, min(pl.calls, 1)
+            pl.reserve, pl.graph = self.grid_reserve, None
+        cur = torch.cuda.current_stream(self.device)
+        pl.streams[cur.cuda_stream] = cur
         if not self.use_graphs:
             return self._run(img, pl)
         # hipGraph replay of the ~55 launches: captured on the caller's image buffer when it
         # comes back with the same one (a resident input, a preprocessing stage writing
-        # into a fixed buffer), otherwise on a private copy that each call is staged into
+        # into a fixed buffer), otherwise on the plan's staging view pl.img that each call is
+        # copied into.  Captured after `graph_after` eager calls, with no host wait
+        # (head.CrossHead2._capture).
+        ptr = img.data_ptr()
+        if pl.graph is not None and not pl.staged and ptr != pl.static_img.data_ptr():
+            pl.graph, pl.staged = None, True        # the caller rotates buffers: stage from now on
         if pl.graph is None:
-            if pl.calls == 0:
-                pl.calls = 1
-                return self._run(img, pl)          # eager warm-up
-            pl.static_img, pl.staged = img, False
+            if pl.calls < self.graph_after:
+                pl.calls += 1
+                pl.last_img = ptr
+                return self._run(img, pl)
+            if not pl.staged and pl.last_img is not None and ptr != pl.last_img:
+                pl.staged = True
+            pl.static_img = pl.img if pl.staged else img
             pl.graph, pl.outs = self._capture(lambda: self._run(pl.static_img, pl))
-        if not pl.staged and img.data_ptr() != pl.static_img.data_ptr():
-            pl.static_img, pl.staged = torch.empty_like(img), True
-            pl.graph, pl.outs = self._capture(lambda: self._run(pl.static_img, pl))
+        pl.last_img = ptr
         if pl.staged:
             pl.static_img.copy_(img)
         pl.graph.replay()
@@ -235,11 +299,9 @@ class ResNet50Hip:
 
     @staticmethod
     def _capture(fn):
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
+        from .head import CrossHead2
         box = {}
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            box["out"] = fn()
+        g = CrossHead2._capture(lambda: box.update(out=fn()))
         return g, box["out"]
 
     def _run(self, img, pl):

@@ -36,7 +36,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
-from .plans import PlanCache
+from .plans import PlanCache, TorchAlloc
 from .config import ConfigDict
 from .head import CrossHead2, _decoder_param_shapes
 
@@ -105,7 +105,7 @@ class CrossHeadBBox(CrossHead2):
             raise NotImplementedError("4 levels, <= 512 proposals, <= 256 classes")
         self._params = OrderedDict((k, torch.zeros(s)) for k, s in self.param_shapes().items())
         self.device, self.w = None, None
-        self._plans, self._post = PlanCache(), OrderedDict()
+        self._plans, self._post, self._consts = PlanCache(), OrderedDict(), {}
         self._pan_jobs = []
         self.use_graphs = False
         self.grid_reserve = 0
@@ -217,7 +217,7 @@ class CrossHeadBBox(CrossHead2):
             self._params["cls_branches.%d.bias" % i].fill_(bias_init)
             self._params["reg_branches.%d.4.weight" % i].zero_()
         self._params["reg_branches.0.4.bias"][2:] = -2.0
-        self.w, self._plans = None, PlanCache()
+        self.w, self._plans, self._consts = None, PlanCache(), {}
 
     # ----------------------------------------------------------------- packing
     def _pack(self):
@@ -313,8 +313,8 @@ class CrossHeadBBox(CrossHead2):
         if self.w is None:
             self._pack()
         dev, w = self.device, self.w
-        E = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-        i64 = lambda *s: torch.empty(*s, device=dev, dtype=torch.int64)
+        E = TorchAlloc(dev)     # (this head keeps per-shape buffers, LRU-bounded: plans.PlanCache)
+        i64 = E.i64
         pl = CrossHead2._Plan()
         pl.B, pl.shapes = B, list(shapes)
         pl.N = [h * wd for h, wd in shapes]
@@ -325,6 +325,7 @@ class CrossHeadBBox(CrossHead2):
                                % (SN, self.num_proposals))
         pl.graph_a = pl.graph_b = pl.graph_cfg = None
         pl.calls_a = pl.calls_b = 0
+        pl.streams = {}
         pl.feats_read = torch.cuda.Event()
         M, P, K = B * SN, self.num_proposals, self.KEPT
         nc = self.cls_out_channels
@@ -572,6 +573,8 @@ class CrossHeadBBox(CrossHead2):
         if pl.graph_cfg != cfg:
             pl.graph_a = pl.graph_b = None
             pl.graph_cfg = cfg
+        cur = torch.cuda.current_stream(self.device)
+        pl.streams[cur.cuda_stream] = cur
         if which == "a":
             if pl.own_tokens:
                 self._stage_a_copy(feats, pl)

@@ -571,3 +571,160 @@ extern "C" int pn_msda_loc_f32(const float* value, int64_t ld_value,
 #undef PN_MSDA_LOC
   return PN_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------
+// Backward of the operator above, in mmcv's shape (`ext_module.ms_deform_attn_backward`,
+// mmcv/ops/csrc/pytorch/cuda/ms_deform_attn_cuda.cu: ms_deformable_col2im): for every
+// (batch, query, head, level, point) with sampling location inside (-1, H) x (-1, W) in
+// pixel coordinates
+//   g      = grad_output[b][q][h][:]                                     (32 channels)
+//   grad_value[b][tap_i][h][:]       += w_i * a * g        for the 4 bilinear taps (atomic)
+//   grad_attn_weight[b][q][h][l][p]   = sum_c g_c * bilinear(value)_c
+//   grad_sampling_loc[...][0] (x)     = W_l * sum_c a g_c * (-hh v1 + hh v2 - lh v3 + lh v4)_c
+//   grad_sampling_loc[...][1] (y)     = H_l * sum_c a g_c * (-hw v1 - lw v2 + hw v3 + lw v4)_c
+// with (lh, lw) the fractional parts, hh = 1 - lh, hw = 1 - lw, taps outside the map
+// contributing value 0 -- mmcv's ms_deform_attn_col2im_bilinear.  Thread layout of the forward
+// kernel: (head, point, 4 channels), the 8 lanes of a point own one 128-byte value row per
+// tap; the channel sums are xor-1/2/4 shuffles (mmcv reduces through shared memory in the
+// same way, one thread per channel).  grad_value is accumulated with hardware fp32 atomics
+// into a buffer the CALLER zeroes (mmcv: at::zeros_like(value)): like mmcv's, its summation
+// order is not deterministic; the other two outputs are.
+template <int L>
+__global__ __launch_bounds__(256) void k_msda_bwd(const float* __restrict__ value,
+                                                  const int64_t* __restrict__ shapes,
+                                                  const int64_t* __restrict__ starts,
+                                                  const float* __restrict__ loc,
+                                                  const float* __restrict__ aw,
+                                                  const float* __restrict__ gout,
+                                                  float* __restrict__ gvalue,
+                                                  float* __restrict__ gloc,
+                                                  float* __restrict__ gaw, const int N,
+                                                  const int Nq, const int64_t ldv) {
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int q = blockIdx.x;
+  constexpr int LP = L * 4;
+  const int c4 = tid & 7, pt = (tid >> 3) & 3, head = tid >> 5;
+  const float4 g = ld4(gout + ((int64_t)b * Nq + q) * 256 + head * 32 + c4 * 4);
+  const float* vb = value + (int64_t)b * N * ldv + head * 32 + c4 * 4;
+  float* gvb = gvalue + (int64_t)b * N * ldv + head * 32 + c4 * 4;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+    const int64_t slot = (((int64_t)b * Nq + q) * 8 + head) * LP + l * 4 + pt;
+    const float2 lc = *reinterpret_cast<const float2*>(loc + 2 * slot);
+    const float a = aw[slot];
+    const float h_im = lc.y * (float)Hl - 0.5f, w_im = lc.x * (float)Wl - 0.5f;
+    float ga = 0.f, gx = 0.f, gy = 0.f;
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {   // (uniform in the 8 lanes)
+      const float fy = floorf(h_im), fx = floorf(w_im);
+      const int y0 = (int)fy, x0 = (int)fx;
+      const float lh = h_im - fy, lw = w_im - fx, hh = 1.f - lh, hw = 1.f - lw;
+      const bool yin0 = y0 >= 0, yin1 = y0 + 1 <= Hl - 1, xin0 = x0 >= 0, xin1 = x0 + 1 <= Wl - 1;
+      const int64_t base = starts[l];
+      const int ya = max(y0, 0), yb = min(y0 + 1, Hl - 1), xa = max(x0, 0), xb = min(x0 + 1, Wl - 1);
+      const int64_t r1 = (base + (int64_t)ya * Wl + xa) * ldv, r2 = (base + (int64_t)ya * Wl + xb) * ldv;
+      const int64_t r3 = (base + (int64_t)yb * Wl + xa) * ldv, r4 = (base + (int64_t)yb * Wl + xb) * ldv;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      // unconditional (clamped) loads, zeroed where the tap lies outside the map
+      float4 v1 = ld4(vb + r1), v2 = ld4(vb + r2), v3 = ld4(vb + r3), v4 = ld4(vb + r4);
+      const bool in1 = yin0 && xin0, in2 = yin0 && xin1, in3 = yin1 && xin0, in4 = yin1 && xin1;
+      v1 = in1 ? v1 : z; v2 = in2 ? v2 : z; v3 = in3 ? v3 : z; v4 = in4 ? v4 : z;
+      const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+      const float4 tg = make_float4(g.x * a, g.y * a, g.z * a, g.w * a);   // top_grad * attn_weight
+#define PN_BWD_CH(c)                                                                          \
+      {                                                                                       \
+        const float gh = -hw * v1.c - lw * v2.c + hw * v3.c + lw * v4.c;                      \
+        const float gw = -hh * v1.c - lh * v3.c + hh * v2.c + lh * v4.c;                      \
+        const float val = w1 * v1.c + w2 * v2.c + w3 * v3.c + w4 * v4.c;                      \
+        ga += g.c * val;                                                                      \
+        gx += (float)Wl * gw * tg.c;                                                          \
+        gy += (float)Hl * gh * tg.c;                                                          \
+      }
+      PN_BWD_CH(x) PN_BWD_CH(y) PN_BWD_CH(z) PN_BWD_CH(w)
+#undef PN_BWD_CH
+      if (in1) { unsafeAtomicAdd(gvb + r1 + 0, w1 * tg.x); unsafeAtomicAdd(gvb + r1 + 1, w1 * tg.y);
+                 unsafeAtomicAdd(gvb + r1 + 2, w1 * tg.z); unsafeAtomicAdd(gvb + r1 + 3, w1 * tg.w); }
+      if (in2) { unsafeAtomicAdd(gvb + r2 + 0, w2 * tg.x); unsafeAtomicAdd(gvb + r2 + 1, w2 * tg.y);
+                 unsafeAtomicAdd(gvb + r2 + 2, w2 * tg.z); unsafeAtomicAdd(gvb + r2 + 3, w2 * tg.w); }
+      if (in3) { unsafeAtomicAdd(gvb + r3 + 0, w3 * tg.x); unsafeAtomicAdd(gvb + r3 + 1, w3 * tg.y);
+                 unsafeAtomicAdd(gvb + r3 + 2, w3 * tg.z); unsafeAtomicAdd(gvb + r3 + 3, w3 * tg.w); }
+      if (in4) { unsafeAtomicAdd(gvb + r4 + 0, w4 * tg.x); unsafeAtomicAdd(gvb + r4 + 1, w4 * tg.y);
+                 unsafeAtomicAdd(gvb + r4 + 2, w4 * tg.z); unsafeAtomicAdd(gvb + r4 + 3, w4 * tg.w); }
+    }
+    // sum over the point's 32 channels: its 8 lanes (fixed order: deterministic)
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      ga += __shfl_xor(ga, o, 64);
+      gx += __shfl_xor(gx, o, 64);
+      gy += __shfl_xor(gy, o, 64);
+    }
+    if (c4 == 0) {
+      gaw[slot] = ga;
+      *reinterpret_cast<float2*>(gloc + 2 * slot) = make_float2(gx, gy);
+    }
+  }
+}
+
+extern "C" int pn_msda_bwd_f32(const float* value, int64_t ld_value,
+                               const int64_t* spatial_shapes, const int64_t* level_start_index,
+                               const float* sampling_locations, const float* attention_weights,
+                               const float* grad_output, float* grad_value,
+                               float* grad_sampling_loc, float* grad_attn_weight, int B, int N,
+                               int Nq, int L, void* stream) {
+  if (!value || !spatial_shapes || !level_start_index || !sampling_locations ||
+      !attention_weights || !grad_output || !grad_value || !grad_sampling_loc ||
+      !grad_attn_weight || B <= 0 || N <= 0 || Nq <= 0 || L <= 0 || L > 4)
+    return PN_BAD_ARG;
+  if (ld_value < 256 || (ld_value & 3) || ((uintptr_t)value & 15) || ((uintptr_t)grad_value & 15) ||
+      ((uintptr_t)grad_output & 15) || ((uintptr_t)sampling_locations & 7) ||
+      ((uintptr_t)grad_sampling_loc & 7))
+    return PN_BAD_ARG;
+  const dim3 grid(Nq, B);
+  hipStream_t s = (hipStream_t)stream;
+#define PN_MSDA_BWD(LL)                                                                        \
+  hipLaunchKernelGGL(k_msda_bwd<LL>, grid, dim3(256), 0, s, value, spatial_shapes,             \
+                     level_start_index, sampling_locations, attention_weights, grad_output,    \
+                     grad_value, grad_sampling_loc, grad_attn_weight, N, Nq, ld_value)
+  switch (L) {
+    case 1: PN_MSDA_BWD(1); break;
+    case 2: PN_MSDA_BWD(2); break;
+    case 3: PN_MSDA_BWD(3); break;
+    default: PN_MSDA_BWD(4); break;
+  }
+#undef PN_MSDA_BWD
+  return PN_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------
+// Diagnostic: the BARE access pattern of the sampling kernels -- 8 lanes read one random
+// 128-byte line as float4s, 12 independent lines per 8-lane group (3 levels x 4 taps), index
+// loads hoisted in front of the gathers, a sum as the only arithmetic -- so that bench.py can
+// measure, in the same run and on the same board, the rate the vector L1 / L2 deliver for
+// this pattern (`roofline_deformable_sampling.gather_peak`): the roof k_msda is actually under
+// once its value rows are L2-resident.  lines = line_mask + 1 (a power of two) 128-byte lines
+// are drawn from; idx [workgroups][32][12] int32; out [workgroups][256].
+__global__ __launch_bounds__(256) void k_gather_probe(const float* __restrict__ v,
+                                                      const int* __restrict__ idx,
+                                                      float* __restrict__ out, const int mask) {
+  const int tid = threadIdx.x, c = tid & 7, grp = tid >> 3;
+  float4 r[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    const int line = idx[((int64_t)blockIdx.x * 32 + grp) * 12 + j] & mask;
+    r[j] = ld4(v + (int64_t)line * 32 + c * 4);
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) acc += (r[j].x + r[j].y) + (r[j].z + r[j].w);
+  out[(int64_t)blockIdx.x * 256 + tid] = acc;
+}
+
+extern "C" int pn_gather_probe_f32(const float* lines, const int32_t* idx, float* out,
+                                   int workgroups, int line_mask, void* stream) {
+  if (!lines || !idx || !out || workgroups <= 0 || line_mask < 0 || (line_mask & (line_mask + 1)))
+    return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_gather_probe, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, lines,
+                     idx, out, line_mask);
+  return PN_LAUNCH_CHECK();
+}

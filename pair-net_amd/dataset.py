@@ -26,8 +26,10 @@ from . import hip
 def load_psg(ann_file, split="test"):
     """`PanopticSceneGraphDataset.__init__`'s view of the annotation file (psg.py:62-110):
     predicate labels become 1-based, images without relations are dropped, the split is taken
-    by `test_image_ids`.  `ann_file`: a path or the loaded dict (mutated like the reference
-    mutates its own).  Returns dict(data, classes, predicates)."""
+    by `test_image_ids`.  `ann_file`: a path or the loaded dict -- left untouched: the entries
+    returned are shallow copies with new relation lists (the reference re-reads the file per
+    dataset object, so it never shifts the labels twice).  Returns dict(data, classes,
+    predicates)."""
     if isinstance(ann_file, (str, bytes)) or hasattr(ann_file, "__fspath__"):
         with open(ann_file) as f:
             dataset = json.load(f)
@@ -35,10 +37,8 @@ def load_psg(ann_file, split="test"):
         dataset = ann_file
     if split not in ("train", "test"):
         raise ValueError("split: 'train' or 'test'")
-    for d in dataset["data"]:
-        for r in d["relations"]:
-            r[2] += 1
-    data = [d for d in dataset["data"] if len(d["relations"]) != 0]
+    data = [dict(d, relations=[[r[0], r[1], r[2] + 1] for r in d["relations"]])
+            for d in dataset["data"] if len(d["relations"]) != 0]
     test_ids = dataset["test_image_ids"]
     keep = (lambda d: d["image_id"] in test_ids) if split == "test" else \
         (lambda d: d["image_id"] not in test_ids)

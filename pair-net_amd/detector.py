@@ -504,7 +504,7 @@ class PSGTr:
         `gt_masks[i]`: image i's instance masks [G, h, w], 0/1 -- a BitmapMasks-like object
         (`.to_ndarray()`), a numpy array or a tensor (host or device)."""
         from . import hip
-        if not hasattr(self.bbox_head, "val_losses"):
+        if type(self.bbox_head) is not CrossHead2:     # (the siblings INHERIT val_losses)
             raise NotImplementedError("loss values are built for CrossHead2 only (%s has no "
                                       "loss forward here)" % type(self.bbox_head).__name__)
         x = self.extract_feat(img)
@@ -542,6 +542,27 @@ class PSGTr:
                                                           device=self.bbox_head.device)
         img, metas = self.test_pipeline(image)
         return self.simple_test(img, metas, rescale=rescale)
+
+    def reserve(self, image_sizes, batch=1, depth=4, orig_sizes=()):
+        """Size every buffer arena of the backbone and the head up front for [batch, 3, H, W]
+        image tensors of the given `image_sizes` [(H, W)] (and post-processing at the original
+        sizes `orig_sizes` [(H0, W0)]) on the `depth` slots of the pipeline.  Optional -- the
+        arenas grow on demand, each growth costing one device wait (plans.py) -- and cheap: a
+        loop that knows its envelope (Resize(img_scale=(1333, 800)): [(800, 1333), (1333, 800)])
+        calls it once and never waits in flight.  Returns the bytes reserved, or None for a
+        backbone / head that keeps per-shape plans (Swin, the box trunk)."""
+        net, head = self.backbone, self.bbox_head
+        if not isinstance(net, ResNet50Hip) or type(head)._plan is not CrossHead2._plan \
+                or self.neck is not None:
+            return None
+        piped = self._pipelines()
+        a_slots = range(len(self.pipeline(depth).streams_a)) if piped else (0,)
+        for H, W in image_sizes:
+            net.reserve(batch, H, W, slots=a_slots)
+            fs = net.feature_shapes(H, W)
+            head.reserve(batch, [fs[3], fs[2], fs[1]], fs[0],
+                         slots=range(depth) if piped else (0,), orig_sizes=orig_sizes)
+        return net.arena_bytes() + head.arena_bytes()
 
     def pipeline(self, depth=4):
         """The detector's `PipelinedHead` for `depth` batches in flight, created once and kept:

@@ -291,21 +291,45 @@ class TripletCollector:
         return self.records
 
 
+def collate(items):
+    """mmcv's `collate` for `samples_per_gpu` test images (tools/test.py:202-214 builds the
+    loader with it): `items` = [(img [1, 3, H, W], [meta])], one image each -> (imgs
+    [k, 3, Hmax, Wmax], [meta] * k).  Images of different sizes are zero-padded at the bottom /
+    right to the largest of the batch, as the DataContainer stacking does; every image keeps
+    its own `img_metas` entry (`img_shape`, `scale_factor`)."""
+    if len(items) == 1:
+        return items[0]
+    imgs = [it[0] for it in items]
+    metas = [m for it in items for m in it[1]]
+    H, W = max(i.shape[-2] for i in imgs), max(i.shape[-1] for i in imgs)
+    if all(tuple(i.shape[-2:]) == (H, W) for i in imgs):
+        return torch.cat(imgs, 0), metas
+    out = imgs[0].new_zeros((sum(i.shape[0] for i in imgs), imgs[0].shape[1], H, W))
+    row = 0
+    for i in imgs:
+        out[row:row + i.shape[0], :, :i.shape[-2], :i.shape[-1]] = i
+        row += i.shape[0]
+    return out, metas
+
+
 def multi_gpu_test(detector, dataset, annotations=None, evaluator=None, metrics=None, *,
                    depth=4, group=None, host_staging=None, force_collective=False,
-                   rescale=False, calibrate=True):
+                   rescale=False, calibrate=True, samples_per_gpu=1):
     """The reference's distributed test loop -- mmdet `multi_gpu_test` + `collect_results_*`
     (tools/test.py:256-267) followed by `dataset.evaluate` (:277-295 ->
     pairnet/datasets/psg.py:285-404) -- for one process per GPU:
 
       * rank r takes the images r, r + W, ... (`shard_indices`: DistributedSampler(
-        shuffle=False)), one per step, and runs them through `detector.stream_triplets`
-        (PSGTr: backbone -> PipelinedHead, `depth` images in flight);
+        shuffle=False)), `samples_per_gpu` consecutive ones of them per step (the loader's
+        batches, tools/test.py:202-214; `collate` pads unequal sizes like mmcv's), and runs
+        them through `detector.stream_triplets` (PSGTr: backbone -> PipelinedHead, `depth`
+        batches in flight);
       * every image's triplet record (labels | rel_dists | sub_pos | obj_pos, ~27 KB) is
         packed on the stream that produced it and all-gathered `depth` steps later on a side
         stream (`TripletGatherer` ring; RCCL for backend "nccl", host-staged for "gloo"), so
         neither the collective nor a slow peer stalls a compute stream; ranks that run out of
-        images contribute zero rows, so every rank issues the same ceil(N / W) collectives;
+        images contribute zero rows, so every rank issues the same
+        ceil(ceil(N / W) / samples_per_gpu) collectives;
       * masks and panoptic maps never travel: with `annotations` + `evaluator`
         (`TripletEvaluator`) every rank matches ITS images against their ground truth on its
         own GPU, and only the per-image match lists (a few KB of Python lists) are gathered
@@ -314,7 +338,7 @@ def multi_gpu_test(detector, dataset, annotations=None, evaluator=None, metrics=
     `dataset[i]` -> `(img, img_metas)` as `simple_test` takes them (one image);
     `annotations[i]` -> dict(gt_rels, gt_labels, gt_masks) (or None).  `calibrate`: on the
     first call per detector, choose the stream -> hardware-queue placement of its pipeline on
-    this rank's first image (`PSGTr.calibrate_pipeline`: ~50 throw-away submissions, worth ~8 %
+    this rank's first batch (`PSGTr.calibrate_pipeline`: ~50 throw-away submissions, worth ~8 %
     of the step).  Returns a dict:
     `records` [N, L] float32 in dataset order on EVERY rank (`unpack_triplets` splits a row),
     `num_images`, `world_size`, `rank`, `collectives`, and on rank 0 `metrics`
@@ -323,37 +347,56 @@ def multi_gpu_test(detector, dataset, annotations=None, evaluator=None, metrics=
     W = dist.get_world_size(group) if ini else 1
     rank = dist.get_rank(group) if ini else 0
     N = len(dataset)
-    steps = (N + W - 1) // W
+    k = int(samples_per_gpu)
+    if k < 1:
+        raise ValueError("samples_per_gpu >= 1")
+    steps = ((N + W - 1) // W + k - 1) // k
     mine = shard_indices(N, rank, W)
-    col = TripletCollector(detector.bbox_head, depth=depth, n_local=1, group=group,
+    groups = [mine[j:j + k] for j in range(0, len(mine), k)]
+    col = TripletCollector(detector.bbox_head, depth=depth, n_local=k, group=group,
                            host_staging=host_staging, force_collective=force_collective,
                            keep_steps=steps)
     if calibrate and mine and hasattr(detector, "calibrate_pipeline") and \
             hasattr(detector, "_pipelines") and detector._pipelines() and \
             not detector.pipeline_calibrated(depth):
-        detector.calibrate_pipeline(*dataset[mine[0]], depth=depth)
+        detector.calibrate_pipeline(*collate([dataset[i] for i in groups[0]]), depth=depth)
     local_evals = []
-    batches = (dataset[i] for i in mine)
+    batches = (collate([dataset[i] for i in grp]) for grp in groups)
     done = 0
     for tb in detector.stream_triplets(batches, rescale=rescale, depth=depth):
-        if len(tb.results) != 1:
-            raise ValueError("multi_gpu_test takes one image per step (samples_per_gpu=1, "
-                             "configs/_base_/datasets/psg.py)")
-        idx = mine[done]
-        ann = annotations[idx] if annotations is not None else None
+        grp = groups[done]
+        if len(tb.results) != len(grp):
+            raise ValueError("the detector returned %d results for a batch of %d images"
+                             % (len(tb.results), len(grp)))
+        anns = [annotations[idx] if annotations is not None else None for idx in grp]
+        # a lazily built annotation (`dataset.eval_ground_truth`: H2D copy + k_pan_masks) is
+        # produced on the CALLER's stream, the evaluator reads it on the chain stream that
+        # produced the result: order the two
+        ann_ready = None
+        if evaluator is not None and col.on_gpu and any(a is not None for a in anns):
+            ann_ready = torch.cuda.Event()
+            ann_ready.record(torch.cuda.current_stream(col.device))
 
-        def evaluate(res, idx=idx, ann=ann):
-            if evaluator is None or ann is None:
+        def evaluate(tb, grp=grp, anns=anns, ann_ready=ann_ready):
+            if evaluator is None:
                 return
-            ev = evaluator(res, ann["gt_rels"], ann["gt_labels"], ann["gt_masks"])
-            iou = evaluator.iou_stats(res, ann["gt_rels"], ann["gt_labels"], ann["gt_masks"]) \
-                if hasattr(evaluator, "iou_stats") and len(ann["gt_rels"]) else None
-            local_evals.append((idx, ev, ann["gt_rels"], iou))
-        col.add(tb, before_release=lambda tb: evaluate(tb.results[0]))
+            if ann_ready is not None:
+                torch.cuda.current_stream(col.device).wait_event(ann_ready)
+            for res, idx, ann in zip(tb.results, grp, anns):
+                if ann is None:
+                    continue
+                ev = evaluator(res, ann["gt_rels"], ann["gt_labels"], ann["gt_masks"])
+                iou = evaluator.iou_stats(res, ann["gt_rels"], ann["gt_labels"],
+                                          ann["gt_masks"]) \
+                    if hasattr(evaluator, "iou_stats") and len(ann["gt_rels"]) else None
+                local_evals.append((idx, ev, ann["gt_rels"], iou))
+        col.add(tb, before_release=evaluate)
         done += 1
-    for _ in range(steps - done):          # ranks with one image fewer: a zero row
+    for _ in range(steps - done):          # ranks with fewer batches: zero rows
         col.pad()
     records = col.finish()
+    if records is None:                    # an empty dataset: no steps, no records
+        records = torch.zeros((0, col.gatherer.L), dtype=torch.float32)
     out = dict(records=records[:N], num_images=N, world_size=W, rank=rank,
                collectives=col.gatherer.gathered, local_indices=mine)
     if evaluator is not None:

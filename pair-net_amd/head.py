@@ -20,7 +20,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
-from .plans import PlanCache
+from .plans import Arena, PlanCache, measure_bytes
 from .config import ConfigDict
 
 INSTANCE_OFFSET = 1000
@@ -113,9 +113,15 @@ class CrossHead2:
         self.device = None
         self.w = None
         self._plans = PlanCache()
+        self._arenas, self._post_arenas, self._consts, self._pe = {}, {}, {}, OrderedDict()
         self._dummies = {}
         self._post = OrderedDict()
         self._pan_jobs = []
+        # stage graphs are captured once a (shape, slot) has been run this many times eagerly
+        # (with the per-slot arenas an eager first sight costs no allocation and no host
+        # synchronisation, and the pipelined eager rate is within 0.5 % of the replayed one:
+        # a shape that shows up once is never captured)
+        self.graph_after = 1
         # Attention masks (see _attn_mask).  True (default since round 3): the reference's
         # operation order -- full-size mask logits -> bilinear resize -> threshold -- evaluated
         # at the 4 logits per key the resize reads; "full": the same, densely (bit-identical,
@@ -253,7 +259,16 @@ class CrossHead2:
             for n in ("value_proj", "output_proj"):
                 self._params[p + n + ".weight"].copy_(U((256, 256), math.sqrt(6.0 / 512)))
                 self._params[p + n + ".bias"].zero_()
-        self.w, self._plans = None, PlanCache()   # plans cache weight-derived buffers and graphs
+        self._drop_weight_state()
+
+    def _drop_weight_state(self):
+        """Everything derived from the parameters: packed weights, the per-batch constants
+        (initial queries and their mask embedding), position tables with the level embeddings
+        folded in, and the plans' hipGraphs (a captured graph bakes the pointers in).  The
+        arenas stay: they depend on shapes only."""
+        self.w = None
+        self._plans = PlanCache(self._plans.max_plans)
+        self._consts, self._pe = {}, OrderedDict()
 
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._params.items())
@@ -270,7 +285,7 @@ class CrossHead2:
                     raise RuntimeError("shape mismatch for %s: %s vs %s"
                                        % (k, tuple(sd[k].shape), tuple(p.shape)))
                 p.copy_(sd[k].detach().to(torch.float32).cpu())
-        self.w, self._plans = None, PlanCache()   # plans cache weight-derived buffers and graphs
+        self._drop_weight_state()
         return missing, unexpected
 
     def eval(self):
@@ -278,8 +293,8 @@ class CrossHead2:
 
     def to(self, device):
         self.device = torch.device(device)
-        self.w = None
-        self._plans = PlanCache()
+        self._drop_weight_state()
+        self._arenas, self._post_arenas = {}, {}
         self._post.clear()
         return self
 
@@ -347,7 +362,127 @@ class CrossHead2:
         w[ml + "2.0.weight"] = w[ml + "2.0.weight"].reshape(64, 49).t().contiguous()
 
     class _Plan:
-        pass
+        """Views of one pipeline slot's arena for one (batch, feature shapes) + the hipGraphs
+        captured on them."""
+
+        def busy_events(self):
+            """Events behind everything queued so far on the streams this plan ran on (the
+            plan cache parks an evicted plan until they have fired)."""
+            out = []
+            for st in getattr(self, "streams", {}).values():
+                ev = torch.cuda.Event()
+                ev.record(st)
+                out.append(ev)
+            return out
+
+    PE_SHAPES = 24       # position tables kept (LRU), shared by the slots: ~44 MB per full-size shape
+    POST_VIEWS = 8       # post-processing view sets / get_bboxes graphs kept per plan
+
+    def _arena(self, slot):
+        """The flat buffer of pipeline slot `slot` (plans.py): every plan of the slot is a
+        set of views of it.  When it grows, the slot's plans are dropped."""
+        a = self._arenas.get(slot)
+        if a is None:
+            a = self._arenas[slot] = Arena(self.device, on_grow=lambda a, s=slot: self._plans.drop(
+                lambda k: k[3] == s))
+        return a
+
+    def _post_arena(self, slot):
+        """The slot's second arena, for the post-processing buffers (sized by the ORIGINAL
+        image size, which is independent of the padded tensor shape).  When it grows, the
+        slot's plans keep their views of the main arena and forget their post-processing
+        views and `get_bboxes` graphs."""
+        a = self._post_arenas.get(slot)
+        if a is None:
+            def on_grow(arena, s=slot):
+                for k, pl in self._plans.items():
+                    if k[3] == s:
+                        pl.post_views, pl.graph_c = OrderedDict(), PlanCache(self.POST_VIEWS)
+            a = self._post_arenas[slot] = Arena(self.device, on_grow=on_grow)
+        return a
+
+    def _const(self, B):
+        """Weight-derived, shape-independent constants of batch size B, shared by every plan:
+        the initial object / relation queries repeated over the batch (`query_feat`,
+        `rel_query_feat`: the first layer reads them in place) and -- filled by `_plan` --
+        `me0`, the mask embedding of the initial queries."""
+        c = self._consts.get(B)
+        if c is None:
+            w = self.w
+            rep = lambda t: t.unsqueeze(0).expand(B, *t.shape).reshape(B * t.shape[0], 256).contiguous()
+            c = self._consts[B] = dict(me0=None)
+            for name, key in (("q0", "query_feat.weight"), ("r0", "rel_query_feat.weight")):
+                if key in w:        # (the box trunk has no learned object queries)
+                    c[name] = rep(w[key])
+        return c
+
+    def _position_tables(self, shapes):
+        """Sine position tables (+ level embeddings) of a feature pyramid: read-only, the
+        same for every slot and batch size -> one copy per shape, LRU-bounded.  Returns
+        (enc_pos [SN,256], [dec_kpos_l], event behind the kernels that fill them)."""
+        key = tuple(shapes)
+        ent = self._pe.get(key)
+        if ent is not None:
+            self._pe.move_to_end(key)
+            return ent
+        w, dev = self.w, self.device
+        N = [h * wd for h, wd in shapes]
+        enc_pos = torch.empty(sum(N), 256, device=dev, dtype=torch.float32)
+        dec_kpos, o = [], 0
+        for l, (h, wd) in enumerate(shapes):
+            hip.sine_pe(enc_pos[o:o + N[l]], w["pixel_decoder.level_encoding.weight"][l], h, wd)
+            kp = torch.empty(N[l], 256, device=dev, dtype=torch.float32)
+            hip.sine_pe(kp, w["level_embed.weight"][l], h, wd)
+            dec_kpos.append(kp)
+            o += N[l]
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        ent = self._pe[key] = (enc_pos, dec_kpos, ev)
+        while len(self._pe) > self.PE_SHAPES:
+            # the plans of a shape whose tables go are dropped with them (their graphs bake
+            # the tables' addresses in; parked until idle, plans.py): device memory per shape
+            # is these tables and nothing else, for at most PE_SHAPES shapes
+            old, _ = self._pe.popitem(last=False)
+            self._plans.drop(lambda k: k[1] == old)
+        return ent
+
+    @staticmethod
+    def _plan_dims(B, shapes, hw2):
+        return (B, hw2[0], hw2[1]) + tuple(v for hw in shapes for v in hw)
+
+    def _layout_for(self, dims, nhwc=False):
+        B, hw2 = dims[0], (dims[1], dims[2])
+        shapes = [(dims[3 + 2 * l], dims[4 + 2 * l]) for l in range(3)]
+
+        def layout(E):
+            pl = CrossHead2._Plan()
+            self._layout(pl, E, B, shapes, hw2, nhwc)
+            return pl
+        return layout
+
+    def _measure(self, dims):
+        return measure_bytes(self._layout_for(dims))
+
+    def reserve(self, batch, shapes, hw2, slots=(0,), orig_sizes=()):
+        """Size the arenas of `slots` up front for a feature pyramid (`shapes`: the three
+        coarse levels low -> high resolution, `hw2`: the 1/4-resolution level) of `batch`
+        images and, with `orig_sizes` [(H0, W0)], for post-processing at those original image
+        sizes.  Optional: an arena also grows on demand (one device wait each time its
+        envelope grows); a loop that knows its largest shapes -- Resize(img_scale=(1333, 800)):
+        800 x 1333 and 1333 x 800 -- reserves them once and never waits."""
+        if self.w is None:
+            self._pack()
+        dims = self._plan_dims(batch, shapes, hw2)
+        for s in slots:
+            self._arena(s).reserve(dims, self._measure)
+            if orig_sizes:
+                self._post_arena(s).reserve(
+                    (batch, max(h * w for h, w in orig_sizes)),
+                    lambda d: measure_bytes(lambda E: self._post_layout(E, [(1, d[1])] * d[0])))
+
+    def arena_bytes(self):
+        """Device bytes held by the slots' arenas (what the plans are views of)."""
+        return sum(a.capacity for t in (self._arenas, self._post_arenas) for a in t.values())
 
     def _plan(self, B, shapes, hw2, slot=0, nhwc=False):
         key = (B, tuple(shapes), tuple(hw2), slot, getattr(self, "return_all_layers", False),
@@ -356,14 +491,35 @@ class CrossHead2:
             return self._plans[key]
         if self.w is None:
             self._pack()
-        dev, f32 = self.device, torch.float32
-        E = lambda *s: torch.empty(*s, device=dev, dtype=f32)
-        pl = CrossHead2._Plan()
-        pl.B, pl.shapes, pl.hw2, pl.nhwc = B, list(shapes), tuple(hw2), nhwc
+
+        dims = self._plan_dims(B, shapes, hw2)
+        pl = self._arena(slot).carve(self._layout_for(dims, nhwc), dims, self._measure)
+        pl.slot, pl.key = slot, key
         pl.graph_a = pl.graph_b = pl.static_feats = pl.graph_cfg = pl.feats_read = None
-        pl.graph_c = {}
-        pl.static_ptrs, pl.staged, pl.me0 = None, False, None
+        pl.graph_c = PlanCache(self.POST_VIEWS)
+        pl.post_views = OrderedDict()
+        pl.static_ptrs = pl.last_ptrs = None
         pl.calls_a = pl.calls_b = 0
+        pl.streams = {}
+        pl.enc_pos, pl.dec_kpos, pl.pe_ready = self._position_tables(shapes)
+        pl.pe_waited = False
+        c = self._const(B)
+        if c["me0"] is None:
+            # the mask embedding of the INITIAL queries: a function of the weights alone,
+            # computed once per batch size on this plan's buffers and kept outside the arena
+            # (complete before any other stream can read it: one host wait per state dict)
+            self._head_embed(pl.q0, pl, False, False)
+            c["me0"] = pl.me.clone()
+            torch.cuda.current_stream(self.device).synchronize()
+        pl.me0 = c["me0"]
+        self._plans[key] = pl
+        return pl
+
+    def _layout(self, pl, E, B, shapes, hw2, nhwc):
+        """Every per-image buffer of the head as views of one arena (`E(*shape)` carves a
+        float32 view).  Sizes are non-decreasing in B and in every height / width, so a plan
+        of any shape within the arena's envelope fits (plans.py)."""
+        pl.B, pl.shapes, pl.hw2, pl.nhwc = B, list(shapes), tuple(hw2), nhwc
         pl.N = [h * w for h, w in shapes]
         pl.start = [0, pl.N[0], pl.N[0] + pl.N[1]]
         pl.SN = sum(pl.N)
@@ -371,16 +527,6 @@ class CrossHead2:
         HW2 = hw2[0] * hw2[1]
         pl.HW2 = HW2
         M = B * SN
-        # ---- shape-dependent constants: positional tables ----
-        w = self.w
-        pl.enc_pos = E(SN, 256)
-        pl.dec_kpos = []
-        for l, (h, wd) in enumerate(shapes):
-            hip.sine_pe(pl.enc_pos[pl.start[l]:pl.start[l] + pl.N[l]],
-                        w["pixel_decoder.level_encoding.weight"][l], h, wd)
-            kp = E(pl.N[l], 256)
-            hip.sine_pe(kp, w["level_embed.weight"][l], h, wd)
-            pl.dec_kpos.append(kp)
         # ---- pixel decoder ----
         pl.X, pl.X1, pl.Y = E(B, SN, 256), E(B, SN, 256), E(B, SN, 256)
         pl.S = E(B, SN, 256)
@@ -389,7 +535,7 @@ class CrossHead2:
         pl.tmpconv = E(B, max(pl.N), 256)
         pl.splitk = E(B * 9 * 1024 * 1024)   # split-K workspace of the C5 / C4 input convs
         nblk = max(hip.groupnorm_nblk(HW2), hip.groupnorm_nblk(max(pl.N)))
-        pl.gn_part = torch.empty(B * nblk * 32 * 2, device=dev, dtype=torch.float64)
+        pl.gn_part = E.f64(B * nblk * 32 * 2)
         pl.T1, pl.T2 = E(B, HW2, 256), E(B, HW2, 256)
         # (grouped input convolutions: one output buffer per level, views of pl.T1, which is
         # idle until the lateral convolution: sum(N) <= HW2 rows)
@@ -399,10 +545,12 @@ class CrossHead2:
             offs = [0, B * pl.N[0] * 256, B * (pl.N[0] + pl.N[1]) * 256]
             pl.tmpconv3 = [t1[o:o + B * n * 256].view(B, n, 256) for o, n in zip(offs, pl.N)]
         # Winograd scratch: F(2x2): 16 planes of B * HW2 / 4 tiles x 256 (even sides only),
-        # F(4x4): 36 planes of B * ceil(H2/4) * ceil(W2/4) tiles x 256
+        # F(4x4): 36 planes of B * ceil(H2/4) * ceil(W2/4) tiles x 256 (sized for both, whatever
+        # the parity of this shape: the arena's envelope must cover every shape below it)
         pl.wino = hw2[0] % 2 == 0 and hw2[1] % 2 == 0
         t4 = B * ((hw2[0] + 3) // 4) * ((hw2[1] + 3) // 4)
-        n = max(16 * B * HW2 // 4 if pl.wino else 0, 36 * t4) * 256
+        t2 = B * ((hw2[0] + 1) // 2) * ((hw2[1] + 1) // 2)
+        n = max(16 * t2, 36 * t4) * 256
         pl.wV, pl.wM = E(n), E(n)
         pl.MF = E(B, HW2, 256)
         # ---- decoder ----
@@ -411,25 +559,24 @@ class CrossHead2:
         pl.Vp = [E(B, pl.N[i % 3], 256) for i in range(nd)]
         BQ = B * Q
         pl.q, pl.q1, pl.q2, pl.qy = E(BQ, 256), E(BQ, 256), E(BQ, 256), E(BQ, 256)
-        pl.q0 = w["query_feat.weight"].unsqueeze(0).expand(B, Q, 256).reshape(BQ, 256).contiguous()
+        pl.q0 = self._const(B)["q0"]
         pl.qn, pl.m1, pl.m2, pl.me = E(BQ, 256), E(BQ, 256), E(BQ, 256), E(BQ, 256)
         pl.Qp, pl.att, pl.Qp0 = E(BQ, 256), E(BQ, 256), E(BQ, 256)
         pl.VQK = E(BQ, 768)
-        pl.MFd = [E(B, n, 256) for n in pl.N]   # mask feature resampled to each level
-        pl.MFs = pl.ML4 = None                  # exact_mask_order=True: stencil rows, their logits
+        pl.MFd = [E(B, n, 256) for n in pl.N]    # mask feature resampled to each level
+        pl.MFs = [E(B, 4 * n, 256) for n in pl.N]   # exact_mask_order=True: stencil rows ...
+        pl.ML4 = E(BQ, 4 * max(pl.N))               # ... and their logits
         pl.hq = E(hip.ffn_scratch_floats(BQ, self.dec_ffn))
         pl.MP = E(B, Q, HW2)
         pl.ML = E(BQ, max(pl.N))
-        pl.bits = torch.empty(BQ * ((max(pl.N) + 31) // 32), device=dev, dtype=torch.int32)
-        pl.rowall = torch.empty(BQ, device=dev, dtype=torch.int32)
+        pl.bits = E.i32(BQ * ((max(pl.N) + 31) // 32))
+        pl.rowall = E.i32(BQ)
         pl.cls = E(B, Q, self.num_classes + 1)
         self._plan_relation(pl, E)
-        self._plans[key] = pl
-        return pl
 
     def _plan_relation(self, pl, E):
         """Buffers of the Pair Proposal Network and the Relation Fusion decoder."""
-        B, Q, R, dev = pl.B, self.num_obj_query, self.num_rel_query, self.device
+        B, Q, R = pl.B, self.num_obj_query, self.num_rel_query
         BQ, HW2 = B * Q, pl.HW2
         scr = max(hip.attn_scratch_floats(B, Q, n) for n in pl.N + [Q])
         scr = max(scr, hip.attn_scratch_floats(B, R, 2 * R), hip.attn_scratch_floats(B, R, R))
@@ -441,15 +588,13 @@ class CrossHead2:
         # split-K workspace of the 64 -> 64 Matrix Learner layer (few output tiles, K = 3136)
         tiles = B * ((Q * Q + 63) // 64)
         pl.ppn_splitk = E(8 * B * Q * Q * 64) if tiles < 512 else None
-        i64 = lambda *s: torch.empty(*s, device=dev, dtype=torch.int64)
-        pl.topk_idx, pl.sub_pos, pl.obj_pos = i64(B, R), i64(B, R), i64(B, R)
-        pl.pair_idx = i64(B, 2 * R)
+        pl.topk_idx, pl.sub_pos, pl.obj_pos = E.i64(B, R), E.i64(B, R), E.i64(B, R)
+        pl.pair_idx = E.i64(B, 2 * R)
         pl.pair = E(B * 2 * R, 256)
         # ---- relation decoder ----
         BR = B * R
         pl.r, pl.r1, pl.r2, pl.ry = E(BR, 256), E(BR, 256), E(BR, 256), E(BR, 256)
-        pl.r0 = self.w["rel_query_feat.weight"].unsqueeze(0).expand(B, R, 256).reshape(
-            BR, 256).contiguous()
+        pl.r0 = self._const(B).get("r0")
         pl.rQp, pl.ratt = E(BR, 256), E(BR, 256)
         pl.rVQK = E(BR, 768)
         pl.rh = E(hip.ffn_scratch_floats(BR, self.rel_ffn))
@@ -551,10 +696,6 @@ class CrossHead2:
                                   pl.N[l] * 256)
         elif self.exact_mask_order != "full":
             # the mask-feature rows each level's bilinear stencils read, once per image
-            if pl.MFs is None:
-                E = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
-                pl.MFs = [E(B, 4 * n, 256) for n in pl.N]
-                pl.ML4 = E(B * self.num_obj_query, 4 * max(pl.N))
             for l, (h, wd) in enumerate(pl.shapes):
                 hip.bilinear_stencil_rows(pl.MF, pl.MFs[l], B, H2, W2, h, wd, 256, HW2 * 256,
                                           4 * pl.N[l] * 256)
@@ -715,14 +856,10 @@ class CrossHead2:
         qpos = w["query_embed.weight"]
         exact = self.exact_mask_order == "full"     # full-resolution logits of every layer
         # the INITIAL queries are learned constants (pl.q0: `query_feat` repeated over the
-        # batch, filled when the plan is made; the first layer reads them in place), and so is
-        # their mask embedding: computed on the plan's first call and kept (a new state dict
-        # drops the plans)
+        # batch; the first layer reads them in place), and so is their mask embedding pl.me0:
+        # both live in `_const(B)`, outside the arenas (a new state dict drops them)
         if exact:
             self._head_embed(pl.q0, pl, False, True)
-        elif pl.me0 is None:
-            self._head_embed(pl.q0, pl, False, False)
-            pl.me0 = pl.me.clone()
         last = self.num_dec_layers - 1
         mp = None
         # post_norm of every layer's output comes out of the layer's FFN kernel
@@ -831,47 +968,48 @@ class CrossHead2:
 
     def _run_stage(self, which, pl, feats=None):
         """Run stage 'a' or 'b' of plan `pl` on the current stream: eagerly, or (with
-        `use_graphs`) as one hipGraph replay.  A stage is captured on its second call
-        (the first, eager one is the warm-up torch requires before capture)."""
+        `use_graphs`) as one hipGraph replay.  A stage is captured once it has run
+        `graph_after` times eagerly -- without any host synchronisation: nothing allocates,
+        every buffer is a view of the slot's arena (plans.py)."""
         cfg = (self.exact_mask_order, self.conv_algo, self.fuse_ppn_front, self.grid_reserve,
                tuple(self.enc_fused_ln), self.group_input_convs)
         if pl.graph_cfg != cfg:          # a captured graph bakes these switches in
-            pl.graph_a = pl.graph_b = pl.me0 = None
-            pl.graph_c = {}
+            pl.graph_a = pl.graph_b = None
+            pl.graph_c = PlanCache(self.POST_VIEWS)
             pl.graph_cfg = cfg
+        cur = torch.cuda.current_stream(self.device)
+        pl.streams[cur.cuda_stream] = cur
         if which == "a":
+            if not pl.pe_waited:
+                # the position tables are shared by the slots and filled on the stream that
+                # first saw the shape: order this stream behind them (until they are done)
+                if pl.pe_ready.query():
+                    pl.pe_waited = True
+                else:
+                    cur.wait_event(pl.pe_ready)
             ptrs = tuple(f.data_ptr() for f in feats)
-            if self.use_graphs and pl.graph_a is None and pl.calls_a >= 1:
-                # captured on the caller's own buffers: a caller that hands over the same
-                # buffers every time (a backbone writing into per-shape outputs, a resident
-                # pyramid) pays no staging copy
-                pl.static_feats, pl.static_ptrs, pl.staged = list(feats), ptrs, False
-                pl.graph_a = self._capture(lambda: self._stage_a(pl.static_feats, pl))
+            if self.use_graphs:
+                if pl.graph_a is not None and ptrs != pl.static_ptrs:
+                    # other buffers than the captured ones: eager (it reads any pointer), and
+                    # captured again as soon as the caller's buffers repeat
+                    pl.graph_a = None
+                if pl.graph_a is None and pl.calls_a >= self.graph_after and ptrs == pl.last_ptrs:
+                    # captured on the caller's own buffers: a caller that hands over the same
+                    # buffers every time (the backbone writing into its slot's arena, a
+                    # resident pyramid) pays no staging copy
+                    pl.static_feats, pl.static_ptrs = list(feats), ptrs
+                    pl.graph_a = self._capture(lambda: self._stage_a(pl.static_feats, pl))
             pl.calls_a += 1
+            pl.last_ptrs = ptrs
             if pl.feats_read is None:
                 pl.feats_read = torch.cuda.Event()
             if self.use_graphs and pl.graph_a is not None:
-                if not pl.staged and ptrs != pl.static_ptrs:
-                    # other buffers than the captured ones: from now on stage the features
-                    # into private copies (one re-capture on them)
-                    pl.static_feats = [torch.empty_like(f) for f in feats]
-                    for dst, src in zip(pl.static_feats, feats):
-                        dst.copy_(src)
-                    pl.static_ptrs, pl.staged = None, True
-                    pl.graph_a = self._capture(lambda: self._stage_a(pl.static_feats, pl))
-                if pl.staged:
-                    for dst, src in zip(pl.static_feats, feats):
-                        dst.copy_(src)
-                    pl.feats_read.record()  # the caller's feature buffers are free again
-                    pl.graph_a.replay()
-                else:
-                    pl.graph_a.replay()
-                    pl.feats_read.record()  # (read in place, up to the FPN level)
+                pl.graph_a.replay()
             else:
                 self._stage_a(feats, pl)
-                pl.feats_read.record()
+            pl.feats_read.record()      # the caller's feature buffers are free again
         else:
-            if self.use_graphs and pl.graph_b is None and pl.calls_b >= 1:
+            if self.use_graphs and pl.graph_b is None and pl.calls_b >= self.graph_after:
                 pl.graph_b = self._capture(lambda: self._stage_b(pl))
             pl.calls_b += 1
             if self.use_graphs and pl.graph_b is not None:
@@ -879,14 +1017,28 @@ class CrossHead2:
             else:
                 self._stage_b(pl)
 
+    _capture_streams = {}
+    captures = 0          # graphs captured so far in this process (a counter for the bench / tests)
+
     @staticmethod
     def _capture(fn):
-        torch.cuda.synchronize()
+        """Record `fn`'s launches into a hipGraph.  Unlike `torch.cuda.graph()` this does not
+        wait for the device, collect garbage or trim the allocator: the launches allocate
+        nothing (arena views), so capture is pure host work on a private stream while the
+        other streams keep executing.  thread_local: other threads (the RCCL watchdog, the
+        result streamer's worker) may touch the runtime while this thread captures."""
+        dev = torch.cuda.current_device()
+        cs = CrossHead2._capture_streams.get(dev)
+        if cs is None:
+            cs = CrossHead2._capture_streams[dev] = torch.cuda.Stream(dev)
+        CrossHead2.captures += 1
         g = torch.cuda.CUDAGraph()
-        # thread_local: other threads (e.g. the RCCL watchdog) may touch the runtime
-        # while this thread captures
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            fn()
+        with torch.cuda.stream(cs):
+            g.capture_begin(capture_error_mode="thread_local")
+            try:
+                fn()
+            finally:
+                g.capture_end()
         return g
 
     @torch.no_grad()
@@ -944,80 +1096,124 @@ class CrossHead2:
         panoptic_jobs = ()
 
     def _post_buffers(self, anchor, key, build):
-        """Post-processing buffers per (input buffer, output size): `anchor` is the tensor whose
-        storage identifies the caller's buffer.  For the head's own outputs (the hot loop: a
-        plan's outputs keep their address, so nothing is allocated per call) the buffers live
-        IN the plan and are freed with it when the LRU evicts the plan; for foreign inputs a
-        small bounded table is kept, oldest entry dropped first."""
+        """Post-processing buffers for FOREIGN inputs (tensors that are not a plan's own
+        outputs), per (input buffer, output size): a small bounded table, oldest entry
+        dropped first.  The head's own outputs -- the hot loop -- take views of the slot's
+        post-processing arena instead (`_post_views`)."""
         k = (anchor.data_ptr(), str(anchor.device)) + tuple(key)
-        pl = getattr(self, "_last_plan", None)
-        owner = None
-        if pl is not None:
-            for name in ("cls", "sub_cls"):
-                t = getattr(pl, name, None)
-                if t is not None and t.data_ptr() <= anchor.data_ptr() < \
-                        t.data_ptr() + t.numel() * t.element_size():
-                    owner = pl.__dict__.setdefault("post", {})
-        table = owner if owner is not None else self._post
+        table = self._post
         pb = table.get(k)
         if pb is None:
             if len(table) >= self.POST_ENTRIES:
-                # bounded either way (an evaluation set with keep-ratio resizing has many
-                # original sizes, ~190 MB of buffers each at 480 x 640): drop the oldest entry.
-                # Rare and not on the steady-state path: wait for the device first (queued
-                # kernels and captured get_bboxes graphs may still reference its buffers),
-                # and forget the plan's get_bboxes graphs (they are re-captured on demand).
+                # rare and not on the steady-state path: wait for the device first (queued
+                # kernels may still reference the entry's buffers)
                 torch.cuda.synchronize(anchor.device)
                 table.pop(next(iter(table)))
-                if owner is not None:
-                    pl.graph_c = {}
             pb = table[k] = build()
-        elif owner is not None and next(reversed(table)) != k:
-            table[k] = table.pop(k)          # most recently used last
         return pb
+
+    def _post_layout(self, E, sizes):
+        """Post-processing buffers of one batch, `sizes` = [(H0, W0)] per image."""
+        R, Q = self.num_rel_query, self.num_obj_query
+        out = []
+        for H0, W0 in sizes:
+            out.append(dict(
+                labels=E.i64(2 * R), sc_tmp=E(2 * R), r_dists=E(R, self.num_relations + 1),
+                masks=E.u8(2 * R, H0, W0), all_labels=E.i64(Q), all_scores=E(Q),
+                state=E.u8(hip.panoptic_state_bytes()), up=E(Q, H0 * W0), area=E.i32(256),
+                seg=E.i64(H0 * W0)))
+        return out
+
+    def _post_views(self, pl, sizes):
+        """Views of slot `pl.slot`'s post-processing arena for a batch whose images have the
+        original sizes `sizes`: like the plans themselves, no allocation per (shape, size) --
+        a keep-ratio evaluation set has about as many original sizes as images."""
+        sizes = tuple(sizes)
+        pv = pl.post_views.get(sizes)
+        if pv is not None:
+            pl.post_views.move_to_end(sizes)
+            return pv
+        # buffer sizes depend on the pixel COUNT only: the arena's envelope is (images,
+        # pixels of the largest image)
+        dims = (len(sizes), max(h * w for h, w in sizes))
+        pv = self._post_arena(pl.slot).carve(
+            lambda E: self._post_layout(E, sizes), dims,
+            lambda d: measure_bytes(lambda E: self._post_layout(E, [(1, d[1])] * d[0])))
+        pl.post_views[sizes] = pv
+        while len(pl.post_views) > self.POST_VIEWS:
+            pl.post_views.popitem(last=False)     # (views: nothing to free, nothing to wait for)
+        return pv
+
+    class _PostGraph:
+        def __init__(self, pl):
+            self.pl, self.calls, self.graph, self.res = pl, 0, None, None
+
+        def busy_events(self):
+            return self.pl.busy_events() if self.graph is not None else []
+
+    def _own_plan(self, cls_scores, mask_preds):
+        """The plan whose outputs these dicts are (None for foreign tensors)."""
+        pl = getattr(self, "_last_plan", None)
+        if pl is not None and "cls" in cls_scores and "mask" in mask_preds \
+                and cls_scores["cls"].data_ptr() == pl.cls.data_ptr() \
+                and mask_preds["mask"].data_ptr() == pl.MP.data_ptr():
+            return pl
+        return None
 
     @torch.no_grad()
     @hip.on_device
     def get_bboxes(self, cls_scores, mask_preds, img_metas, rescale=False):
         """pairnet_head.py:760-786.  With `use_graphs`, the post-processing of a plan's own
-        outputs is replayed as one hipGraph per (plan, image sizes)."""
-        pl = getattr(self, "_last_plan", None)
-        mine = (pl is not None and self.use_graphs and "cls" in cls_scores
-                and cls_scores["cls"].data_ptr() == pl.cls.data_ptr()
-                and mask_preds["mask"].data_ptr() == pl.MP.data_ptr())
-        if not mine:
-            return self._get_bboxes_all(cls_scores, mask_preds, img_metas, rescale)
+        outputs is replayed as one hipGraph per (plan, image sizes), captured like the stage
+        graphs after `graph_after` eager calls."""
+        pl = self._own_plan(cls_scores, mask_preds)
+        if pl is None or not self.use_graphs:
+            return self._get_bboxes_all(cls_scores, mask_preds, img_metas, rescale, pl)
+        cur = torch.cuda.current_stream(self.device)
+        pl.streams[cur.cuda_stream] = cur
         key = (tuple((tuple(m["img_shape"]), tuple(float(v) for v in m["scale_factor"]))
                      for m in img_metas), bool(rescale))
-        ent = pl.graph_c.setdefault(key, dict(calls=0, graph=None, res=None))
-        if ent["graph"] is None:
-            if ent["calls"] == 0:          # eager warm-up (allocates the buffers)
-                ent["calls"] = 1
-                return self._get_bboxes_all(cls_scores, mask_preds, img_metas, rescale)
+        ent = pl.graph_c.get(key)
+        if ent is None:
+            ent = pl.graph_c[key] = CrossHead2._PostGraph(pl)
+        if ent.graph is None:
+            if ent.calls < self.graph_after:
+                ent.calls += 1
+                return self._get_bboxes_all(cls_scores, mask_preds, img_metas, rescale, pl)
+            self._post_views(pl, self._orig_sizes(img_metas))   # (made / grown outside the capture)
+            pl.graph_c[key] = ent
             box = {}
-            ent["graph"] = self._capture(lambda: box.update(
-                res=self._get_bboxes_all(cls_scores, mask_preds, img_metas, rescale)))
-            ent["res"] = box["res"]
-        ent["graph"].replay()
-        self._pan_jobs = list(ent["res"].panoptic_jobs)
-        return ent["res"]
+            ent.graph = self._capture(lambda: box.update(
+                res=self._get_bboxes_all(cls_scores, mask_preds, img_metas, rescale, pl)))
+            ent.res = box["res"]
+        ent.graph.replay()
+        self._pan_jobs = list(ent.res.panoptic_jobs)
+        return ent.res
 
-    def _get_bboxes_all(self, cls_scores, mask_preds, img_metas, rescale):
+    @staticmethod
+    def _orig_sizes(img_metas):
+        return [(round(m["img_shape"][0] / m["scale_factor"][1]),
+                 round(m["img_shape"][1] / m["scale_factor"][0])) for m in img_metas]
+
+    def _get_bboxes_all(self, cls_scores, mask_preds, img_metas, rescale, pl=None):
         self._pan_jobs = []
+        pv = self._post_views(pl, self._orig_sizes(img_metas)) if pl is not None else None
         res = CrossHead2.ResultList(self._get_bboxes_single(
             mask_preds["mask"][i], cls_scores["cls"][i], cls_scores["sub"][i],
             cls_scores["obj"][i], cls_scores["rel"][i], mask_preds["sub_seg"][i],
             mask_preds["obj_seg"][i], img_metas[i]["img_shape"],
-            img_metas[i]["scale_factor"], rescale) for i in range(len(img_metas)))
+            img_metas[i]["scale_factor"], rescale, pb=pv[i] if pv is not None else None)
+            for i in range(len(img_metas)))
         res.panoptic_jobs = tuple(self._pan_jobs)
         return res
 
     def _get_bboxes_single(self, all_masks, all_cls, s_cls, o_cls, r_cls, s_seg, o_seg,
-                           img_shape, scale_factor, rescale=False):
+                           img_shape, scale_factor, rescale=False, pb=None):
         """pairnet_head.py:788-924 on the device, without any host round trip (every
         launch is asynchronous; `panoptic_status()` reads the loop flags back at the
-        caller's D2H point).  The outputs are views of buffers owned by the head, one set
-        per (input buffer, output size): the next call on the same inputs overwrites them."""
+        caller's D2H point).  The outputs are views of buffers owned by the head -- for the
+        head's own outputs views of the slot's post-processing arena (`pb`), for foreign
+        inputs one set per (input buffer, output size): the next call overwrites them."""
         assert len(s_cls) == len(o_cls) == len(r_cls)
         dev = all_cls.device
         R, Q = self.num_rel_query, all_cls.shape[0]
@@ -1038,7 +1234,8 @@ class CrossHead2:
                         state=torch.empty(hip.panoptic_state_bytes(), device=dev, dtype=torch.uint8),
                         up=f32(Q, H0 * W0), area=torch.empty(256, device=dev, dtype=torch.int32),
                         seg=i64(H0 * W0))
-        pb = self._post_buffers(all_cls, (H0, W0, Q, R), build)
+        if pb is None:
+            pb = self._post_buffers(all_cls, (H0, W0, Q, R), build)
         # triplet labels (1-based) and relation distributions (:811-820)
         labels = pb["labels"]
         hip.cls_argmax(s_cls, labels[:R], pb["sc_tmp"][:R], R, nc, 1)

@@ -80,6 +80,8 @@ _SIGS = {
                                      _vp]),
     "pn_bce_posw_mean_f32": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp]),
     "pn_msda_loc_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pn_msda_bwd_f32": (C.c_int, [_vp, _i64] + [_vp] * 8 + [_i32, _i32, _i32, _i32, _vp]),
+    "pn_gather_probe_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "pn_sine_pe_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "pn_sine_pe_offset_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp]),
     "pn_bilinear_nhwc_f32": (C.c_int, [_vp, _vp] + [_i32] * 7 + [_i64, _i64, _vp]),
@@ -136,7 +138,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 18   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 19   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -584,6 +586,19 @@ def msda_loc(value, ld_value, spatial_shapes, level_start_index, loc, aw, out, B
                                                  _ptr(level_start_index, torch.int64), _ptr(loc),
                                                  _ptr(aw), _ptr(out), B, N, Nq, L, _stream())),
            "pn_msda_loc_f32")
+
+
+def msda_bwd(value, ld_value, spatial_shapes, level_start_index, loc, aw, grad_out, grad_value,
+             grad_loc, grad_aw, B, N, Nq, L):
+    _check(lib().pn_msda_bwd_f32(_ptr(value), ld_value, _ptr(spatial_shapes, torch.int64),
+                                 _ptr(level_start_index, torch.int64), _ptr(loc), _ptr(aw),
+                                 _ptr(grad_out), _ptr(grad_value), _ptr(grad_loc), _ptr(grad_aw),
+                                 B, N, Nq, L, _stream()), "pn_msda_bwd_f32")
+
+
+def gather_probe(lines, idx, out, workgroups, line_mask):
+    _check(lib().pn_gather_probe_f32(_ptr(lines), _ptr(idx, torch.int32), _ptr(out), workgroups,
+                                     line_mask, _stream()), "pn_gather_probe_f32")
 
 
 def sine_pe(out, add, h, w, C_=256, temperature=10000.0, offset=0.0, valid=None):

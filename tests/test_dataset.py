@@ -139,6 +139,21 @@ def test_product_host_logic_equals_the_oracle(split, all_bboxes):
         P.load_psg(copy.deepcopy(dataset), "val")
 
 
+def test_load_psg_leaves_the_callers_dict_alone():
+    """loading both splits from ONE loaded dict must not shift the predicate labels
+    twice (the reference re-reads the file per dataset object)."""
+    from pairnet_amd import dataset as P
+    dataset, _ = synthetic_psg(9, n_images=9)
+    d = copy.deepcopy(dataset)
+    test = P.load_psg(d, "test")
+    assert d == dataset
+    again = P.load_psg(d, "test")
+    assert again["data"] == test["data"]
+    train = P.load_psg(d, "train")
+    want = D.load_psg(copy.deepcopy(dataset), "train")
+    assert [x["relations"] for x in train["data"]] == [x["relations"] for x in want]
+
+
 def test_load_psg_reads_a_file(tmp_path):
     from pairnet_amd import dataset as P
     dataset, _ = synthetic_psg(2)

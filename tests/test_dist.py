@@ -187,8 +187,10 @@ class _HostDetector:
         def rel(stream):
             self.released += 1
         for img, metas in batches:
-            r, s, o = self.detect(img)
-            queue.append(TripletBatch([r], [s], [o], stream=None, release=rel))
+            assert img.shape[0] == len(metas)
+            got = [self.detect(img[b]) for b in range(img.shape[0])]      # (one record per image)
+            queue.append(TripletBatch([g[0] for g in got], [g[1] for g in got],
+                                      [g[2] for g in got], stream=None, release=rel))
             if len(queue) > self.lag:
                 yield queue.pop(0)
         while queue:
@@ -221,14 +223,15 @@ def _host_annotations(n):
     return out
 
 
-def _loop_worker(rank, world, port, n_images, q):
+def _loop_worker(rank, world, port, n_images, q, k=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pairnet_amd.dist import multi_gpu_test
     from pairnet_amd.evaluation import SceneGraphMetrics
     det = _HostDetector()
     out = multi_gpu_test(det, _host_dataset(n_images), annotations=_host_annotations(n_images),
-                         evaluator=_ListEvaluator(), metrics=SceneGraphMetrics(56), depth=2)
+                         evaluator=_ListEvaluator(), metrics=SceneGraphMetrics(56), depth=2,
+                         samples_per_gpu=k)
     q.put((rank, out["records"].numpy(), out["collectives"], det.released, out.get("metrics")))
     dist.barrier()
     dist.destroy_process_group()
@@ -266,6 +269,66 @@ def test_multi_gpu_test_world2_equals_world1_gloo():
         assert ncoll == 3                                  # ceil(5 / 2) collectives on BOTH ranks
         assert released == len(shard_indices(n, r, world))
     assert outs[1][3] is None and outs[0][3] == one["metrics"]
+
+
+@pytest.mark.parametrize("n,k", [(5, 2), (7, 3), (4, 2)])
+def test_multi_gpu_test_samples_per_gpu_world2_equals_world1_gloo(n, k):
+    """BASELINE configs[2] through the product loop (tools/test.py:202-214: `samples_per_gpu`
+    images per step): rank r batches its images r, r + W, ... k at a time; the records come
+    back in dataset order on every rank, uneven tails (a last batch of fewer images, a rank
+    with no batch left) are zero rows behind the dataset's end, and records and metrics equal
+    those of the one-image-per-step, one-process run."""
+    from pairnet_amd.dist import multi_gpu_test
+    from pairnet_amd.evaluation import SceneGraphMetrics
+    det = _HostDetector()
+    one = multi_gpu_test(det, _host_dataset(n), annotations=_host_annotations(n),
+                         evaluator=_ListEvaluator(), metrics=SceneGraphMetrics(56), depth=2)
+    det = _HostDetector()
+    onek = multi_gpu_test(det, _host_dataset(n), annotations=_host_annotations(n),
+                          evaluator=_ListEvaluator(), metrics=SceneGraphMetrics(56), depth=2,
+                          samples_per_gpu=k)
+    expect = torch.stack([_record(i) for i in range(n)])
+    assert torch.equal(onek["records"], expect) and onek["metrics"] == one["metrics"]
+    assert onek["collectives"] == -(-n // k) and det.released == -(-n // k)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, port = 2, _free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, world, port, n, q, k)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {r: rest for r, *rest in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    steps = -(-(-(-n // world)) // k)
+    for r in range(world):
+        rec, ncoll, released, metrics = outs[r]
+        assert torch.equal(torch.from_numpy(rec), expect)
+        assert ncoll == steps                              # the same collectives on BOTH ranks
+        assert released == -(-len(shard_indices(n, r, world)) // k)
+    assert outs[1][3] is None and outs[0][3] == one["metrics"]
+
+
+def test_multi_gpu_test_of_an_empty_dataset_returns_no_records():
+    """N == 0 -> an empty [0, L] record tensor, not a TypeError."""
+    from pairnet_amd.dist import multi_gpu_test
+    out = multi_gpu_test(_HostDetector(), [], depth=2)
+    assert out["records"].shape == (0, triplet_record_len(100, 56)) and out["collectives"] == 0
+
+
+def test_collate_pads_unequal_images_like_mmcv():
+    """`collate` (the loader's batching, tools/test.py:202-214): equal sizes are stacked,
+    unequal ones zero-padded at the bottom / right to the batch maximum; metas stay per image."""
+    from pairnet_amd.dist import collate
+    a, b = torch.ones(1, 3, 4, 6), 2 * torch.ones(1, 3, 5, 3)
+    ma, mb = [dict(img_shape=(4, 6, 3))], [dict(img_shape=(5, 3, 3))]
+    img, metas = collate([(a, ma), (b, mb)])
+    assert img.shape == (2, 3, 5, 6) and metas == ma + mb
+    assert torch.equal(img[0, :, :4, :], a[0]) and float(img[0, :, 4:, :].abs().sum()) == 0
+    assert torch.equal(img[1, :, :, :3], b[0]) and float(img[1, :, :, 3:].abs().sum()) == 0
+    img, metas = collate([(a, ma), (a + 1, ma)])
+    assert img.shape == (2, 3, 4, 6) and torch.equal(img[1], a[0] + 1)
+    assert collate([(a, ma)])[0] is a
 
 
 def test_collector_pads_partial_batches_and_keeps_step_order():

@@ -362,7 +362,8 @@ def test_graph_replay_and_two_stream_pipeline_are_bitwise_the_eager_path():
 def test_graph_reads_reused_feature_buffers_in_place():
     """A caller that hands over the SAME buffers every step (new contents written in place)
     gets stage A's graph captured on those buffers -- no staging copy -- and still sees
-    every step's own features; a caller that switches buffers falls back to staging."""
+    every step's own features; a caller that switches buffers is served eagerly (no private
+    copies per shape), and the graph comes back once its buffers repeat."""
     _, sd, _ = oracle_head(77)
     head = _hip_head(sd)
     H, W = 64, 96
@@ -380,15 +381,20 @@ def test_graph_reads_reused_feature_buffers_in_place():
                 dst.copy_(src)
             cls, _ = head.forward(bufs, metas)
             assert torch.equal(cls["rel"], want)
-    assert head._last_plan.graph_a is not None and head._last_plan.staged is False
-    for b, want in zip(batches, eager):                    # other buffers: staged from now on
+    pl = head._last_plan
+    assert pl.graph_a is not None and pl.static_ptrs == tuple(f.data_ptr() for f in bufs)
+    mem = torch.cuda.memory_allocated()
+    for b, want in zip(batches, eager):                    # other buffers every call: eager
         cls, _ = head.forward(b, metas)
         assert torch.equal(cls["rel"], want)
-    assert head._last_plan.staged is True
-    for dst, src in zip(bufs, batches[2]):
-        dst.copy_(src)
-    cls, _ = head.forward(bufs, metas)
-    assert torch.equal(cls["rel"], eager[2])
+    assert head._last_plan is pl and pl.graph_a is None
+    assert torch.cuda.memory_allocated() == mem            # ... and nothing was staged
+    for rep in range(2):                                   # the same buffers again: re-captured
+        for dst, src in zip(bufs, batches[2]):
+            dst.copy_(src)
+        cls, _ = head.forward(bufs, metas)
+        assert torch.equal(cls["rel"], eager[2])
+    assert pl.graph_a is not None
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 64, 80)])

@@ -444,6 +444,71 @@ def test_mmcv_shaped_msda_on_the_golden_fixture_equals_the_fused_entry(hip):
     close(out, _run_msda(hip, value, off, logits, shapes).cpu(), 2e-6, "mmcv-shaped vs fused entry")
 
 
+def _msda_grads_ref(value, shapes, loc, aw, gout):
+    """Autograd through the oracle's (HF-pinned) restatement of mmcv's CPU formula, in fp64."""
+    v, l, a = (t.double().clone().requires_grad_(True) for t in (value, loc, aw))
+    out = L.msda_core(v, shapes, l, a)
+    out.backward(gout.double())
+    return out.detach().float(), v.grad.float(), l.grad.float(), a.grad.float()
+
+
+def _rel_close(got, want, tol, what):
+    got, want = got.detach().cpu().float(), want.float()
+    err = float((got - want).abs().max()) / max(float(want.abs().max()), 1e-30)
+    assert err < tol, "%s: max err / max |ref| = %.3e" % (what, err)
+
+
+@pytest.mark.parametrize("shapes,bs,nq,lo,hi", [([(3, 4), (6, 8), (12, 16)], 2, 252, -0.3, 1.3),
+                                                 ([(5, 7)], 1, 1, 0.0, 1.0),
+                                                 ([(2, 3), (4, 5), (7, 9), (13, 17)], 2, 301, -0.2, 1.2),
+                                                 ([(9, 1), (17, 3)], 3, 100, -1.0, 2.0),
+                                                 ([(25, 42), (50, 84), (100, 167)], 1, 21950, -0.05, 1.05)])
+def test_mmcv_shaped_msda_backward(hip, shapes, bs, nq, lo, hi):
+    """`ms_deform_attn_backward` in mmcv's own signature (the second half of
+    the reference's one native boundary) against autograd through the oracle's sampling, 1e-4
+    relative: small pyramids with samples off the map on every side, and the production
+    pyramid of an 800 x 1333 image with one query per token."""
+    from pairnet_amd.mmcv_ops import ms_deform_attn_backward
+    value, ss, starts, loc, aw = _mmcv_inputs(shapes, bs, nq, 31, lo=lo, hi=hi)
+    gout = R(bs, nq, 256, seed=34)
+    _, gv, gl, ga = _msda_grads_ref(value, shapes, loc, aw, gout)
+    d = lambda t: t.to(DEV)
+    grad_value, grad_loc, grad_aw = (torch.zeros_like(d(t)) for t in (value, loc, aw))
+    grad_loc.fill_(7.0)                  # (overwritten, whatever it held)
+    ms_deform_attn_backward(d(value), d(ss), d(starts), d(loc), d(aw), d(gout), grad_value,
+                            grad_loc, grad_aw, 64)
+    _rel_close(grad_value, gv, 1e-4, "grad_value")
+    _rel_close(grad_loc, gl, 1e-4, "grad_sampling_loc")
+    _rel_close(grad_aw, ga, 1e-4, "grad_attn_weight")
+    # grad_value is accumulated into: a second call doubles it
+    ms_deform_attn_backward(d(value), d(ss), d(starts), d(loc), d(aw), d(gout), grad_value,
+                            grad_loc, grad_aw, 64)
+    _rel_close(grad_value, 2 * gv, 1e-4, "grad_value accumulated")
+    _rel_close(grad_aw, ga, 1e-4, "grad_attn_weight overwritten")
+
+
+def test_mmcv_autograd_function_matches_the_oracle(hip):
+    """`MultiScaleDeformableAttnFunction.apply` (mmcv's autograd function of that name): the
+    forward value and all three gradients through torch.autograd."""
+    from pairnet_amd.mmcv_ops import MultiScaleDeformableAttnFunction
+    shapes = [(6, 8), (12, 16), (24, 32)]
+    value, ss, starts, loc, aw = _mmcv_inputs(shapes, 2, 333, 41)
+    gout = R(2, 333, 256, seed=44)
+    out_ref, gv, gl, ga = _msda_grads_ref(value, shapes, loc, aw, gout)
+    v, l, a = (t.to(DEV).requires_grad_(True) for t in (value, loc, aw))
+    out = MultiScaleDeformableAttnFunction.apply(v, ss.to(DEV), starts.to(DEV), l, a, 64)
+    out.backward(gout.to(DEV))
+    close(out.detach(), out_ref, 2e-6, "autograd function forward")
+    _rel_close(v.grad, gv, 1e-4, "value.grad")
+    _rel_close(l.grad, gl, 1e-4, "sampling_locations.grad")
+    _rel_close(a.grad, ga, 1e-4, "attention_weights.grad")
+    with pytest.raises(RuntimeError):
+        from pairnet_amd.mmcv_ops import ms_deform_attn_backward
+        ms_deform_attn_backward(v.detach(), ss.to(DEV), starts.to(DEV), l.detach(), a.detach(),
+                                gout.to(DEV), torch.zeros(1, device=DEV), torch.zeros_like(l),
+                                torch.zeros_like(a))
+
+
 # ----------------------------------------------------------------------------- PE / resize
 def test_sine_pe(hip):
     pe = L.SinePositionalEncoding(128, normalize=True)

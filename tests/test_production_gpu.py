@@ -394,44 +394,110 @@ def test_keep_ratio_shapes_portrait_and_odd_sides(H, W):
     assert res[0].masks.shape == (200, H, W) and res[0].pan_results.shape == (H, W)
 
 
-def test_plan_caches_stay_bounded_over_many_shapes():
-    """ADVICE r2 (medium): a keep-ratio evaluation pass meets hundreds of distinct shapes;
-    plans (buffers + captured graphs) are LRU-bounded, device memory stays flat, and a shape
-    that comes back after its plan was evicted gives bit-for-bit the same result."""
+def test_many_shapes_share_one_arena_per_slot():
+    """VERDICT r4 next 1 (was ADVICE r2): a keep-ratio evaluation pass meets hundreds of
+    distinct shapes (tools/test.py:199-267 with Pad(size_divisor=1)).  Plans are VIEWS of one
+    arena per slot, sized for the envelope of the shapes met: after `reserve` (or after the
+    largest shapes have passed) a new shape allocates nothing, waits for nothing and evicts
+    nothing; device memory is independent of the number of shapes; every image's result is
+    bitwise the one a fresh detector gives for that shape alone; graphs are captured on a
+    shape's second sight and replayed from then on (zero recaptures)."""
+    from oracle.backbone import seeded_backbone_state
+    from pairnet_amd import build_detector, pairnet_r50
+
+    def make():
+        det = build_detector(pairnet_r50())
+        det.backbone.load_state_dict(seeded_backbone_state(41))
+        det.to(DEV)
+        return det
+    det = make()
+    head, net = det.bbox_head, det.backbone
+    head.use_graphs = net.use_graphs = True
+    shapes = [(96 + 8 * (i % 7), 128 + 16 * (i % 5)) for i in range(35)]   # 35 distinct (H, W)
+    assert len(set(shapes)) == 35
+    env = [(max(h for h, _ in shapes), max(w for _, w in shapes))]
+    reserved = det.reserve(env, orig_sizes=env)
+    assert reserved == net.arena_bytes() + head.arena_bytes() > 0
+    grows = [a.grows for a in list(head._arenas.values()) + list(head._post_arenas.values())
+             + list(net._arenas.values())]
+
+    def run(d, H, W, seed, reps):
+        img = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(seed)).to(DEV)
+        metas = [dict(img_shape=(H, W, 3), scale_factor=[1.0] * 4)]
+        out = None
+        for _ in range(reps):                   # eager, capture, replay
+            r = d.bbox_head.simple_test_bboxes(d.extract_feat(img), metas)[0]
+            out = [t.clone() for t in (r[1], r[7], r[4])]
+        return out
+    torch.cuda.synchronize()
+    syncs = []
+    real_sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: (syncs.append(1), real_sync(*a, **k))[1]
+    try:
+        outs, mem = [], []
+        for i, (H, W) in enumerate(shapes):
+            outs.append(run(det, H, W, 1 + i, 3))
+            mem.append(torch.cuda.memory_allocated())
+    finally:
+        torch.cuda.synchronize = real_sync
+    assert not syncs                                   # no device-wide wait: not for plans, not for capture
+    assert [a.grows for a in list(head._arenas.values()) + list(head._post_arenas.values())
+            + list(net._arenas.values())] == grows     # the reserved arenas never grew
+    assert head._plans.evictions == 0 and net._plans.evictions == 0
+    assert all(pl.graph_a is not None and pl.graph_b is not None for pl in head._plans.values())
+    # memory: the arenas + the shared position tables (one set per shape, LRU-bounded) +
+    # the clones of this loop; independent of how many shapes have passed
+    pe = max(sum(t.numel() * 4 for t in [e[0]] + e[1]) for e in head._pe.values())
+    assert len(head._pe) <= head.PE_SHAPES
+    assert max(mem[12:]) - mem[11] <= head.PE_SHAPES * pe + (1 << 20), (mem[11], max(mem[12:]))
+    # the first shape again: its plan is still there, replayed, same bits
+    again = run(det, *shapes[0], 1, 1)
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], again))
+    # against a fresh detector that only ever sees that one shape (eager): no aliasing error
+    for i in (0, 17, 34):
+        fresh = make()
+        want = run(fresh, *shapes[i], 1 + i, 1)
+        assert all(torch.equal(a, b) for a, b in zip(outs[i], want)), i
+    # a shape beyond the envelope: the arenas grow once (a device wait), results stay right
+    big = (env[0][0] + 32, env[0][1] + 32)
+    got = run(det, *big, 99, 3)
+    assert head._arenas[0].grows == grows[0] + 1
+    want = run(make(), *big, 99, 1)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    again = run(det, *shapes[5], 6, 2)                 # (plans of the slot were rebuilt)
+    assert all(torch.equal(a, b) for a, b in zip(outs[5], again))
+
+
+def test_plan_cache_eviction_parks_busy_plans():
+    """More live (shape, slot) plans than the cache holds: the oldest is evicted without a
+    host wait -- parked until the streams it ran on have passed -- and a shape that comes
+    back is served again (views + a new capture), bit for bit."""
     from oracle.backbone import seeded_backbone_state
     from pairnet_amd import build_detector, pairnet_r50
     det = build_detector(pairnet_r50())
     det.backbone.load_state_dict(seeded_backbone_state(41))
     det.to(DEV)
-    det.bbox_head.use_graphs = det.backbone.use_graphs = True
-    for cache in (det.bbox_head._plans, det.backbone._plans):
-        cache.max_plans = 3
-    g = torch.Generator().manual_seed(11)
-    shapes = [(96 + 8 * (i % 7), 128 + 16 * (i % 5)) for i in range(35)]   # 35 distinct (H, W)
-    assert len(set(shapes)) == 35
-
-    def run(H, W, seed):
-        img = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(seed)).to(DEV)
-        metas = [dict(img_shape=(H, W, 3), scale_factor=[1.0] * 4)]
-        out = None
-        for _ in range(3):                      # eager warm-up, capture, replay
-            r = det.bbox_head.simple_test_bboxes(det.extract_feat(img), metas)[0]
+    head, net = det.bbox_head, det.backbone
+    head.use_graphs = net.use_graphs = True
+    head._plans.max_plans = net._plans.max_plans = 3
+    shapes = [(96 + 8 * i, 128 + 16 * (i % 3)) for i in range(8)]
+    det.reserve([(160, 160)], orig_sizes=[(160, 160)])    # (arena growth also drops plans)
+    first = {}
+    for rep in range(2):
+        for i, (H, W) in enumerate(shapes):
+            img = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(i)).to(DEV)
+            metas = [dict(img_shape=(H, W, 3), scale_factor=[1.0] * 4)]
+            for _ in range(2):
+                r = head.simple_test_bboxes(det.extract_feat(img), metas)[0]
             out = [t.clone() for t in (r[1], r[7], r[4])]
-        return out
-    first = run(*shapes[0], seed=1)
+            if rep == 0:
+                first[i] = out
+            else:
+                assert all(torch.equal(a, b) for a, b in zip(first[i], out)), i
+    assert len(head._plans) <= 3 and head._plans.evictions == 13 and net._plans.evictions == 13
+    assert head._arenas[0].grows == 1 and net._arenas[0].grows == 1
     torch.cuda.synchronize()
-    mem = []
-    for i, (H, W) in enumerate(shapes[1:]):
-        run(H, W, seed=2 + i)
-        torch.cuda.synchronize()
-        mem.append(torch.cuda.memory_allocated())
-    assert len(det.bbox_head._plans) <= 3 and det.bbox_head._plans.evictions >= 30
-    assert len(det.backbone._plans) <= 3
-    # flat: the last third of the pass allocates no more than the first third did
-    assert max(mem[-10:]) <= 1.25 * max(mem[:10]), (max(mem[:10]), max(mem[-10:]))
-    again = run(*shapes[0], seed=1)              # its plan was evicted long ago
-    for a, b in zip(first, again):
-        assert torch.equal(a, b)
+    assert head._plans.reap() == 0 and net._plans.reap() == 0
 
 
 def test_simple_test_mask_arrays_are_private_and_recycled():

@@ -607,6 +607,19 @@ def main():
                         "what": "pairnet_amd.dist.multi_gpu_test(detector, dataset) on one rank: "
                                 "every image through PSGTr.stream_triplets, its triplet record "
                                 "packed on the chain stream and gathered `depth` steps later"}
+        # BASELINE configs[2]'s per-GPU batch through the same product loop: two images per
+        # step (`samples_per_gpu=2`, tools/test.py:202-214; `dist.collate` stacks them)
+        multi_gpu_test(det, data[:4 * args.depth], depth=args.depth, force_collective=one_rank,
+                       samples_per_gpu=2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got2 = multi_gpu_test(det, data, depth=args.depth, force_collective=one_rank,
+                              samples_per_gpu=2)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        product_loop["samples_per_gpu_2"] = {
+            "images_per_s": n / dt2, "ms_per_step": 2e3 * dt2 / n, "images": n,
+            "collectives": got2["collectives"], "records": list(got2["records"].shape)}
         head.use_graphs = not args.no_graphs
         backbone.use_graphs = not args.no_graphs
         head.grid_reserve = backbone.grid_reserve = engine.grid_reserve

@@ -91,6 +91,14 @@ class ResNet50Hip:
         # K = 64 layers of stage 1 -- measured in round 4)
         self.wino_min_planes = 128
 
+    def _weights_version(self):
+        return sum(p._version for p in self._params.values())
+
+    def parameters(self):
+        """The live (host) parameter / buffer tensors; in-place updates are picked up by the
+        next forward (folded weights and captured graphs are rebuilt)."""
+        return list(self._params.values())
+
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._params.items())
 
@@ -156,6 +164,7 @@ class ResNet50Hip:
                         w[p + "conv2.wino"] = hip.winograd_weights(cw.to(dev))
                         w[p + "conv2.wino4"] = hip.winograd43_weights(cw.to(dev))
         self.w = w
+        self._packed_version = self._weights_version()
 
     class _Plan:
         """Views of one slot's arena for one (batch, image size) + the captured hipGraph."""
@@ -265,6 +274,8 @@ class ResNet50Hip:
             raise RuntimeError("img must be a [B,3,H,W] fp32 device tensor")
         if self.device is None:
             self.to(img.device)
+        if self.w is not None and self._packed_version != self._weights_version():
+            self.w, self._plans = None, PlanCache(self._plans.max_plans)   # updated in place
         img = img.contiguous()
         B, _, H, W = img.shape
         pl = self._plan(B, H, W, slot)

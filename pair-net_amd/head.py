@@ -270,6 +270,17 @@ class CrossHead2:
         self._plans = PlanCache(self._plans.max_plans)
         self._consts, self._pe = {}, OrderedDict()
 
+    def _weights_version(self):
+        """Changes whenever a parameter tensor is written in place (torch's per-tensor version
+        counters): `parameters()` hands out the live tensors, and an optimizer step or a manual
+        `p.copy_()` must not leave packed weights, constants and captured graphs stale."""
+        return sum(p._version for p in self._params.values())
+
+    def parameters(self):
+        """The live (host, fp32) parameter tensors; in-place updates are picked up by the next
+        forward (the packed device copies and everything derived from them are rebuilt)."""
+        return list(self._params.values())
+
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._params.items())
 
@@ -336,6 +347,7 @@ class CrossHead2:
                                            w[p + "attention_weights.bias"]], 0).contiguous()
         self._pack_relation(w)
         self.w = w
+        self._packed_version = self._weights_version()
 
     @staticmethod
     def _pack_vqk(w, attn_prefix):
@@ -951,6 +963,9 @@ class CrossHead2:
                      obj_seg=pl.obj_seg.view(B, R, H2, W2)))
 
     def _check_feats(self, feats, img_metas):
+        pv = getattr(self, "_packed_version", None)
+        if self.w is not None and pv is not None and pv != self._weights_version():
+            self._drop_weight_state()          # a parameter was updated in place
         B = len(img_metas)
         assert len(feats) == 4 and all(f.shape[0] == B for f in feats)
         nchw = all(f.is_contiguous() for f in feats)

@@ -519,6 +519,8 @@ import numpy as np
 import torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 backend, rank, world, port, out_path = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6]
+k = int(sys.argv[7]) if len(sys.argv) > 7 else 1          # samples_per_gpu
+lazy = len(sys.argv) > 8 and sys.argv[8] == "lazy"       # annotations built on demand, on the device
 from oracle.backbone import seeded_backbone_state      # (seeded weights only: test infrastructure)
 from pairnet_amd import build_detector, pairnet_r50
 from pairnet_amd.dist import multi_gpu_test
@@ -543,16 +545,33 @@ for i in range(N):
     # (odd images: masks already on the device, as pairnet_amd.dataset.eval_ground_truth leaves them)
     ann.append(dict(gt_rels=rels, gt_labels=np.array([1 + i, 20, 90]),
                     gt_masks=gm.to("cuda:0") if i % 2 else gm.numpy()))
-if world == 0:      # the optional stream -> hardware-queue calibration of the detector's pipeline
+if lazy:
+    class LazyAnn:
+        # what pairnet_amd.dataset.eval_ground_truth does per image, WHEN the loop asks for it:
+        # an H2D copy from pinned memory and a kernel on the caller's current stream -- the
+        # evaluator reads the masks on the chain stream that produced the result (ADVICE r4)
+        def __init__(self, anns):
+            self.anns = anns
+            self.pinned = [torch.as_tensor(a["gt_masks"]).cpu().pin_memory() for a in anns]
+        def __len__(self):
+            return len(self.anns)
+        def __getitem__(self, i):
+            m = self.pinned[i].to("cuda:0", non_blocking=True)
+            big = torch.zeros(64, 1 << 20, device="cuda:0").cumsum(1)     # (keeps the stream busy)
+            m = (m.to(torch.uint8) + (big[0, :1] * 0).to(torch.uint8)) > 0
+            return dict(self.anns[i], gt_masks=m)
+    ann = LazyAnn(ann)
+if world == 0 and k == 1:      # the optional stream -> hardware-queue calibration of the detector's pipeline
     times = det.calibrate_pipeline(*data[0], depth=3, steps=2)
     assert len(times) == 4 and all(t > 0 for t in times) and det.pipeline(3) is det.pipeline(3)
     assert det.bbox_head.grid_reserve == 0 and not det.bbox_head.use_graphs
 out = multi_gpu_test(det, data, annotations=ann, evaluator=TripletEvaluator(),
                      metrics=SceneGraphMetrics(56), depth=3,
-                     force_collective=(backend == "nccl"))
+                     force_collective=(backend == "nccl"), samples_per_gpu=k)
 if rank == 0:
     # second call in the same process: the cached plans / graphs serve it
-    again = multi_gpu_test(det, data, depth=3, force_collective=(backend == "nccl")) if world <= 1 else None
+    again = multi_gpu_test(det, data, depth=3, force_collective=(backend == "nccl"),
+                           samples_per_gpu=k) if world <= 1 else None
     np.savez(out_path, records=out["records"].cpu().numpy(), collectives=out["collectives"],
              metrics=json.dumps(out.get("metrics")),
              again=(again["records"].cpu().numpy() if again is not None else np.zeros(0)))
@@ -563,17 +582,17 @@ print("LOOP_DONE", rank)
 """
 
 
-def _run_loop(tmp_path, backend, world):
+def _run_loop(tmp_path, backend, world, *extra):
     import subprocess
     import sys
     import numpy as np
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items()
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
-    out_path = str(tmp_path / ("loop_%s_%d.npz" % (backend, world)))
+    out_path = str(tmp_path / ("loop_%s_%d%s.npz" % (backend, world, "_".join(("",) + extra))))
     port = str(_free_port())
     procs = [subprocess.Popen([sys.executable, "-c", _LOOP_SCRIPT, root, backend, str(r),
-                               str(world), port, out_path], env=env, cwd=root,
+                               str(world), port, out_path] + list(extra), env=env, cwd=root,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(max(world, 1))]
     outs = []
@@ -621,6 +640,57 @@ def test_multi_gpu_test_on_the_gpu_equals_simple_test_and_two_gloo_ranks(tmp_pat
         assert p.returncode == 0, se[-3000:]
     assert np.array_equal(two["records"], one["records"]) and int(two["collectives"]) == 3
     assert json.loads(str(two["metrics"])) == m1
+
+
+@pytest.mark.gpu
+def test_multi_gpu_test_two_samples_per_gpu_and_lazy_device_annotations(tmp_path):
+    """BASELINE configs[2] through product code (tools/test.py:202-214, `samples_per_gpu=2`):
+    (a) one process: every record equals the one packed from `simple_test` on the same
+    two-image batch; (b) two gloo ranks on this GPU, uneven split: the same records in dataset
+    order and the same metrics; (c) ADVICE r4: annotations produced lazily ON THE DEVICE while
+    the loop runs (H2D copy + kernels on the caller's stream) give the metrics of the eagerly
+    loaded ones -- the evaluator's chain stream is ordered behind the stream that made them."""
+    import json
+    import numpy as np
+    from oracle.backbone import seeded_backbone_state
+    from pairnet_amd import build_detector, pairnet_r50
+    procs, outs, one = _run_loop(tmp_path, "none", 0, "2")
+    assert procs[0].returncode == 0, outs[0][1][-3000:]
+    det = build_detector(pairnet_r50())
+    det.backbone.load_state_dict(seeded_backbone_state(41))
+    det.bbox_head.init_weights(seed=3)
+    det.to("cuda:0")
+    H, W = 160, 224
+    meta = dict(img_shape=(H, W, 3), scale_factor=[2.0] * 4)
+    g = torch.Generator().manual_seed(3)
+    imgs = [torch.randn(1, 3, H, W, generator=g).to("cuda:0") for _ in range(5)]
+    head = det.bbox_head
+    for grp in ((0, 1), (2, 3), (4,)):
+        res = head.simple_test(det.extract_feat(torch.cat([imgs[i] for i in grp])), [meta] * len(grp))
+        sub, obj = head.pair_positions()
+        for j, i in enumerate(grp):
+            want = pack_triplets(res[j][1].cpu(), res[j][7].cpu(), sub[j].cpu(), obj[j].cpu())
+            assert np.array_equal(one["records"][i], want.numpy()), i
+    assert int(one["collectives"]) == 3 and np.array_equal(one["again"], one["records"])
+    m1 = json.loads(str(one["metrics"]))
+    assert m1["images"] == 4 and m1["skipped"] == 1
+    # (b) rank 0 batches images (0, 2), (4,), rank 1 (1, 3): each image's record is the one
+    # of its own two-image batch
+    procs, outs, two = _run_loop(tmp_path, "gloo", 2, "2")
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    assert int(two["collectives"]) == 2 and two["records"].shape == one["records"].shape
+    for grp in ((0, 2), (1, 3), (4,)):
+        res = head.simple_test(det.extract_feat(torch.cat([imgs[i] for i in grp])), [meta] * len(grp))
+        sub, obj = head.pair_positions()
+        for j, i in enumerate(grp):
+            want = pack_triplets(res[j][1].cpu(), res[j][7].cpu(), sub[j].cpu(), obj[j].cpu())
+            assert np.array_equal(two["records"][i], want.numpy()), i
+    # (c) lazily built device annotations
+    procs, outs, lazy = _run_loop(tmp_path, "none", 0, "2", "lazy")
+    assert procs[0].returncode == 0, outs[0][1][-3000:]
+    assert np.array_equal(lazy["records"], one["records"])
+    assert json.loads(str(lazy["metrics"])) == m1
 
 
 @pytest.mark.gpu

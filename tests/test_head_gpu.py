@@ -397,6 +397,35 @@ def test_graph_reads_reused_feature_buffers_in_place():
     assert pl.graph_a is not None
 
 
+def test_in_place_weight_updates_invalidate_packed_weights_constants_and_graphs():
+    """plans cache weight-derived state (packed / folded weights, the mask
+    embedding of the initial queries, position tables with the level embeddings folded in,
+    captured graphs).  A parameter written IN PLACE -- what an optimizer step does -- must be
+    seen by the next forward: the result equals a fresh head loaded with the updated state."""
+    _, sd, _ = oracle_head(77)
+    head = _hip_head(sd)
+    head.use_graphs = True
+    H, W = 64, 96
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[1.0] * 4)]
+    feats = [f.to(DEV) for f in seeded.seeded_feats(301, 1, H, W)]
+    for _ in range(3):                                      # eager, capture, replay
+        cls, _ = head.forward(feats, metas)
+    before = cls["rel"].clone()
+    assert head._last_plan.graph_b is not None
+    params = dict(zip(head.state_dict().keys(), head.parameters()))
+    with torch.no_grad():
+        params["level_embed.weight"].mul_(1.5)              # folded into the position tables
+        params["query_feat.weight"].add_(0.25)              # the constants q0 / me0
+        params["rel_cls_embed.bias"].add_(1.0)              # a packed weight
+    for _ in range(3):
+        cls, _ = head.forward(feats, metas)
+    after = cls["rel"].clone()
+    assert not torch.equal(before, after)
+    fresh = _hip_head(head.state_dict())
+    want, _ = fresh.forward(feats, metas)
+    assert torch.equal(after, want["rel"])
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 64, 80)])
 def test_swin_l_200_query_configuration(B, H, W):
     """BASELINE.json configs[3]: Swin-L channel widths, 200 object queries (200x200

@@ -478,7 +478,15 @@ def test_mmcv_shaped_msda_backward(hip, shapes, bs, nq, lo, hi):
     ms_deform_attn_backward(d(value), d(ss), d(starts), d(loc), d(aw), d(gout), grad_value,
                             grad_loc, grad_aw, 64)
     _rel_close(grad_value, gv, 1e-4, "grad_value")
-    _rel_close(grad_loc, gl, 1e-4, "grad_sampling_loc")
+    # the gradient with respect to a sampling location is piecewise constant in the location:
+    # it jumps where the sample crosses a pixel centre, and fp32 (the kernel, like mmcv's) and
+    # fp64 (the reference here) may floor() a coordinate within rounding of an integer to
+    # different cells -- a discrete decision, exempted like the mask-bit and top-k near-ties
+    hw = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float64)     # (x, y) order
+    pix = loc.double() * hw[None, None, None, :, None, :] - 0.5
+    near = ((pix - pix.round()).abs() < 1e-3).any(-1, keepdim=True).expand_as(gl)
+    assert float(near.float().mean()) < 0.01
+    _rel_close(torch.where(near, gl, grad_loc.cpu()), gl, 1e-4, "grad_sampling_loc")
     _rel_close(grad_aw, ga, 1e-4, "grad_attn_weight")
     # grad_value is accumulated into: a second call doubles it
     ms_deform_attn_backward(d(value), d(ss), d(starts), d(loc), d(aw), d(gout), grad_value,

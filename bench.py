@@ -414,7 +414,7 @@ def main():
             res = head.simple_test_bboxes(backbone(im) if with_backbone else feats, metas)
         elif with_backbone:
             # two chip-filling kernel sequences on different streams time-slice badly
-            # (DESIGN.md 6a): the backbone goes in front of stage A on its stream
+            # (LABNOTES.md 6a): the backbone goes in front of stage A on its stream
             # (each stage-A stream has its own set of backbone buffers)
             sl = engine.count % len(engine.streams_a)
             with torch.cuda.stream(engine.streams_a[sl]):

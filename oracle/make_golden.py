@@ -254,7 +254,7 @@ def gen_e2e_full(head, sd):
 # pair list is STABLE -- every gap between consecutive scores among the top k+1 is far
 # above what fp32 re-association can move a score by -- and strict index equality is a
 # meaningful assertion.  With purely random weights it is not, for two measured reasons
-# (DESIGN.md section 3): (1) the nine post-norm decoder layers collapse all queries onto
+# (LABNOTES.md section 3): (1) the nine post-norm decoder layers collapse all queries onto
 # one common vector (diversity 1-3 % of the norm), so the pair scores differ by 1e-5 while
 # a single flipped attention-mask bit (a mask logit within 1e-6 of zero; a few per 800x1333
 # forward, also between the reference's own fp32 and fp64 runs) moves them by 1e-6; (2) a

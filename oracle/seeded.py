@@ -53,7 +53,7 @@ def seeded_state_dict(shapes, seed):
 # A fixture cannot carry 30 M parameters, so it stores a weight seed plus a few edits
 # (the keys below, applied in this order).  The "separated" fixtures use them to give the
 # random-weight head the two properties of a trained one that exact top-k parity needs
-# (DESIGN.md section 3): queries that do not collapse onto one common vector, and an
+# (LABNOTES.md section 3): queries that do not collapse onto one common vector, and an
 # importance matrix whose top scores are spread far wider than fp32 rounding noise.
 #   reseed_<name>   = seed            redraw that parameter from its own seed
 #   keeprows_<name> = n               zero every row from n on

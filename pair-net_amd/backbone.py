@@ -88,7 +88,7 @@ class ResNet50Hip:
         # stage 4; "direct" = implicit GEMM
         self.conv_algo = "winograd4"
         # narrowest 3x3 layer that takes the Winograd form (128: stages 2-4; 64 adds the three
-        # K = 64 layers of stage 1 -- measured in round 4)
+        # K = 64 layers of stage 1 -- measured in round 4, LABNOTES.md 6.0-r4)
         self.wino_min_planes = 128
 
     def _weights_version(self):

@@ -41,7 +41,7 @@
 #define PN_GEMM_WGS128x64 3
 #endif
 #ifndef PN_GEMM_BIGM_128x64         // 1: plain row-major launches with M >= 16384, N >= 256 take
-#define PN_GEMM_BIGM_128x64 0       // 128x64 tiles (power experiment)
+#define PN_GEMM_BIGM_128x64 0       // 128x64 tiles (power experiment, LABNOTES.md 6.0-r4)
 #endif
 #ifndef PN_GEMM_WGS64_SPILLING      // the instantiations that spill a few registers at 5
 #define PN_GEMM_WGS64_SPILLING 5

@@ -6,7 +6,7 @@
 // LayerNorm moments never leave the chip -- the stand-alone pair (k_gemm_tile, then
 // k_layernorm256) writes the 22.5 MB pre-norm map and reads it straight back, twelve times
 // per image.  At M ~ 100 (the decoders' query side) a row-owning tile is 4 workgroups and
-// loses; this kernel is only launched for M >= 2048.
+// loses (LABNOTES.md 6.0); this kernel is only launched for M >= 2048.
 //
 // Tile: 32 rows x 256 columns per workgroup, 4 waves, wave w owns columns [64 w, 64 w + 64)
 // as two 32x32 fp32 MFMA accumulators that share every A fragment.  32-deep k-chunks are

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_msda_lo(const float* __restrict__ value
 // run): batched 57.5-62.2 us against 49.9-57.5 us one-shot at the init offsets, 70.0 against
 // 65.6 with N(0, 8 px) offsets -- more loads in flight per CU do not help a kernel that is
 // bound by the vector L1's request rate, and 4 resident workgroups instead of 5 cost more
-// than the hidden launch / phase-1 latency buys.
+// than the hidden launch / phase-1 latency buys (LABNOTES.md 6.0).
 template <int L, bool BATCH>
 __global__ __launch_bounds__(256) void k_msda_pipe(const float* __restrict__ value,
                                                    const float* __restrict__ offaw,

@@ -144,7 +144,7 @@ class ResultStreamer:
     worker thread of this object waits for the copy and expands the bits into the bool arrays
     the Results hold (`pn_unpack_bits_host`).  The host never allocates (a multi-MB host
     allocation per image is an mmap / munmap pair, and every munmap runs the amdgpu MMU
-    notifier against the busy GPU: ~75 ms stalls measured).
+    notifier against the busy GPU: ~75 ms stalls measured, LABNOTES.md 6b).
 
         streamer = ResultStreamer(head, ring=4)
         streamer.push(results, pipe)      # results of PipelinedHead.submit() / get_bboxes()
@@ -361,7 +361,7 @@ class ResultStreamer:
                 raise IndexError("every panoptic segment was filtered (the reference fails "
                                  "here too, pairnet_head.py:882)")
             if active:
-                # The reference's drop-and-redo loop takes at most three rounds (DESIGN.md
+                # The reference's drop-and-redo loop takes at most three rounds (LABNOTES.md
                 # 1c) and hip.PAN_ROUNDS = 4 are enqueued, so this is unreachable unless that
                 # bound is wrong; the slot's device buffers may already be reused, so the
                 # loop cannot be continued here the way PSGTr.simple_test does -- fail loudly.
@@ -535,12 +535,7 @@ class PSGTr:
         """Decoded uint8 (H, W, 3) BGR image (cv2 order, host or device) -> [Result]: the
         reference's test pipeline (configs/mask2former/pairnet.py:310-331) on the GPU
         (preprocess.TestPipeline), then `simple_test`."""
-        if self.test_pipeline is None:
-            from .config import test_pipeline_cfg
-            from .preprocess import TestPipeline
-            self.test_pipeline = TestPipeline.from_config(test_pipeline_cfg(),
-                                                          device=self.bbox_head.device)
-        img, metas = self.test_pipeline(image)
+        img, metas = self._pipeline_of_images()(image)
         return self.simple_test(img, metas, rescale=rescale)
 
     def reserve(self, image_sizes, batch=1, depth=4, orig_sizes=()):
@@ -597,13 +592,37 @@ class PSGTr:
             if slots:
                 net.use_graphs, net.grid_reserve = saved[2], saved[3]
 
+    def _pipeline_of_images(self):
+        if self.test_pipeline is None:
+            from .config import test_pipeline_cfg
+            from .preprocess import TestPipeline
+            self.test_pipeline = TestPipeline.from_config(test_pipeline_cfg(),
+                                                          device=self.bbox_head.device)
+        return self.test_pipeline
+
+    @staticmethod
+    def _is_decoded(img):
+        """A batch given as DECODED images: one uint8 (H, W, 3) array / tensor or a list of them
+        (instead of the normalised float (B, 3, H, W) tensor `simple_test` takes)."""
+        one = img[0] if isinstance(img, (list, tuple)) and len(img) else img
+        return getattr(one, "dtype", None) in (torch.uint8, "uint8") or \
+            str(getattr(one, "dtype", "")) == "uint8"
+
     def _submit(self, pipe, slots, img, metas, rescale):
-        """Queue one batch: backbone + stage A on the pipeline's next stage-A stream."""
+        """Queue one batch: [test pipeline +] backbone + stage A on the pipeline's next
+        stage-A stream."""
         head, net = self.bbox_head, self.backbone
         sl = pipe.count % len(pipe.streams_a)
         sa = pipe.streams_a[sl]
         sa.wait_stream(torch.cuda.current_stream(head.device))
         with torch.cuda.stream(sa):
+            if self._is_decoded(img):
+                # decoded uint8 BGR image(s): the reference's test pipeline (Resize keep-ratio,
+                # Normalize, Pad, collate; configs/mask2former/pairnet.py:310-331) as one
+                # kernel per image in front of the backbone, on this batch's stage-A stream,
+                # into that stream's own grow-only buffer
+                images = list(img) if isinstance(img, (list, tuple)) else [img]
+                img, metas = self._pipeline_of_images().batch(images, slot=sl)
             feats = net(img, slot=sl) if slots else net(img)
             if len(feats) == 4 and self.out_indices != (0, 1, 2, 3):
                 feats = tuple(feats[j] for j in self.out_indices)
@@ -681,6 +700,9 @@ class PSGTr:
         head = self.bbox_head
         if not self._pipelines():
             for img, metas in batches:
+                if self._is_decoded(img):
+                    img, metas = self._pipeline_of_images().batch(
+                        list(img) if isinstance(img, (list, tuple)) else [img])
                 yield self.simple_test(img, metas, rescale=rescale)
             return
         out = ResultStreamer(head, ring=ring, private_masks=copy)
@@ -710,6 +732,9 @@ class PSGTr:
         head = self.bbox_head
         if not self._pipelines():
             for img, metas in batches:
+                if self._is_decoded(img):
+                    img, metas = self._pipeline_of_images().batch(
+                        list(img) if isinstance(img, (list, tuple)) else [img])
                 feat = self.extract_feat(img)
                 res = head.simple_test(feat, metas, rescale=rescale)
                 yield TripletBatch(res, *head.pair_positions(getattr(head, "_last_plan", None)))

@@ -299,6 +299,10 @@ def collate(items):
     its own `img_metas` entry (`img_shape`, `scale_factor`)."""
     if len(items) == 1:
         return items[0]
+    if str(getattr(items[0][0], "dtype", "")).endswith("uint8"):
+        # DECODED images (uint8 (H, W, 3)): the detector's own test pipeline resizes, normalises
+        # and pads them into one batch tensor on the GPU (`TestPipeline.batch`)
+        return [it[0] for it in items], None
     imgs = [it[0] for it in items]
     metas = [m for it in items for m in it[1]]
     H, W = max(i.shape[-2] for i in imgs), max(i.shape[-1] for i in imgs)
@@ -335,7 +339,9 @@ def multi_gpu_test(detector, dataset, annotations=None, evaluator=None, metrics=
         own GPU, and only the per-image match lists (a few KB of Python lists) are gathered
         once at the end; rank 0 adds them to `metrics` (`SceneGraphMetrics`) in dataset order.
 
-    `dataset[i]` -> `(img, img_metas)` as `simple_test` takes them (one image);
+    `dataset[i]` -> `(img, img_metas)` as `simple_test` takes them (one image), or
+    `(decoded uint8 (H, W, 3) BGR image, None)`: the detector then runs the reference's test
+    pipeline on the GPU in front of the backbone (`preprocess.TestPipeline`);
     `annotations[i]` -> dict(gt_rels, gt_labels, gt_masks) (or None).  `calibrate`: on the
     first call per detector, choose the stream -> hardware-queue placement of its pipeline on
     this rank's first batch (`PSGTr.calibrate_pipeline`: ~50 throw-away submissions, worth ~8 %

@@ -164,7 +164,7 @@ def _e2e_full(conv_algo, exact_order):
                                      head._last_plan.topk_idx[0].cpu().numpy(), TIE_TOL_FULL)
     print("%d/100 top-k positions identical" % exact)
     # (the reference's own fp64 evaluation agrees with its fp32 list in no more positions:
-    # a few attention-mask bits flip per 800x1333 forward)
+    # a few attention-mask bits flip per 800x1333 forward, LABNOTES.md section 3)
     assert ok and exact >= 85
     # size-independent properties at the full size
     first_rel, first_idx = cls["rel"].clone(), head._last_plan.topk_idx.clone()

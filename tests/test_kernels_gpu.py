@@ -210,7 +210,7 @@ def test_gemm_ragged_edges_are_exact(hip, M):
     past M) and in N (200 = 3 x 64 + 8): with integer-valued operands the result must be the
     exact product -- bias, ReLU, residual, batches with their own W, split-K partials.  (Written
     for the round-4 experiment that ran such blocks as 4-row v_mfma_f32_4x4x1 strips / skipped
-    them; kept as the edge-case test of the kernel that stayed.)"""
+    them, LABNOTES.md 6.0-r4; kept as the edge-case test of the kernel that stayed.)"""
     g = torch.Generator().manual_seed(M)
     B, N, K = 2, 200, 96
     x = torch.randint(-8, 9, (B, M, K), generator=g).float()

@@ -468,6 +468,50 @@ def test_many_shapes_share_one_arena_per_slot():
     assert all(torch.equal(a, b) for a, b in zip(outs[5], again))
 
 
+def test_product_loop_takes_decoded_images_of_mixed_sizes():
+    """`dist.multi_gpu_test` fed like the reference's loader feeds `multi_gpu_test`
+    (tools/test.py:199-267): DECODED uint8 images of different original sizes; the detector's
+    own test pipeline (Resize keep-ratio -> Normalize -> Pad -> collate, one kernel per image on
+    the batch's stage-A stream, one grow-only buffer per stream) runs in front of the backbone.
+    Every record equals the synchronous `test_pipeline -> simple_test` path, one image per step
+    and two per step (unequal sizes zero-padded to the batch maximum, like mmcv's collate)."""
+    from oracle.backbone import seeded_backbone_state
+    from pairnet_amd import TestPipeline, build_detector, pairnet_r50
+    from pairnet_amd.dist import multi_gpu_test, pack_triplets
+    det = build_detector(pairnet_r50())
+    det.backbone.load_state_dict(seeded_backbone_state(41))
+    det.bbox_head.init_weights(seed=3)
+    det.to(DEV)
+    det.test_pipeline = TestPipeline(img_scale=(224, 160), device=DEV)
+    g = torch.Generator().manual_seed(9)
+    sizes = [(60, 80), (80, 60), (64, 64), (60, 80), (50, 90), (75, 100), (90, 50)]
+    images = [torch.randint(0, 256, (h, w, 3), generator=g, dtype=torch.uint8) for h, w in sizes]
+    images[1] = images[1].numpy()                        # (numpy arrays and host tensors both work)
+    head = det.bbox_head
+
+    def want(batch):
+        img, metas = det.test_pipeline.batch(batch, slot=9)
+        res = head.simple_test(det.extract_feat(img), metas)
+        sub, obj = head.pair_positions()
+        return [pack_triplets(r[1].cpu(), r[7].cpu(), sub[j].cpu(), obj[j].cpu())
+                for j, r in enumerate(res)], metas
+    single = [want([im])[0][0] for im in images]
+    _, metas = want([images[0]])
+    assert metas[0]["ori_shape"] == (60, 80, 3) and metas[0]["img_shape"] == (160, 213, 3)
+    data = [(im, None) for im in images]
+    out = multi_gpu_test(det, data, depth=3, calibrate=False)
+    assert out["records"].shape[0] == len(images)
+    for i, w in enumerate(single):
+        assert torch.equal(out["records"][i].cpu(), w), i
+    out2 = multi_gpu_test(det, data, depth=3, calibrate=False, samples_per_gpu=2)
+    for grp in ((0, 1), (2, 3), (4, 5), (6,)):
+        ws, ms = want([images[i] for i in grp])
+        assert len({m["batch_input_shape"] for m in ms}) == 1          # one padded batch tensor
+        for j, i in enumerate(grp):
+            assert torch.equal(out2["records"][i].cpu(), ws[j]), i
+    assert len(det.test_pipeline._slots) <= 3                # one buffer per stage-A stream (+ slot 9)
+
+
 def test_plan_cache_eviction_parks_busy_plans():
     """More live (shape, slot) plans than the cache holds: the oldest is evicted without a
     host wait -- parked until the streams it ran on have passed -- and a shape that comes

@@ -1,6 +1,6 @@
 """Tuning aid: fp32 GEMM variants on N(0,1) data vs low-entropy data (values k/4, |k| <= 8):
 how much of each tile shape's rate is taken by the power management when the operand buses
-toggle (the MFMA pipe alone sustains 154 TFLOP/s on N(0,1) register operands,
+toggle (LABNOTES.md 6: the MFMA pipe alone sustains 154 TFLOP/s on N(0,1) register operands,
 tools/mfma_power_probe.hip)."""
 import sys, time, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -215,7 +215,7 @@ def main():
                       "bank conflicts 0, barrier / misc instructions 1 %.  What separates 0.87 busy "
                       "from 0.64 of the 157.3 TFLOP/s roof is the CLOCK: implied_mfma_clock_ghz = "
                       "1.7-1.8 GHz under this load against 2.4 GHz nominal (the board throttles on "
-                      "fp32-MFMA power, DESIGN.md 6.1).",
+                      "fp32-MFMA power, LABNOTES.md 6.1).",
            "source": "tools/gemm_stalls.py: rocprofv3 --pmc (counters only, one pass per counter "
                      "group), MI355X, pn_gemm_f32 on N(0,1) operands, mean over %d launches after "
                      "%d warm-up launches per shape" % (REP, WARM),

@@ -1,6 +1,6 @@
 """Robustness sweep (not a test): both heads against their CPU oracles at odd image sizes and
 batch sizes, seeded weights, reporting the worst output errors.  Index selections are compared
-as sets with a near-tie allowance (random weights: see DESIGN.md section 3)."""
+as sets with a near-tie allowance (random weights: see LABNOTES.md section 3)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

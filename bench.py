@@ -998,7 +998,8 @@ def main():
             # together as the fp32-MFMA GEMM work of the step
             if "k_gemm_rowln" in prof:
                 out["roofline_linear_res_ln"] = roof("k_gemm_rowln")
-            gemms = [k for k in prof if k.startswith(("k_gemm_tile", "k_gemm_rowln", "k_gemm_group"))]
+            gemms = [k for k in prof if k.startswith(("k_gemm_tile", "k_gemm_rowln", "k_gemm_group",
+                                                      "k_gemm_stencil"))]
             if gemms:
                 fl = sum(prof[k]["flops"] for k in gemms)
                 ms = sum(prof[k]["ms"] for k in gemms)

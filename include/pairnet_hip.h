@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 19
+#define PN_ABI_VERSION 20
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -380,6 +380,22 @@ int pn_mask_pack(const float* logits, uint32_t* bits, int32_t* rowall,
  * computes it from the (hi, wi) map) < 0.  ho, wo <= 1024. */
 int pn_mask_pack_stencil(const float* logits4, uint32_t* bits, int32_t* rowall, int64_t R,
                          int hi, int wi, int ho, int wo, void* stream);
+
+/* The two steps above -- a layer's stencil logits and their blend / threshold / pack -- as ONE
+ * launch (round 5): logits = me . rows^T over the level's 4 Nk tap-major stencil rows
+ * (pn_bilinear_stencil_rows_f32) on the 64x64 tile loop of pn_gemm_f32 (the same products in
+ * the same order: every logit is the bit pattern pn_gemm_f32 would have stored), blended with
+ * the single tap_blend definition, thresholded (`< 0`) and bit-packed in the epilogue; the
+ * Q x 4 Nk logit map is never written.  Output exactly pn_mask_pack_stencil's: bits
+ * [B*Q][ceil(Nk/32)] (padding bits 0), rowall [B*Q] = 1 where every key of the row is masked
+ * (set to 1 by a fill launch in front, cleared by any tile that finds an unmasked key).
+ *   me [B][Q][ld_me] (K used), rows [B][4*Nk][ld_rows]; (hi, wi) the full-resolution mask map,
+ *   (ho, wo) the level's map, Nk == ho * wo; K % 32 == 0.  `flags`: PN_GEMM_RESERVE(n) only.
+ * Replaces pairnet_head.py:244-256 (interpolate -> sigmoid < 0.5) + :300 for one layer. */
+int pn_mask_stencil_gemm_f32(const float* me, int64_t ld_me, int64_t stride_me, const float* rows,
+                             int64_t ld_rows, int64_t stride_rows, uint32_t* bits,
+                             int32_t* rowall, int B, int Q, int Nk, int K, int hi, int wi, int ho,
+                             int wo, int flags, void* stream);
 
 /* softmax(q k^T * scale + mask) v per head, flash-style over key chunks
  * (f32 MFMA for both contractions), then a combine pass.

@@ -88,7 +88,7 @@ struct TileRef {
 // stores drain under the next tile's MFMAs.  (Measured on MI355X with
 // tools/gemm_probe.hip: 83-96 -> 99-112 TFLOP/s on the encoder shapes versus one
 // workgroup per tile; the matrix pipe alone peaks at ~140.)
-template <int BM, int BN, int WM, int WN, int AMODE, bool ADD, typename Locator>
+template <int BM, int BN, int WM, int WN, int AMODE, bool ADD, typename Locator, int EPI = 0>
 __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int ntiles,
                                                 float* smem) {
   constexpr int BK = 32, LD = BK + 4;
@@ -181,9 +181,23 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
                                    (unsigned)(p.Aadd ? p.ldaadd : p.lda) + kc) * 4u;
       }
     }
+    if constexpr (EPI == 1) {
+      const StencilP& st = loc.st;
+      // stencil-mask mode: tile column c <-> (wave sub-tile c / 32, tap (c % 32) / 8, key
+      // 16 tn + 8 (c / 32) + c % 8): the four taps of a key sit in ONE wave's 32 columns, 8
+      // lanes apart, so the epilogue blends them with three lane shuffles.  W rows are
+      // tap-major (tap t of key p at row t * Nk + p, pn_bilinear_stencil_rows_f32).
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
-      w_off[j] = ((unsigned)min(n0 + (tid >> 3) + RPP * j, p.N - 1) * (unsigned)p.ldw + kc) * 4u;
+      for (int j = 0; j < NB; ++j) {
+        const int c = (tid >> 3) + RPP * j;
+        const int key = min(tr.tn * 16 + (c >> 5) * 8 + (c & 7), st.nk - 1);
+        w_off[j] = ((unsigned)(((c >> 3) & 3) * st.nk + key) * (unsigned)p.ldw + kc) * 4u;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        w_off[j] = ((unsigned)min(n0 + (tid >> 3) + RPP * j, p.N - 1) * (unsigned)p.ldw + kc) * 4u;
+    }
   };
 
   // Raw loaded chunk + what store_chunk has to do to it.  Nothing here may CONSUME a
@@ -377,6 +391,53 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
     // accumulator are fetched as 16 independent loads (clamped, unconditional) before
     // any is used: one memory round trip per accumulator instead of sixteen. ----
     const int m0 = cur.tm * BM, n0 = cur.tn * BN;
+    if constexpr (EPI == 1) {
+      const StencilP& st = loc.st;
+      // ---- stencil-mask epilogue: blend (the ONE tap_blend every resampling kernel uses),
+      // threshold, pack; nothing of C reaches memory.  Lane (half lh, column li): key slot
+      // pl = li % 8 of this wave's 8 keys; register r is query row mfma32_row(r, lh). ----
+      static_assert(EPI == 0 || (TM == 1 && TN == 1 && BN == 64), "stencil mode: 64x64 tiles of 32x32 waves");
+      const int pl = li & 7;
+      const int key0 = cur.tn * 16 + wn * 8;
+      const int key = key0 + pl;
+      const bool kvalid = key < st.nk;
+      const int kk = min(key, st.nk - 1);
+      const int oy = kk / st.wo, ox = kk - oy * st.wo;
+      const Tap ty = make_tap(oy, st.hi, st.ho), tx = make_tap(ox, st.wi, st.wo);
+      const int src = (lane & 32) | pl;
+      const int nwords = (st.nk + 31) / 32;
+      const int nvalid = min(max(st.nk - key0, 0), 8);
+      const unsigned vm = (1u << nvalid) - 1u;
+      const int rbase = m0 + wm * WM;
+      const bool writer = li == 0;                     // lanes 0 and 32: one per row half
+      const bool last_tile = (cur.tn + 1) * 16 >= st.nk && wn == WAVES_N - 1;
+      // (stores only inside the loop -- fire and forget; a LOAD of the row flag per register
+      // would put 16 dependent round trips into every tile's epilogue, and keeping the 16
+      // bytes for a store block afterwards spills at this kernel's 96-register bound)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float a = acc[0][0][r];
+        const float v00 = __shfl(a, src, 64), v01 = __shfl(a, src + 8, 64);
+        const float v10 = __shfl(a, src + 16, 64), v11 = __shfl(a, src + 24, 64);
+        const float res = tap_blend(ty, tx, v00, v01, v10, v11);
+        const unsigned long long bal = __ballot(kvalid && res < 0.f);
+        const int row = rbase + mfma32_row(r, lh);
+        if (writer && row < p.M) {
+          const unsigned byte = (unsigned)(bal >> (32 * lh)) & 0xffu;
+          const int64_t grow = (int64_t)cur.bz * p.M + row;
+          unsigned char* bp = reinterpret_cast<unsigned char*>(st.bits + grow * nwords);
+          bp[cur.tn * 2 + wn] = (unsigned char)byte;
+          if (last_tile)        // padding bytes of the row's last word
+            for (int e = cur.tn * 2 + wn + 1; e < nwords * 4; ++e) bp[e] = 0;
+          // rowall starts at 1 (every key masked) and is cleared by any tile that finds an
+          // unmasked valid key: plain stores of the same value 0 (no atomics: ~2000 tiles per
+          // row would serialise on them)
+          if (~byte & vm) st.rowall[grow] = 0;
+        }
+      }
+      cur = nxt;
+      continue;
+    }
     float* __restrict__ C = p.C + (int64_t)cur.bz * p.sC;
     const float* __restrict__ Res = p.Res ? p.Res + (int64_t)cur.bz * p.sRes : nullptr;
     const bool full = m0 + BM <= p.M && n0 + BN <= p.N;
@@ -444,6 +505,36 @@ void k_gemm_tile(const GemmP p, const int batch) {
   __shared__ __attribute__((aligned(16))) float smem[TileSmem<BM, BN, AMODE>::FLOATS];
   const SingleLocator loc{p, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN};
   gemm_persistent<BM, BN, WM, WN, AMODE, ADD>(loc, loc.mt * loc.nt * batch, smem);
+}
+
+// Attention-mask bits of one decoder layer in ONE launch (round 5): logits = me . MFs^T over
+// the level's 4 N_l stencil rows -- the products and their order are k_gemm_tile's, so every
+// logit is bit for bit the one pn_gemm_f32 + pn_mask_pack_stencil see -- blended, thresholded
+// and packed in the epilogue: the Q x 4 N_l logit map (26.7 MB at the finest level) is neither
+// written nor read back, and the pack launch is gone from the query chain.
+__global__ __launch_bounds__(256) void k_fill_i32(int32_t* __restrict__ p, const int v, const int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+struct StencilLocator {
+  const GemmP& p;
+  const StencilP& st;
+  int mt, nt;
+  __device__ __forceinline__ const GemmP& P(int) const { return p; }
+  __device__ __forceinline__ TileRef operator()(int T) const {
+    const int per_b = mt * nt;
+    const int bz = T / per_b, r = T - bz * per_b;
+    const int tm = r / nt;
+    return TileRef{0, bz, tm, r - tm * nt};
+  }
+};
+
+__global__ __launch_bounds__(256, (TileWgs<64, 64, A_ROW, false>::min_waves))
+void k_gemm_stencil(const GemmP p, const StencilP st, const int batch) {
+  __shared__ __attribute__((aligned(16))) float smem[TileSmem<64, 64, A_ROW>::FLOATS];
+  const StencilLocator loc{p, st, (p.M + 63) / 64, (p.N + 63) / 64};
+  gemm_persistent<64, 64, 32, 32, A_ROW, false, StencilLocator, 1>(loc, loc.mt * loc.nt * batch, smem);
 }
 
 // Several independent row-major GEMMs in ONE launch: the 64x64 tiles of all
@@ -889,6 +980,32 @@ extern "C" int pn_conv2d_nhwc_f32(const float* in, const float* Wp, const float*
   return pn_conv2d_nhwc_ex_f32(in, Wp, bias, nullptr, out, B, H, W, Cin, Cout, KH, KW, 1, pad,
                                (flags & ~PN_GEMM_RELU) | (relu ? PN_GEMM_RELU : 0), nullptr, 0,
                                stream);
+}
+
+extern "C" int pn_mask_stencil_gemm_f32(const float* me, int64_t ld_me, int64_t stride_me,
+                                        const float* rows, int64_t ld_rows, int64_t stride_rows,
+                                        uint32_t* bits, int32_t* rowall, int B, int Q, int Nk,
+                                        int K, int hi, int wi, int ho, int wo, int flags,
+                                        void* stream) {
+  if (!me || !rows || !bits || !rowall || B <= 0 || Q <= 0 || Nk <= 0 || K <= 0 || K % 32)
+    return PN_BAD_ARG;
+  if (hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0 || (int64_t)ho * wo != Nk) return PN_BAD_ARG;
+  if (ld_me % 4 || ld_rows % 4 || stride_me % 4 || stride_rows % 4 || !aligned16(me) || !aligned16(rows))
+    return PN_BAD_ARG;
+  const int64_t lim = (int64_t)1 << 29;
+  if ((int64_t)(Q - 1) * ld_me + K >= lim || ((int64_t)4 * Nk - 1) * ld_rows + K >= lim)
+    return PN_BAD_ARG;
+  GemmP p{};
+  p.A = me; p.W = rows; p.lda = ld_me; p.ldw = ld_rows; p.sA = stride_me; p.sW = stride_rows;
+  p.M = Q; p.K = K; p.aadd_rows = 1;
+  p.N = pn_cdiv(Nk, 16) * 64;            // 16 keys x 4 taps per 64-column tile
+  const StencilP st{bits, rowall, Nk, hi, wi, ho, wo};
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_fill_i32, dim3(pn_cdiv(B * Q, 256)), dim3(256), 0, s, rowall, 1, B * Q);
+  const int64_t ntiles = (int64_t)pn_cdiv(Q, 64) * (p.N / 64) * B;
+  static const int wgs = resident_wgs(k_gemm_stencil, TileWgs<64, 64, A_ROW, false>::value, 256);
+  hipLaunchKernelGGL(k_gemm_stencil, dim3(persistent_grid(ntiles, wgs, flags)), dim3(256), 0, s, p, st, B);
+  return PN_LAUNCH_CHECK();
 }
 
 extern "C" int pn_abi_version(void) { return PN_ABI_VERSION; }

@@ -17,6 +17,14 @@ struct GemmP {
   int H, Wd, Cin, KW, pad, stride, Wo;
 };
 
+// stencil-mask mode (k_gemm_stencil): W = the 4 * nk tap-major stencil rows of one level; the
+// epilogue blends each key's four logits like pn_bilinear_planar_f32, thresholds and packs bits
+// instead of storing C.  (Its own struct: GemmP x 18 must fit k_gemm_group's kernarg block.)
+struct StencilP {
+  uint32_t* bits; int32_t* rowall;
+  int nk, hi, wi, ho, wo;
+};
+
 // A operand: row-major matrix | column-major matrix | implicit im2col of a channel-last
 // image | implicit im2col of the NCHW RGB image for ResNet's 7x7/2 stem (K = 147 -> 160)
 enum { A_ROW = 0, A_COL = 1, A_CONV = 2 };

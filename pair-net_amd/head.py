@@ -141,6 +141,10 @@ class CrossHead2:
         # (a per-call hint, hip.reserve_slots; PipelinedHead sets it for its own schedule)
         self.grid_reserve = 0
         self.fuse_ppn_front = True      # normalise + cosine matrix + first Matrix Learner layer in one launch
+        # a layer's attention-mask bits (reference operation order) as one launch: stencil
+        # logits, blend, threshold and pack in the GEMM's epilogue (pn_mask_stencil_gemm_f32;
+        # bit-identical to the GEMM -> pn_mask_pack_stencil pair, which False restores)
+        self.fuse_mask_pack = True
         # encoder sites whose Linear + identity + LayerNorm run as one row-owning launch
         # (pn_linear_res_ln_f32): "proj" = output_proj -> norms.0, "ffn" = FFN-2 -> norms.1;
         # () = the GEMM -> LayerNorm pairs of rounds 1-3 (bit-identical either way)
@@ -764,6 +768,12 @@ class CrossHead2:
         if self.exact_mask_order == "full":
             hip.bilinear_planar(pl.MP if mp is None else mp, pl.ML, B * Q, pl.hw2[0], pl.hw2[1],
                                 h, wd)
+        elif self.exact_mask_order and self.fuse_mask_pack:
+            # logits, blend, threshold and pack in ONE launch: the same products in the same
+            # order as the pair below (bit-identical bits), without the Q x 4 N_l logit map
+            hip.mask_stencil_gemm(pl.me if me is None else me, pl.MFs[lvl], pl.bits, pl.rowall,
+                                  B, Q, pl.hw2[0], pl.hw2[1], h, wd)
+            return
         elif self.exact_mask_order:
             hip.gemm(pl.me if me is None else me, pl.MFs[lvl], pl.ML4, M=Q, N=4 * n, K=256,
                      lda=256, ldw=256, ldc=4 * n, batch=B, sA=Q * 256, sW=4 * n * 256,
@@ -987,7 +997,8 @@ class CrossHead2:
         `graph_after` times eagerly -- without any host synchronisation: nothing allocates,
         every buffer is a view of the slot's arena (plans.py)."""
         cfg = (self.exact_mask_order, self.conv_algo, self.fuse_ppn_front, self.grid_reserve,
-               tuple(self.enc_fused_ln), self.group_input_convs)
+               tuple(self.enc_fused_ln), self.group_input_convs,
+               getattr(self, "fuse_mask_pack", True))
         if pl.graph_cfg != cfg:          # a captured graph bakes these switches in
             pl.graph_a = pl.graph_b = None
             pl.graph_c = PlanCache(self.POST_VIEWS)

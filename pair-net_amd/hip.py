@@ -89,6 +89,8 @@ _SIGS = {
     "pn_bilinear_planar_gt0_u8": (C.c_int, [_vp, _vp, _i64] + [_i32] * 4 + [_vp]),
     "pn_mask_pack": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "pn_mask_pack_stencil": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "pn_mask_stencil_gemm_f32": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp] +
+                                 [_i32] * 9 + [_vp]),
     "pn_bilinear_stencil_rows_f32": (C.c_int, [_vp, _vp] + [_i32] * 6 + [_i64, _i64, _vp]),
     "pn_attn_scratch_floats": (_i64, [_i32, _i32, _i32]),
     "pn_attention_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
@@ -138,7 +140,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 19   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 20   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -633,6 +635,20 @@ def mask_pack_stencil(logits4, bits, rowall, R, hi, wi, ho, wo):
     _check(lib().pn_mask_pack_stencil(_ptr(logits4), _ptr(bits, torch.int32),
                                       _ptr(rowall, torch.int32), R, hi, wi, ho, wo, _stream()),
            "pn_mask_pack_stencil")
+
+
+def mask_stencil_gemm(me, rows, bits, rowall, B, Q, hi, wi, ho, wo, K=256):
+    """bits / rowall of one layer's attention mask from the mask embedding `me` [B*Q, K] and the
+    level's stencil rows [B, 4*ho*wo, K] in one launch (csrc/gemm.hip k_gemm_stencil)."""
+    Nk = ho * wo
+    _check(_launch("k_gemm_stencil", 2.0 * B * Q * 4 * Nk * K,
+                   4.0 * B * (Q * K + 4 * Nk * K) + B * Q * Nk / 8.0,
+                   lambda: lib().pn_mask_stencil_gemm_f32(
+                       _ptr(me), me.stride(0), Q * me.stride(0), _ptr(rows), rows.stride(-2),
+                       rows.stride(0) if rows.dim() == 3 else 4 * Nk * rows.stride(-2),
+                       _ptr(bits, torch.int32), _ptr(rowall, torch.int32), B, Q, Nk, K, hi, wi,
+                       ho, wo, _reserve_flag(), _stream()),
+                   meta=(Q, 4 * Nk, K, B, False)), "pn_mask_stencil_gemm_f32")
 
 
 def bilinear_stencil_rows(x, out, B, hi, wi, ho, wo, Cc, in_bstride, out_bstride):

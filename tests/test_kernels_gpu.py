@@ -796,7 +796,7 @@ def test_mask_bits_round_trip(hip, n):
 
 @pytest.mark.parametrize("hi,wi,ho,wo", [(200, 334, 25, 42), (200, 334, 50, 84),
                                          (200, 334, 100, 167), (24, 32, 3, 4), (19, 26, 5, 7),
-                                         (7, 9, 7, 9)])
+                                         (7, 9, 7, 9), (200, 267, 25, 34), (13, 17, 1, 1)])
 def test_stencil_rows_and_stencil_mask_pack(hip, hi, wi, ho, wo):
     """pn_bilinear_stencil_rows_f32 gathers the 4 source rows of every output pixel of an
     align_corners=False bilinear resize; logits against those rows, blended by
@@ -838,7 +838,21 @@ def test_stencil_rows_and_stencil_mask_pack(hip, hi, wi, ho, wo):
     hip.mask_pack_stencil(l4, bits_s, all_s, B * Q, hi, wi, ho, wo)
     torch.cuda.synchronize()
     assert torch.equal(bits_s, bits_d) and torch.equal(all_s, all_d)
-    # an all-masked row is flagged
+    # round 5: the same two steps as ONE launch (pn_mask_stencil_gemm_f32: blend / threshold /
+    # pack in the GEMM epilogue) -- the same bits and flags, starting from garbage outputs
+    bits_f = torch.full_like(bits_d, 0x5a5a5a5a)
+    all_f = torch.full_like(all_d, 7)
+    hip.mask_stencil_gemm(me, rows, bits_f, all_f, B, Q, hi, wi, ho, wo, K=C)
+    torch.cuda.synchronize()
+    assert torch.equal(bits_f, bits_d) and torch.equal(all_f, all_d)
+    # an all-masked row is flagged (a mask embedding whose logits are all negative: the rows
+    # are made non-negative and the embedding -1)
+    rows_pos, me_neg = rows.abs(), me.clone()
+    me_neg[3] = -1.0
+    hip.mask_stencil_gemm(me_neg, rows_pos, bits_f, all_f, B, Q, hi, wi, ho, wo, K=C)
+    torch.cuda.synchronize()
+    assert int(all_f[3]) == 1 and int(all_f[4]) == int(all_d[4]) == 0
+    assert bool((bits_f.view(B * Q, nw)[3].cpu().numpy().view("uint32") != 0).any())
     l4[3].fill_(-1.0)
     hip.mask_pack_stencil(l4, bits_s, all_s, B * Q, hi, wi, ho, wo)
     assert int(all_s[3]) == 1

@@ -105,7 +105,7 @@ class CrossHeadBBox(CrossHead2):
             raise NotImplementedError("4 levels, <= 512 proposals, <= 256 classes")
         self._params = OrderedDict((k, torch.zeros(s)) for k, s in self.param_shapes().items())
         self.device, self.w = None, None
-        self._plans, self._post, self._consts = PlanCache(), OrderedDict(), {}
+        self._plans, self._post, self._consts = PlanCache(8), OrderedDict(), {}
         self._pan_jobs = []
         self.use_graphs = False
         self.grid_reserve = 0
@@ -217,7 +217,7 @@ class CrossHeadBBox(CrossHead2):
             self._params["cls_branches.%d.bias" % i].fill_(bias_init)
             self._params["reg_branches.%d.4.weight" % i].zero_()
         self._params["reg_branches.0.4.bias"][2:] = -2.0
-        self.w, self._plans, self._consts = None, PlanCache(), {}
+        self.w, self._plans, self._consts = None, PlanCache(8), {}
 
     # ----------------------------------------------------------------- packing
     def _pack(self):

@@ -545,16 +545,17 @@ class PSGTr:
         arenas grow on demand, each growth costing one device wait (plans.py) -- and cheap: a
         loop that knows its envelope (Resize(img_scale=(1333, 800)): [(800, 1333), (1333, 800)])
         calls it once and never waits in flight.  Returns the bytes reserved, or None for a
-        backbone / head that keeps per-shape plans (Swin, the box trunk)."""
+        head that keeps per-shape plans (the box trunk)."""
         net, head = self.backbone, self.bbox_head
-        if not isinstance(net, ResNet50Hip) or type(head)._plan is not CrossHead2._plan \
-                or self.neck is not None:
+        if type(head)._plan is not CrossHead2._plan or self.neck is not None:
             return None
         piped = self._pipelines()
         a_slots = range(len(self.pipeline(depth).streams_a)) if piped else (0,)
         for H, W in image_sizes:
             net.reserve(batch, H, W, slots=a_slots)
             fs = net.feature_shapes(H, W)
+            if len(fs) != 4:
+                return None
             head.reserve(batch, [fs[3], fs[2], fs[1]], fs[0],
                          slots=range(depth) if piped else (0,), orig_sizes=orig_sizes)
         return net.arena_bytes() + head.arena_bytes()
@@ -578,19 +579,26 @@ class PSGTr:
         replay, the workgroup slots stage A leaves free), restored afterwards: grid_reserve is
         part of the stage graphs' key, so a later simple_test() finds its own graphs again."""
         head, net = self.bbox_head, self.backbone
-        slots = isinstance(net, ResNet50Hip)
+        # both native backbones take a buffer slot per stage-A stream (two images' backbones
+        # run side by side); only the ResNet replays as a hipGraph
+        slots = isinstance(net, (ResNet50Hip, SwinTransformerHip))
+        graphs = isinstance(net, ResNet50Hip)
         saved = (head.use_graphs, getattr(head, "grid_reserve", 0),
                  getattr(net, "use_graphs", None), getattr(net, "grid_reserve", 0))
         pipe = self.pipeline(depth)
         head.use_graphs, head.grid_reserve = True, pipe.grid_reserve
         if slots:
-            net.use_graphs, net.grid_reserve = True, pipe.grid_reserve
+            net.grid_reserve = pipe.grid_reserve
+        if graphs:
+            net.use_graphs = True
         try:
             yield pipe, slots
         finally:
             head.use_graphs, head.grid_reserve = saved[0], saved[1]
             if slots:
-                net.use_graphs, net.grid_reserve = saved[2], saved[3]
+                net.grid_reserve = saved[3]
+            if graphs:
+                net.use_graphs = saved[2]
 
     def _pipeline_of_images(self):
         if self.test_pipeline is None:

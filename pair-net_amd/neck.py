@@ -32,7 +32,7 @@ class ChannelMapper:
         if self.num_outs - len(self.in_channels) not in (0, 1):
             raise NotImplementedError("at most one extra level")
         self._params = OrderedDict((k, torch.zeros(s)) for k, s in self.param_shapes().items())
-        self.device, self.w, self._plans = None, None, PlanCache()
+        self.device, self.w, self._plans = None, None, PlanCache(8)
         self.init_weights()
 
     def param_shapes(self):
@@ -56,7 +56,7 @@ class ChannelMapper:
                 fan_in, fan_out = p[0].numel(), p.shape[0] * p.shape[2] * p.shape[3]
                 a = math.sqrt(6.0 / (fan_in + fan_out))
                 p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * a)
-        self.w, self._plans = None, PlanCache()
+        self.w, self._plans = None, PlanCache(8)
 
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._params.items())
@@ -70,7 +70,7 @@ class ChannelMapper:
         for k, p in self._params.items():
             if k in sd:
                 p.copy_(sd[k].detach().to(torch.float32).cpu().reshape(p.shape))
-        self.w, self._plans = None, PlanCache()
+        self.w, self._plans = None, PlanCache(8)
         return missing, unexpected
 
     def eval(self):
@@ -78,7 +78,7 @@ class ChannelMapper:
 
     def to(self, device):
         self.device = torch.device(device)
-        self.w, self._plans = None, PlanCache()
+        self.w, self._plans = None, PlanCache(8)
         return self
 
     def cuda(self, index=0):

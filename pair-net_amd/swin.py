@@ -22,7 +22,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
-from .plans import PlanCache
+from .plans import Arena, PlanCache, measure_bytes
 
 EPS = 1e-5
 
@@ -127,6 +127,7 @@ class SwinTransformerHip:
 
     def to(self, device):
         self.device, self.w, self._plans = torch.device(device), None, PlanCache()
+        self._arenas = {}
         return self
 
     def eval(self):
@@ -155,7 +156,53 @@ class SwinTransformerHip:
         self.w = w
 
     class _Plan:
-        pass
+        def busy_events(self):
+            out = []
+            for st in getattr(self, "streams", {}).values():
+                ev = torch.cuda.Event()
+                ev.record(st)
+                out.append(ev)
+            return out
+
+    def _arena(self, slot):
+        """One flat buffer per slot; every (batch, image size) plan of the slot is a set of
+        views of it (plans.py: a keep-ratio evaluation pass meets hundreds of sizes)."""
+        arenas = self.__dict__.setdefault("_arenas", {})
+        a = arenas.get(slot)
+        if a is None:
+            a = arenas[slot] = Arena(self.device, on_grow=lambda a, s=slot: self._plans.drop(
+                lambda k: k[3] == s))
+        return a
+
+    def _layout_for(self, dims):
+        def layout(E):
+            pl = SwinTransformerHip._Plan()
+            self._layout(pl, E, *dims)
+            return pl
+        return layout
+
+    def _measure(self, dims):
+        return measure_bytes(self._layout_for(dims))
+
+    def reserve(self, batch, H, W, slots=(0,)):
+        """Size the arenas of `slots` up front for [batch, 3, H, W] images (optional)."""
+        if self.w is None:
+            self._pack()
+        for s in slots:
+            self._arena(s).reserve((batch, H, W), self._measure)
+
+    def arena_bytes(self):
+        return sum(a.capacity for a in self.__dict__.get("_arenas", {}).values())
+
+    def feature_shapes(self, H, W):
+        """[(h, w)] of the output stages for an H x W image (4x4 patches, then /2 per stage)."""
+        h, w = -(-H // 4), -(-W // 4)
+        out = []
+        for i in range(len(self.depths)):
+            if i in self.out_indices:
+                out.append((h, w))
+            h, w = -(-h // 2), -(-w // 2)
+        return out
 
     def _plan(self, B, H, W, slot=0):
         key = (B, H, W, slot)
@@ -163,8 +210,14 @@ class SwinTransformerHip:
             return self._plans[key]
         if self.w is None:
             self._pack()
-        E = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
-        pl = SwinTransformerHip._Plan()
+        dims = (B, H, W)
+        pl = self._arena(slot).carve(self._layout_for(dims), dims, self._measure)
+        pl.streams = {}
+        self._plans[key] = pl
+        return pl
+
+    def _layout(self, pl, E, B, H, W):
+        """Every activation buffer as a view of the slot's arena (sizes non-decreasing in B, H, W)."""
         h, wd = -(-H // 4), -(-W // 4)
         pl.hw = []
         for i in range(len(self.depths)):
@@ -183,8 +236,6 @@ class SwinTransformerHip:
                            for (hh, ww), c in zip(pl.hw[1:], self.num_features[1:])] + [4]))
         pl.out = {i: E(B, pl.hw[i][0], pl.hw[i][1], self.num_features[i]) for i in self.out_indices}
         pl.scratch = E(B * 8 * 1024 * 1024)
-        self._plans[key] = pl
-        return pl
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -200,6 +251,8 @@ class SwinTransformerHip:
         img = img.contiguous()
         B, _, H, W = img.shape
         pl = self._plan(B, H, W, slot)
+        cur = torch.cuda.current_stream(self.device)
+        pl.streams[cur.cuda_stream] = cur
         w, ws = self.w, self.ws
         lin = lambda x, wk, bk, out, **kw: hip.linear(x, w[wk], w[bk] if bk else None, out,
                                                       scratch=pl.scratch, **kw)

@@ -200,3 +200,34 @@ def test_detector_end_to_end_swin_backbone():
     res = det.simple_test(img, metas)
     assert len(res) == 1 and res[0].rel_dists.shape == (100, 57)
     assert res[0].masks.shape == (200, 128, 160)
+
+
+def test_swin_detector_pipelined_over_mixed_shapes_equals_the_synchronous_path():
+    """Round 5: the Swin backbone's plans are views of one arena per slot too, and it takes a
+    slot per stage-A stream in the detector's pipeline.  Images of several shapes through
+    `dist.multi_gpu_test` (two backbones side by side, query chains beside them) give the
+    records of the synchronous `simple_test` path, bit for bit; reserved arenas never grow."""
+    from pairnet_amd import build_detector, pairnet_swin
+    from pairnet_amd.dist import multi_gpu_test, pack_triplets
+    cfg = pairnet_swin("B")
+    cfg["backbone"]["depths"] = [2, 2, 2, 2]
+    det = build_detector(cfg).to(DEV)
+    shapes = [(128, 160), (96, 128), (160, 128), (128, 160), (112, 144), (96, 128), (160, 128)]
+    data = []
+    for i, (H, W) in enumerate(shapes):
+        data.append((R(1, 3, H, W, seed=40 + i).to(DEV),
+                     [dict(img_shape=(H, W, 3), scale_factor=[1.0] * 4)]))
+    got = det.reserve([(160, 160)], depth=3, orig_sizes=[(160, 160)])
+    assert got == det.backbone.arena_bytes() + det.bbox_head.arena_bytes() > 0
+    head = det.bbox_head
+    want = []
+    for img, metas in data:
+        res = head.simple_test(det.extract_feat(img), metas)[0]
+        sub, obj = head.pair_positions()
+        want.append(pack_triplets(res[1].cpu(), res[7].cpu(), sub[0].cpu(), obj[0].cpu()))
+    out = multi_gpu_test(det, data, depth=3, calibrate=False)
+    for i, w in enumerate(want):
+        assert torch.equal(out["records"][i].cpu(), w), i
+    assert sorted(det.backbone._arenas) == [0, 1]            # a slot per stage-A stream
+    assert all(a.grows == 1 for a in det.backbone._arenas.values())
+    assert all(a.grows == 1 for a in head._arenas.values())

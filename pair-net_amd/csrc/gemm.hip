@@ -47,10 +47,20 @@
 #define PN_GEMM_WGS64_SPILLING 5
 #endif
 
+// -DPN_GEMM_LDS2=1 (round-5 experiment): TWO LDS stages and ONE barrier per 32-deep chunk -- the
+// chunk after next goes global -> registers and the next chunk registers -> the other stage
+// while the current stage is multiplied -- instead of one stage with two barriers per chunk.
+// 36.9 KB per 64x64 workgroup: four resident workgroups per CU instead of five.  See LABNOTES
+// R5.8 for the measurement.
+#ifndef PN_GEMM_LDS2
+#define PN_GEMM_LDS2 0
+#endif
+
 template <int BM, int BN, int AMODE>
 struct TileSmem {
   static constexpr int A_ELEMS = (AMODE == A_COL) ? 32 * (BM + 4) : BM * 36;
-  static constexpr int FLOATS = A_ELEMS + BN * 36;
+  static constexpr int STAGE = A_ELEMS + BN * 36;
+  static constexpr int FLOATS = STAGE * (PN_GEMM_LDS2 ? 2 : 1);
 };
 
 // -DPN_GEMM_W2=1 (round-4 experiment, NOT adopted): the default 64x64 launches run as TWO waves
@@ -268,7 +278,9 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
 #pragma unroll
     for (int j = 0; j < NB; ++j) rb[j] = buf_ld4(rW, w_off[j], ragged ? 0 : k0 * 4);
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](const int so = 0) {     // so: float offset of the LDS stage written
+    float* const sA = smem + so;
+    float* const sB = smem + so + A_ELEMS;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
@@ -323,10 +335,13 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
   f32x16 acc[TM][TN];
   // MFMA operand fragments, double-buffered in registers: the ds_reads of k-step kb+1
   // are in flight while the MFMAs of kb issue
-  const float* fA = (AMODE == A_COL) ? sA + (4 * lh) * LDK + wm * WM + li
-                                     : sA + (wm * WM + li) * LD + 4 * lh;
-  const float* fB = sB + (wn * WN + li) * LD + 4 * lh;
+  const float* fA0 = (AMODE == A_COL) ? sA + (4 * lh) * LDK + wm * WM + li
+                                      : sA + (wm * WM + li) * LD + 4 * lh;
+  const float* fB0 = sB + (wn * WN + li) * LD + 4 * lh;
+  int rso = 0;     // float offset of the LDS stage being read (PN_GEMM_LDS2)
   auto read_frag = [&](int kb, float4 (&fa)[TM], float4 (&fb)[TN]) {
+    const float* const fA = fA0 + rso;
+    const float* const fB = fB0 + rso;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
       if (AMODE == A_COL) {
@@ -363,6 +378,25 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
   TileRef cur = loc(base + slot);
   set_tile(cur);
   load_chunk(0);
+#if PN_GEMM_LDS2
+  constexpr int STAGE = TileSmem<BM, BN, AMODE>::STAGE;
+  int wso = 0;                     // stage the NEXT store_chunk writes
+  {
+    // prologue: chunk 0 -> stage 0; the chunk after it -> registers
+    const GemmP& p0 = loc.P(cur.pi);
+    int nk0 = (p0.K + BK - 1) / BK;
+    if (p0.ksplit > 1) nk0 = min(p0.split_chunks, nk0 - (cur.bz % p0.ksplit) * p0.split_chunks);
+    store_chunk(0);
+    wso = STAGE;
+    if (nk0 > 1) {
+      load_chunk(1);
+    } else {
+      set_tile(loc(base + min(slot + per, cnt - 1)));
+      load_chunk(0);
+    }
+    __syncthreads();
+  }
+#endif
   for (int t = slot; t < cnt; t += per) {
     const GemmP& p = loc.P(cur.pi);
     // the tile after this one (clamped: the last tile re-loads its own first chunk, unused)
@@ -378,6 +412,36 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
       for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+#if PN_GEMM_LDS2
+    // Stage rso holds chunk kt (visible since the last barrier), the registers hold the chunk
+    // after it (loaded one iteration ago): it goes to the OTHER stage -- which every wave
+    // finished reading before the last barrier -- the chunk after that is requested, and only
+    // then the current stage is multiplied.  One barrier per chunk.
+    for (int kt = 0; kt < nk; ++kt) {
+      store_chunk(wso);
+      // the chunk two ahead: kt + 2 of this tile, or chunk 0 / 1 of the next one
+      if (kt + 2 < nk) {
+        load_chunk(kt + 2);
+      } else if (kt + 2 == nk) {       // registers held this tile's last chunk: next tile starts
+        set_tile(nxt);
+        load_chunk(0);
+      } else {                          // kt + 1 == nk: registers held the next tile's chunk 0
+        const GemmP& pn = loc.P(nxt.pi);
+        int nkn = (pn.K + BK - 1) / BK;
+        if (pn.ksplit > 1) nkn = min(pn.split_chunks, nkn - (nxt.bz % pn.ksplit) * pn.split_chunks);
+        if (nkn > 1) {
+          load_chunk(1);
+        } else {                        // single-chunk tiles: the tile after the next one
+          set_tile(loc(base + min(t + 2 * per, cnt - 1)));
+          load_chunk(0);
+        }
+      }
+      compute();
+      __syncthreads();
+      rso = wso;
+      wso = STAGE - wso;
+    }
+#else
     for (int kt = 0; kt < nk; ++kt) {
       __syncthreads();
       store_chunk();
@@ -387,6 +451,7 @@ __device__ __forceinline__ void gemm_persistent(const Locator& loc, const int nt
       load_chunk(last ? 0 : kt + 1);
       compute();
     }
+#endif
     // ---- epilogue: bias -> act -> residual.  The residual values of a 32x32
     // accumulator are fetched as 16 independent loads (clamped, unconditional) before
     // any is used: one memory round trip per accumulator instead of sixteen. ----

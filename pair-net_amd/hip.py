@@ -13,6 +13,11 @@ import torch
 
 from .build import LIB_PATH
 
+# (tuning aid: PAIRNET_LIB=<path> runs the package against an alternative BUILD of the same
+# library -- a kernel variant compiled with a build-time knob, tools/bench_variant.py -- with
+# the same ABI check; there is still no fallback)
+LIB_PATH = os.environ.get("PAIRNET_LIB") or LIB_PATH
+
 _i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 GEMM_RELU, GEMM_A_COLMAJOR, GEMM_FORCE_TILE, GEMM_FORCE_SKINNY = 1, 2, 4, 8

@@ -663,6 +663,7 @@ def main():
             list(backbone._arenas.values())
         grows0 = sum(a.grows for a in arenas)
         caps0, ev0 = _H.captures, head._plans.evictions + backbone._plans.evictions
+        recap0 = getattr(head, "recaptures", 0)
         torch.cuda.synchronize()
         mem0 = torch.cuda.memory_allocated()
         t0 = time.perf_counter()
@@ -717,13 +718,17 @@ def main():
             "plan_evictions_in_run": head._plans.evictions + backbone._plans.evictions - ev0,
             "graph_captures_first_pass": caps1 - caps0,
             "graph_captures_second_pass": _H.captures - caps1,
+            "stage_graph_recaptures_in_run": getattr(head, "recaptures", 0) - recap0,
             "arena_bytes": head.arena_bytes() + backbone.arena_bytes(),
             "device_bytes_growth_over_both_passes": int(mem1 - mem0),
             "records_bitwise_eager_single_shape": bool(same),
             "what": "pairnet_amd.dist.multi_gpu_test over %d images of %d padded shapes "
                     "(original sizes from the COCO histogram, seeded order): first pass incl. "
                     "every shape's first sight, then a second pass; `ideal` = each image at "
-                    "the steady-state rate of its own shape run alone" % (
+                    "the steady-state rate of its own shape run alone; a graph is captured on a "
+                    "(shape, slot)'s SECOND sight (captures of the second pass are such second "
+                    "sights), a recapture would be a capture of a (shape, slot, stage) that had "
+                    "a graph before" % (
                         n_mix, len(imgs_by_shape))}
         del imgs_by_shape, items, data
 

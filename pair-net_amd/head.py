@@ -1024,6 +1024,7 @@ class CrossHead2:
                     # buffers every time (the backbone writing into its slot's arena, a
                     # resident pyramid) pays no staging copy
                     pl.static_feats, pl.static_ptrs = list(feats), ptrs
+                    self._note_capture(pl, "a")
                     pl.graph_a = self._capture(lambda: self._stage_a(pl.static_feats, pl))
             pl.calls_a += 1
             pl.last_ptrs = ptrs
@@ -1036,12 +1037,23 @@ class CrossHead2:
             pl.feats_read.record()      # the caller's feature buffers are free again
         else:
             if self.use_graphs and pl.graph_b is None and pl.calls_b >= self.graph_after:
+                self._note_capture(pl, "b")
                 pl.graph_b = self._capture(lambda: self._stage_b(pl))
             pl.calls_b += 1
             if self.use_graphs and pl.graph_b is not None:
                 pl.graph_b.replay()
             else:
                 self._stage_b(pl)
+
+    def _note_capture(self, pl, stage):
+        """Bookkeeping for the bench / tests: a capture of a (plan key, stage) that had been
+        captured before in this head's life is a RE-capture (the plan was evicted, its arena
+        grew, the weights or the caller's buffers changed)."""
+        seen = self.__dict__.setdefault("_captured", set())
+        k = (pl.key, stage)
+        if k in seen:
+            self.recaptures = getattr(self, "recaptures", 0) + 1
+        seen.add(k)
 
     _capture_streams = {}
     captures = 0          # graphs captured so far in this process (a counter for the bench / tests)

@@ -445,6 +445,7 @@ def test_many_shapes_share_one_arena_per_slot():
             + list(net._arenas.values())] == grows     # the reserved arenas never grew
     assert head._plans.evictions == 0 and net._plans.evictions == 0
     assert all(pl.graph_a is not None and pl.graph_b is not None for pl in head._plans.values())
+    assert getattr(head, "recaptures", 0) == 0
     # memory: the arenas + the shared position tables (one set per shape, LRU-bounded) +
     # the clones of this loop; independent of how many shapes have passed
     pe = max(sum(t.numel() * 4 for t in [e[0]] + e[1]) for e in head._pe.values())

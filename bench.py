@@ -268,6 +268,8 @@ def main():
                          "the run (e.g. --set group_input_convs=0)")
     ap.add_argument("--bb-set", action="append", default=[], metavar="ATTR=VALUE",
                     help="integer attribute of the native ResNet backbone (tuning A/B)")
+    ap.add_argument("--mix-images", type=int, default=240,
+                    help="images of the shape_mix_product_loop leg (>= 200 by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -450,9 +452,13 @@ def main():
     # hardware-queue placement of the pipeline is chosen empirically (pipeline.py) ----
     # (setup, not warm-up: buffers are planned on the first call of a shape and the hipGraphs
     # are captured on the second, per pipeline slot -- two passes over the slots)
+    # (graphs are captured at QUIET points only -- no other stream executing, LABNOTES R5.9 --
+    # so the set-up runs one batch at a time: stage A, device wait, chain + get_bboxes, wait)
     for _ in range(2 * args.depth if engine is not None else 2):
         step()
-    drain()
+        torch.cuda.synchronize()
+        drain()
+        torch.cuda.synchronize()
     calibration = None
     if engine is not None:
         calibration = engine.calibrate(feats, metas, submit=step)
@@ -640,7 +646,7 @@ def main():
                 ((375, 500), 5), ((428, 640), 3), ((640, 427), 3), ((425, 640), 2),
                 ((333, 500), 2), ((360, 640), 2), ((500, 375), 2), ((424, 640), 2),
                 ((612, 612), 2), ((640, 640), 1), ((512, 640), 1), ((640, 426), 1)]
-        n_mix = 240
+        n_mix = max(len(ORIG), args.mix_images)
         gm = torch.Generator().manual_seed(77)
         wts = torch.tensor([float(wt) for _, wt in ORIG])
         draw = torch.multinomial(wts, n_mix, replacement=True, generator=gm).tolist()
@@ -725,9 +731,9 @@ def main():
             "what": "pairnet_amd.dist.multi_gpu_test over %d images of %d padded shapes "
                     "(original sizes from the COCO histogram, seeded order): first pass incl. "
                     "every shape's first sight, then a second pass; `ideal` = each image at "
-                    "the steady-state rate of its own shape run alone; a graph is captured on a "
-                    "(shape, slot)'s SECOND sight (captures of the second pass are such second "
-                    "sights), a recapture would be a capture of a (shape, slot, stage) that had "
+                    "the steady-state rate of its own shape run alone; graphs are captured at quiet "
+                    "points only (no other stream executing), so shapes first met in flight run "
+                    "eagerly; a recapture would be a capture of a (shape, slot, stage) that had "
                     "a graph before" % (
                         n_mix, len(imgs_by_shape))}
         del imgs_by_shape, items, data

@@ -17,6 +17,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
+from . import plans
 from .plans import Arena, PlanCache, measure_bytes
 
 BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}   # bottleneck ResNets (mmdet arch_settings)
@@ -283,6 +284,7 @@ class ResNet50Hip:
             pl.reserve, pl.graph = self.grid_reserve, None
         cur = torch.cuda.current_stream(self.device)
         pl.streams[cur.cuda_stream] = cur
+        plans.note_stream(cur)
         if not self.use_graphs:
             return self._run(img, pl)
         # hipGraph replay of the ~55 launches: captured on the caller's image buffer when it
@@ -294,7 +296,7 @@ class ResNet50Hip:
         if pl.graph is not None and not pl.staged and ptr != pl.static_img.data_ptr():
             pl.graph, pl.staged = None, True        # the caller rotates buffers: stage from now on
         if pl.graph is None:
-            if pl.calls < self.graph_after:
+            if pl.calls < self.graph_after or not plans.quiet(cur):   # (capture at quiet points only)
                 pl.calls += 1
                 pl.last_img = ptr
                 return self._run(img, pl)

@@ -641,14 +641,34 @@ class PSGTr:
         """Choose the stream -> hardware-queue placement of this detector's pipeline on a
         representative batch (`PipelinedHead.calibrate` with the backbone in front, the way
         `stream()` queues it).  Optional, once per process; returns the per-rotation times."""
+        self.warm_graphs(img, img_metas, depth=depth)
         with self._scheduled(depth) as (pipe, slots):
-            for _ in range(2 * depth):      # plans made, stage graphs captured
-                self._submit(pipe, slots, img, img_metas, False)
-            pipe.flush()
             times = pipe.calibrate(None, img_metas, steps=steps,
                                    submit=lambda: self._submit(pipe, slots, img, img_metas, False))
         self.__dict__.setdefault("_calibrated", set()).add(depth)
         return times
+
+    @torch.no_grad()
+    def warm_graphs(self, img, img_metas, depth=4, rescale=False):
+        """Capture the hipGraphs of this batch's shape for every slot of the pipeline, at quiet
+        points: graphs are only ever captured while no other stream of the process is executing
+        (plans.quiet, LABNOTES R5.9), so a shape first met IN FLIGHT runs eagerly (within 0.5 %
+        of the replay rate) until such a point comes.  This runs one batch at a time through
+        each slot -- stage A, device wait, query chain + get_bboxes, device wait -- once eagerly
+        and once capturing.  Optional; `calibrate_pipeline` starts with it."""
+        if not self._pipelines():
+            return
+        head = self.bbox_head
+        with self._scheduled(depth) as (pipe, slots):
+            if pipe.queue:
+                raise RuntimeError("warm_graphs() needs an empty pipeline")
+            for _ in range(getattr(head, "graph_after", 1) + 1):
+                for _ in range(depth):
+                    self._submit(pipe, slots, img, img_metas, rescale)
+                    torch.cuda.synchronize(head.device)
+                    with torch.cuda.stream(pipe.streams_a[0]):
+                        pipe.flush()
+                    torch.cuda.synchronize(head.device)
 
     def pipeline_calibrated(self, depth=4):
         """Whether `calibrate_pipeline` has run for this depth (on the current device)."""

@@ -20,6 +20,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
+from . import plans
 from .plans import Arena, PlanCache, measure_bytes
 from .config import ConfigDict
 
@@ -391,6 +392,7 @@ class CrossHead2:
                 out.append(ev)
             return out
 
+    STAGE_A_GRAPHS = 4   # stage-A graphs kept per plan (one per set of caller feature buffers)
     PE_SHAPES = 24       # position tables kept (LRU), shared by the slots: ~44 MB per full-size shape
     POST_VIEWS = 8       # post-processing view sets / get_bboxes graphs kept per plan
 
@@ -514,7 +516,8 @@ class CrossHead2:
         pl.graph_a = pl.graph_b = pl.static_feats = pl.graph_cfg = pl.feats_read = None
         pl.graph_c = PlanCache(self.POST_VIEWS)
         pl.post_views = OrderedDict()
-        pl.static_ptrs = pl.last_ptrs = None
+        pl.static_ptrs = None
+        pl.graphs_a = OrderedDict()
         pl.calls_a = pl.calls_b = 0
         pl.streams = {}
         pl.enc_pos, pl.dec_kpos, pl.pe_ready = self._position_tables(shapes)
@@ -1001,10 +1004,12 @@ class CrossHead2:
                getattr(self, "fuse_mask_pack", True))
         if pl.graph_cfg != cfg:          # a captured graph bakes these switches in
             pl.graph_a = pl.graph_b = None
+            pl.graphs_a = OrderedDict()
             pl.graph_c = PlanCache(self.POST_VIEWS)
             pl.graph_cfg = cfg
         cur = torch.cuda.current_stream(self.device)
         pl.streams[cur.cuda_stream] = cur
+        plans.note_stream(cur)
         if which == "a":
             if not pl.pe_waited:
                 # the position tables are shared by the slots and filled on the stream that
@@ -1014,29 +1019,42 @@ class CrossHead2:
                 else:
                     cur.wait_event(pl.pe_ready)
             ptrs = tuple(f.data_ptr() for f in feats)
-            if self.use_graphs:
-                if pl.graph_a is not None and ptrs != pl.static_ptrs:
-                    # other buffers than the captured ones: eager (it reads any pointer), and
-                    # captured again as soon as the caller's buffers repeat
-                    pl.graph_a = None
-                if pl.graph_a is None and pl.calls_a >= self.graph_after and ptrs == pl.last_ptrs:
-                    # captured on the caller's own buffers: a caller that hands over the same
-                    # buffers every time (the backbone writing into its slot's arena, a
-                    # resident pyramid) pays no staging copy
-                    pl.static_feats, pl.static_ptrs = list(feats), ptrs
-                    self._note_capture(pl, "a")
-                    pl.graph_a = self._capture(lambda: self._stage_a(pl.static_feats, pl))
+            # A stage-A graph is tied to the caller's feature buffers (captured on them: no
+            # staging copy).  One plan can meet several buffer sets -- image sizes that differ
+            # by a pixel share a feature pyramid, hence this plan, but not the backbone's
+            # buffers -- so up to STAGE_A_GRAPHS graphs are kept per plan, by pointer; a
+            # caller that hands over new buffers every time is simply served eagerly.
+            ent = pl.graphs_a.get(ptrs)
+            if ent is None:
+                if len(pl.graphs_a) >= self.STAGE_A_GRAPHS:     # forget the oldest entry that
+                    for k, e in pl.graphs_a.items():            # never got as far as a graph
+                        if e["graph"] is None:
+                            del pl.graphs_a[k]
+                            break
+                if len(pl.graphs_a) < self.STAGE_A_GRAPHS:
+                    ent = pl.graphs_a[ptrs] = dict(calls=0, graph=None, feats=None)
+            else:
+                pl.graphs_a.move_to_end(ptrs)
+            if self.use_graphs and ent is not None and ent["graph"] is None \
+                    and ent["calls"] >= self.graph_after and plans.quiet(cur):
+                ent["feats"] = list(feats)
+                self._note_capture(pl, ("a", ptrs))
+                ent["graph"] = self._capture(lambda: self._stage_a(ent["feats"], pl))
+            if ent is not None:
+                ent["calls"] += 1
             pl.calls_a += 1
-            pl.last_ptrs = ptrs
+            graph = ent["graph"] if (self.use_graphs and ent is not None) else None
+            pl.graph_a, pl.static_ptrs = graph, (ptrs if graph is not None else None)
             if pl.feats_read is None:
                 pl.feats_read = torch.cuda.Event()
-            if self.use_graphs and pl.graph_a is not None:
-                pl.graph_a.replay()
+            if graph is not None:
+                graph.replay()
             else:
                 self._stage_a(feats, pl)
             pl.feats_read.record()      # the caller's feature buffers are free again
         else:
-            if self.use_graphs and pl.graph_b is None and pl.calls_b >= self.graph_after:
+            if self.use_graphs and pl.graph_b is None and pl.calls_b >= self.graph_after \
+                    and plans.quiet(cur):
                 self._note_capture(pl, "b")
                 pl.graph_b = self._capture(lambda: self._stage_b(pl))
             pl.calls_b += 1
@@ -1060,11 +1078,13 @@ class CrossHead2:
 
     @staticmethod
     def _capture(fn):
-        """Record `fn`'s launches into a hipGraph.  Unlike `torch.cuda.graph()` this does not
-        wait for the device, collect garbage or trim the allocator: the launches allocate
-        nothing (arena views), so capture is pure host work on a private stream while the
-        other streams keep executing.  thread_local: other threads (the RCCL watchdog, the
-        result streamer's worker) may touch the runtime while this thread captures."""
+        """Record `fn`'s launches into a hipGraph, on a private stream.  Callers capture at quiet
+        points only (`plans.quiet`, see there for the measurement behind it); the device wait in
+        front makes that robust against streams this package does not know.  Unlike
+        `torch.cuda.graph()` no garbage collection / allocator trim: the launches allocate
+        nothing (arena views).  thread_local: other threads (the RCCL watchdog, the result
+        streamer's worker) may touch the runtime while this thread captures."""
+        torch.cuda.synchronize()
         dev = torch.cuda.current_device()
         cs = CrossHead2._capture_streams.get(dev)
         if cs is None:
@@ -1214,8 +1234,9 @@ class CrossHead2:
         ent = pl.graph_c.get(key)
         if ent is None:
             ent = pl.graph_c[key] = CrossHead2._PostGraph(pl)
+        plans.note_stream(cur)
         if ent.graph is None:
-            if ent.calls < self.graph_after:
+            if ent.calls < self.graph_after or not plans.quiet(cur):
                 ent.calls += 1
                 return self._get_bboxes_all(cls_scores, mask_preds, img_metas, rescale, pl)
             self._post_views(pl, self._orig_sizes(img_metas))   # (made / grown outside the capture)

@@ -31,6 +31,32 @@ DEFAULT_MAX_PLANS = 64   # e.g. 4 pipeline slots x 16 shapes; plans are views (+
 ALIGN = 256
 
 
+# ---- when a hipGraph may be captured -----------------------------------------------------
+# Measured in round 5 (LABNOTES R5.9): capturing a graph while OTHER streams of the process are
+# executing (the pipeline in flight: a backbone graph replaying on one stream while the head's
+# stage graph is captured for the next) corrupted ~10 % of the runs of a 12-image test -- one
+# image's result slightly off, only with backbone AND head graphs on, never with a device wait
+# in front of the capture (0 / 20), never eagerly (0 / 28).  Capture therefore happens only at
+# QUIET points: no stream this package has launched on, other than the caller's current one, has
+# unfinished work; the capture then waits for the device (which at a quiet point costs at most
+# the caller's own queued work).  In flight, a (shape, slot) without a graph simply runs eagerly
+# -- within 0.5 % of the replay rate -- until a quiet point comes (warm-up, a synchronous caller,
+# `PSGTr.warm_graphs`).
+_STREAMS = {}
+
+
+def note_stream(stream):
+    _STREAMS[(stream.device_index, stream.cuda_stream)] = stream
+
+
+def quiet(current):
+    """True when no noted stream of `current`'s device other than `current` has unfinished work."""
+    for (dev, handle), st in _STREAMS.items():
+        if dev == current.device_index and handle != current.cuda_stream and not st.query():
+            return False
+    return True
+
+
 class ArenaOverflow(RuntimeError):
     pass
 

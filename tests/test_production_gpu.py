@@ -178,10 +178,28 @@ def test_r50_800x1333_graph_replay_and_pipeline_give_the_eager_result():
     pipe = PipelinedHead(head, depth=4, a_streams=2)
     order = [0, 1, 1, 0, 0, 1, 0, 1, 1, 0, 1, 0]
     got = []
+    # graphs are captured at quiet points only (plans.quiet, LABNOTES R5.9): one batch at a time
+    # through every slot, twice (eager, then capturing), as PSGTr.warm_graphs does
+    for _ in range(2 * pipe.depth):
+        sl = pipe.count % len(pipe.streams_a)
+        with torch.cuda.stream(pipe.streams_a[sl]):
+            pipe.submit(net(imgs[0], slot=sl), metas[:1])
+        torch.cuda.synchronize()
+        pipe.flush()
+        torch.cuda.synchronize()
+    assert len(head._plans) == 4 and all(
+        pl.graph_b is not None and any(e["graph"] is not None for e in pl.graphs_a.values())
+        for pl in head._plans.values())
+    assert all(pl.graph is not None for pl in net._plans.values())
 
     def take(res):
+        # read on the chain stream that produced the results (ordered behind get_bboxes and in
+        # front of the slot's next query chain, which runs on the same stream) and say so:
+        # plan internals like topk_idx are slot buffers, not part of the returned tuple
         pl = head._last_plan
-        got.append([t.clone() for t in (res[0][1], res[0][7], res[0][4], pl.topk_idx)])
+        with torch.cuda.stream(res.pipeline_stream):
+            got.append([t.clone() for t in (res[0][1], res[0][7], res[0][4], pl.topk_idx)])
+            pipe.consumed(res, res.pipeline_stream)
     for i in order:
         sl = pipe.count % len(pipe.streams_a)
         pipe.streams_a[sl].wait_stream(torch.cuda.current_stream())
@@ -401,7 +419,8 @@ def test_many_shapes_share_one_arena_per_slot():
     largest shapes have passed) a new shape allocates nothing, waits for nothing and evicts
     nothing; device memory is independent of the number of shapes; every image's result is
     bitwise the one a fresh detector gives for that shape alone; graphs are captured on a
-    shape's second sight and replayed from then on (zero recaptures)."""
+    shape's second sight -- this caller is single-stream, i.e. always at a quiet point
+    (plans.quiet) -- and replayed from then on (zero recaptures)."""
     from oracle.backbone import seeded_backbone_state
     from pairnet_amd import build_detector, pairnet_r50
 
@@ -430,6 +449,8 @@ def test_many_shapes_share_one_arena_per_slot():
             out = [t.clone() for t in (r[1], r[7], r[4])]
         return out
     torch.cuda.synchronize()
+    from pairnet_amd.head import CrossHead2
+    caps = CrossHead2.captures
     syncs = []
     real_sync = torch.cuda.synchronize
     torch.cuda.synchronize = lambda *a, **k: (syncs.append(1), real_sync(*a, **k))[1]
@@ -440,7 +461,9 @@ def test_many_shapes_share_one_arena_per_slot():
             mem.append(torch.cuda.memory_allocated())
     finally:
         torch.cuda.synchronize = real_sync
-    assert not syncs                                   # no device-wide wait: not for plans, not for capture
+    # the only device-wide waits are the ones in front of a graph capture (a single-stream
+    # caller is always at a quiet point): none for plans, none for new shapes as such
+    assert len(syncs) == CrossHead2.captures - caps >= 35 * 3
     assert [a.grows for a in list(head._arenas.values()) + list(head._post_arenas.values())
             + list(net._arenas.values())] == grows     # the reserved arenas never grew
     assert head._plans.evictions == 0 and net._plans.evictions == 0
@@ -511,6 +534,45 @@ def test_product_loop_takes_decoded_images_of_mixed_sizes():
         for j, i in enumerate(grp):
             assert torch.equal(out2["records"][i].cpu(), ws[j]), i
     assert len(det.test_pipeline._slots) <= 3                # one buffer per stage-A stream (+ slot 9)
+
+
+def test_image_sizes_sharing_a_feature_pyramid_keep_their_own_stage_graphs():
+    """Image widths 129 and 130 give the same feature pyramid -- one head plan -- but two
+    backbone plans, i.e. two sets of feature buffers.  The head keeps a stage-A graph per
+    buffer set (by pointer), so alternating the two sizes replays both instead of dropping
+    and re-capturing one graph every time (20 recaptures in the first round-5 shape-mix run:
+    800 x 1201 and 800 x 1202 share a pyramid)."""
+    from oracle.backbone import seeded_backbone_state
+    from pairnet_amd import build_detector, pairnet_r50
+
+    def make():
+        det = build_detector(pairnet_r50())
+        det.backbone.load_state_dict(seeded_backbone_state(41))
+        det.to(DEV)
+        return det
+    det = make()
+    head, net = det.bbox_head, det.backbone
+    head.use_graphs = net.use_graphs = True
+    sizes = [(96, 129), (96, 130)]
+    assert net.feature_shapes(*sizes[0]) == net.feature_shapes(*sizes[1])
+    det.reserve([(96, 130)], orig_sizes=[(96, 130)])     # (a growing arena moves the buffers)
+    imgs = [torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(i)).to(DEV)
+            for i, (H, W) in enumerate(sizes)]
+    metas = [[dict(img_shape=(H, W, 3), scale_factor=[1.0] * 4)] for H, W in sizes]
+    outs = [[], []]
+    for rep in range(4):
+        for i in (0, 1):
+            r = head.simple_test_bboxes(det.extract_feat(imgs[i]), metas[i])[0]
+            outs[i].append([t.clone() for t in (r[1], r[7], r[4])])
+    assert len(head._plans) == 1 and len(net._plans) == 2
+    pl = head._last_plan
+    assert len(pl.graphs_a) == 2 and all(e["graph"] is not None for e in pl.graphs_a.values())
+    assert getattr(head, "recaptures", 0) == 0
+    for i in (0, 1):
+        fresh = make()
+        r = fresh.bbox_head.simple_test_bboxes(fresh.extract_feat(imgs[i]), metas[i])[0]
+        for got in outs[i]:
+            assert all(torch.equal(a, b) for a, b in zip(got, (r[1], r[7], r[4]))), i
 
 
 def test_plan_cache_eviction_parks_busy_plans():

@@ -284,7 +284,12 @@ class ResNet50Hip:
             pl.reserve, pl.graph = self.grid_reserve, None
         cur = torch.cuda.current_stream(self.device)
         pl.streams[cur.cuda_stream] = cur
-        plans.note_stream(cur)
+        try:
+            return self._forward_on(img, pl, cur)
+        finally:
+            plans.note_use(cur)
+
+    def _forward_on(self, img, pl, cur):
         if not self.use_graphs:
             return self._run(img, pl)
         # hipGraph replay of the ~55 launches: captured on the caller's image buffer when it

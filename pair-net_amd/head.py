@@ -1009,7 +1009,12 @@ class CrossHead2:
             pl.graph_cfg = cfg
         cur = torch.cuda.current_stream(self.device)
         pl.streams[cur.cuda_stream] = cur
-        plans.note_stream(cur)
+        try:
+            self._run_stage_on(which, pl, feats, cur)
+        finally:
+            plans.note_use(cur)
+
+    def _run_stage_on(self, which, pl, feats, cur):
         if which == "a":
             if not pl.pe_waited:
                 # the position tables are shared by the slots and filled on the stream that
@@ -1234,11 +1239,12 @@ class CrossHead2:
         ent = pl.graph_c.get(key)
         if ent is None:
             ent = pl.graph_c[key] = CrossHead2._PostGraph(pl)
-        plans.note_stream(cur)
         if ent.graph is None:
             if ent.calls < self.graph_after or not plans.quiet(cur):
                 ent.calls += 1
-                return self._get_bboxes_all(cls_scores, mask_preds, img_metas, rescale, pl)
+                res = self._get_bboxes_all(cls_scores, mask_preds, img_metas, rescale, pl)
+                plans.note_use(cur)
+                return res
             self._post_views(pl, self._orig_sizes(img_metas))   # (made / grown outside the capture)
             pl.graph_c[key] = ent
             box = {}
@@ -1246,6 +1252,7 @@ class CrossHead2:
                 res=self._get_bboxes_all(cls_scores, mask_preds, img_metas, rescale, pl)))
             ent.res = box["res"]
         ent.graph.replay()
+        plans.note_use(cur)
         self._pan_jobs = list(ent.res.panoptic_jobs)
         return ent.res
 

@@ -37,22 +37,30 @@ ALIGN = 256
 # stage graph is captured for the next) corrupted ~10 % of the runs of a 12-image test -- one
 # image's result slightly off, only with backbone AND head graphs on, never with a device wait
 # in front of the capture (0 / 20), never eagerly (0 / 28).  Capture therefore happens only at
-# QUIET points: no stream this package has launched on, other than the caller's current one, has
-# unfinished work; the capture then waits for the device (which at a quiet point costs at most
+# QUIET points: nothing this package queued on any stream other than the caller's current one is
+# unfinished; the capture then waits for the device (which at a quiet point costs at most
 # the caller's own queued work).  In flight, a (shape, slot) without a graph simply runs eagerly
 # -- within 0.5 % of the replay rate -- until a quiet point comes (warm-up, a synchronous caller,
 # `PSGTr.warm_graphs`).
-_STREAMS = {}
+_LAST = {}       # (device index, stream handle) -> event behind this package's last launches there
 
 
-def note_stream(stream):
-    _STREAMS[(stream.device_index, stream.cuda_stream)] = stream
+def note_use(stream):
+    """Call after queueing work on `stream`: (re-)records that stream's event.  (An event of our
+    own rather than `stream.query()`: the legacy default stream's query is not a reliable idle
+    test on this stack -- it was seen False right after a device wait.)"""
+    key = (stream.device_index, stream.cuda_stream)
+    ev = _LAST.get(key)
+    if ev is None:
+        ev = _LAST[key] = torch.cuda.Event()
+    ev.record(stream)
 
 
 def quiet(current):
-    """True when no noted stream of `current`'s device other than `current` has unfinished work."""
-    for (dev, handle), st in _STREAMS.items():
-        if dev == current.device_index and handle != current.cuda_stream and not st.query():
+    """True when the work this package queued on every stream of `current`'s device other than
+    `current` has finished."""
+    for (dev, handle), ev in _LAST.items():
+        if dev == current.device_index and handle != current.cuda_stream and not ev.query():
             return False
     return True
 

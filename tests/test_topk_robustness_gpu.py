@@ -96,8 +96,12 @@ def _case(seed, H, W, sf):
 
 
 def test_topk_flip_rate_on_unseparated_seeded_weights():
-    cases = [(100 + i, 256, 320, 1.0) for i in range(20)] + \
-            [(900 + i, 800, 1333, 2.083) for i in range(2)]
+    # the committed study (profiles/r05_topk_flip_rate.json) is the FULL set: 20 seeds at
+    # 256 x 320 + 2 at 800 x 1333, PAIRNET_TOPK_FULL=1 (two fp64 oracle passes at full size take
+    # most of its two minutes); the default run asserts the same property on a subset
+    full = bool(os.environ.get("PAIRNET_TOPK_FULL"))
+    cases = [(100 + i, 256, 320, 1.0) for i in range(20 if full else 8)] + \
+            [(900 + i, 800, 1333, 2.083) for i in range(2 if full else 1)]
     recs, failures = [], []
     for seed, H, W, sf in cases:
         rec, bad, bad64 = _case(seed, H, W, sf)
@@ -118,6 +122,8 @@ def test_topk_flip_rate_on_unseparated_seeded_weights():
         per_seed=recs)
     out = os.path.join(ROOT, "gpurun_out")
     try:
+        if not full:
+            raise OSError("subset run: the committed record is written by the full set only")
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, "r05_topk_flip_rate.json"), "w") as f:
             json.dump(summary, f, indent=1)

@@ -1073,6 +1073,8 @@ class CrossHead2:
         captured before in this head's life is a RE-capture (the plan was evicted, its arena
         grew, the weights or the caller's buffers changed)."""
         seen = self.__dict__.setdefault("_captured", set())
+        if len(seen) > 8192:          # (bookkeeping only: never let it grow with a long run)
+            seen.clear()
         k = (pl.key, stage)
         if k in seen:
             self.recaptures = getattr(self, "recaptures", 0) + 1

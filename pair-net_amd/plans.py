@@ -163,7 +163,8 @@ class Arena:
         if need <= self.capacity:
             return
         # kernels queued on any stream (and captured graphs) may still use the old buffer
-        torch.cuda.synchronize(self.device)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
         self.buf = None
         if self.on_grow is not None:
             self.on_grow(self)

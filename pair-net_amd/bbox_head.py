@@ -36,7 +36,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
-from .plans import PlanCache, TorchAlloc
+from .plans import Arena, PlanCache, measure_bytes
 from .config import ConfigDict
 from .head import CrossHead2, _decoder_param_shapes
 
@@ -105,7 +105,8 @@ class CrossHeadBBox(CrossHead2):
             raise NotImplementedError("4 levels, <= 512 proposals, <= 256 classes")
         self._params = OrderedDict((k, torch.zeros(s)) for k, s in self.param_shapes().items())
         self.device, self.w = None, None
-        self._plans, self._post, self._consts = PlanCache(8), OrderedDict(), {}
+        self._plans, self._post, self._consts = PlanCache(), OrderedDict(), {}
+        self._arenas, self._post_arenas, self._pe, self._box = {}, {}, OrderedDict(), OrderedDict()
         self._pan_jobs = []
         self.use_graphs = False
         self.grid_reserve = 0
@@ -217,7 +218,7 @@ class CrossHeadBBox(CrossHead2):
             self._params["cls_branches.%d.bias" % i].fill_(bias_init)
             self._params["reg_branches.%d.4.weight" % i].zero_()
         self._params["reg_branches.0.4.bias"][2:] = -2.0
-        self.w, self._plans, self._consts = None, PlanCache(8), {}
+        self.w, self._plans, self._consts, self._box = None, PlanCache(), {}, OrderedDict()
 
     # ----------------------------------------------------------------- packing
     def _pack(self):
@@ -301,53 +302,46 @@ class CrossHeadBBox(CrossHead2):
             out.append(tuple(per))
         return tuple(out)
 
-    def _plan(self, B, shapes, hw2=None, slot=0, nhwc=False, tokens=None):
-        """(`hw2`, `nhwc`: CrossHead2's plan signature, unused here -- PipelinedHead calls
-        every head the same way.)"""
-        if tokens is None:
-            tokens = getattr(self, "_tokens", None)
-        valid_sizes = getattr(self, "_valid_sizes", None)     # None: no padding in this batch
-        key = (B, tuple(shapes), slot, None if tokens is None else tokens.data_ptr(), valid_sizes)
-        if key in self._plans:
-            return self._plans[key]
-        if self.w is None:
-            self._pack()
+    BOX_SHAPES = 16      # per-(shapes, padding) constant sets kept (LRU)
+
+    def _drop_weight_state(self):
+        super()._drop_weight_state()
+        self._box = OrderedDict()      # (the position tables carry the level embeddings)
+
+    def _box_constants(self, B, shapes, valid_sizes):
+        """What depends on the level shapes (and, for a padded batch, on every image's valid
+        sizes) but not on the input: position tables with the level embeddings, the encoder's
+        proposal boxes and their validity, token validity and valid ratios, the level geometry
+        as device tensors.  Read-only, shared by the slots, one set per (batch, shapes,
+        padding) in a small LRU; `ready` is an event behind the kernels / copies that fill it."""
+        key = (B, tuple(shapes), valid_sizes)
+        c = self._box.get(key)
+        if c is not None:
+            self._box.move_to_end(key)
+            return c
         dev, w = self.device, self.w
-        E = TorchAlloc(dev)     # (this head keeps per-shape buffers, LRU-bounded: plans.PlanCache)
-        i64 = E.i64
-        pl = CrossHead2._Plan()
-        pl.B, pl.shapes = B, list(shapes)
-        pl.N = [h * wd for h, wd in shapes]
-        pl.start = [sum(pl.N[:l]) for l in range(4)]
-        pl.SN = SN = sum(pl.N)
-        if SN < self.num_proposals or SN > 65536:
-            raise RuntimeError("%d encoder tokens: need between the %d proposals and 65536"
-                               % (SN, self.num_proposals))
-        pl.graph_a = pl.graph_b = pl.graph_cfg = None
-        pl.calls_a = pl.calls_b = 0
-        pl.streams = {}
-        pl.feats_read = torch.cuda.Event()
-        M, P, K = B * SN, self.num_proposals, self.KEPT
-        nc = self.cls_out_channels
-        # ---- shape constants ----
-        pl.padded = valid_sizes is not None
-        if not pl.padded:
-            pl.enc_pos = E(SN, 256)
+        E = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        N = [h * wd for h, wd in shapes]
+        start = [sum(N[:l]) for l in range(4)]
+        SN = sum(N)
+        c = dict(padded=valid_sizes is not None)
+        if not c["padded"]:
+            c["enc_pos"] = E(SN, 256)
             for l, (h, wd) in enumerate(shapes):
-                hip.sine_pe(pl.enc_pos[pl.start[l]:pl.start[l] + pl.N[l]],
+                hip.sine_pe(c["enc_pos"][start[l]:start[l] + N[l]],
                             w["transformer.level_embeds"][l], h, wd,
                             temperature=self.pe_temperature, offset=self.pe_offset)
             prop, valid = self.proposals(shapes)
-            pl.prop = prop.unsqueeze(0).expand(B, SN, 4).contiguous().to(dev)
-            pl.valid = valid.to(torch.uint8).to(dev)
-            pl.vr = None
+            c["prop"] = prop.unsqueeze(0).expand(B, SN, 4).contiguous().to(dev)
+            c["valid"] = valid.to(torch.uint8).to(dev)
+            c["vr"] = c["tok_valid"] = None
         else:
             # padded batch: per-image positional tables, validity and valid ratios
-            pl.enc_pos = E(B, SN, 256)
+            c["enc_pos"] = E(B, SN, 256)
             props, valids, toks, vrs = [], [], [], []
             for b in range(B):
                 for l, (h, wd) in enumerate(shapes):
-                    hip.sine_pe(pl.enc_pos[b, pl.start[l]:pl.start[l] + pl.N[l]],
+                    hip.sine_pe(c["enc_pos"][b, start[l]:start[l] + N[l]],
                                 w["transformer.level_embeds"][l], h, wd,
                                 temperature=self.pe_temperature, offset=self.pe_offset,
                                 valid=valid_sizes[b][l])
@@ -361,16 +355,88 @@ class CrossHeadBBox(CrossHead2):
                     torch.stack([torch.tensor(vw, dtype=torch.float32) / wd,
                                  torch.tensor(vh, dtype=torch.float32) / h])
                     for (h, wd), (vh, vw) in zip(shapes, valid_sizes[b])]))
-            pl.prop = torch.stack(props).contiguous().to(dev)
-            pl.valid = torch.stack(valids).to(torch.uint8).contiguous().to(dev)       # [B, SN]
-            pl.tok_valid = torch.stack(toks).to(torch.uint8).contiguous().to(dev)     # [B, SN]
-            pl.vr = torch.stack(vrs).to(torch.float32).contiguous().to(dev)           # [B, 4, 2]
-            pl.tloc, pl.taw = E(B, SN, 8, 4, 4, 2), E(B, SN, 8, 4, 4)
-        pl.shapes_dev = torch.tensor(shapes, dtype=torch.int64, device=dev)
-        pl.starts_dev = torch.tensor(pl.start, dtype=torch.int64, device=dev)
+            c["prop"] = torch.stack(props).contiguous().to(dev)
+            c["valid"] = torch.stack(valids).to(torch.uint8).contiguous().to(dev)       # [B, SN]
+            c["tok_valid"] = torch.stack(toks).to(torch.uint8).contiguous().to(dev)     # [B, SN]
+            c["vr"] = torch.stack(vrs).to(torch.float32).contiguous().to(dev)           # [B, 4, 2]
+        c["shapes_dev"] = torch.tensor(shapes, dtype=torch.int64, device=dev)
+        c["starts_dev"] = torch.tensor(start, dtype=torch.int64, device=dev)
+        c["ready"] = torch.cuda.Event()
+        c["ready"].record(torch.cuda.current_stream(dev))
+        self._box[key] = c
+        while len(self._box) > self.BOX_SHAPES:
+            old, _ = self._box.popitem(last=False)
+            self._plans.drop(lambda k: (k[0], k[1], k[4]) == old)
+        return c
+
+    def _arena(self, slot):
+        a = self._arenas.get(slot)
+        if a is None:
+            a = self._arenas[slot] = Arena(self.device, on_grow=lambda a, s=slot: self._plans.drop(
+                lambda k: k[2] == s))
+        return a
+
+    def _layout_for(self, dims, own_tokens=True):
+        B, shapes = dims[0], [(dims[1 + 2 * l], dims[2 + 2 * l]) for l in range(4)]
+
+        def layout(E):
+            pl = CrossHead2._Plan()
+            self._layout(pl, E, B, shapes, own_tokens)
+            return pl
+        return layout
+
+    def _measure(self, dims):
+        return measure_bytes(self._layout_for(dims))
+
+    def reserve(self, *a, **k):
+        raise NotImplementedError("CrossHeadBBox sizes its arenas on demand")
+
+    def _plan(self, B, shapes, hw2=None, slot=0, nhwc=False, tokens=None):
+        """(`hw2`, `nhwc`: CrossHead2's plan signature, unused here -- PipelinedHead calls
+        every head the same way.)  A plan is a set of views of the slot's arena (plans.py) plus
+        the shared constants of its (shapes, padding); its encoder rows are the neck's token
+        buffer when the features are the neck's in-place views (`tokens`)."""
+        if tokens is None:
+            tokens = getattr(self, "_tokens", None)
+        valid_sizes = getattr(self, "_valid_sizes", None)     # None: no padding in this batch
+        key = (B, tuple(shapes), slot, None if tokens is None else tokens.data_ptr(), valid_sizes)
+        if key in self._plans:
+            return self._plans[key]
+        if self.w is None:
+            self._pack()
+        SN = sum(h * wd for h, wd in shapes)
+        if SN < self.num_proposals or SN > 65536:
+            raise RuntimeError("%d encoder tokens: need between the %d proposals and 65536"
+                               % (SN, self.num_proposals))
+        dims = (B,) + tuple(v for hw in shapes for v in hw)
+        pl = self._arena(slot).carve(self._layout_for(dims, tokens is None), dims, self._measure)
+        pl.graph_a = pl.graph_b = pl.graph_cfg = None
+        pl.calls_a = pl.calls_b = 0
+        pl.streams = {}
+        pl.feats_read = torch.cuda.Event()
+        if tokens is not None:
+            pl.X = tokens
+        c = self._box_constants(B, shapes, valid_sizes)
+        pl.padded, pl.enc_pos, pl.prop, pl.valid = c["padded"], c["enc_pos"], c["prop"], c["valid"]
+        pl.tok_valid, pl.vr = c["tok_valid"], c["vr"]
+        pl.shapes_dev, pl.starts_dev, pl.consts_ready = c["shapes_dev"], c["starts_dev"], c["ready"]
+        self._plans[key] = pl
+        return pl
+
+    def _layout(self, pl, E, B, shapes, own_tokens):
+        """Every per-image buffer as a view of the slot's arena (sizes non-decreasing in B and
+        in every level's height / width)."""
+        i64 = E.i64
+        pl.B, pl.shapes = B, list(shapes)
+        pl.N = [h * wd for h, wd in shapes]
+        pl.start = [sum(pl.N[:l]) for l in range(4)]
+        pl.SN = SN = sum(pl.N)
+        M, P, K = B * SN, self.num_proposals, self.KEPT
+        nc = self.cls_out_channels
+        pl.tloc, pl.taw = E(B, SN, 8, 4, 4, 2), E(B, SN, 8, 4, 4)     # (padded batches)
         # ---- encoder ----
-        pl.X = tokens if tokens is not None else E(B, SN, 256)
-        pl.own_tokens = tokens is None
+        pl.X = E(B, SN, 256)          # (replaced by the neck's token rows when those come in place)
+        pl.own_tokens = own_tokens
         pl.X1, pl.Y, pl.S = E(B, SN, 256), E(B, SN, 256), E(B, SN, 256)
         pl.VOA = E(B, SN, 640)
         pl.H = E(M, self.enc_ffn)
@@ -407,8 +473,6 @@ class CrossHeadBBox(CrossHead2):
         R = self.num_rel_query
         pl.sub_cls, pl.obj_cls = E(B, R, nc), E(B, R, nc)
         pl.sub_box, pl.obj_box = E(B, R, 4), E(B, R, 4)
-        self._plans[key] = pl
-        return pl
 
     # ------------------------------------------------------------------ stages
     def _encoder(self, pl):
@@ -576,6 +640,8 @@ class CrossHeadBBox(CrossHead2):
         cur = torch.cuda.current_stream(self.device)
         pl.streams[cur.cuda_stream] = cur
         if which == "a":
+            if not pl.consts_ready.query():     # (shared constants filled on another stream)
+                cur.wait_event(pl.consts_ready)
             if pl.own_tokens:
                 self._stage_a_copy(feats, pl)
                 pl.feats_read.record()       # the caller's feature buffers are free again

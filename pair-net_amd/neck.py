@@ -17,7 +17,7 @@ import math
 import torch
 
 from . import hip
-from .plans import PlanCache
+from .plans import Arena, PlanCache, measure_bytes
 
 
 class ChannelMapper:
@@ -32,7 +32,7 @@ class ChannelMapper:
         if self.num_outs - len(self.in_channels) not in (0, 1):
             raise NotImplementedError("at most one extra level")
         self._params = OrderedDict((k, torch.zeros(s)) for k, s in self.param_shapes().items())
-        self.device, self.w, self._plans = None, None, PlanCache(8)
+        self.device, self.w, self._plans = None, None, PlanCache()
         self.init_weights()
 
     def param_shapes(self):
@@ -56,7 +56,7 @@ class ChannelMapper:
                 fan_in, fan_out = p[0].numel(), p.shape[0] * p.shape[2] * p.shape[3]
                 a = math.sqrt(6.0 / (fan_in + fan_out))
                 p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * a)
-        self.w, self._plans = None, PlanCache(8)
+        self.w, self._plans = None, PlanCache()
 
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._params.items())
@@ -70,7 +70,7 @@ class ChannelMapper:
         for k, p in self._params.items():
             if k in sd:
                 p.copy_(sd[k].detach().to(torch.float32).cpu().reshape(p.shape))
-        self.w, self._plans = None, PlanCache(8)
+        self.w, self._plans = None, PlanCache()
         return missing, unexpected
 
     def eval(self):
@@ -78,7 +78,7 @@ class ChannelMapper:
 
     def to(self, device):
         self.device = torch.device(device)
-        self.w, self._plans = None, PlanCache(8)
+        self.w, self._plans, self._arenas = None, PlanCache(), {}
         return self
 
     def cuda(self, index=0):
@@ -97,7 +97,39 @@ class ChannelMapper:
         self.w = w
 
     class _Plan:
-        pass
+        def busy_events(self):
+            out = []
+            for st in getattr(self, "streams", {}).values():
+                ev = torch.cuda.Event()
+                ev.record(st)
+                out.append(ev)
+            return out
+
+    def _arena(self, slot):
+        """One flat buffer per slot; a (batch, level shapes) plan is a set of views of it
+        (plans.py).  The token rows a plan hands to the box trunk keep their address for a
+        (shape, slot) as long as the arena does not grow."""
+        arenas = self.__dict__.setdefault("_arenas", {})
+        a = arenas.get(slot)
+        if a is None:
+            a = arenas[slot] = Arena(self.device, on_grow=lambda a, s=slot: self._plans.drop(
+                lambda k: k[2] == s))
+        return a
+
+    def _layout_for(self, dims):
+        B, shapes = dims[0], [(dims[1 + 2 * l], dims[2 + 2 * l]) for l in range((len(dims) - 1) // 2)]
+
+        def layout(E):
+            pl = ChannelMapper._Plan()
+            self._layout(pl, E, B, shapes)
+            return pl
+        return layout
+
+    def _measure(self, dims):
+        return measure_bytes(self._layout_for(dims))
+
+    def arena_bytes(self):
+        return sum(a.capacity for a in self.__dict__.get("_arenas", {}).values())
 
     def _plan(self, B, shapes, slot):
         key = (B, tuple(shapes), slot)
@@ -105,9 +137,13 @@ class ChannelMapper:
             return self._plans[key]
         if self.w is None:
             self._pack()
-        dev = self.device
-        E = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-        pl = ChannelMapper._Plan()
+        dims = (B,) + tuple(v for hw in shapes for v in hw)
+        pl = self._arena(slot).carve(self._layout_for(dims), dims, self._measure)
+        pl.streams = {}
+        self._plans[key] = pl
+        return pl
+
+    def _layout(self, pl, E, B, shapes):
         pl.shapes = list(shapes)
         if self.num_outs > len(shapes):
             h, w = shapes[-1]
@@ -119,13 +155,14 @@ class ChannelMapper:
         pl.tmp = E(B, max(pl.N), 256)
         pl.splitk = E(B * 9 * 1024 * 1024)
         nblk = hip.groupnorm_nblk(max(pl.N))
-        pl.gn_part = torch.empty(B * nblk * self.groups * 2, device=dev, dtype=torch.float64)
-        pl.last_nhwc = None
+        pl.gn_part = E.f64(B * nblk * self.groups * 2)
+        # channel-last staging copy of the last input level for the extra 3x3 / 2 convolution
+        # (contiguous NCHW inputs only; channels_last inputs are read in place)
+        h, w = shapes[-1]
+        pl.last_nhwc = E(B, h, w, self.in_channels[-1]) if self.num_outs > len(shapes) else None
         # the reference's (B, 256, h, w) tensors as views of the token rows
         pl.outs = tuple(pl.tok[:, s:s + n].view(B, h, w, 256).permute(0, 3, 1, 2)
                         for s, n, (h, w) in zip(pl.start, pl.N, pl.shapes))
-        self._plans[key] = pl
-        return pl
 
     @torch.no_grad()
     @hip.on_device
@@ -145,6 +182,8 @@ class ChannelMapper:
                                    "with channels %s, all contiguous or all channels_last"
                                    % self.in_channels)
         pl = self._plan(B, [tuple(f.shape[-2:]) for f in inputs], slot)
+        cur = torch.cuda.current_stream(self.device)
+        pl.streams[cur.cuda_stream] = cur
         w = self.w
         for l, f in enumerate(inputs):
             cin, n = f.shape[1], pl.N[l]
@@ -160,8 +199,6 @@ class ChannelMapper:
             l = len(inputs)
             x = f.permute(0, 2, 3, 1)
             if not nhwc:                        # the implicit-GEMM conv reads channel-last
-                if pl.last_nhwc is None:
-                    pl.last_nhwc = torch.empty(B, h, wd, f.shape[1], device=f.device)
                 pl.last_nhwc.copy_(x)
                 x = pl.last_nhwc
             hip.conv2d_ex(x, w["extra_convs.0.conv.weight"], None, None, pl.tmp, B, h, wd,

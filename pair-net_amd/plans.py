@@ -108,35 +108,6 @@ class Carver:
         return self._take(shape, torch.uint8)
 
 
-class TorchAlloc:
-    """The `Carver` interface on private allocations (`torch.empty`): for modules that still
-    keep their buffers per shape (the box trunk of CrossHeadBBox) and share plan-building code
-    with the arena-based head."""
-
-    def __init__(self, device):
-        self.device = device
-
-    def _take(self, shape, dtype):
-        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
-            shape = tuple(shape[0])
-        return torch.empty(tuple(int(d) for d in shape), dtype=dtype, device=self.device)
-
-    def __call__(self, *shape):
-        return self._take(shape, torch.float32)
-
-    def f64(self, *shape):
-        return self._take(shape, torch.float64)
-
-    def i64(self, *shape):
-        return self._take(shape, torch.int64)
-
-    def i32(self, *shape):
-        return self._take(shape, torch.int32)
-
-    def u8(self, *shape):
-        return self._take(shape, torch.uint8)
-
-
 class Arena:
     """One flat device buffer; `carve(layout, dims, measure)` returns what `layout(E)` builds
     on views of it.  `dims`: the tuple of integers that drive the layout's sizes (batch,

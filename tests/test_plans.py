@@ -3,7 +3,7 @@ part of the shape-polymorphic execution that needs no GPU.  (An `Arena` on the C
 the same bump allocator over a host buffer; the head / backbone only ever make CUDA ones.)"""
 import torch
 
-from pairnet_amd.plans import ALIGN, Arena, Carver, PlanCache, TorchAlloc, measure_bytes
+from pairnet_amd.plans import ALIGN, Arena, Carver, PlanCache, measure_bytes
 
 
 def _layout_for(dims):
@@ -88,12 +88,6 @@ def test_plan_cache_parks_busy_values_until_their_events_fire():
     assert c.get(("k", 9)) is None and c.get(("k", 2)) is plans[2]
 
 
-def test_torch_alloc_has_the_carver_interface():
-    E = TorchAlloc("cpu")
-    assert E(2, 3).shape == (2, 3) and E.i64(4).dtype == torch.int64
-    assert E.i32(1).dtype == torch.int32 and E.u8(2).dtype == torch.uint8 and E.f64(2).dtype == torch.float64
-
-
 def test_head_and_backbone_layouts_are_monotone_in_every_dimension():
     """What the envelope rule rests on: the bytes a layout carves never shrink when one
     size-driving dimension grows (checked on a grid around the production sizes, on meta
@@ -117,3 +111,30 @@ def test_head_and_backbone_layouts_are_monotone_in_every_dimension():
                     assert f(B + 1, H, W) >= here and f(B, H + 1, W) >= here and f(B, H, W + 1) >= here
     # odd and even sides of the quarter-resolution map share one Winograd scratch size rule
     assert head_bytes(1, 800, 1333) >= head_bytes(1, 799, 1332)
+    # the Swin backbone, the neck and the box trunk follow the same rule
+    from pairnet_amd import (ChannelMapper, CrossHeadBBox, SwinTransformerHip, bbox_head_cfg,
+                             channel_mapper_cfg, swin_backbone_cfg)
+    sc = swin_backbone_cfg("T")
+    sc.pop("type")
+    swin = SwinTransformerHip(**sc)
+    swin.device, swin.w = torch.device("cpu"), {}
+    nc = channel_mapper_cfg()
+    nc.pop("type", None)
+    neck = ChannelMapper(**nc)
+    neck.device = torch.device("cpu")
+    bc = bbox_head_cfg()
+    bc.pop("type", None)
+    box = CrossHeadBBox(**bc)
+    box.device, box.w = torch.device("cpu"), {"rel_query_feat.weight": torch.zeros(100, 256)}
+
+    def lvl(H, W):          # C3..C5 of a ResNet (the neck's inputs); + the neck's extra level
+        fs = net.feature_shapes(H, W)[1:]
+        return fs, fs + [((fs[-1][0] - 1) // 2 + 1, (fs[-1][1] - 1) // 2 + 1)]
+    fns = (lambda B, H, W: swin._measure((B, H, W)),
+           lambda B, H, W: neck._measure((B,) + tuple(v for hw in lvl(H, W)[0] for v in hw)),
+           lambda B, H, W: box._measure((B,) + tuple(v for hw in lvl(H, W)[1] for v in hw)))
+    for f in fns:
+        for B in (1, 2):
+            for H, W in ((800, 1333), (801, 1201), (1067, 800)):
+                here = f(B, H, W)
+                assert f(B + 1, H, W) >= here and f(B, H + 8, W) >= here and f(B, H, W + 8) >= here

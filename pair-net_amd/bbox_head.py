@@ -36,6 +36,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
+from . import plans
 from .plans import Arena, PlanCache, measure_bytes
 from .config import ConfigDict
 from .head import CrossHead2, _decoder_param_shapes
@@ -630,8 +631,8 @@ class CrossHeadBBox(CrossHead2):
 
     def _run_stage(self, which, pl, feats=None):
         """Stage 'a' or 'b' of plan `pl` on the current stream: eagerly, or (with `use_graphs`,
-        from the second call on) as one hipGraph replay.  A stage-A graph is tied to the
-        buffers it was captured on: the neck's in-place token rows belong to the plan (its
+        from the second call on, at quiet points only: plans.quiet) as one hipGraph replay.  A
+        stage-A graph is tied to the buffers it was captured on: the neck's in-place token rows belong to the plan (its
         key), plain feature tensors are staged through the plan's own token rows."""
         cfg = (self.fuse_ppn_front, self.grid_reserve, tuple(self.enc_fused_ln))
         if pl.graph_cfg != cfg:
@@ -639,6 +640,12 @@ class CrossHeadBBox(CrossHead2):
             pl.graph_cfg = cfg
         cur = torch.cuda.current_stream(self.device)
         pl.streams[cur.cuda_stream] = cur
+        try:
+            self._run_stage_on(which, pl, feats, cur)
+        finally:
+            plans.note_use(cur)
+
+    def _run_stage_on(self, which, pl, feats, cur):
         if which == "a":
             if not pl.consts_ready.query():     # (shared constants filled on another stream)
                 cur.wait_event(pl.consts_ready)
@@ -649,7 +656,7 @@ class CrossHeadBBox(CrossHead2):
                 with hip.reserve_slots(self.grid_reserve):
                     self._encoder(pl)
                     self._two_stage(pl)
-            if self.use_graphs and pl.graph_a is None and pl.calls_a >= 1:
+            if self.use_graphs and pl.graph_a is None and pl.calls_a >= 1 and plans.quiet(cur):
                 pl.graph_a = self._capture(body)
             pl.calls_a += 1
             if self.use_graphs and pl.graph_a is not None:
@@ -659,7 +666,7 @@ class CrossHeadBBox(CrossHead2):
             if not pl.own_tokens:
                 pl.feats_read.record()       # (the neck's token rows are encoded in place)
         else:
-            if self.use_graphs and pl.graph_b is None and pl.calls_b >= 1:
+            if self.use_graphs and pl.graph_b is None and pl.calls_b >= 1 and plans.quiet(cur):
                 pl.graph_b = self._capture(lambda: self._stage_b(pl))
             pl.calls_b += 1
             if self.use_graphs and pl.graph_b is not None:

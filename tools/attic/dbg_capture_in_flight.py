@@ -55,6 +55,28 @@ if mode == "sync":
         torch.cuda.synchronize()
         return orig(fn)
     HH.CrossHead2._capture = staticmethod(cap)
+NSUB = [0]
+if mode.startswith("stall"):
+    # no graphs at all; the HOST stalls where a capture would have stalled it (in front of the
+    # backbone, stage A, stage B and get_bboxes launches of submissions 4..7): does a late host
+    # alone perturb a result?
+    import time
+    import pairnet_amd.head as HH
+    import pairnet_amd.backbone as BB
+    head.use_graphs = net.use_graphs = False
+    ms = float(mode[5:] or 3) * 1e-3
+    def stalled(fn):
+        def w(*a, **k):
+            if 4 <= NSUB[0] < 8:
+                t = time.perf_counter()
+                while time.perf_counter() - t < ms:
+                    pass
+            return fn(*a, **k)
+        return w
+    HH.CrossHead2._stage_a = stalled(HH.CrossHead2._stage_a)
+    HH.CrossHead2._stage_b = stalled(HH.CrossHead2._stage_b)
+    HH.CrossHead2._get_bboxes_all = stalled(HH.CrossHead2._get_bboxes_all)
+    BB.ResNet50Hip._run = stalled(BB.ResNet50Hip._run)
 pipe = PipelinedHead(head, depth=4, a_streams=2)
 order = [0, 1, 1, 0, 0, 1, 0, 1, 1, 0, 1, 0] * 3
 got = []
@@ -62,6 +84,7 @@ def take(res):
     pl = head._last_plan
     got.append([t.clone() for t in (res[0][1], res[0][7], res[0][4], pl.topk_idx)] + [pl.slot, [(e["calls"], e["graph"] is not None) for e in pl.graphs_a.values()]])
 for i in order:
+    NSUB[0] = pipe.count
     sl = pipe.count % len(pipe.streams_a)
     pipe.streams_a[sl].wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(pipe.streams_a[sl]):

@@ -470,6 +470,321 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split3(
 }
 
 
+// ---- ablations of v3: FLAGS 1 = no global loads after the prologue, 2 = no split arithmetic,
+// 4 = no LDS writes, 8 = no LDS reads / MFMAs in the contracting waves (timing only) ----------
+template <int TERMS, int D, int FLAGS>
+__global__ __launch_bounds__(512, 1) void k_gemm_ablate(
+    const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ C, int M, int N, int K, int relu) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+  const int nt = (N + BN - 1) / BN, mt = (M + BM - 1) / BM;
+  const int nk = K / BK;
+  const int L = blockIdx.x, per = gridDim.x >> 3, jx = L >> 3;
+  int cnt;
+  const int base = xcd_range(nt * mt, L & 7, cnt);
+  const int mine = jx < cnt ? (cnt - jx + per - 1) / per : 0;
+  const int total = mine * nk;
+  if (total == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  const int pt = tid & 255, lr = pt >> 2, lc = (pt & 3) * 8;
+  auto gload = [&](Ring& R, int g) {
+    g = g < total ? g : total - 1;
+    const int ti = g / nk, kt = g - ti * nk;
+    const int T = base + jx + ti * per;
+    const int tm = T / nt, tn = T - tm * nt;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      int gm = tm * BM + lr + 64 * p; gm = gm < M ? gm : M - 1;
+      int gn = tn * BN + lr + 64 * p; gn = gn < N ? gn : N - 1;
+      const float* ap = A + (long long)gm * K + kt * BK + lc;
+      const float* wp = W + (long long)gn * K + kt * BK + lc;
+      gl16(R.v[2 * p], ap); gl16(R.v[2 * p + 1], ap + 4);
+      gl16(R.v[4 + 2 * p], wp); gl16(R.v[4 + 2 * p + 1], wp + 4);
+    }
+  };
+  auto lstore = [&](const Ring& R, int stage) {
+    __bf16* sA = smem + stage * STAGE;
+    __bf16* sW = sA + 3 * PIECE;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      bf16x8 p0, p1, p2;
+      const int off = (lr + 64 * p) * LDK + lc;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (FLAGS & 2) {     // no split arithmetic: the raw words
+          union { f32x4 f; bf16x8 b; } u0, u1;
+          u0.f = R.v[4 * h + 2 * p]; u1.f = R.v[4 * h + 2 * p + 1];
+          p0 = u0.b; p1 = u1.b; p2 = u0.b;
+        } else {
+          split8v(R.v[4 * h + 2 * p], R.v[4 * h + 2 * p + 1], p0, p1, p2);
+        }
+        __bf16* dst = h ? sW : sA;
+        if (FLAGS & 4) {     // no LDS writes (the values stay alive)
+          asm volatile("" :: "v"(p0), "v"(p1), "v"(p2));
+        } else {
+          *reinterpret_cast<bf16x8*>(dst + off) = p0;
+          *reinterpret_cast<bf16x8*>(dst + PIECE + off) = p1;
+          *reinterpret_cast<bf16x8*>(dst + 2 * PIECE + off) = p2;
+        }
+      }
+    }
+  };
+  const int wm = (wave & 3) >> 1, wn = wave & 1;
+  const int fa = (wm * 64 + (lane & 31)) * LDK + (lane >> 5) * 8;
+  const int fb = (wn * 64 + (lane & 31)) * LDK + (lane >> 5) * 8;
+  f32x16 acc[2][2];
+  auto zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  auto epilogue = [&](int ti) {
+    const int T = base + jx + ti * per;
+    const int tm = T / nt, tn = T - tm * nt;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gn = tn * BN + wn * 64 + j * 32 + (lane & 31);
+      if (gn >= N) continue;
+      const float bv = bias ? bias[gn] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int gm = tm * BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (gm < M) {
+            float v = acc[i][j][r] + bv;
+            if (relu) v = v > 0.f ? v : 0.f;
+            C[(long long)gm * N + gn] = v;
+          }
+        }
+    }
+  };
+  auto compute = [&](int stage) {
+    const __bf16* sA = smem + stage * STAGE;
+    const __bf16* sW = sA + 3 * PIECE;
+    bf16x8 a[2][3][2], b[2][3][2];
+    // FLAGS & 16: all 24 fragment reads of the k-step first, then its 48 MFMAs (one exposed LDS
+    // latency per step instead of one per 16-deep half)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (FLAGS & 64) {   // MFMAs only: fragments made up in registers
+            union { bf16x8 b; unsigned u[4]; } z;
+            z.u[0] = z.u[1] = z.u[2] = z.u[3] = (FLAGS & 128) ? 0u : (FLAGS & 256) ? (0x3c003c00u ^ (lane * 0x9e3779b1u + (s * 6 + q * 2 + i) * 0x85ebca6bu)) & 0xbfffbfffu : 0x3c003c00u + lane + s + q + i;
+            a[s][q][i] = z.b; b[s][q][i] = z.b;
+            asm volatile("" : "+v"(a[s][q][i]), "+v"(b[s][q][i]));
+          } else {
+          a[s][q][i] = *reinterpret_cast<const bf16x8*>(sA + q * PIECE + fa + i * 32 * LDK + s * 16);
+          b[s][q][i] = *reinterpret_cast<const bf16x8*>(sW + q * PIECE + fb + i * 32 * LDK + s * 16);
+          }
+        }
+    if (FLAGS & 16) __builtin_amdgcn_sched_barrier(0);
+    if (FLAGS & 32) {      // fragment reads only: keep them alive, no MFMA
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(a[s][q][i]), "v"(b[s][q][i]));
+      return;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#define TERM(qa, qb)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+      acc[i][j] = mfma(a[s][qa][i], b[s][qb][j], acc[i][j]);
+      if (TERMS >= 6) { TERM(2, 0) TERM(1, 1) TERM(0, 2) }
+      if (TERMS >= 3) { TERM(1, 0) TERM(0, 1) }
+      TERM(0, 0)
+#undef TERM
+    }
+  };
+  int kt = 0, ti = 0;
+  Ring R[D];
+  zero();
+  if (producer) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) gload(R[d], d);
+    wait_ring<(D - 1) * 8>(R[0]);
+    lstore(R[0], 0);
+    gload(R[0], D);
+  }
+  __syncthreads();
+  constexpr int U = (D % 2 == 0) ? D : 2 * D;
+  bool done = false;
+  for (int g = 0; !done; g += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (producer) {
+        Ring& S = R[(u + 1) % D];
+        wait_ring<(D - 1) * 8>(S);
+        lstore(S, (u + 1) & 1);
+        if (!(FLAGS & 1)) gload(S, g + u + 1 + D);
+      } else {
+        if (!(FLAGS & 8)) compute(u & 1);
+        if (++kt == nk) { epilogue(ti); zero(); kt = 0; ++ti; }
+      }
+      __syncthreads();
+      if (g + u + 1 >= total) { done = true; break; }
+    }
+  }
+  if (producer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+
+
+// ---- v5: v3 with the staging lanes laid along the rows (8 lanes x 16 B = one whole 128-byte line
+// per row and instruction, as k_gemm_tile stages) instead of 4 lanes x 2 instructions ---------
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4(const f32x4 x, bf16x4& p0, bf16x4& p1, bf16x4& p2) {
+  p0 = __builtin_convertvector(x, bf16x4);
+  const f32x4 r1 = x - __builtin_convertvector(p0, f32x4);
+  p1 = __builtin_convertvector(r1, bf16x4);
+  const f32x4 r2 = r1 - __builtin_convertvector(p1, f32x4);
+  p2 = __builtin_convertvector(r2, bf16x4);
+}
+template <int TERMS, int D>
+__global__ __launch_bounds__(512, 1) void k_gemm_split5(
+    const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ C, int M, int N, int K, int relu) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+  const int nt = (N + BN - 1) / BN, mt = (M + BM - 1) / BM;
+  const int nk = K / BK;
+  const int L = blockIdx.x, per = gridDim.x >> 3, jx = L >> 3;
+  int cnt;
+  const int base = xcd_range(nt * mt, L & 7, cnt);
+  const int mine = jx < cnt ? (cnt - jx + per - 1) / per : 0;
+  const int total = mine * nk;
+  if (total == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  const int pt = tid & 255, lr = pt >> 3, lc = (pt & 7) * 4;   // 8 lanes x 16 B = one 128-byte line per row
+  auto gload = [&](Ring& R, int g) {
+    g = g < total ? g : total - 1;
+    const int ti = g / nk, kt = g - ti * nk;
+    const int T = base + jx + ti * per;
+    const int tm = T / nt, tn = T - tm * nt;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int gm = tm * BM + lr + 32 * p; gm = gm < M ? gm : M - 1;
+      int gn = tn * BN + lr + 32 * p; gn = gn < N ? gn : N - 1;
+      gl16(R.v[p], A + (long long)gm * K + kt * BK + lc);
+      gl16(R.v[4 + p], W + (long long)gn * K + kt * BK + lc);
+    }
+  };
+  auto lstore = [&](const Ring& R, int stage) {
+    __bf16* sA = smem + stage * STAGE;
+    __bf16* sW = sA + 3 * PIECE;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      bf16x4 p0, p1, p2;
+      const int off = (lr + 32 * p) * LDK + lc;
+      split4(R.v[p], p0, p1, p2);
+      *reinterpret_cast<bf16x4*>(sA + off) = p0;
+      *reinterpret_cast<bf16x4*>(sA + PIECE + off) = p1;
+      *reinterpret_cast<bf16x4*>(sA + 2 * PIECE + off) = p2;
+      split4(R.v[4 + p], p0, p1, p2);
+      *reinterpret_cast<bf16x4*>(sW + off) = p0;
+      *reinterpret_cast<bf16x4*>(sW + PIECE + off) = p1;
+      *reinterpret_cast<bf16x4*>(sW + 2 * PIECE + off) = p2;
+    }
+  };
+  const int wm = (wave & 3) >> 1, wn = wave & 1;
+  const int fa = (wm * 64 + (lane & 31)) * LDK + (lane >> 5) * 8;
+  const int fb = (wn * 64 + (lane & 31)) * LDK + (lane >> 5) * 8;
+  f32x16 acc[2][2];
+  auto zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  auto epilogue = [&](int ti) {
+    const int T = base + jx + ti * per;
+    const int tm = T / nt, tn = T - tm * nt;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gn = tn * BN + wn * 64 + j * 32 + (lane & 31);
+      if (gn >= N) continue;
+      const float bv = bias ? bias[gn] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int gm = tm * BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (gm < M) {
+            float v = acc[i][j][r] + bv;
+            if (relu) v = v > 0.f ? v : 0.f;
+            C[(long long)gm * N + gn] = v;
+          }
+        }
+    }
+  };
+  auto compute = [&](int stage) {
+    const __bf16* sA = smem + stage * STAGE;
+    const __bf16* sW = sA + 3 * PIECE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[3][2], b[3][2];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[q][i] = *reinterpret_cast<const bf16x8*>(sA + q * PIECE + fa + i * 32 * LDK + s * 16);
+          b[q][i] = *reinterpret_cast<const bf16x8*>(sW + q * PIECE + fb + i * 32 * LDK + s * 16);
+        }
+#define TERM(qa, qb)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+      acc[i][j] = mfma(a[qa][i], b[qb][j], acc[i][j]);
+      if (TERMS >= 6) { TERM(2, 0) TERM(1, 1) TERM(0, 2) }
+      if (TERMS >= 3) { TERM(1, 0) TERM(0, 1) }
+      TERM(0, 0)
+#undef TERM
+    }
+  };
+  int kt = 0, ti = 0;
+  Ring R[D];
+  zero();
+  if (producer) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) gload(R[d], d);
+    wait_ring<(D - 1) * 8>(R[0]);
+    lstore(R[0], 0);
+    gload(R[0], D);
+  }
+  __syncthreads();
+  constexpr int U = (D % 2 == 0) ? D : 2 * D;
+  bool done = false;
+  for (int g = 0; !done; g += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (producer) {
+        Ring& S = R[(u + 1) % D];
+        wait_ring<(D - 1) * 8>(S);
+        lstore(S, (u + 1) & 1);
+        gload(S, g + u + 1 + D);
+      } else {
+        compute(u & 1);
+        if (++kt == nk) { epilogue(ti); zero(); kt = 0; ++ti; }
+      }
+      __syncthreads();
+      if (g + u + 1 >= total) { done = true; break; }
+    }
+  }
+  if (producer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+
+
 // ---- v4: v3 with the weights pre-split (three bf16 planes, no conversion in the kernel),
 // incremental addressing in the staging waves, and a choice of splitter (hardware
 // v_cvt_pk_bf16_f32 vs round-to-nearest-even in integer arithmetic) --------------------------
@@ -766,6 +1081,52 @@ static void run_split3(const char* tag, int M, int N, int K, int relu, bool veri
 }
 
 
+template <int TERMS, int D, int FLAGS>
+static void run_ablate(const char* tag, int M, int N, int K, int relu, bool verify, int grid) {
+  const int smem = 2 * STAGE * 2;
+  CK(hipFuncSetAttribute((const void*)k_gemm_ablate<TERMS, D, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  CK(hipMemset(dC, 0xff, (size_t)M * N * 4));
+  auto launch = [&]() {
+    k_gemm_ablate<TERMS, D, FLAGS><<<grid, 512, smem>>>(dA, dW, dBias, dC, M, N, K, relu);
+  };
+  for (int i = 0; i < 3; ++i) launch();
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int R = 20;
+  hipEventRecord(e0);
+  for (int i = 0; i < R; ++i) launch();
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double us = ms * 1e3 / R, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+  printf("  %-28s %8.1f us  %7.1f TFLOP/s fp32-equivalent (%.2f of 157.3; bf16 pipe %.2f of 2500)\n",
+         tag, us, tf, tf / 157.3, tf * TERMS / 2500.0);
+  if (verify) check(dC, M, N, K, relu, tag);
+}
+
+
+template <int TERMS, int D>
+static void run_split5(const char* tag, int M, int N, int K, int relu, bool verify, int grid) {
+  const int smem = 2 * STAGE * 2;
+  CK(hipFuncSetAttribute((const void*)k_gemm_split5<TERMS, D>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  CK(hipMemset(dC, 0xff, (size_t)M * N * 4));
+  auto launch = [&]() {
+    k_gemm_split5<TERMS, D><<<grid, 512, smem>>>(dA, dW, dBias, dC, M, N, K, relu);
+  };
+  for (int i = 0; i < 3; ++i) launch();
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int R = 20;
+  hipEventRecord(e0);
+  for (int i = 0; i < R; ++i) launch();
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double us = ms * 1e3 / R, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+  printf("  %-28s %8.1f us  %7.1f TFLOP/s fp32-equivalent (%.2f of 157.3; bf16 pipe %.2f of 2500)\n",
+         tag, us, tf, tf / 157.3, tf * TERMS / 2500.0);
+  if (verify) check(dC, M, N, K, relu, tag);
+}
+
+
 template <int TERMS, int D, int CVT>
 static void run_split4(const char* tag, int M, int N, int K, int relu, bool verify, int grid) {
   const long long plane = (long long)N * K;
@@ -840,10 +1201,29 @@ int main(int argc, char** argv) {
     run_prod(M, N, K, relu, verify);
     run_split<6>("v1 x6", M, N, K, relu, verify);
     run_split3<6, 2>("v3 x6 D=2", M, N, K, relu, verify, 256);
-    run_split4<6, 2, 0>("v4 x6 D=2 cvt_pk", M, N, K, relu, verify, 256);
-    run_split4<1, 2, 0>("v4 x1 D=2 cvt_pk", M, N, K, relu, false, 256);
-    run_split4<6, 2, 1>("v4 x6 D=2 int RNE", M, N, K, relu, verify, 256);
-    run_split4<1, 2, 1>("v4 x1 D=2 int RNE", M, N, K, relu, false, 256);
+    run_split5<6, 2>("v5 x6 D=2 (whole lines)", M, N, K, relu, verify, 256);
+    run_split5<1, 2>("v5 x1 D=2", M, N, K, relu, false, 256);
+    run_split5<6, 3>("v5 x6 D=3", M, N, K, relu, verify, 256);
+    if (only >= 0) {
+      run_ablate<6, 2, 0>("ablate: none", M, N, K, relu, false, 256);
+      run_ablate<6, 2, 1>("ablate: no global loads", M, N, K, relu, false, 256);
+      run_ablate<6, 2, 2>("ablate: no split arithmetic", M, N, K, relu, false, 256);
+      run_ablate<6, 2, 4>("ablate: no LDS writes", M, N, K, relu, false, 256);
+      run_ablate<6, 2, 8>("ablate: no LDS reads / MFMA", M, N, K, relu, false, 256);
+      run_ablate<6, 2, 3>("ablate: no loads, no split", M, N, K, relu, false, 256);
+      run_ablate<6, 2, 7>("ablate: staging waves idle", M, N, K, relu, false, 256);
+      run_ablate<6, 2, 14>("ablate: loads only", M, N, K, relu, false, 256);
+      run_ablate<6, 2, 16>("reads first: full kernel", M, N, K, relu, verify, 256);
+      run_ablate<6, 2, 23>("reads first: staging waves idle", M, N, K, relu, false, 256);
+      run_ablate<6, 2, 7 + 32>("staging idle, LDS reads only", M, N, K, relu, false, 256);
+      run_ablate<6, 2, 7 + 64>("staging idle, MFMA only", M, N, K, relu, false, 256);
+      run_ablate<1, 2, 7 + 64>("staging idle, MFMA only x1", M, N, K, relu, false, 256);
+      run_ablate<6, 2, 15>("barriers + epilogue only", M, N, K, relu, false, 256);
+      run_ablate<6, 2, 7 + 64 + 128>("staging idle, MFMA only, zero operands", M, N, K, relu, false, 256);
+      run_ablate<6, 2, 7 + 64 + 256>("staging idle, MFMA only, random bits", M, N, K, relu, false, 256);
+      run_split4<6, 2, 0>("v4 x6 D=2 cvt_pk", M, N, K, relu, verify, 256);
+      run_split4<6, 2, 1>("v4 x6 D=2 int RNE", M, N, K, relu, verify, 256);
+    }
   }
   return 0;
 }

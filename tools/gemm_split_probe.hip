@@ -977,6 +977,253 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split4(
   if (producer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+
+// ---- v8: the plain structure again (every wave stages, splits and contracts; one LDS stage;
+// two workgroups per CU), but 8 waves of 32 x 64 per 128 x 128 tile instead of 4 of 64 x 64:
+// four waves per SIMD at <= 128 registers, so that one wave's split arithmetic, fragment reads
+// and barrier waits run under another's MFMAs.  Both operands fp32, split on the fly. ---------
+template <int TERMS, int SWZ>
+__global__ __launch_bounds__(512, 2) void k_gemm_split8(
+    const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ C, int M, int N, int K, int relu) {
+  __shared__ __attribute__((aligned(16))) __bf16 sA[3 * PIECE];
+  __shared__ __attribute__((aligned(16))) __bf16 sW[3 * PIECE];
+  const int nt = (N + BN - 1) / BN, mt = (M + BM - 1) / BM;
+  int T = blockIdx.x;
+  if (SWZ) {   // XCD-aware: workgroup L -> tile of its XCD's contiguous range
+    int cnt;
+    const int base = xcd_range(nt * mt, T & 7, cnt);
+    T = base + (T >> 3);
+    if ((int)(blockIdx.x >> 3) >= cnt) return;
+  }
+  const int tm = T / nt, tn = T - tm * nt;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves of 32 x 64
+  const int lr = tid >> 2, lc = (tid & 3) * 8;      // staging: 128 rows x 4 lanes x 8 floats
+  int gm = m0 + lr; gm = gm < M ? gm : M - 1;
+  int gn = n0 + lr; gn = gn < N ? gn : N - 1;
+  const float* a_ptr = A + (long long)gm * K + lc;
+  const float* w_ptr = W + (long long)gn * K + lc;
+  f32x8 ra, rw;
+  auto gload = [&](int kt) {
+    ra = *reinterpret_cast<const f32x8*>(a_ptr + kt * BK);
+    rw = *reinterpret_cast<const f32x8*>(w_ptr + kt * BK);
+  };
+  auto lstore = [&]() {
+    bf16x8 p0, p1, p2;
+    const int off = lr * LDK + lc;
+    split8(ra, p0, p1, p2);
+    *reinterpret_cast<bf16x8*>(sA + off) = p0;
+    *reinterpret_cast<bf16x8*>(sA + PIECE + off) = p1;
+    *reinterpret_cast<bf16x8*>(sA + 2 * PIECE + off) = p2;
+    split8(rw, p0, p1, p2);
+    *reinterpret_cast<bf16x8*>(sW + off) = p0;
+    *reinterpret_cast<bf16x8*>(sW + PIECE + off) = p1;
+    *reinterpret_cast<bf16x8*>(sW + 2 * PIECE + off) = p2;
+  };
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int nk = K / BK;
+  const int fa = (wm * 32 + (lane & 31)) * LDK + (lane >> 5) * 8;
+  const int fb = (wn * 64 + (lane & 31)) * LDK + (lane >> 5) * 8;
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[3], b[3][2];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        a[q] = *reinterpret_cast<const bf16x8*>(sA + q * PIECE + fa + s * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          b[q][j] = *reinterpret_cast<const bf16x8*>(sW + q * PIECE + fb + j * 32 * LDK + s * 16);
+      }
+#define TERM(qa, qb) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[j] = mfma(a[qa], b[qb][j], acc[j]);
+      if (TERMS >= 6) { TERM(2, 0) TERM(1, 1) TERM(0, 2) }
+      if (TERMS >= 3) { TERM(1, 0) TERM(0, 1) }
+      TERM(0, 0)
+#undef TERM
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      lstore();
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int gcol = n0 + wn * 64 + j * 32 + (lane & 31);
+    if (gcol >= N) continue;
+    const float bv = bias ? bias[gcol] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int grow = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (grow < M) {
+        float v = acc[j][r] + bv;
+        if (relu) v = v > 0.f ? v : 0.f;
+        C[(long long)grow * N + gcol] = v;
+      }
+    }
+  }
+}
+
+
+// ---- v9: eight symmetric waves (32 x 64 each), ONE workgroup per CU, persistent, two LDS
+// stages, one barrier per k-step: every wave splits its 16 elements of step g+1 into the other
+// stage IN THE SAME BASIC BLOCK as its 24 MFMAs of step g (SCHED: the two interleaved by
+// sched_group_barrier), loads two steps ahead in two register sets (inline asm, counted vmcnt) --
+struct Ring9 { f32x4 v[4]; };    // A row (8 floats), W row (8 floats)
+template <int N>
+__device__ __forceinline__ void wait_ring9(Ring9& R) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(R.v[0]), "+v"(R.v[1]), "+v"(R.v[2]), "+v"(R.v[3]) : "n"(N) : "memory");
+}
+
+template <int TERMS, int SCHED>
+__global__ __launch_bounds__(512, 1) void k_gemm_split9(
+    const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ C, int M, int N, int K, int relu) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+  const int nt = (N + BN - 1) / BN, mt = (M + BM - 1) / BM;
+  const int nk = K / BK;
+  const int L = blockIdx.x, per = gridDim.x >> 3, jx = L >> 3;
+  int cnt;
+  const int base = xcd_range(nt * mt, L & 7, cnt);
+  const int mine = jx < cnt ? (cnt - jx + per - 1) / per : 0;
+  const int total = mine * nk;
+  if (total == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = tid >> 2, lc = (tid & 3) * 8;
+  // staging cursor
+  int p_ti = 0, p_kt = 0;
+  const float *ap, *wp;
+  auto set_tile = [&](int ti) {
+    ti = ti < mine ? ti : mine - 1;
+    const int T = base + jx + ti * per;
+    const int tm = T / nt, tn = T - tm * nt;
+    int gm = tm * BM + lr; gm = gm < M ? gm : M - 1;
+    int gn = tn * BN + lr; gn = gn < N ? gn : N - 1;
+    ap = A + (long long)gm * K + lc;
+    wp = W + (long long)gn * K + lc;
+  };
+  auto gload = [&](Ring9& R) {
+    gl16(R.v[0], ap); gl16(R.v[1], ap + 4);
+    gl16(R.v[2], wp); gl16(R.v[3], wp + 4);
+    ap += BK; wp += BK;
+    if (++p_kt == nk) { p_kt = 0; set_tile(++p_ti); }
+  };
+  const int soff = lr * LDK + lc;
+  auto lstore = [&](const Ring9& R, int stage) {
+    __bf16* sA = smem + stage * STAGE;
+    __bf16* sW = sA + 3 * PIECE;
+    bf16x8 p0, p1, p2;
+    split8v(R.v[0], R.v[1], p0, p1, p2);
+    *reinterpret_cast<bf16x8*>(sA + soff) = p0;
+    *reinterpret_cast<bf16x8*>(sA + PIECE + soff) = p1;
+    *reinterpret_cast<bf16x8*>(sA + 2 * PIECE + soff) = p2;
+    split8v(R.v[2], R.v[3], p0, p1, p2);
+    *reinterpret_cast<bf16x8*>(sW + soff) = p0;
+    *reinterpret_cast<bf16x8*>(sW + PIECE + soff) = p1;
+    *reinterpret_cast<bf16x8*>(sW + 2 * PIECE + soff) = p2;
+  };
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fa = (wm * 32 + (lane & 31)) * LDK + (lane >> 5) * 8;
+  const int fb = (wn * 64 + (lane & 31)) * LDK + (lane >> 5) * 8;
+  f32x16 acc[2];
+  auto zero = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  };
+  auto epilogue = [&](int ti) {
+    const int T = base + jx + ti * per;
+    const int tm = T / nt, tn = T - tm * nt;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gcol = tn * BN + wn * 64 + j * 32 + (lane & 31);
+      if (gcol >= N) continue;
+      const float bv = bias ? bias[gcol] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int grow = tm * BM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (grow < M) {
+          float v = acc[j][r] + bv;
+          if (relu) v = v > 0.f ? v : 0.f;
+          C[(long long)grow * N + gcol] = v;
+        }
+      }
+    }
+  };
+  auto compute = [&](int stage) {
+    const __bf16* sA = smem + stage * STAGE;
+    const __bf16* sW = sA + 3 * PIECE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[3], b[3][2];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        a[q] = *reinterpret_cast<const bf16x8*>(sA + q * PIECE + fa + s * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          b[q][j] = *reinterpret_cast<const bf16x8*>(sW + q * PIECE + fb + j * 32 * LDK + s * 16);
+      }
+#define TERM(qa, qb) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[j] = mfma(a[qa], b[qb][j], acc[j]);
+      if (TERMS >= 6) { TERM(2, 0) TERM(1, 1) TERM(0, 2) }
+      if (TERMS >= 3) { TERM(1, 0) TERM(0, 1) }
+      TERM(0, 0)
+#undef TERM
+    }
+  };
+  int kt = 0, ti = 0;
+  Ring9 R[2];
+  zero();
+  set_tile(0);
+  gload(R[0]); gload(R[1]);
+  wait_ring9<4>(R[0]);
+  lstore(R[0], 0);
+  gload(R[0]);
+  __syncthreads();
+  bool done = false;
+  for (int g = 0; !done; g += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      Ring9& S = R[(u + 1) & 1];
+      wait_ring9<4>(S);
+      if (SCHED) {
+        // fragment reads first (they need only the barrier), then the split arithmetic of step
+        // g + 1 between the MFMAs of step g, the LDS writes last
+        compute(u & 1);
+        lstore(S, (u + 1) & 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+#pragma unroll
+          for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, 6, 0);
+      } else {
+        lstore(S, (u + 1) & 1);
+        compute(u & 1);
+      }
+      gload(S);
+      if (++kt == nk) { epilogue(ti); zero(); kt = 0; ++ti; }
+      __syncthreads();
+      if (g + u + 1 >= total) { done = true; break; }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 static float *dA, *dW, *dC, *dC2, *dBias;
 static __bf16* dWs;
 static std::vector<float> hA, hW, hBias;
@@ -1151,6 +1398,48 @@ static void run_split4(const char* tag, int M, int N, int K, int relu, bool veri
   if (verify) check(dC, M, N, K, relu, tag);
 }
 
+
+template <int TERMS, int SWZ>
+static void run_split8(const char* tag, int M, int N, int K, int relu, bool verify) {
+  const int nt = (N + BN - 1) / BN, mt = (M + BM - 1) / BM;
+  const int grid = SWZ ? ((nt * mt + 7) / 8) * 8 : nt * mt;
+  CK(hipMemset(dC, 0xff, (size_t)M * N * 4));
+  auto launch = [&]() { k_gemm_split8<TERMS, SWZ><<<grid, 512>>>(dA, dW, dBias, dC, M, N, K, relu); };
+  for (int i = 0; i < 3; ++i) launch();
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int R = 20;
+  hipEventRecord(e0);
+  for (int i = 0; i < R; ++i) launch();
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double us = ms * 1e3 / R, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+  printf("  %-28s %8.1f us  %7.1f TFLOP/s fp32-equivalent (%.2f of 157.3; bf16 pipe %.2f of 2500)\n",
+         tag, us, tf, tf / 157.3, tf * TERMS / 2500.0);
+  if (verify) check(dC, M, N, K, relu, tag);
+}
+
+
+template <int TERMS, int SCHED>
+static void run_split9(const char* tag, int M, int N, int K, int relu, bool verify, int grid) {
+  const int smem = 2 * STAGE * 2;
+  CK(hipFuncSetAttribute((const void*)k_gemm_split9<TERMS, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  CK(hipMemset(dC, 0xff, (size_t)M * N * 4));
+  auto launch = [&]() { k_gemm_split9<TERMS, SCHED><<<grid, 512, smem>>>(dA, dW, dBias, dC, M, N, K, relu); };
+  for (int i = 0; i < 3; ++i) launch();
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int R = 20;
+  hipEventRecord(e0);
+  for (int i = 0; i < R; ++i) launch();
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double us = ms * 1e3 / R, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+  printf("  %-28s %8.1f us  %7.1f TFLOP/s fp32-equivalent (%.2f of 157.3; bf16 pipe %.2f of 2500)\n",
+         tag, us, tf, tf / 157.3, tf * TERMS / 2500.0);
+  if (verify) check(dC, M, N, K, relu, tag);
+}
+
 static void run_prod(int M, int N, int K, int relu, bool verify) {
   pn_gemm_desc d;
   memset(&d, 0, sizeof(d));
@@ -1201,9 +1490,16 @@ int main(int argc, char** argv) {
     run_prod(M, N, K, relu, verify);
     run_split<6>("v1 x6", M, N, K, relu, verify);
     run_split3<6, 2>("v3 x6 D=2", M, N, K, relu, verify, 256);
-    run_split5<6, 2>("v5 x6 D=2 (whole lines)", M, N, K, relu, verify, 256);
-    run_split5<1, 2>("v5 x1 D=2", M, N, K, relu, false, 256);
-    run_split5<6, 3>("v5 x6 D=3", M, N, K, relu, verify, 256);
+    run_split8<6, 0>("v8 x6 (8 waves of 32x64)", M, N, K, relu, verify);
+    run_split8<6, 1>("v8 x6 XCD-aware", M, N, K, relu, verify);
+    run_split8<1, 1>("v8 x1 XCD-aware", M, N, K, relu, false);
+    run_split9<6, 0>("v9 x6 compiler order", M, N, K, relu, verify, 256);
+    run_split9<6, 1>("v9 x6 MFMA/VALU interleaved", M, N, K, relu, verify, 256);
+    run_split9<1, 0>("v9 x1", M, N, K, relu, false, 256);
+    if (only >= 0) {
+      run_split5<6, 2>("v5 x6 D=2 (whole lines)", M, N, K, relu, verify, 256);
+      run_split5<1, 2>("v5 x1 D=2", M, N, K, relu, false, 256);
+    }
     if (only >= 0) {
       run_ablate<6, 2, 0>("ablate: none", M, N, K, relu, false, 256);
       run_ablate<6, 2, 1>("ablate: no global loads", M, N, K, relu, false, 256);

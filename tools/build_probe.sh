@@ -9,3 +9,4 @@ $HIPCC -Iinclude -Ipair-net_amd/csrc tools/gemm_split_probe.hip pair-net_amd/csr
 for p in mfma_probe mfma_power_probe gather_probe lds_gather_probe grid_barrier_probe placement_probe; do
   $HIPCC tools/$p.hip -o tools/bin/$p
 done
+$HIPCC -shared -fPIC tools/mfma_hammer.hip -o tools/bin/libmfma_hammer.so

@@ -22,6 +22,12 @@ jobs = {}
 jobs["voa (k_gemm_tile + addend)"] = (lambda o: hip.linear(x, wvoa, bvoa, o, aadd=pos, aadd_from_col=256), (SN, 544))
 jobs["ffn1 (k_gemm_tile relu)"] = (lambda o: hip.linear(x, w1, b1, o, relu=True), (SN, 1024))
 jobs["msda"] = (lambda o: hip.msda(voa_in, 544, voa_in.view(-1)[256:], 544, o, 1, shapes), (1, SN, 256))
+jobs["msda low occupancy (84 VGPRs)"] = (lambda o: hip.msda(voa_in, 544, voa_in.view(-1)[256:], 544, o, 1, shapes, flags=4), (1, SN, 256))
+jobs["msda persistent"] = (lambda o: hip.msda(voa_in, 544, voa_in.view(-1)[256:], 544, o, 1, shapes, flags=1), (1, SN, 256))
+NL = 1 << 18
+glines = torch.randn(NL * 32, device=DEV)
+gidx = torch.randint(0, NL, (16384, 32, 12), device=DEV, dtype=torch.int32)
+jobs["gather probe (loads only)"] = (lambda o: hip.gather_probe(glines, gidx, o, 16384, NL - 1), (16384, 256))
 jobs["rowln K=256"] = (lambda o: hip.linear_res_ln(x, wo, b2, pos, g, be, o), (SN, 256))
 jobs["rowln K=1024"] = (lambda o: hip.linear_res_ln(h, w2, b2, x, g, be, o), (SN, 256))
 jobs["layernorm"] = (lambda o: hip.layernorm(x, g, be, o), (SN, 256))

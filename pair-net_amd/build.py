@@ -11,7 +11,13 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpairnet_hip.so")
 SOURCES = ["gemm", "gemm_ln", "stem", "winograd", "ffn", "norm", "msda", "resize", "attn", "ppn", "postproc", "swin", "preprocess", "detr", "loss"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+# -fno-slp-vectorize: no compiler-made packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).
+# Measured in round 5 (LABNOTES R5.12): while waves of a bf16-MFMA GEMM are resident on a CU,
+# packed-fp32 results of OTHER kernels' waves there come out wrong (k_msda: 29 of 30 launches);
+# the same kernels built without them never did.  Nothing in this library issues bf16 MFMAs, but
+# a process that runs other work beside it (a bf16 model on another stream) may; the scalar
+# form is the same IEEE arithmetic, bit for bit, and costs 0.2 % of the pipelined step.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

@@ -59,7 +59,7 @@ def note_use(stream):
 def quiet(current):
     """True when the work this package queued on every stream of `current`'s device other than
     `current` has finished."""
-    for (dev, handle), ev in _LAST.items():
+    for (dev, handle), ev in list(_LAST.items()):     # (a snapshot: another thread may add a stream)
         if dev == current.device_index and handle != current.cuda_stream and not ev.query():
             return False
     return True

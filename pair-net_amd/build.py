@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libpairnet_hip.so")
 SOURCES = ["gemm", "gemm_ln", "stem", "winograd", "ffn", "norm", "msda", "resize", "attn", "ppn", "postproc", "swin", "preprocess", "detr", "loss"]
 # NOTE (round 5, LABNOTES R5.12): while waves of a bf16-MFMA GEMM of ANOTHER stream are resident
 # on a CU, compiler-made packed-fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32; this
-# library has ~1 600, most of them in k_msda) were measured to give wrong results; nothing in this
+# library has 3 385 in 134 kernels, tools/check_packed_fp32.py; half of them in the k_msda forms) were measured to give wrong results; nothing in this
 # library issues bf16 MFMAs, and beside its own fp32-MFMA kernels five rounds of bitwise pipeline
 # checks never saw it.  Two ways of building without those instructions were tried and NOT adopted:
 # `-fno-slp-vectorize` and `-Xclang -target-feature -Xclang -packed-fp32-ops` (no packed fp32 at all).

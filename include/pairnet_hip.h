@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 20
+#define PN_ABI_VERSION 21
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -697,6 +697,51 @@ int pn_seesaw_mean_f32(const float* logits, int64_t ld, const int64_t* target,
  * out[1] = pos_weight. */
 int pn_bce_posw_mean_f32(const float* logits, const float* target, float* out /* [2] */, int64_t n,
                          float loss_weight, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * fp32 GEMMs on the bf16 matrix pipe from PRE-SPLIT operands (csrc/gemm_s3.hip, round 6)
+ *
+ * Arithmetic: every fp32 number is exactly x0 + x1 + x2 with bf16 pieces (each the
+ * round-to-nearest-even bf16 of what is left); a product of bf16 numbers is exact in fp32; of the
+ * nine piece products of a*b the six largest are summed by v_mfma_f32_32x32x16_bf16 into fp32
+ * accumulators, the three dropped ones are together < 2^-26 |ab|.  Measured against fp64 the
+ * result is at or below the error of the exact-fp32 MFMA of pn_gemm_f32 on every shape of the
+ * path (profiles/r06_gemm_s3_error.txt).  Same call sites as pn_gemm_f32 /
+ * pn_linear_res_ln_f32 for the pixel decoder's encoder (value_proj / sampling_offsets /
+ * attention_weights / output_proj / FFN behind pairnet_head.py:262).
+ *
+ * "S3" operand of an [R x K] matrix (K % 16 == 0): blocks of 32 rows x 16 k, block (rb, kb) at
+ * byte (rb * K/16 + kb) * 3072; three 1 KiB planes (x0, x1, x2) per block; inside a plane 16
+ * bytes (8 consecutive k) per MFMA lane, lane = (k % 16 / 8) * 32 + r % 32.  Rows are padded to
+ * a multiple of 32 (pn_s3_bytes); A and W operands use the same layout.
+ * ------------------------------------------------------------------------- */
+int64_t pn_s3_bytes(int rows, int K);
+/* S = split(X[r][0:K] + add[r % add_rows][0:K]) for fp32 rows X [rows][ld] (add may be NULL;
+ * ld % 4 == 0, 16-byte aligned).  Rows of the last block beyond `rows` are written as zeros. */
+int pn_s3_split_f32(const float* X, int64_t ld, const float* add, int add_rows, void* S, int rows,
+                    int K, void* stream);
+/* The exact fp32 values back: X[r][0:K] = x0 + x1 + x2. */
+int pn_s3_join_f32(const void* S, float* X, int64_t ld, int rows, int K, void* stream);
+/*   out[m][n] = act( sum_k A*[m][k] W[n][k] + bias[n] ),   A* = A2 for n >= a2_from_col, else A
+ * or, with gamma != NULL (N == 256):
+ *   out[m][:] = LayerNorm(sum_k A[m][k] W[:][k] + bias + res[m][:]) * gamma + beta
+ * (two-pass moments, eps inside the square root: [3P] nn.LayerNorm).  Any subset of three outputs:
+ *   C      fp32 rows [M][ldc]
+ *   CS     S3 [M x N] of out                      (the next GEMM's A operand)
+ *   CS_pos S3 [M x N] of out + pos[m % pos_rows]  (the next layer's query operand, `query + query_pos`)
+ * A, A2, W, res_s3 are S3 operands ([M x K], [M x K], [N x K], [M x 256]); K % 32 == 0, N % 32 == 0,
+ * a2_from_col % 256 == 0.  One workgroup of 8 waves per 96 x 256 tile. */
+typedef struct pn_gemm_s3_desc {
+  const void* A;  const void* A2;  int32_t a2_from_col;
+  const void* W;  const float* bias;            /* bias [N] or NULL */
+  int32_t M, N, K;
+  int32_t relu;
+  float* C;       int64_t ldc;
+  void* CS;
+  void* CS_pos;   const float* pos;  int32_t pos_rows;   /* pos [pos_rows][N] fp32 */
+  const void* res_s3;  const float* gamma;  const float* beta;  float eps;
+} pn_gemm_s3_desc;
+int pn_gemm_s3_f32(const pn_gemm_s3_desc* d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpairnet_hip.so")
-SOURCES = ["gemm", "gemm_ln", "stem", "winograd", "ffn", "norm", "msda", "resize", "attn", "ppn", "postproc", "swin", "preprocess", "detr", "loss"]
+SOURCES = ["gemm", "gemm_ln", "gemm_s3", "stem", "winograd", "ffn", "norm", "msda", "resize", "attn", "ppn", "postproc", "swin", "preprocess", "detr", "loss"]
 # NOTE (round 5, LABNOTES R5.12): while waves of a bf16-MFMA GEMM of ANOTHER stream are resident
 # on a CU, compiler-made packed-fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32; this
 # library has 3 385 in 134 kernels, tools/check_packed_fp32.py; half of them in the k_msda forms) were measured to give wrong results; nothing in this

@@ -40,8 +40,22 @@ class GemmDesc(C.Structure):
                 ("splitk_scratch", _vp), ("splitk_scratch_floats", _i64)]
 
 
+class GemmS3Desc(C.Structure):
+    _fields_ = [("A", _vp), ("A2", _vp), ("a2_from_col", _i32),
+                ("W", _vp), ("bias", _vp),
+                ("M", _i32), ("N", _i32), ("K", _i32), ("relu", _i32),
+                ("C", _vp), ("ldc", _i64),
+                ("CS", _vp),
+                ("CS_pos", _vp), ("pos", _vp), ("pos_rows", _i32),
+                ("res_s3", _vp), ("gamma", _vp), ("beta", _vp), ("eps", _f32)]
+
+
 _SIGS = {
     "pn_abi_version": (C.c_int, []),
+    "pn_s3_bytes": (_i64, [_i32, _i32]),
+    "pn_s3_split_f32": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _i32, _i32, _vp]),
+    "pn_s3_join_f32": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "pn_gemm_s3_f32": (C.c_int, [C.POINTER(GemmS3Desc), _vp]),
     "pn_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "pn_gemm_variant": (C.c_int, [C.POINTER(GemmDesc)]),
     "pn_gemm_grid_size": (C.c_int, [C.POINTER(GemmDesc)]),
@@ -145,7 +159,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 20   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 21   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -493,6 +507,60 @@ def linear_res_ln(x, weight, bias, res, gamma, beta, out, eps=1e-5):
                                                       _ptr(res), ldr, _ptr(gamma), _ptr(beta),
                                                       _ptr(out), ldo, M, N, K, eps, _stream()),
                    meta=(M, N, K, 1, False)), "pn_linear_res_ln_f32")
+
+
+def s3_floats(rows, K):
+    """Size of the S3 operand of a [rows x K] matrix, in float32 elements (arena carving)."""
+    return ((rows + 31) // 32) * (K // 16) * 768
+
+
+def s3_split(x, out, add=None):
+    """out (an S3 buffer, any dtype, >= s3_floats(rows, K) * 4 bytes) = split(x + add[row % len(add)])
+    for 2-D fp32 rows x: the three-bf16-plane operand format of gemm_s3 (include/pairnet_hip.h)."""
+    rows, ld = _rowmajor(x)
+    K = x.shape[1]
+    assert out.numel() * out.element_size() >= s3_floats(rows, K) * 4
+    ar = 0
+    if add is not None:
+        ar, lda = _rowmajor(add)
+        assert lda == K and add.shape[1] == K
+    _check(_launch("k_s3_split", 0.0, 10.0 * rows * K,
+                   lambda: lib().pn_s3_split_f32(_ptr(x), ld, _ptr(add), ar, _ptr(out), rows, K,
+                                                 _stream())), "pn_s3_split_f32")
+
+
+def s3_join(s3, out):
+    """out (2-D fp32 rows) = the exact fp32 values of the S3 operand."""
+    rows, ld = _rowmajor(out)
+    _check(_launch("k_s3_join", 0.0, 10.0 * rows * out.shape[1],
+                   lambda: lib().pn_s3_join_f32(_ptr(s3), _ptr(out), ld, rows, out.shape[1],
+                                                _stream())), "pn_s3_join_f32")
+
+
+def gemm_s3(a, w, M, N, K, *, bias=None, relu=False, out=None, out_s3=None, out_s3_pos=None,
+            pos=None, a2=None, a2_from_col=0, res_s3=None, gamma=None, beta=None, eps=1e-5):
+    """fp32 GEMM on the bf16 matrix pipe from pre-split operands (csrc/gemm_s3.hip):
+    out = act(a @ w.T + bias), or LayerNorm(a @ w.T + bias + res) * gamma + beta (N == 256).
+    a, a2, w, res_s3, out_s3, out_s3_pos are S3 buffers; out is 2-D fp32 rows."""
+    d = GemmS3Desc()
+    d.A, d.A2, d.a2_from_col = _ptr(a), _ptr(a2), a2_from_col
+    d.W, d.bias = _ptr(w), _ptr(bias)
+    d.M, d.N, d.K, d.relu = M, N, K, int(relu)
+    if out is not None:
+        Mo, ldc = _rowmajor(out)
+        assert Mo == M and out.shape[1] >= N
+        d.C, d.ldc = _ptr(out), ldc
+    d.CS, d.CS_pos = _ptr(out_s3), _ptr(out_s3_pos)
+    if out_s3_pos is not None:
+        pr, ldp = _rowmajor(pos)
+        assert ldp == N
+        d.pos, d.pos_rows = _ptr(pos), pr
+    d.res_s3, d.gamma, d.beta, d.eps = _ptr(res_s3), _ptr(gamma), _ptr(beta), eps
+    nbytes = 6.0 * (M * K + N * K) + (4.0 * M * N if out is not None else 0.0) + \
+        6.0 * M * N * ((out_s3 is not None) + (out_s3_pos is not None) + (res_s3 is not None))
+    name = "k_gemm_s3<ln>" if gamma is not None else "k_gemm_s3"
+    _check(_launch(name, 2.0 * M * N * K, nbytes, lambda: lib().pn_gemm_s3_f32(C.byref(d), _stream()),
+                   meta=(M, N, K, 1, False)), "pn_gemm_s3_f32")
 
 
 def layernorm_rows(x, gamma, beta, out, eps=1e-5):

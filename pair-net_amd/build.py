@@ -11,17 +11,15 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpairnet_hip.so")
 SOURCES = ["gemm", "gemm_ln", "gemm_s3", "stem", "winograd", "ffn", "norm", "msda", "resize", "attn", "ppn", "postproc", "swin", "preprocess", "detr", "loss"]
-# NOTE (round 5, LABNOTES R5.12): while waves of a bf16-MFMA GEMM of ANOTHER stream are resident
-# on a CU, compiler-made packed-fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32; this
-# library has 3 385 in 134 kernels, tools/check_packed_fp32.py; half of them in the k_msda forms) were measured to give wrong results; nothing in this
-# library issues bf16 MFMAs, and beside its own fp32-MFMA kernels five rounds of bitwise pipeline
-# checks never saw it.  Two ways of building without those instructions were tried and NOT adopted:
-# `-fno-slp-vectorize` and `-Xclang -target-feature -Xclang -packed-fp32-ops` (no packed fp32 at all).
-# Either makes k_msda right beside the bf16 GEMM and costs 0.2-0.5 %; under either, the GPU suite
-# stops at the two-image Swin-L fixture, which misses its score-error margin (top-k lists still
-# equal): sums get contracted / ordered differently.  A maintainer who runs bf16 work beside this
-# head in one process should revisit this.
+# No packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in the
+# library: while waves of the bf16-MFMA GEMM (csrc/gemm_s3.hip: dense MFMAs + LDS-DMA) are
+# resident on a CU, such instructions in OTHER kernels' waves were measured to return wrong
+# results on this stack (k_msda: 31-34 of 40 launches wrong beside it, 0 of 40 without them;
+# reproducer from a clean checkout: tools/coresidency_probe.py, profiles/r06_coresidency.txt;
+# history: labnotes R5.12, R6.3).  The target feature is switched off rather than the SLP
+# vectoriser: not one v_pk_*_f32 is left (tests/test_boundary.py checks the built library).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
@@ -38,6 +36,7 @@ def _stale():
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     deps.append(os.path.join(ROOT, "include", "pairnet_hip.h"))
+    deps.append(os.path.abspath(__file__))          # the flags are part of the build
     return any(os.path.getmtime(d) > t for d in deps)
 
 

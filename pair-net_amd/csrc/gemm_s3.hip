@@ -65,6 +65,13 @@ __device__ __forceinline__ void s3_glds16(const void* g, void* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// The `+ pos` table in "P8" order: fp32, 8-column pieces in the S3 piece order --
+// [row / 32][col / 16][col % 16 / 8][row % 32][8] -- so that the lanes of an epilogue wave read 2 KiB
+// contiguous (row-major rows would be 32-byte pieces 1 KiB apart).  hip.pos8() builds it.
+__device__ __forceinline__ int64_t pos8_offset(int row, int col, int N) {
+  return ((((int64_t)(row >> 5) * (N >> 4) + (col >> 4)) * 2 + ((col >> 3) & 1)) * 32 + (row & 31)) * 8;
+}
+
 // ---------------------------------------------------------------- fp32 rows -> S3
 // One wave per (row block, k block): lane (k half, row) reads 8 consecutive floats.
 __global__ __launch_bounds__(256) void k_s3_split(const float* __restrict__ X, int64_t ld,
@@ -123,6 +130,7 @@ struct s3_args {
   float* C; int64_t ldc; uint4* CS; uint4* CSP;
   const uint4* RES; const float* gamma; const float* beta; const float* pos; int pos_rows; float eps;
   int M, N, K, relu;
+  int nout;      // columns of the S3 outputs' rows (N, or the whole row when N is a column range)
 };
 
 // LN: the row epilogue out = LayerNorm(acc + bias + residual) (N == 256, one column tile)
@@ -161,12 +169,20 @@ __global__ __launch_bounds__(512, 1) void k_gemm_s3(const s3_args p) {
     lA[j] = e * 64;
   }
   const bool a3 = wq == 0;
+  // (diagnostic builds for tools/coresidency_probe.py: -DS3_DIAG_NO_DMA drops the LDS-DMA of the
+  // main loop, -DS3_DIAG_NO_MFMA the MFMAs; results are then meaningless)
   auto issueB = [&](int s) {               // this group's W columns of stage s
+#ifdef S3_DIAG_NO_DMA
+    if (s > 0) return;
+#endif
     const int base = BRING + (s & 1) * BST;
 #pragma unroll
     for (int j = 0; j < 6; ++j) s3_glds16(gB[j] + (int64_t)s * 384, &smem[base + lB[j]]);
   };
   auto issueA = [&](int s, int as, int half) {   // one 16-deep half of A's stage s into ring slot as
+#ifdef S3_DIAG_NO_DMA
+    if (s > 0) return;
+#endif
     const int base = as * AST + half * AH;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
@@ -197,6 +213,15 @@ __global__ __launch_bounds__(512, 1) void k_gemm_s3(const s3_args p) {
     // operand: acc[m] lane l, register r = output row (rb0 + m) * 32 + l % 32, column
     // n0 + (r & 3) + 8 (r >> 2) + 4 (l >> 5)
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#ifdef S3_DIAG_NO_MFMA
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) acc[m][q] += __uint_as_float(b[h][q].u.x ^ a[h][m][q].u.y);
+    return;
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -365,7 +390,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_s3(const s3_args p) {
     }
   }
   if (!cols_ok) return;
-  const int KBo = N >> 4;
+  const int KBo = p.nout >> 4;
 #pragma unroll
   for (int m = 0; m < MB; ++m) {
     if (rb0 + m >= RB) break;
@@ -386,7 +411,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_s3(const s3_args p) {
       }
       if (p.CSP) {
         // the next layer's query operand: split(out + pos[row % pos_rows])
-        const float* pp = p.pos + (int64_t)(min(row, M - 1) % p.pos_rows) * N + n0 + 16 * j + 8 * lh;
+        const float* pp = p.pos + pos8_offset(min(row, M - 1) % p.pos_rows, n0 + 16 * j + 8 * lh, p.nout);
         const float4 p0 = ld4(pp), p1 = ld4(pp + 4);
         const float w[8] = {v[m][j][0] + p0.x, v[m][j][1] + p0.y, v[m][j][2] + p0.z, v[m][j][3] + p0.w,
                             v[m][j][4] + p1.x, v[m][j][5] + p1.y, v[m][j][6] + p1.z, v[m][j][7] + p1.w};
@@ -395,6 +420,64 @@ __global__ __launch_bounds__(512, 1) void k_gemm_s3(const s3_args p) {
         uint4* o = p.CSP + piece;
         o[0] = q0.u; o[64] = q1.u; o[128] = q2.u;
       }
+    }
+  }
+}
+
+// Leftover columns (N % 256 of at most 64, e.g. the last 32 of the encoder's 544-column
+// [value | offsets | logits] projection): one wave per (row block, column block), operands straight
+// to registers -- nothing is shared, 0.4 GFLOP, latency-bound and short.
+__global__ __launch_bounds__(256) void k_gemm_s3_narrow(const s3_args p, const int col0) {
+  const int lane = threadIdx.x & 63;
+  const int KB = p.K >> 4, RB = (p.M + 31) >> 5, ncb = (p.N - col0) >> 5;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= RB * ncb) return;
+  const int rb = unit / ncb, cb = (col0 >> 5) + unit - rb * ncb;
+  const uint4* ga = ((p.A2 && (cb >> 3) >= p.a2_from_tile) ? p.A2 : p.A) + (int64_t)rb * KB * 192 + lane;
+  const uint4* gw = p.W + (int64_t)cb * KB * 192 + lane;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll 2
+  for (int kb = 0; kb < KB; ++kb) {
+    s3_frag a[3], b[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { a[q].u = ga[kb * 192 + q * 64]; b[q].u = gw[kb * 192 + q * 64]; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[PB[q]].v, a[PA[q]].v, acc, 0, 0, 0);
+  }
+  const int li = lane & 31, lh = lane >> 5, n0 = cb * 32, row = rb * 32 + li;
+  const int KBo = p.nout >> 4;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * j + i]),
+                                                       __float_as_uint(acc[8 * j + 4 + i]), false, false);
+      v[i] = __uint_as_float(sw[0]);
+      v[4 + i] = __uint_as_float(sw[1]);
+    }
+    if (p.bias) {
+      const float4 b0 = ld4(p.bias + n0 + 16 * j + 8 * lh), b1 = ld4(p.bias + n0 + 16 * j + 8 * lh + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    if (p.C && row < p.M) {
+      float* c = p.C + (int64_t)row * p.ldc + n0 + 16 * j + 8 * lh;
+      st4(c, make_float4(v[0], v[1], v[2], v[3]));
+      st4(c + 4, make_float4(v[4], v[5], v[6], v[7]));
+    }
+    if (p.CS) {
+      s3_frag q0, q1, q2;
+      s3_split8(v, q0, q1, q2);
+      uint4* o = p.CS + ((int64_t)rb * KBo + (n0 >> 4) + j) * 192 + lane;
+      o[0] = q0.u; o[64] = q1.u; o[128] = q2.u;
     }
   }
 }
@@ -437,8 +520,23 @@ extern "C" int pn_gemm_s3_f32(const pn_gemm_s3_desc* d, void* stream) {
   a.C = d->C; a.ldc = d->ldc; a.CS = (uint4*)d->CS; a.CSP = (uint4*)d->CS_pos;
   a.RES = (const uint4*)d->res_s3; a.gamma = d->gamma; a.beta = d->beta; a.pos = d->pos;
   a.pos_rows = d->pos_rows; a.eps = d->eps;
-  a.M = d->M; a.N = d->N; a.K = d->K; a.relu = d->relu;
-  const int RB = (d->M + 31) / 32, mt = (RB + 2) / 3, nt = (d->N + 255) / 256;
+  a.M = d->M; a.N = d->N; a.K = d->K; a.relu = d->relu; a.nout = d->N;
+  // columns beyond the last whole 256-column tile: at most 64 of them go to the narrow kernel
+  // (a whole tile for 32 columns would run 7 of its 8 waves empty)
+  const int rem = d->N % 256;
+  const bool narrow = !ln && !d->CS_pos && d->N > 256 && rem > 0 && rem <= 64;
+  const int RB = (d->M + 31) / 32, mt = (RB + 2) / 3;
+  if (narrow) {
+    a.N = d->N - rem;                       // the main launch sees only the whole tiles ...
+    const int nt = a.N / 256;
+    k_gemm_s3<false><<<dim3(mt * nt), dim3(512), 0, (hipStream_t)stream>>>(a);
+    a.N = d->N;                             // ... S3 outputs keep the full row pitch
+    s3_args b = a;
+    const int units = RB * (rem / 32);
+    k_gemm_s3_narrow<<<dim3((units + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(b, d->N - rem);
+    return PN_LAUNCH_CHECK();
+  }
+  const int nt = (d->N + 255) / 256;
   if (ln) k_gemm_s3<true><<<dim3(mt * nt), dim3(512), 0, (hipStream_t)stream>>>(a);
   else k_gemm_s3<false><<<dim3(mt * nt), dim3(512), 0, (hipStream_t)stream>>>(a);
   return PN_LAUNCH_CHECK();

@@ -156,6 +156,13 @@ class CrossHead2:
         # split 209.9 / 209.4 / 209.8 -- the grouped kernel has no K split, and the 68 deep-K
         # tiles of the C5 convolution (64 chunks each) become its tail
         self.group_input_convs = False
+        # arithmetic of the encoder's GEMMs (value / offsets / logits projection, output_proj,
+        # FFN: 192 of the head's 364 GFLOP at 800x1333).  "bf16x3" (default, round 6): fp32
+        # operands kept as three exact bf16 planes by the kernels that produce them, six bf16 MFMA
+        # products, fp32 accumulation (csrc/gemm_s3.hip: error against fp64 at or below the fp32
+        # MFMA's); "fp32": the exact-fp32 MFMA kernels of rounds 1-5 (pn_gemm_f32,
+        # pn_linear_res_ln_f32).  Everything else is fp32 MFMA either way.
+        self.gemm_arithmetic = "bf16x3"
         self.init_weights()
 
     # ------------------------------------------------------------------ params
@@ -350,6 +357,14 @@ class CrossHead2:
             w[p + "voa.bias"] = torch.cat([w[p + "value_proj.bias"],
                                            w[p + "sampling_offsets.bias"],
                                            w[p + "attention_weights.bias"]], 0).contiguous()
+        # the encoder's weights as S3 operands (three bf16 planes; exact), split once
+        for i in range(self.num_enc_layers):
+            p = pd + "encoder.layers.%d." % i
+            for k in (p + "attentions.0.voa.weight", p + "attentions.0.output_proj.weight",
+                      p + "ffns.0.layers.0.0.weight", p + "ffns.0.layers.1.weight"):
+                s3 = torch.empty(hip.s3_floats(*w[k].shape), device=dev, dtype=torch.float32)
+                hip.s3_split(w[k], s3)
+                w[k + ".s3"] = s3
         self._pack_relation(w)
         self.w = w
         self._packed_version = self._weights_version()
@@ -453,9 +468,11 @@ class CrossHead2:
             hip.sine_pe(kp, w["level_embed.weight"][l], h, wd)
             dec_kpos.append(kp)
             o += N[l]
+        # the encoder table once more in the order gemm_s3's `out + pos` epilogue reads
+        enc_pos8 = hip.pos8(enc_pos)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        ent = self._pe[key] = (enc_pos, dec_kpos, ev)
+        ent = self._pe[key] = (enc_pos, dec_kpos, ev, enc_pos8)
         while len(self._pe) > self.PE_SHAPES:
             # the plans of a shape whose tables go are dropped with them (their graphs bake
             # the tables' addresses in; parked until idle, plans.py): device memory per shape
@@ -520,7 +537,7 @@ class CrossHead2:
         pl.graphs_a = OrderedDict()
         pl.calls_a = pl.calls_b = 0
         pl.streams = {}
-        pl.enc_pos, pl.dec_kpos, pl.pe_ready = self._position_tables(shapes)
+        pl.enc_pos, pl.dec_kpos, pl.pe_ready, pl.enc_pos8 = self._position_tables(shapes)
         pl.pe_waited = False
         c = self._const(B)
         if c["me0"] is None:
@@ -551,6 +568,12 @@ class CrossHead2:
         pl.S = E(B, SN, 256)
         pl.VOA = E(B, SN, 544)          # [value | offsets | logits] per token
         pl.H = E(M, self.enc_ffn)
+        # S3 operands of the encoder (gemm_arithmetic == "bf16x3"): tokens, tokens + positions,
+        # sampled values, the norms.0 output; the FFN's hidden rows live in pl.H (6 of its 4 bytes
+        # per element would not fit: its own buffer)
+        pl.XS, pl.XPS = E(hip.s3_floats(M, 256)), E(hip.s3_floats(M, 256))
+        pl.SS, pl.X1S = E(hip.s3_floats(M, 256)), E(hip.s3_floats(M, 256))
+        pl.HS = E(hip.s3_floats(M, self.enc_ffn))
         pl.tmpconv = E(B, max(pl.N), 256)
         pl.splitk = E(B * 9 * 1024 * 1024)   # split-K workspace of the C5 / C4 input convs
         nblk = max(hip.groupnorm_nblk(HW2), hip.groupnorm_nblk(max(pl.N)))
@@ -654,34 +677,10 @@ class CrossHead2:
                                w[pd + "input_convs.%d.gn.bias" % l], pl.X[:, pl.start[l]:],
                                pl.gn_part, B, n, self.gn_groups, False, n * 256, SN * 256)
         X2, X12, Y2 = pl.X.view(-1, 256), pl.X1.view(-1, 256), pl.Y.view(-1, 256)
-        for i in range(self.num_enc_layers):
-            p = pd + "encoder.layers.%d." % i
-            a = p + "attentions.0."
-            hip.gemm(X2, w[a + "voa.weight"], pl.VOA, M=B * SN, N=544, K=256, lda=256, ldw=256,
-                     ldc=544, bias=w[a + "voa.bias"], aadd=pl.enc_pos, ldaadd=256, aadd_rows=SN,
-                     aadd_from_col=256)
-            hip.msda(pl.VOA, 544, pl.VOA.view(-1)[256:], 544, pl.S, B, pl.shapes)
-            # output_proj + identity + norms.0, and ffns.0.layers.1 + identity + norms.1: each
-            # one launch whose workgroups own whole rows (csrc/gemm_ln.hip; bitwise the
-            # GEMM -> LayerNorm pair it replaces, `enc_fused_ln` selects per site)
-            if "proj" in self.enc_fused_ln:
-                hip.linear_res_ln(pl.S.view(-1, 256), w[a + "output_proj.weight"],
-                                  w[a + "output_proj.bias"], X2, w[p + "norms.0.weight"],
-                                  w[p + "norms.0.bias"], X12)
-            else:
-                hip.linear(pl.S.view(-1, 256), w[a + "output_proj.weight"],
-                           w[a + "output_proj.bias"], Y2, res=X2)
-                hip.layernorm(Y2, w[p + "norms.0.weight"], w[p + "norms.0.bias"], X12)
-            hip.linear(X12, w[p + "ffns.0.layers.0.0.weight"], w[p + "ffns.0.layers.0.0.bias"],
-                       pl.H, relu=True)
-            if "ffn" in self.enc_fused_ln:
-                hip.linear_res_ln(pl.H, w[p + "ffns.0.layers.1.weight"],
-                                  w[p + "ffns.0.layers.1.bias"], X12, w[p + "norms.1.weight"],
-                                  w[p + "norms.1.bias"], X2)
-            else:
-                hip.linear(pl.H, w[p + "ffns.0.layers.1.weight"], w[p + "ffns.0.layers.1.bias"],
-                           Y2, res=X12)
-                hip.layernorm(Y2, w[p + "norms.1.weight"], w[p + "norms.1.bias"], X2)
+        if self.gemm_arithmetic == "bf16x3":
+            self._encoder_s3(pl)
+        else:
+            self._encoder_fp32(pl)
         # FPN level (C2): lateral 1x1 + GN, + bilinear-up(finest memory), 3x3 + GN + ReLU
         f = feats[0]
         cin, HW2 = f.shape[1], pl.HW2
@@ -718,6 +717,73 @@ class CrossHead2:
             for l, (h, wd) in enumerate(pl.shapes):
                 hip.bilinear_stencil_rows(pl.MF, pl.MFs[l], B, H2, W2, h, wd, 256, HW2 * 256,
                                           4 * pl.N[l] * 256)
+
+    def _encoder_fp32(self, pl):
+        """The six encoder layers on the exact-fp32 MFMA kernels (rounds 1-5)."""
+        w, B, SN = self.w, pl.B, pl.SN
+        pd = "pixel_decoder."
+        X2, X12, Y2 = pl.X.view(-1, 256), pl.X1.view(-1, 256), pl.Y.view(-1, 256)
+        for i in range(self.num_enc_layers):
+            p = pd + "encoder.layers.%d." % i
+            a = p + "attentions.0."
+            hip.gemm(X2, w[a + "voa.weight"], pl.VOA, M=B * SN, N=544, K=256, lda=256, ldw=256,
+                     ldc=544, bias=w[a + "voa.bias"], aadd=pl.enc_pos, ldaadd=256, aadd_rows=SN,
+                     aadd_from_col=256)
+            hip.msda(pl.VOA, 544, pl.VOA.view(-1)[256:], 544, pl.S, B, pl.shapes)
+            # output_proj + identity + norms.0, and ffns.0.layers.1 + identity + norms.1: each
+            # one launch whose workgroups own whole rows (csrc/gemm_ln.hip; bitwise the
+            # GEMM -> LayerNorm pair it replaces, `enc_fused_ln` selects per site)
+            if "proj" in self.enc_fused_ln:
+                hip.linear_res_ln(pl.S.view(-1, 256), w[a + "output_proj.weight"],
+                                  w[a + "output_proj.bias"], X2, w[p + "norms.0.weight"],
+                                  w[p + "norms.0.bias"], X12)
+            else:
+                hip.linear(pl.S.view(-1, 256), w[a + "output_proj.weight"],
+                           w[a + "output_proj.bias"], Y2, res=X2)
+                hip.layernorm(Y2, w[p + "norms.0.weight"], w[p + "norms.0.bias"], X12)
+            hip.linear(X12, w[p + "ffns.0.layers.0.0.weight"], w[p + "ffns.0.layers.0.0.bias"],
+                       pl.H, relu=True)
+            if "ffn" in self.enc_fused_ln:
+                hip.linear_res_ln(pl.H, w[p + "ffns.0.layers.1.weight"],
+                                  w[p + "ffns.0.layers.1.bias"], X12, w[p + "norms.1.weight"],
+                                  w[p + "norms.1.bias"], X2)
+            else:
+                hip.linear(pl.H, w[p + "ffns.0.layers.1.weight"], w[p + "ffns.0.layers.1.bias"],
+                           Y2, res=X12)
+                hip.layernorm(Y2, w[p + "norms.1.weight"], w[p + "norms.1.bias"], X2)
+
+    def _encoder_s3(self, pl):
+        """The six encoder layers with their GEMMs on the bf16 matrix pipe (csrc/gemm_s3.hip).
+        Activations travel between the GEMMs as S3 operands (three exact bf16 planes) written by
+        the producing kernel's epilogue: XS = tokens, XPS = tokens + positions (the reference's
+        `query + query_pos`), X1S = norms.0 output, HS = FFN hidden rows; residuals are read back
+        from those planes (exact).  fp32 rows exist where a non-GEMM consumer reads them: VOA (the
+        sampling kernel) and the final memory pl.X."""
+        w, B, SN = self.w, pl.B, pl.SN
+        pd = "pixel_decoder."
+        M, F = B * SN, self.enc_ffn
+        X2 = pl.X.view(-1, 256)
+        pos8 = (pl.enc_pos8, SN)
+        hip.s3_split(X2, pl.XS)
+        hip.s3_split(X2, pl.XPS, add=pl.enc_pos)
+        for i in range(self.num_enc_layers):
+            p = pd + "encoder.layers.%d." % i
+            a = p + "attentions.0."
+            last = i + 1 == self.num_enc_layers
+            hip.gemm_s3(pl.XS, w[a + "voa.weight.s3"], M, 544, 256, bias=w[a + "voa.bias"],
+                        out=pl.VOA.view(-1, 544), a2=pl.XPS, a2_from_col=256)
+            hip.msda(pl.VOA, 544, pl.VOA.view(-1)[256:], 544, pl.S, B, pl.shapes)
+            hip.s3_split(pl.S.view(-1, 256), pl.SS)
+            hip.gemm_s3(pl.SS, w[a + "output_proj.weight.s3"], M, 256, 256,
+                        bias=w[a + "output_proj.bias"], out_s3=pl.X1S, res_s3=pl.XS,
+                        gamma=w[p + "norms.0.weight"], beta=w[p + "norms.0.bias"])
+            hip.gemm_s3(pl.X1S, w[p + "ffns.0.layers.0.0.weight.s3"], M, F, 256,
+                        bias=w[p + "ffns.0.layers.0.0.bias"], relu=True, out_s3=pl.HS)
+            hip.gemm_s3(pl.HS, w[p + "ffns.0.layers.1.weight.s3"], M, 256, F,
+                        bias=w[p + "ffns.0.layers.1.bias"], res_s3=pl.X1S,
+                        gamma=w[p + "norms.1.weight"], beta=w[p + "norms.1.bias"],
+                        out=X2 if last else None, out_s3=None if last else pl.XS,
+                        out_s3_pos=None if last else pl.XPS, pos=pos8)
 
     def _mlp3(self, prefix, src, dst, pl):
         """Linear-ReLU-Linear-ReLU-Linear (`mask_embed`-style heads) via pl.m1 / pl.m2."""

@@ -514,6 +514,16 @@ def s3_floats(rows, K):
     return ((rows + 31) // 32) * (K // 16) * 768
 
 
+def pos8(pos):
+    """The `out + pos` table of gemm_s3 in the order its epilogue reads ("P8",
+    csrc/gemm_s3.hip): [rows / 32][cols / 16][2][32][8] from fp32 rows [rows][cols]."""
+    rows, cols = pos.shape
+    rb = (rows + 31) // 32
+    p = pos.new_zeros(rb * 32, cols)
+    p[:rows] = pos
+    return p.view(rb, 32, cols // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
 def s3_split(x, out, add=None):
     """out (an S3 buffer, any dtype, >= s3_floats(rows, K) * 4 bytes) = split(x + add[row % len(add)])
     for 2-D fp32 rows x: the three-bf16-plane operand format of gemm_s3 (include/pairnet_hip.h)."""
@@ -552,8 +562,9 @@ def gemm_s3(a, w, M, N, K, *, bias=None, relu=False, out=None, out_s3=None, out_
         d.C, d.ldc = _ptr(out), ldc
     d.CS, d.CS_pos = _ptr(out_s3), _ptr(out_s3_pos)
     if out_s3_pos is not None:
-        pr, ldp = _rowmajor(pos)
-        assert ldp == N
+        # pos: the table in P8 order (pos8()), pos_rows its true row count
+        pos, pr = pos
+        assert pos.numel() == (pr + 31) // 32 * 32 * N
         d.pos, d.pos_rows = _ptr(pos), pr
     d.res_s3, d.gamma, d.beta, d.eps = _ptr(res_s3), _ptr(gamma), _ptr(beta), eps
     nbytes = 6.0 * (M * K + N * K) + (4.0 * M * N if out is not None else 0.0) + \

@@ -27,6 +27,29 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert declared == set(hip.EXPORTS)
 
 
+def test_library_has_no_packed_fp32_and_bf16_mfma_only_in_the_split_gemm(built_lib):
+    """Packed-fp32 VALU results were measured wrong in waves that share a CU with the bf16-MFMA
+    GEMM (tools/coresidency_probe.py, profiles/r06_coresidency.txt): the library is built without
+    the instructions (pair-net_amd/build.py), checked here by disassembling every embedded gfx950
+    code object.  The bf16 MFMAs live in csrc/gemm_s3.hip's kernels and nowhere else."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_packed_fp32 as chk
+    packed, bf16 = 0, {}
+    cur = None
+    for asm in chk.code_objects(built_lib):
+        for line in asm.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+            if m:
+                cur = m.group(1)
+            elif re.search(r"v_pk_[a-z0-9]+_f32", line):
+                packed += 1
+            elif "v_mfma_f32_32x32x16_bf16" in line:
+                bf16[cur] = bf16.get(cur, 0) + 1
+    assert packed == 0
+    assert bf16 and all("k_gemm_s3" in k for k in bf16), sorted(bf16)
+
+
 def test_bad_arguments_are_refused_without_launching(built_lib):
     from pairnet_amd import hip
     lib = hip.lib()
@@ -34,6 +57,9 @@ def test_bad_arguments_are_refused_without_launching(built_lib):
     assert lib.pn_gemm_f32(ctypes.byref(d), None) == -1
     assert lib.pn_topk_pairs(None, None, None, None, None, 1, 100, 100, None) == -1
     assert lib.pn_gemm_group_f32(None, 3, None) == -1
+    s3 = hip.GemmS3Desc()   # all NULL
+    assert lib.pn_gemm_s3_f32(ctypes.byref(s3), None) == -1
+    assert lib.pn_s3_split_f32(None, 256, None, 0, None, 32, 256, None) == -1
     assert lib.pn_layernorm_f32(None, None, None, None, 4, 256, 1e-5, None) == -1
     # round 4 entries: refused before anything is launched (NULL operands, N != 256, K % 32)
     assert lib.pn_linear_res_ln_f32(None, 256, None, 256, None, None, 256, None, None, None, 256,

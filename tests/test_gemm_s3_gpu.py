@@ -64,7 +64,7 @@ def test_split_is_exact_and_join_returns_the_bits(hip, rows, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(96, 256, 32), (100, 256, 256), (333, 96, 64), (2000, 512, 256),
-                                   (21950, 1024, 256), (21950, 256, 1024), (4200, 544 - 32, 256)])
+                                   (21950, 1024, 256), (21950, 256, 1024), (4200, 544, 256), (333, 320, 64)])
 def test_integer_problems_are_exact(hip, M, N, K):
     """Small-integer operands: every piece product and every partial sum is an integer below 2^24,
     so the result must equal the integer product exactly -- on every tile, ragged edges included,
@@ -136,7 +136,7 @@ def test_residual_layernorm_row_epilogue(hip, M, K):
     out_s = torch.empty(hip.s3_floats(M, 256), device=DEV)
     out_p = torch.empty(hip.s3_floats(M, 256), device=DEV)
     hip.gemm_s3(s3(hip, x), s3(hip, w), M, 256, K, bias=b, out=out, out_s3=out_s, out_s3_pos=out_p,
-                pos=pos, res_s3=s3(hip, res), gamma=g, beta=be)
+                pos=(hip.pos8(pos), pos.shape[0]), res_s3=s3(hip, res), gamma=g, beta=be)
     ref = F.layer_norm(res.double() + x.double() @ w.double().T + b.double(), (256,), g.double(),
                        be.double(), 1e-5)
     err = (out.double() - ref).abs().max().item()

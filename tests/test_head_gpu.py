@@ -210,7 +210,7 @@ def test_e2e_topk_pair_indices_bit_exact_on_separated_fixtures(name, fuse):
     assert np.array_equal(pl.topk_idx.cpu().numpy(), fx["topk_idx"])
     assert np.array_equal(pl.sub_pos.cpu().numpy(), fx["sub_pos"])
     assert np.array_equal(pl.obj_pos.cpu().numpy(), fx["obj_pos"])
-    assert e_top < float(fx["min_gap"]) / 4
+    assert 2 * e_top < float(fx["min_gap"])     # order-preserving bound (test_production_gpu._check_head)
     errs = {k: _err(cls[k], fx[k]) for k in ("rel", "cls", "sub", "obj")}
     errs["importance"] = float(np.abs(imp - ref).max()) / max(1.0, float(np.abs(ref).max()))
     probe = masks["mask"].flatten()[torch.from_numpy(fx["mask_probe_idx"]).to(DEV)]

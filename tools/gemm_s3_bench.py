@@ -31,11 +31,11 @@ def main():
     hip.lib()
     torch.manual_seed(0)
     for (M, N, K, relu, ln) in [(21950, 1024, 256, True, False), (21950, 256, 1024, False, True),
-                                (21950, 512, 256, False, False), (21950, 256, 256, False, True),
+                                (21950, 544, 256, False, False), (21950, 256, 256, False, True),
                                 (66800, 256, 256, False, False), (16700, 512, 256, False, False)]:
         a, w, b = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV) / 16, torch.randn(N, device=DEV)
         res, g, be = torch.randn(M, 256, device=DEV), torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
-        pos = torch.randn(M, 256, device=DEV)
+        pos = (hip.pos8(torch.randn(M, 256, device=DEV)), M)
         a_s, w_s, res_s = s3(a), s3(w), s3(res)
         out = torch.empty(M, N, device=DEV)
         out_s = torch.empty(hip.s3_floats(M, N), device=DEV)

@@ -46,7 +46,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+# kernels whose matrix work is ISSUED as six bf16 MFMA products per fp32 multiply-add
+# (csrc/gemm_s3.hip); hip.py's flop count for them is the fp32-equivalent 2 M N K
+BF16X3_KERNELS = ("k_gemm_s3", "k_gemm_s3<ln>")
+GEMM_ARITHMETIC = {
+    "bf16x3": "encoder GEMMs: fp32 = 3 x bf16 exact split, 6 products, fp32 accumulate "
+              "(csrc/gemm_s3.hip); everything else: exact-fp32 MFMA",
+    "fp32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere"}
 HBM_KERNELS = ("k_msda",)
 
 
@@ -280,6 +288,13 @@ def main():
                     help="integer attribute of the native ResNet backbone (tuning A/B)")
     ap.add_argument("--mix-images", type=int, default=240,
                     help="images of the shape_mix_product_loop leg (>= 200 by default)")
+    ap.add_argument("--gemm-arithmetic", choices=["bf16x3", "fp32"], default="bf16x3",
+                    help="encoder GEMMs: bf16x3 = fp32 operands as three exact bf16 planes, six "
+                         "bf16 MFMA products, fp32 accumulation (default); fp32 = the exact-fp32 "
+                         "MFMA kernels of rounds 1-5")
+    ap.add_argument("--no-sub-legs", action="store_true",
+                    help="skip the Swin-L / 200-query and box-trunk legs (each a short run of this "
+                         "script in a child process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -342,6 +357,7 @@ def main():
     head.to(dev)
     MASK_ORDER = {"reference": True, "dense": "full", "resampled": False}
     head.exact_mask_order = MASK_ORDER[args.mask_order]
+    head.gemm_arithmetic = args.gemm_arithmetic
     if args.conv:
         head.conv_algo = args.conv
     for kv in args.set:
@@ -938,6 +954,7 @@ def main():
                     "dense": "the reference's: all full-size mask logits, then the resize",
                     "resampled": "shortcut: logits against the mask feature resampled once per "
                                  "level"}[args.mask_order],
+                "gemm_arithmetic": GEMM_ARITHMETIC[args.gemm_arithmetic],
                 "global_batch": world * B, "per_gpu_batch": B, "image": [H, W],
                 "stream_placement_calibration_ms": calibration,
                 "parallelism": "dp%d" % world,
@@ -971,6 +988,11 @@ def main():
                 sec = agg["ms"] * 1e-3
                 if name in HBM_KERNELS:
                     ach, peak, unit, bound = agg["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+                elif name in BF16X3_KERNELS:
+                    # issued work: six bf16 MFMA products per fp32 multiply-add, against the
+                    # dense bf16 MFMA peak
+                    ach, peak, unit = 6.0 * agg["flops"] / sec / 1e12, PEAK_BF16_MFMA_TFLOPS, "TFLOP/s"
+                    bound = "mfma"
                 else:
                     ach, peak, unit = agg["flops"] / sec / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
                     bound = "mfma"
@@ -993,7 +1015,13 @@ def main():
                                             for v in sq) / sum(v["launches_profiled"] for v in sq)
                 except (OSError, ValueError, KeyError, TypeError):
                     pass
+                extra = {}
+                if name in BF16X3_KERNELS:
+                    extra = {"mfma_dtype": "bf16 (six products per fp32 multiply-add, fp32 accumulate)",
+                             "fp32_equivalent_tflops": agg["flops"] / sec / 1e12,
+                             "fp32_equivalent_over_fp32_mfma_peak": agg["flops"] / sec / 1e12 / PEAK_F32_MFMA_TFLOPS}
                 return {
+                    **extra,
                     "kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
                     "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
                     "mfma_util_pmc": mfma_util,
@@ -1023,17 +1051,29 @@ def main():
             # together as the fp32-MFMA GEMM work of the step
             if "k_gemm_rowln" in prof:
                 out["roofline_linear_res_ln"] = roof("k_gemm_rowln")
-            gemms = [k for k in prof if k.startswith(("k_gemm_tile", "k_gemm_rowln", "k_gemm_group",
-                                                      "k_gemm_stencil"))]
+            # round 6: the encoder's GEMMs on the bf16 matrix pipe (both instantiations)
+            for k in BF16X3_KERNELS:
+                if k in prof and k != dominant:
+                    out["roofline_" + k.replace("<", "_").replace(">", "")] = roof(k)
+            f32g = [k for k in prof if k.startswith(("k_gemm_tile", "k_gemm_rowln", "k_gemm_group",
+                                                     "k_gemm_stencil"))]
+            gemms = f32g + [k for k in prof if k in BF16X3_KERNELS]
             if gemms:
                 fl = sum(prof[k]["flops"] for k in gemms)
                 ms = sum(prof[k]["ms"] for k in gemms)
+                # all GEMM kernels of the step in fp32-EQUIVALENT work (2 M N K per GEMM whatever
+                # instruction carries it) over their summed time; the fp32 MFMA peak beside it is
+                # the roof of the fp32 kernels only -- kept as the yardstick of rounds 1-5
                 out["roofline_all_gemm_kernels"] = {
-                    "kernels": sorted(gemms), "bound": "mfma", "unit": "TFLOP/s",
+                    "kernels": sorted(gemms), "bound": "mfma", "unit": "TFLOP/s fp32-equivalent",
                     "achieved": fl / (ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                     "frac": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                     "ms_per_step": ms / nprof,
-                    "launches_per_step": sum(prof[k]["launches"] for k in gemms) // nprof}
+                    "launches_per_step": sum(prof[k]["launches"] for k in gemms) // nprof,
+                    "fp32_mfma_kernels": {
+                        "achieved": sum(prof[k]["flops"] for k in f32g) /
+                        (sum(prof[k]["ms"] for k in f32g) * 1e-3) / 1e12 if f32g else None,
+                        "ms_per_step": sum(prof[k]["ms"] for k in f32g) / nprof}}
             # the north star's other named kernel: achieved HBM GB/s of the deformable sampling
             msda = [k for k in prof if k.startswith("k_msda")]
             if msda:
@@ -1181,6 +1221,23 @@ def main():
                         "launch overhead: a 8 MB problem is launch-latency sized"}
         except Exception as e:      # noqa: BLE001 -- an extra, never the headline
             out["ground_truth_masks"] = repr(e)
+        if engine is not None and args.gemm_arithmetic == "bf16x3":
+            # the same pipelined steps with the encoder on the exact-fp32 MFMA kernels of rounds
+            # 1-5 (one flag away: head.gemm_arithmetic = "fp32")
+            head.gemm_arithmetic = "fp32"
+            for _ in range(2 * args.depth):      # (graphs are re-captured for the new setting)
+                step()
+            drain()
+            n = min(args.steps, 40)
+            dt = timed(n)
+            head.gemm_arithmetic = "bf16x3"
+            for _ in range(2 * args.depth):
+                step()
+            drain()
+            out["fp32_mfma_encoder"] = {
+                "images_per_s": B * n / dt, "ms_per_step": 1e3 * dt / n, "steps": n,
+                "what": GEMM_ARITHMETIC["fp32"] + " (head.gemm_arithmetic = 'fp32'); the headline "
+                        "runs the encoder's GEMMs as " + GEMM_ARITHMETIC["bf16x3"]}
         if engine is not None and args.mask_order == "reference":
             # the same pipelined steps with the opt-in shortcut for the attention masks: the
             # mask feature is resampled to each level once per image and every layer's logits
@@ -1315,6 +1372,36 @@ def main():
                 del bb
             except Exception as e:  # pragma: no cover
                 out["breakdown_ms"]["backbone_torch_error"] = repr(e)
+
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_sub_legs and \
+            args.head == "pairnet" and args.path == "image" and (H, W) == (800, 1333) and not swin:
+        # BASELINE configs[3] ("Swin-L + Mask2Former, 200 object queries", one image per GPU) and
+        # the box-trunk sibling, each as a short run of this script in a child process (its own
+        # weights, plans and calibration; this process is idle meanwhile): driver-timed lines
+        # for the configurations the headline does not cover
+        def leg(extra, steps=16, warm=6):
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps),
+                   "--warmup", str(warm), "--no-extras", "--no-cpu-baseline", "--no-sub-legs",
+                   "--gemm-arithmetic", args.gemm_arithmetic] + extra
+            t0 = time.perf_counter()
+            try:
+                cp = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                line = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+                if not line:
+                    return "no result (rc %d): %s" % (cp.returncode, cp.stderr[-400:])
+                r = json.loads(line[-1])
+                keep = ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "pipeline_check",
+                        "roofline", "roofline_all_gemm_kernels")
+                res = {k: r[k] for k in keep if k in r}
+                res["workload"] = r["config"]["workload"]
+                res["gemm_arithmetic"] = r["config"].get("gemm_arithmetic")
+                res["child_process_s"] = time.perf_counter() - t0
+                return res
+            except Exception as e:      # noqa: BLE001 -- a secondary leg, never the headline
+                return repr(e)
+        torch.cuda.synchronize()
+        out["swin_l_200q"] = leg(["--in-channels", "192,384,768,1536", "--queries", "200"])
+        out["box_trunk"] = leg(["--head", "bbox"])
 
     gc.enable()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

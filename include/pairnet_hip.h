@@ -730,7 +730,10 @@ int pn_s3_join_f32(const void* S, float* X, int64_t ld, int rows, int K, void* s
  *   CS     S3 [M x N] of out                      (the next GEMM's A operand)
  *   CS_pos S3 [M x N] of out + pos[m % pos_rows]  (the next layer's query operand, `query + query_pos`)
  * A, A2, W, res_s3 are S3 operands ([M x K], [M x K], [N x K], [M x 256]); K % 32 == 0, N % 32 == 0,
- * a2_from_col % 256 == 0.  One workgroup of 8 waves per 96 x 256 tile. */
+ * a2_from_col % 256 == 0.  pos is in "P8" order: [pos_rows / 32][N / 16][2][32][8] (the S3 piece
+ * order with fp32 elements; pair-net_amd/hip.py pos8()).  One workgroup of 8 waves per 96 x 256 tile
+ * (192 x 256 with W shared by two row groups when N >= 512 and there is no row epilogue); up to 64
+ * columns beyond the last whole 256-column tile go to a one-wave-per-block kernel. */
 typedef struct pn_gemm_s3_desc {
   const void* A;  const void* A2;  int32_t a2_from_col;
   const void* W;  const float* bias;            /* bias [N] or NULL */
@@ -740,7 +743,9 @@ typedef struct pn_gemm_s3_desc {
   void* CS;
   void* CS_pos;   const float* pos;  int32_t pos_rows;   /* pos [pos_rows][N] fp32 */
   const void* res_s3;  const float* gamma;  const float* beta;  float eps;
+  int32_t flags;                                 /* PN_GEMM_S3_* (tuning / tests), else 0 */
 } pn_gemm_s3_desc;
+#define PN_GEMM_S3_TILE96 1   /* force the 96 x 256 tile where the 192 x 256 one would be taken */
 int pn_gemm_s3_f32(const pn_gemm_s3_desc* d, void* stream);
 
 #ifdef __cplusplus

@@ -424,31 +424,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm_s3(const s3_args p) {
   }
 }
 
-// Leftover columns (N % 256 of at most 64, e.g. the last 32 of the encoder's 544-column
-// [value | offsets | logits] projection): one wave per (row block, column block), operands straight
-// to registers -- nothing is shared, 0.4 GFLOP, latency-bound and short.
-__global__ __launch_bounds__(256) void k_gemm_s3_narrow(const s3_args p, const int col0) {
-  const int lane = threadIdx.x & 63;
-  const int KB = p.K >> 4, RB = (p.M + 31) >> 5, ncb = (p.N - col0) >> 5;
-  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (unit >= RB * ncb) return;
-  const int rb = unit / ncb, cb = (col0 >> 5) + unit - rb * ncb;
-  const uint4* ga = ((p.A2 && (cb >> 3) >= p.a2_from_tile) ? p.A2 : p.A) + (int64_t)rb * KB * 192 + lane;
-  const uint4* gw = p.W + (int64_t)cb * KB * 192 + lane;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll 2
-  for (int kb = 0; kb < KB; ++kb) {
-    s3_frag a[3], b[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) { a[q].u = ga[kb * 192 + q * 64]; b[q].u = gw[kb * 192 + q * 64]; }
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[PB[q]].v, a[PA[q]].v, acc, 0, 0, 0);
-  }
-  const int li = lane & 31, lh = lane >> 5, n0 = cb * 32, row = rb * 32 + li;
+// One 32 x 32 accumulator block's plain epilogue (bias, ReLU, fp32 rows and / or S3 pieces): the
+// accumulator is the TRANSPOSED block (lane l: output row rb * 32 + l % 32; register r: column
+// n0 + (r & 3) + 8 (r >> 2) + 4 (l >> 5)); four v_permlane32_swap per 16 columns give each lane 8
+// consecutive columns, the S3 piece order.
+__device__ __forceinline__ void s3_block_epilogue(const f32x16& acc, const s3_args& p, int rb, int n0,
+                                                  int lane) {
+  const int li = lane & 31, lh = lane >> 5, row = rb * 32 + li;
   const int KBo = p.nout >> 4;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -480,6 +462,185 @@ __global__ __launch_bounds__(256) void k_gemm_s3_narrow(const s3_args p, const i
       o[0] = q0.u; o[64] = q1.u; o[128] = q2.u;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same ping-pong for shapes with at least two column tiles (N >= 512: FFN-1, the [value |
+// offsets | logits] projection): tile 192 rows x 256 columns, the two groups own the upper and
+// the lower 96 rows and SHARE W, each wave 96 x 64 (six accumulators).  42 KiB of operands per
+// 16-deep k-step feed both groups' MMA phases -- 21 LDS-DMA pieces per phase instead of the 33 of
+// the 96 x 256 tile, whose L2 -> LDS traffic is what bounds it (labnotes R6.2).  Phases are one
+// 16-deep k-step (36 MFMAs) each:
+//   phase 2j-1: G0 READ(j); issues its A rows of step j+1 and W's first 4 column blocks of j+1
+//   phase 2j  : G0 MMA(j)  | G1 READ(j); issues its A rows of j+1 and W's last 4 column blocks of j+2
+//   phase 2j+1:            | G1 MMA(j)
+// Rings: W 3 steps x 24 KiB, A 2 groups x 2 steps x 9 KiB (108 KiB).  Waits and barriers as in
+// k_gemm_s3: a piece is waited for at the end of its issuer's next phase and read a barrier later.
+__global__ __launch_bounds__(512, 1) void k_gemm_s3_wide(const s3_args p) {
+  constexpr int MB = 3;
+  constexpr int AS = 9 * 64, WS = 24 * 64;            // uint4 per A step (one group) / W step
+  constexpr int WRING = 4 * AS;                       // [A: group][slot] first, then W [3]
+  __shared__ __attribute__((aligned(1024))) uint4 smem[4 * AS + 3 * WS];    // 108 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wq = wave & 3;
+  const int KB = p.K >> 4;
+  const int RB = (p.M + 31) >> 5, CB = (p.N + 31) >> 5;
+  const int nt = (p.N + 255) >> 8, mt = (RB + 2 * MB - 1) / (2 * MB);
+  const int t = xcd_tile_index(blockIdx.x, nt * mt);
+  const int tm = t / nt, tn = t - tm * nt;
+  const int rb0 = tm * 2 * MB + grp * MB;             // this group's first row block
+  const uint4* Aop = (p.A2 && tn >= p.a2_from_tile) ? p.A2 : p.A;
+  // A pieces of this wave: e = wq + 4 i < 9 -> (row block, plane); W pieces: this group's half
+  // (column blocks 4 grp .. 4 grp + 3) x 3 planes = 12, three per wave
+  const uint4* gA[3]; int lA[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = min(wq + 4 * i, 8), m = e / 3, plane = e - m * 3;
+    gA[i] = Aop + (int64_t)min(rb0 + m, RB - 1) * KB * 192 + plane * 64 + lane;
+    lA[i] = e * 64;
+  }
+  const bool a3 = wq == 0;
+  const uint4* gW[3]; int lW[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = grp * 12 + wq + 4 * i, cbl = e / 3, plane = e - cbl * 3;
+    gW[i] = p.W + (int64_t)min(tn * 8 + cbl, CB - 1) * KB * 192 + plane * 64 + lane;
+    lW[i] = e * 64;
+  }
+  auto issueA = [&](int j) {
+    const int base = (grp * 2 + (j & 1)) * AS;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < 2 || a3) s3_glds16(gA[i] + (int64_t)j * 192, &smem[base + lA[i]]);
+  };
+  auto issueW = [&](int j, int slot) {     // this group's half of W's step j
+    const int base = WRING + slot * WS;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s3_glds16(gW[i] + (int64_t)j * 192, &smem[base + lW[i]]);
+  };
+  s3_frag a[MB][3], b[2][3];
+  f32x16 acc[MB][2];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][c][r] = 0.f;
+  auto read = [&](int j, int slot) {
+    const uint4* pa = smem + (grp * 2 + (j & 1)) * AS + lane;
+    const uint4* pb = smem + WRING + slot * WS + wq * 6 * 64 + lane;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a[m][q].u = pa[(m * 3 + q) * 64];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) b[c][q].u = pb[(c * 3 + q) * 64];
+  };
+  auto mma = [&] {
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c][PB[q]].v, a[m][PA[q]].v, acc[m][c], 0, 0, 0);
+  };
+  auto bar = [&] {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto drain_bar = [&] {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
+    bar();
+  };
+  // prologue: step 0 whole (each group its A rows and its half of W), W's second half of step 1
+  issueA(0);
+  issueW(0, 0);
+  if (grp == 1 && KB > 1) issueW(1, 1);
+  drain_bar();
+  if (grp == 0) {
+    int ws = 0;                              // j % 3
+    for (int j = 0; j < KB; ++j) {
+      const int ws1 = ws == 2 ? 0 : ws + 1;
+      __builtin_amdgcn_s_setprio(1);
+      read(j, ws);
+      if (j + 1 < KB) { issueA(j + 1); issueW(j + 1, ws1); }
+      __builtin_amdgcn_s_setprio(0);
+      bar();
+      mma();
+      drain_bar();
+      ws = ws1;
+    }
+  } else {
+    bar();
+    int ws = 0;
+    for (int j = 0; j < KB; ++j) {
+      const int ws2 = ws == 0 ? 2 : ws - 1;  // (j + 2) % 3
+      __builtin_amdgcn_s_setprio(1);
+      read(j, ws);
+      if (j + 1 < KB) issueA(j + 1);
+      if (j + 2 < KB) issueW(j + 2, ws2);
+      __builtin_amdgcn_s_setprio(0);
+      bar();
+      mma();
+      if (j + 1 < KB) drain_bar();
+      ws = ws == 2 ? 0 : ws + 1;
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+    if (rb0 + m >= RB) break;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int n0 = tn * 256 + wq * 64 + c * 32;
+      if (n0 < p.N) s3_block_epilogue(acc[m][c], p, rb0 + m, n0, lane);
+    }
+  }
+}
+
+// Leftover columns (N % 256 of at most 64, e.g. the last 32 of the encoder's 544-column
+// [value | offsets | logits] projection): one wave per (row block, column block), operands straight
+// to registers -- nothing is shared, 0.4 GFLOP, latency-bound and short.
+__global__ __launch_bounds__(256) void k_gemm_s3_narrow(const s3_args p, const int col0) {
+  const int lane = threadIdx.x & 63;
+  const int KB = p.K >> 4, RB = (p.M + 31) >> 5, ncb = (p.N - col0) >> 5;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= RB * ncb) return;
+  const int rb = unit / ncb, cb = (col0 >> 5) + unit - rb * ncb;
+  const uint4* ga = ((p.A2 && (cb >> 3) >= p.a2_from_tile) ? p.A2 : p.A) + (int64_t)rb * KB * 192 + lane;
+  const uint4* gw = p.W + (int64_t)cb * KB * 192 + lane;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+  // nothing hides a load here but the wave's own earlier loads: four k-blocks (24 loads) in flight
+  constexpr int D = 4;
+  s3_frag a[D][3], b[D][3];
+  auto load = [&](int kb, int slot) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { a[slot][q].u = ga[kb * 192 + q * 64]; b[slot][q].u = gw[kb * 192 + q * 64]; }
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < KB) load(d, d);
+  for (int kb = 0; kb < KB; kb += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (kb + d >= KB) break;
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[d][PB[q]].v, a[d][PA[q]].v, acc, 0, 0, 0);
+      if (kb + d + D < KB) load(kb + d + D, d);
+    }
+  }
+  s3_block_epilogue(acc, p, rb, cb * 32, lane);
 }
 
 // ---------------------------------------------------------------- C ABI
@@ -526,10 +687,13 @@ extern "C" int pn_gemm_s3_f32(const pn_gemm_s3_desc* d, void* stream) {
   const int rem = d->N % 256;
   const bool narrow = !ln && !d->CS_pos && d->N > 256 && rem > 0 && rem <= 64;
   const int RB = (d->M + 31) / 32, mt = (RB + 2) / 3;
+  // two or more column tiles: the 192-row tile whose row groups share W
+  const bool wide = !ln && !d->CS_pos && (d->N - (narrow ? rem : 0)) >= 512 && !(d->flags & PN_GEMM_S3_TILE96);
   if (narrow) {
     a.N = d->N - rem;                       // the main launch sees only the whole tiles ...
     const int nt = a.N / 256;
-    k_gemm_s3<false><<<dim3(mt * nt), dim3(512), 0, (hipStream_t)stream>>>(a);
+    if (wide) k_gemm_s3_wide<<<dim3((RB + 5) / 6 * nt), dim3(512), 0, (hipStream_t)stream>>>(a);
+    else k_gemm_s3<false><<<dim3(mt * nt), dim3(512), 0, (hipStream_t)stream>>>(a);
     a.N = d->N;                             // ... S3 outputs keep the full row pitch
     s3_args b = a;
     const int units = RB * (rem / 32);
@@ -537,6 +701,10 @@ extern "C" int pn_gemm_s3_f32(const pn_gemm_s3_desc* d, void* stream) {
     return PN_LAUNCH_CHECK();
   }
   const int nt = (d->N + 255) / 256;
+  if (wide) {
+    k_gemm_s3_wide<<<dim3((RB + 5) / 6 * nt), dim3(512), 0, (hipStream_t)stream>>>(a);
+    return PN_LAUNCH_CHECK();
+  }
   if (ln) k_gemm_s3<true><<<dim3(mt * nt), dim3(512), 0, (hipStream_t)stream>>>(a);
   else k_gemm_s3<false><<<dim3(mt * nt), dim3(512), 0, (hipStream_t)stream>>>(a);
   return PN_LAUNCH_CHECK();

@@ -631,6 +631,12 @@ class PSGTr:
                 # into that stream's own grow-only buffer
                 images = list(img) if isinstance(img, (list, tuple)) else [img]
                 img, metas = self._pipeline_of_images().batch(images, slot=sl)
+            if isinstance(img, torch.Tensor) and img.is_cuda:
+                # a batch tensor the caller (or `dist.collate`) allocated on ITS stream is read
+                # here on the stage-A stream: tell the caching allocator, or the block could be
+                # handed to the next collate while the backbone of this batch still reads it
+                # (the host runs several batches ahead of the device)
+                img.record_stream(sa)
             feats = net(img, slot=sl) if slots else net(img)
             if len(feats) == 4 and self.out_indices != (0, 1, 2, 3):
                 feats = tuple(feats[j] for j in self.out_indices)

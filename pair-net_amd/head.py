@@ -542,10 +542,16 @@ class CrossHead2:
         c = self._const(B)
         if c["me0"] is None:
             # the mask embedding of the INITIAL queries: a function of the weights alone,
-            # computed once per batch size on this plan's buffers and kept outside the arena
+            # computed once per batch size on PRIVATE scratch outside the arena -- this plan's
+            # arena views alias the buffers of the slot's previous batch, which may still be
+            # executing on another stream when a plan of a new batch size is first built
             # (complete before any other stream can read it: one host wait per state dict)
-            self._head_embed(pl.q0, pl, False, False)
-            c["me0"] = pl.me.clone()
+            from types import SimpleNamespace
+            BQ = B * self.num_obj_query
+            tmp = SimpleNamespace(B=B, **{n: torch.empty(BQ, 256, device=self.device)
+                                          for n in ("qn", "m1", "m2", "me")})
+            self._head_embed(pl.q0, tmp, False, False)
+            c["me0"] = tmp.me
             torch.cuda.current_stream(self.device).synchronize()
         pl.me0 = c["me0"]
         self._plans[key] = pl
@@ -1067,7 +1073,7 @@ class CrossHead2:
         every buffer is a view of the slot's arena (plans.py)."""
         cfg = (self.exact_mask_order, self.conv_algo, self.fuse_ppn_front, self.grid_reserve,
                tuple(self.enc_fused_ln), self.group_input_convs,
-               getattr(self, "fuse_mask_pack", True))
+               getattr(self, "fuse_mask_pack", True), self.gemm_arithmetic)
         if pl.graph_cfg != cfg:          # a captured graph bakes these switches in
             pl.graph_a = pl.graph_b = None
             pl.graphs_a = OrderedDict()
@@ -1162,14 +1168,21 @@ class CrossHead2:
         cs = CrossHead2._capture_streams.get(dev)
         if cs is None:
             cs = CrossHead2._capture_streams[dev] = torch.cuda.Stream(dev)
-        CrossHead2.captures += 1
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(cs):
             g.capture_begin(capture_error_mode="thread_local")
             try:
                 fn()
-            finally:
-                g.capture_end()
+            except BaseException as first:
+                # end the capture so that the stream leaves capture mode, but report what went
+                # wrong inside it (a refused launch, a shape error), not the invalidated capture
+                try:
+                    g.capture_end()
+                except Exception:
+                    pass
+                raise first
+            g.capture_end()
+        CrossHead2.captures += 1          # (counted once it exists)
         return g
 
     @torch.no_grad()

@@ -47,7 +47,7 @@ class GemmS3Desc(C.Structure):
                 ("C", _vp), ("ldc", _i64),
                 ("CS", _vp),
                 ("CS_pos", _vp), ("pos", _vp), ("pos_rows", _i32),
-                ("res_s3", _vp), ("gamma", _vp), ("beta", _vp), ("eps", _f32)]
+                ("res_s3", _vp), ("gamma", _vp), ("beta", _vp), ("eps", _f32), ("flags", _i32)]
 
 
 _SIGS = {
@@ -548,7 +548,8 @@ def s3_join(s3, out):
 
 
 def gemm_s3(a, w, M, N, K, *, bias=None, relu=False, out=None, out_s3=None, out_s3_pos=None,
-            pos=None, a2=None, a2_from_col=0, res_s3=None, gamma=None, beta=None, eps=1e-5):
+            pos=None, a2=None, a2_from_col=0, res_s3=None, gamma=None, beta=None, eps=1e-5,
+            tile96=False):
     """fp32 GEMM on the bf16 matrix pipe from pre-split operands (csrc/gemm_s3.hip):
     out = act(a @ w.T + bias), or LayerNorm(a @ w.T + bias + res) * gamma + beta (N == 256).
     a, a2, w, res_s3, out_s3, out_s3_pos are S3 buffers; out is 2-D fp32 rows."""
@@ -567,9 +568,10 @@ def gemm_s3(a, w, M, N, K, *, bias=None, relu=False, out=None, out_s3=None, out_
         assert pos.numel() == (pr + 31) // 32 * 32 * N
         d.pos, d.pos_rows = _ptr(pos), pr
     d.res_s3, d.gamma, d.beta, d.eps = _ptr(res_s3), _ptr(gamma), _ptr(beta), eps
+    d.flags = 1 if tile96 else 0     # PN_GEMM_S3_TILE96
     nbytes = 6.0 * (M * K + N * K) + (4.0 * M * N if out is not None else 0.0) + \
         6.0 * M * N * ((out_s3 is not None) + (out_s3_pos is not None) + (res_s3 is not None))
-    name = "k_gemm_s3<ln>" if gamma is not None else "k_gemm_s3"
+    name = "k_gemm_s3<ln>" if gamma is not None else "k_gemm_s3"    # (both tile forms)
     _check(_launch(name, 2.0 * M * N * K, nbytes, lambda: lib().pn_gemm_s3_f32(C.byref(d), _stream()),
                    meta=(M, N, K, 1, False)), "pn_gemm_s3_f32")
 

@@ -126,5 +126,8 @@ class TestPipeline:
         for i, (im, (H, W, (Hn, Wn), _)) in enumerate(zip(imgs, geo)):
             hip.preprocess_u8(im, H, W, out[i], Hn, Wn, Hp, Wp, self._mean[0], self._mean[1],
                               self.to_rgb)
-            metas.append(self._meta(H, W, Hn, Wn, Hp, Wp, batch_shape=(Hp, Wp)))
+            # per-image `pad_shape` (the reference's Pad(size_divisor) runs before mmcv's collate,
+            # which only adds `batch_input_shape`): consumers that derive valid regions from it
+            # (the box trunk's padding masks) see what the reference pipeline gives them
+            metas.append(self._meta(H, W, Hn, Wn, *geo[i][3], batch_shape=(Hp, Wp)))
         return out, metas

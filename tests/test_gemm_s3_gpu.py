@@ -84,6 +84,11 @@ def test_integer_problems_are_exact(hip, M, N, K):
     hip.gemm_s3(s3(hip, a), s3(hip, w), M, N, K, bias=b, relu=True, out=wide[:, :N])
     assert torch.equal(wide[:, :N], want.clamp_min(0))
     assert torch.all(wide[:, N:] == -7.0)
+    if N >= 512:
+        # N >= 512 takes the 192 x 256 tile (two row groups share W); the 96 x 256 tile on request
+        out.fill_(float("nan"))
+        hip.gemm_s3(s3(hip, a), s3(hip, w), M, N, K, bias=b, out=out, out_s3=out_s, tile96=True)
+        assert torch.equal(out, want) and torch.equal(joined(hip, out_s, M, N), want)
 
 
 @pytest.mark.parametrize("M,N,K,relu", [(21950, 1024, 256, True), (21950, 256, 1024, False),

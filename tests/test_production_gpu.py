@@ -475,7 +475,8 @@ def test_many_shapes_share_one_arena_per_slot():
     assert getattr(head, "recaptures", 0) == 0
     # memory: the arenas + the shared position tables (one set per shape, LRU-bounded) +
     # the clones of this loop; independent of how many shapes have passed
-    pe = max(sum(t.numel() * 4 for t in [e[0]] + e[1]) for e in head._pe.values())
+    # (e[3]: the encoder table once more in the order gemm_s3's `out + pos` epilogue reads)
+    pe = max(sum(t.numel() * 4 for t in [e[0]] + e[1] + [e[3]]) for e in head._pe.values())
     assert len(head._pe) <= head.PE_SHAPES
     assert max(mem[12:]) - mem[11] <= head.PE_SHAPES * pe + (1 << 20), (mem[11], max(mem[12:]))
     # the first shape again: its plan is still there, replayed, same bits

@@ -52,6 +52,9 @@ def main():
             rows.append(("fp32 MFMA k_gemm_tile", timed(lambda: hip.linear(a, w, b, out, relu=relu))))
             rows.append(("s3 -> fp32", timed(lambda: hip.gemm_s3(a_s, w_s, M, N, K, bias=b, relu=relu, out=out))))
             rows.append(("s3 -> S3", timed(lambda: hip.gemm_s3(a_s, w_s, M, N, K, bias=b, relu=relu, out_s3=out_s))))
+            if N >= 512:
+                rows.append(("s3 -> S3, 96-row tile", timed(lambda: hip.gemm_s3(a_s, w_s, M, N, K, bias=b, relu=relu, out_s3=out_s, tile96=True))))
+                rows.append(("s3 -> fp32, 96-row tile", timed(lambda: hip.gemm_s3(a_s, w_s, M, N, K, bias=b, relu=relu, out=out, tile96=True))))
         rows.append(("split A", timed(lambda: hip.s3_split(a, a_s))))
         print("M=%d N=%d K=%d" % (M, N, K))
         for name, us in rows:

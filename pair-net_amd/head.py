@@ -548,8 +548,9 @@ class CrossHead2:
             # (complete before any other stream can read it: one host wait per state dict)
             from types import SimpleNamespace
             BQ = B * self.num_obj_query
-            tmp = SimpleNamespace(B=B, **{n: torch.empty(BQ, 256, device=self.device)
-                                          for n in ("qn", "m1", "m2", "me")})
+            tmp = SimpleNamespace(B=B, cls=None, MP=None,
+                                  **{n: torch.empty(BQ, 256, device=self.device)
+                                     for n in ("qn", "m1", "m2", "me")})
             self._head_embed(pl.q0, tmp, False, False)
             c["me0"] = tmp.me
             torch.cuda.current_stream(self.device).synchronize()

@@ -317,6 +317,10 @@ def main():
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    numa_bound = None
+    if world > 1 or os.environ.get("PAIRNET_NUMA_BIND"):
+        from pairnet_amd.dist import bind_to_gpu_numa
+        numa_bound = bind_to_gpu_numa(dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -502,6 +506,8 @@ def main():
         step()
     drain()
 
+    host_submit = [0.0, 0]           # host seconds spent inside step() / steps (this rank)
+
     def timed(n, **kw):
         torch.cuda.synchronize()
         if world > 1 or one_rank:
@@ -509,6 +515,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(n):
             step(**kw)
+        host_submit[0] += time.perf_counter() - t0
+        host_submit[1] += n
         drain()                      # the last batch finishes inside the timed region
         torch.cuda.synchronize()
         if world > 1 or one_rank:
@@ -523,6 +531,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     records = gatherer.records_gathered if gatherer is not None else 0
+    # host side of the step on THIS rank (the only new bottleneck a full node adds: 8 ranks'
+    # launch threads): time spent submitting a step vs the step itself, slowest rank
+    host_ms = 1e3 * host_submit[0] / max(1, host_submit[1])
+    if world > 1:
+        t = torch.tensor([host_ms], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        host_ms = float(t.item())
 
     # ---- the pipelined schedule only reorders launches: for EVERY image of the pool the
     # pipelined result must equal, bit for bit, what one eager single-stream call gives ----
@@ -971,6 +986,13 @@ def main():
             "triplet_records_gathered": records,
             "triplet_record_bytes": 4 * gatherer.L if gatherer is not None else None,
             "pipeline_check": pipeline_check,
+            "host": {"submit_ms_per_step_max_over_ranks": host_ms,
+                     "submit_fraction_of_step": host_ms / (1e3 * elapsed / args.steps),
+                     "numa_binding": numa_bound,
+                     "what": "host time inside step() per step (graph replays + eager launches "
+                             "+ the per-step collective's enqueue) on the slowest rank; ranks "
+                             "are bound to the NUMA node of their GPU when --gpus > 1 "
+                             "(dist.bind_to_gpu_numa; PAIRNET_NUMA_BIND=1 forces it on one GPU)"},
         }
         if simple_test is not None:
             out["simple_test_incl_result_d2h"] = simple_test

@@ -274,6 +274,9 @@ int pn_msda_f32(const float* value, int64_t ld_value, const float* offaw,
 #define PN_MSDA_PERSISTENT_BATCHED 2
 #define PN_MSDA_LOW_OCCUPANCY 4    /* one-shot form with the compiler's register choice (84 VGPRs, 5
                                       workgroups per CU: rounds 1-3); default: 62 VGPRs, 8 per CU */
+#define PN_MSDA_S3_OUT 8           /* `out` is an S3 operand [B * N x 256] (three bf16 planes, see
+                                    * pn_gemm_s3_f32): the output_proj GEMM's A operand written pre-split,
+                                    * the fp32 map is not written; default (one-shot) form only */
 int pn_msda_ex_f32(const float* value, int64_t ld_value, const float* offaw,
                    int64_t ld_offaw, float* out, int B, int L,
                    const int32_t* level_h /* host */, const int32_t* level_w /* host */,

@@ -38,28 +38,8 @@
 // and read at least one barrier later; a ring slot is overwritten at least one barrier after its
 // last reader's phase.  Rings: A 3 stages x 18 KiB, W 2 stages x 48 KiB (150 KiB of LDS).
 #include "common.h"
+#include "s3_common.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-union s3_frag { uint4 u; bf16x8 v; __bf16 e[8]; };
-
-__device__ __forceinline__ void s3_split(float x, __bf16& a, __bf16& b, __bf16& c) {
-  a = (__bf16)x;
-  float r = x - (float)a;      // exact
-  b = (__bf16)r;
-  r = r - (float)b;            // exact
-  c = (__bf16)r;
-}
-// 8 floats -> three planes
-__device__ __forceinline__ void s3_split8(const float (&v)[8], s3_frag& p0, s3_frag& p1, s3_frag& p2) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s3_split(v[i], p0.e[i], p1.e[i], p2.e[i]);
-}
-// three planes -> 8 floats, exactly the fp32 values that were split
-__device__ __forceinline__ void s3_join8(const s3_frag& p0, const s3_frag& p1, const s3_frag& p2,
-                                         float (&v)[8]) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = ((float)p2.e[i] + (float)p1.e[i]) + (float)p0.e[i];
-}
 __device__ __forceinline__ void s3_glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -134,9 +114,12 @@ struct s3_args {
 };
 
 // LN: the row epilogue out = LayerNorm(acc + bias + residual) (N == 256, one column tile)
+#ifndef S3_LATE_B
+#define S3_LATE_B 0
+#endif
 template <bool LN>
 __global__ __launch_bounds__(512, 1) void k_gemm_s3(const s3_args p) {
-  constexpr int MB = 3;
+  constexpr int MB = 3, LATE_B = S3_LATE_B;   // (A/B knob: W pieces per wave issued in the MMA phase)
   constexpr int AH = 9 * 64, AST = 2 * AH;           // uint4 per A half (16-deep) / A stage
   constexpr int BH = 24 * 64, BST = 2 * BH;          // uint4 per W half / W stage
   constexpr int BRING = 3 * AST;
@@ -171,13 +154,15 @@ __global__ __launch_bounds__(512, 1) void k_gemm_s3(const s3_args p) {
   const bool a3 = wq == 0;
   // (diagnostic builds for tools/coresidency_probe.py: -DS3_DIAG_NO_DMA drops the LDS-DMA of the
   // main loop, -DS3_DIAG_NO_MFMA the MFMAs; results are then meaningless)
-  auto issueB = [&](int s) {               // this group's W columns of stage s
+  // this group's W columns of stage s: pieces [j0, j1) of this wave's six
+  auto issueB = [&](int s, int j0 = 0, int j1 = 6) {
 #ifdef S3_DIAG_NO_DMA
     if (s > 0) return;
 #endif
     const int base = BRING + (s & 1) * BST;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) s3_glds16(gB[j] + (int64_t)s * 384, &smem[base + lB[j]]);
+    for (int j = 0; j < 6; ++j)
+      if (j >= j0 && j < j1) s3_glds16(gB[j] + (int64_t)s * 384, &smem[base + lB[j]]);
   };
   auto issueA = [&](int s, int as, int half) {   // one 16-deep half of A's stage s into ring slot as
 #ifdef S3_DIAG_NO_DMA
@@ -208,7 +193,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_s3(const s3_args p) {
       for (int q = 0; q < 3; ++q) b[h][q].u = pb[h * BH + q * 64];
     }
   };
-  auto mma = [&] {
+  auto mma = [&](int late) {
     // smallest terms first; consecutive MFMAs go to different accumulators.  W is the MFMA's A
     // operand: acc[m] lane l, register r = output row (rb0 + m) * 32 + l % 32, column
     // n0 + (r & 3) + 8 (r >> 2) + 4 (l >> 5)
@@ -225,10 +210,20 @@ __global__ __launch_bounds__(512, 1) void k_gemm_s3(const s3_args p) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
+      for (int q = 0; q < 6; ++q) {
 #pragma unroll
         for (int m = 0; m < MB; ++m)
           acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[h][PB[q]].v, a[h][m][PA[q]].v, acc[m], 0, 0, 0);
+        // the LATE pieces of this group's W columns of stage `late` (two stages ahead: their
+        // ring slot is this stage's, consumed in this wave's READ phase) ride between the
+        // MFMAs, one per three of them: an LDS-DMA piece costs ~120 cycles of issue in a READ
+        // phase beside the other group's MFMAs and about half of that here (labnotes R6.2)
+        if (LATE_B > 0 && h == 0 && q < LATE_B && late >= 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          issueB(late, 6 - LATE_B + q, 6 - LATE_B + q + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
   };
   auto bar = [&] {
     __builtin_amdgcn_sched_barrier(0);
@@ -247,6 +242,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_s3(const s3_args p) {
   // ---- prologue: stage 0 whole (W columns by their group, A's halves one per group), and A's
   // second half of stage 1 ----
   issueB(0);
+  if (LATE_B > 0 && S > 1) issueB(1, 6 - LATE_B, 6);     // (stage 1's late pieces have no MMA phase to ride in)
   issueA(0, 0, grp);
   if (grp == 1 && S > 1) issueA(1, 1, 1);
   drain_bar();
@@ -256,10 +252,10 @@ __global__ __launch_bounds__(512, 1) void k_gemm_s3(const s3_args p) {
       const int as1 = as == 2 ? 0 : as + 1;
       __builtin_amdgcn_s_setprio(1);
       read(s, as);
-      if (s + 1 < S) { issueB(s + 1); issueA(s + 1, as1, 0); }
+      if (s + 1 < S) { issueB(s + 1, 0, 6 - LATE_B); issueA(s + 1, as1, 0); }
       __builtin_amdgcn_s_setprio(0);
       bar();
-      mma();
+      mma(s + 2 < S ? s + 2 : -1);
       drain_bar();
       as = as1;
     }
@@ -270,11 +266,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_s3(const s3_args p) {
       const int as2 = as == 0 ? 2 : as - 1;          // (s + 2) % 3
       __builtin_amdgcn_s_setprio(1);
       read(s, as);
-      if (s + 1 < S) issueB(s + 1);
+      if (s + 1 < S) issueB(s + 1, 0, 6 - LATE_B);
       if (s + 2 < S) issueA(s + 2, as2, 1);
       __builtin_amdgcn_s_setprio(0);
       bar();
-      mma();
+      mma(s + 2 < S ? s + 2 : -1);
       if (s + 1 < S) drain_bar();
       as = as == 2 ? 0 : as + 1;
     }

@@ -11,6 +11,7 @@
 //   loc = ref + off / (W_l, H_l);  g = 2 loc - 1;  ix = ((g + 1) W_l - 1) / 2
 // with zero padding outside the map.
 #include "common.h"
+#include "s3_common.h"
 
 struct MsdaLevels {
   int h[4], w[4], start[4];
@@ -53,7 +54,7 @@ struct __attribute__((aligned(16))) MsdaTap {
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int L>
+template <int L, bool S3OUT = false>
 __device__ __forceinline__ void msda_one_shot(const float* __restrict__ value,
                                               const float* __restrict__ offaw,
                                               float* __restrict__ out,
@@ -186,7 +187,25 @@ __device__ __forceinline__ void msda_one_shot(const float* __restrict__ value,
             o4, reinterpret_cast<f32x4*>(out + ((int64_t)b * lv.N + nq) * 256 + h2 * 32 + c4 * 4));
       }
 #else
-      if (p2 == 0) st4(out + ((int64_t)b * lv.N + nq) * 256 + h2 * 32 + c4 * 4, acc);
+      if (S3OUT) {
+        // the output_proj GEMM's A operand, pre-split (csrc/gemm_s3.hip): even-c4 lanes take
+        // their neighbour's four channels and write the three 16-byte plane pieces of 8
+        // consecutive channels of this token (the fp32 map is then never written)
+        const float4 nb = make_float4(__shfl_xor(acc.x, 1, 64), __shfl_xor(acc.y, 1, 64),
+                                      __shfl_xor(acc.z, 1, 64), __shfl_xor(acc.w, 1, 64));
+        if (p2 == 0 && (c4 & 1) == 0) {
+          const float v8[8] = {acc.x, acc.y, acc.z, acc.w, nb.x, nb.y, nb.z, nb.w};
+          s3_frag q0, q1, q2;
+          s3_split8(v8, q0, q1, q2);
+          const int64_t row = (int64_t)b * lv.N + nq;
+          const int k0 = h2 * 32 + c4 * 4;
+          uint4* o = reinterpret_cast<uint4*>(out) + ((row >> 5) * 16 + (k0 >> 4)) * 192 +
+                     ((k0 >> 3) & 1) * 32 + (row & 31);
+          o[0] = q0.u; o[64] = q1.u; o[128] = q2.u;
+        }
+      } else if (p2 == 0) {
+        st4(out + ((int64_t)b * lv.N + nq) * 256 + h2 * 32 + c4 * 4, acc);
+      }
 #endif
     }
   }
@@ -200,12 +219,12 @@ __device__ __forceinline__ void msda_one_shot(const float* __restrict__ value,
 // the init offsets (second / first pass of the probe), 63.7 against 65.3 with N(0, 8 px)
 // offsets: 1.08 GB of value rows pass the vector L1 in 45.9 us = 23.6 TB/s, 0.9 of what the
 // bare gather pattern reaches (26 TB/s, tools/gather_probe.hip).
-template <int L>
+template <int L, bool S3OUT = false>
 __global__ __launch_bounds__(256, 6) void k_msda(const float* __restrict__ value,
                                                  const float* __restrict__ offaw,
                                                  float* __restrict__ out, const MsdaLevels lv,
                                                  const int64_t ldv, const int64_t ldo) {
-  msda_one_shot<L>(value, offaw, out, lv, ldv, ldo);
+  msda_one_shot<L, S3OUT>(value, offaw, out, lv, ldv, ldo);
 }
 template <int L>
 __global__ __launch_bounds__(256) void k_msda_lo(const float* __restrict__ value,
@@ -408,6 +427,8 @@ extern "C" int pn_msda_ex_f32(const float* value, int64_t ld_value, const float*
   if ((int64_t)n * ld_value * 4 >= ((int64_t)1 << 32)) return PN_BAD_ARG;   // 32-bit tap offsets
   hipStream_t s = (hipStream_t)stream;
   const int pairs = (per_band + MSDA_TQ - 1) / MSDA_TQ;
+  if ((flags & PN_MSDA_S3_OUT) && (flags & (PN_MSDA_PERSISTENT | PN_MSDA_PERSISTENT_BATCHED | PN_MSDA_LOW_OCCUPANCY)))
+    return PN_BAD_ARG;                 // the pre-split output exists in the default form only
   if (!(flags & (PN_MSDA_PERSISTENT | PN_MSDA_PERSISTENT_BATCHED))) {
     // one workgroup per query pair
     const dim3 grid(pairs * 8, B);
@@ -417,6 +438,15 @@ extern "C" int pn_msda_ex_f32(const float* value, int64_t ld_value, const float*
         case 2: hipLaunchKernelGGL(k_msda_lo<2>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
         case 3: hipLaunchKernelGGL(k_msda_lo<3>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
         default: hipLaunchKernelGGL(k_msda_lo<4>, grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+      }
+      return PN_LAUNCH_CHECK();
+    }
+    if (flags & PN_MSDA_S3_OUT) {      // `out` is an S3 operand [B * N x 256] (pn_gemm_s3_f32's A)
+      switch (L) {
+        case 1: hipLaunchKernelGGL((k_msda<1, true>), grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+        case 2: hipLaunchKernelGGL((k_msda<2, true>), grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+        case 3: hipLaunchKernelGGL((k_msda<3, true>), grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
+        default: hipLaunchKernelGGL((k_msda<4, true>), grid, dim3(256), 0, s, value, offaw, out, lv, ld_value, ld_offaw); break;
       }
       return PN_LAUNCH_CHECK();
     }

@@ -20,6 +20,57 @@ def shard_indices(num_images, rank, world_size):
     return list(range(rank, num_images, world_size))
 
 
+def _cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(pci_bdf, sysfs="/sys"):
+    """(numa node, cpu list) of the PCI device `pci_bdf` ("0000:c1:00.0") from sysfs, or
+    (None, None) when the platform does not say (node -1, missing files)."""
+    try:
+        with open("%s/bus/pci/devices/%s/numa_node" % (sysfs, pci_bdf.lower())) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None, None
+        with open("%s/devices/system/node/node%d/cpulist" % (sysfs, node)) as f:
+            return node, _cpulist(f.read())
+    except (OSError, ValueError):
+        return None, None
+
+
+def bind_to_gpu_numa(device_index, sysfs="/sys"):
+    """One process per GPU (tools/dist_test.sh:7 launches them unpinned): keep this rank's host
+    threads on the NUMA node its GPU hangs off, so that the ~330 kernel launches per image (or
+    the graph replays) and the pinned-memory traffic of 8 ranks do not cross sockets.  Best
+    effort: returns dict(numa_node, cpus) on success, None when the topology is unknown or the
+    affinity cannot be set (containers with a restricted cpuset keep what they have)."""
+    import os
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:       # noqa: BLE001 -- no GPU, or a torch without the PCI fields
+        return None
+    node, cpus = gpu_numa_cpus(bdf, sysfs)
+    if not cpus or not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = os.sched_getaffinity(0)
+    want = sorted(set(cpus) & allowed)
+    if not want:
+        return None
+    try:
+        os.sched_setaffinity(0, want)
+    except OSError:
+        return None
+    return dict(numa_node=node, cpus=len(want), pci=bdf)
+
+
 def triplet_record_len(num_rel_query, num_relations):
     """float32 words per image: labels(2R) | rel_dists(R*(C+1)) | sub_pos(R) | obj_pos(R)."""
     return 2 * num_rel_query + num_rel_query * (num_relations + 1) + 2 * num_rel_query

@@ -163,6 +163,9 @@ class CrossHead2:
         # MFMA's); "fp32": the exact-fp32 MFMA kernels of rounds 1-5 (pn_gemm_f32,
         # pn_linear_res_ln_f32).  Everything else is fp32 MFMA either way.
         self.gemm_arithmetic = "bf16x3"
+        # bf16x3: the sampling kernel writes output_proj's A operand pre-split (True) instead of
+        # fp32 rows + a split pass (False); the same values either way
+        self.msda_s3_out = True
         self.init_weights()
 
     # ------------------------------------------------------------------ params
@@ -779,8 +782,11 @@ class CrossHead2:
             last = i + 1 == self.num_enc_layers
             hip.gemm_s3(pl.XS, w[a + "voa.weight.s3"], M, 544, 256, bias=w[a + "voa.bias"],
                         out=pl.VOA.view(-1, 544), a2=pl.XPS, a2_from_col=256)
-            hip.msda(pl.VOA, 544, pl.VOA.view(-1)[256:], 544, pl.S, B, pl.shapes)
-            hip.s3_split(pl.S.view(-1, 256), pl.SS)
+            if self.msda_s3_out:
+                hip.msda(pl.VOA, 544, pl.VOA.view(-1)[256:], 544, pl.SS, B, pl.shapes, s3_out=True)
+            else:
+                hip.msda(pl.VOA, 544, pl.VOA.view(-1)[256:], 544, pl.S, B, pl.shapes)
+                hip.s3_split(pl.S.view(-1, 256), pl.SS)
             hip.gemm_s3(pl.SS, w[a + "output_proj.weight.s3"], M, 256, 256,
                         bias=w[a + "output_proj.bias"], out_s3=pl.X1S, res_s3=pl.XS,
                         gamma=w[p + "norms.0.weight"], beta=w[p + "norms.0.bias"])
@@ -1074,7 +1080,7 @@ class CrossHead2:
         every buffer is a view of the slot's arena (plans.py)."""
         cfg = (self.exact_mask_order, self.conv_algo, self.fuse_ppn_front, self.grid_reserve,
                tuple(self.enc_fused_ln), self.group_input_convs,
-               getattr(self, "fuse_mask_pack", True), self.gemm_arithmetic)
+               getattr(self, "fuse_mask_pack", True), self.gemm_arithmetic, self.msda_s3_out)
         if pl.graph_cfg != cfg:          # a captured graph bakes these switches in
             pl.graph_a = pl.graph_b = None
             pl.graphs_a = OrderedDict()

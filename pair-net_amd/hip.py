@@ -653,7 +653,13 @@ def l2normalize(x, out, eps=1e-12):
 MSDA_PERSISTENT, MSDA_PERSISTENT_BATCHED, MSDA_LOW_OCCUPANCY = 1, 2, 4   # PN_MSDA_* launch forms (A/B)
 
 
-def msda(value, ld_value, offaw, ld_offaw, out, B, shapes, flags=0):
+MSDA_S3_OUT = 8     # PN_MSDA_S3_OUT
+
+
+def msda(value, ld_value, offaw, ld_offaw, out, B, shapes, flags=0, s3_out=False):
+    """`s3_out`: `out` is an S3 operand buffer [B * N x 256] (gemm_s3's A) instead of fp32 rows."""
+    if s3_out:
+        flags |= MSDA_S3_OUT
     L = len(shapes)
     hs = (_i32 * L)(*[s[0] for s in shapes])
     ws = (_i32 * L)(*[s[1] for s in shapes])

@@ -741,3 +741,24 @@ def test_multi_gpu_test_with_the_sibling_heads(model):
         assert torch.equal(out["records"][i].cpu(), want[i]), (model, i)
     d = unpack_triplets(out["records"][0].cpu(), head.num_rel_query, head.num_relations)
     assert d["rel_dists"].shape == (head.num_rel_query, head.num_relations + 1)
+
+
+def test_numa_binding_reads_sysfs_and_is_best_effort(tmp_path):
+    """`dist.bind_to_gpu_numa` (bench.py --gpus N binds every rank to its GPU's NUMA node):
+    the node and cpu list come from sysfs; unknown topology (node -1, no files, no GPU) means
+    "leave the affinity alone", never an error."""
+    from pairnet_amd.dist import _cpulist, bind_to_gpu_numa, gpu_numa_cpus
+    assert _cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and _cpulist("") == []
+    root = tmp_path / "sys"
+    dev = root / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = root / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text("64-127\n")
+    assert gpu_numa_cpus("0000:C1:00.0", str(root)) == (1, list(range(64, 128)))
+    (dev / "numa_node").write_text("-1\n")
+    assert gpu_numa_cpus("0000:c1:00.0", str(root)) == (None, None)
+    assert gpu_numa_cpus("0000:ff:00.0", str(root)) == (None, None)
+    if not torch.cuda.is_available():
+        assert bind_to_gpu_numa(0) is None       # no GPU: nothing is touched

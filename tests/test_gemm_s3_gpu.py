@@ -172,3 +172,17 @@ def test_launches_are_deterministic_and_reject_bad_contracts(hip):
         hip.gemm_s3(a, w, M, N, K)                    # no output
     with pytest.raises(RuntimeError):
         hip.gemm_s3(a, w, M, N, K, out=o, gamma=o, beta=o)   # LayerNorm needs N == 256
+
+
+def test_sampling_kernel_writes_the_same_values_pre_split(hip):
+    """pn_msda_ex_f32 with PN_MSDA_S3_OUT: output_proj's A operand straight from the sampling
+    kernel -- bit for bit the split of its fp32 output (800x1333 pyramid and a small ragged one)."""
+    for shapes in ([(25, 42), (50, 84), (100, 167)], [(3, 5), (6, 9), (12, 17)]):
+        SN = sum(h * w for h, w in shapes)
+        voa = G(1, SN, 544, seed=30)
+        voa[..., 256:448] *= 3.0
+        ref = torch.full((1, SN, 256), float("nan"), device=DEV)
+        hip.msda(voa, 544, voa.view(-1)[256:], 544, ref, 1, shapes)
+        out = torch.zeros(hip.s3_floats(SN, 256), device=DEV)
+        hip.msda(voa, 544, voa.view(-1)[256:], 544, out, 1, shapes, s3_out=True)
+        assert torch.equal(joined(hip, out, SN, 256), ref.view(SN, 256))

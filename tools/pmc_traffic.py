@@ -19,6 +19,10 @@ def bench_name(name):
                                                  AMODE.get(m.group(5), "A_STEM"))
     if name.startswith("void k_attn_small") or name.startswith("k_attn_chunk"):
         return "k_attn_chunk"     # (bench.py reports both attention kernels under this name)
+    if name.startswith("void k_gemm_s3<true>"):
+        return "k_gemm_s3<ln>"    # (bench.py: the row-epilogue instantiation)
+    if name.startswith(("void k_gemm_s3<false>", "k_gemm_s3_wide", "k_gemm_s3_narrow")):
+        return "k_gemm_s3"        # (bench.py reports the plain-epilogue tile forms under one name)
     m = re.match(r"void k_gemm_skinny<(\d), \d+>", name)
     if m:
         return "k_gemm_skinny<%s>" % AMODE[m.group(1)]

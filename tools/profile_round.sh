@@ -4,8 +4,7 @@
 #   gpurun_out/<tag>_kernel_stats.csv            rocprofv3 --kernel-trace --stats of
 #                                                `bench.py --no-extras --no-cpu-baseline`
 #   gpurun_out/<tag>_kernel_stats_head_only.csv  same with `--path head`
-#   gpurun_out/<tag>_swinl_bench.json            configs[3] shape (Swin-L, 200 queries), image -> triplets
-#   gpurun_out/<tag>_bbox_bench.json             `bench.py --head bbox` (cross_r101_vg: R101 -> neck -> CrossHeadBBox)
+#   (Swin-L / 200 queries and the box trunk are child legs of the default bench line since round 6)
 #   gpurun_out/pmc_traffic.json                  tools/pmc_traffic.sh (separate --pmc passes)
 # usage: tools/profile_round.sh r04_v1
 set -u
@@ -19,11 +18,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$
   python "$ROOT/bench.py" --no-extras --no-cpu-baseline > "$OUT/prof_${TAG}_full.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}" -o head -- \
   python "$ROOT/bench.py" --path head --no-extras --no-cpu-baseline > "$OUT/prof_${TAG}_head.log" 2>&1
-timeout 900 python "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 50 --queries 200 \
-  --in-channels 192,384,768,1536 2> "$OUT/${TAG}_swinl_bench.err" | tail -1 > "$OUT/${TAG}_swinl_bench.json"
 f=$(find "$OUT/prof_${TAG}" -name "full_kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_kernel_stats.csv"
 f=$(find "$OUT/prof_${TAG}" -name "head_kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_kernel_stats_head_only.csv"
-timeout 600 python "$ROOT/bench.py" --head bbox --steps 100 2> "$OUT/${TAG}_bbox_bench.err" | tail -1 > "$OUT/${TAG}_bbox_bench.json"
 # drop the bulky traces, keep the summaries
 find "$OUT/prof_${TAG}" -name "*_kernel_trace.csv" -delete
 bash "$ROOT/tools/pmc_traffic.sh" > "$OUT/pmc_${TAG}.log" 2>&1

@@ -163,9 +163,12 @@ class CrossHead2:
         # MFMA's); "fp32": the exact-fp32 MFMA kernels of rounds 1-5 (pn_gemm_f32,
         # pn_linear_res_ln_f32).  Everything else is fp32 MFMA either way.
         self.gemm_arithmetic = "bf16x3"
-        # bf16x3: the sampling kernel writes output_proj's A operand pre-split (True) instead of
-        # fp32 rows + a split pass (False); the same values either way
-        self.msda_s3_out = True
+        # bf16x3: the sampling kernel can write output_proj's A operand pre-split (True) instead of
+        # fp32 rows + a split pass (False): the same values either way (tested bit for bit), but
+        # its scattered 16-byte stores cost the L1-bound kernel 8 us per layer where the split
+        # pass costs 12, and under the pipeline the step is the same (221.1 vs 219.7 images/s,
+        # labnotes R6.5): off
+        self.msda_s3_out = False
         self.init_weights()
 
     # ------------------------------------------------------------------ params

@@ -52,8 +52,9 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 # (csrc/gemm_s3.hip); hip.py's flop count for them is the fp32-equivalent 2 M N K
 BF16X3_KERNELS = ("k_gemm_s3", "k_gemm_s3<ln>")
 GEMM_ARITHMETIC = {
-    "bf16x3": "encoder GEMMs: fp32 = 3 x bf16 exact split, 6 products, fp32 accumulate "
-              "(csrc/gemm_s3.hip); everything else: exact-fp32 MFMA",
+    "bf16x3": "pixel-decoder encoder GEMMs (and a Swin backbone's block GEMMs): fp32 = 3 x bf16 "
+              "exact split, 6 products, fp32 accumulate (csrc/gemm_s3.hip); everything else: "
+              "exact-fp32 MFMA",
     "fp32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere"}
 HBM_KERNELS = ("k_msda",)
 
@@ -391,6 +392,7 @@ def main():
             scfg = swin_backbone_cfg(swin)
             scfg.pop("type")
             backbone, bname = SwinTransformerHip(**scfg).to(dev), "Swin-%s" % swin
+            backbone.gemm_arithmetic = args.gemm_arithmetic     # (its block GEMMs: same switch)
         else:
             backbone, bname = ResNet50Hip().to(dev), "ResNet-50"
             for kv in args.bb_set:
@@ -1247,12 +1249,16 @@ def main():
             # the same pipelined steps with the encoder on the exact-fp32 MFMA kernels of rounds
             # 1-5 (one flag away: head.gemm_arithmetic = "fp32")
             head.gemm_arithmetic = "fp32"
+            if hasattr(backbone, "gemm_arithmetic"):
+                backbone.gemm_arithmetic = "fp32"
             for _ in range(2 * args.depth):      # (graphs are re-captured for the new setting)
                 step()
             drain()
             n = min(args.steps, 40)
             dt = timed(n)
             head.gemm_arithmetic = "bf16x3"
+            if hasattr(backbone, "gemm_arithmetic"):
+                backbone.gemm_arithmetic = "bf16x3"
             for _ in range(2 * args.depth):
                 step()
             drain()

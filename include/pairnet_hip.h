@@ -172,6 +172,11 @@ int pn_layernorm_f32(const float* x, const float* gamma, const float* beta,
  * block, the output norm of every stage). */
 int pn_layernorm_rows_f32(const float* x, int64_t ldx, const float* gamma, const float* beta,
                           float* y, int64_t ldy, int64_t rows, int C, float eps, void* stream);
+/* The same LayerNorm written as an S3 operand [rows x C] (three bf16 planes, pn_gemm_s3_f32's A:
+ * the Swin blocks' norm1 / norm2 in front of the qkv / FFN GEMMs); C % 16 == 0.  Rows of the last
+ * 32-row block beyond `rows` are not written (the GEMM never stores what it computes from them). */
+int pn_layernorm_rows_s3_f32(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                             void* y_s3, int64_t rows, int C, float eps, void* stream);
 
 /* Swin patch merging up to its Linear: x [B][H*W][C] -> y [B][H2*W2][4C], H2 = ceil(H/2),
  * row (b, y2, x2) = LayerNorm_4C([x(2y2,2x2) | x(2y2,2x2+1) | x(2y2+1,2x2) | x(2y2+1,2x2+1)])
@@ -747,8 +752,12 @@ typedef struct pn_gemm_s3_desc {
   void* CS_pos;   const float* pos;  int32_t pos_rows;   /* pos [pos_rows][N] fp32 */
   const void* res_s3;  const float* gamma;  const float* beta;  float eps;
   int32_t flags;                                 /* PN_GEMM_S3_* (tuning / tests), else 0 */
+  /* plain epilogue only (round 6, the Swin blocks): out = act(sum + bias) + res[m][n]; act 0 = `relu`
+   * decides, 1 ReLU, 2 exact (erf) GELU; res fp32 rows [M][ldres] or NULL */
+  int32_t act;  const float* res;  int64_t ldres;
 } pn_gemm_s3_desc;
 #define PN_GEMM_S3_TILE96 1   /* force the 96 x 256 tile where the 192 x 256 one would be taken */
+#define PN_GEMM_S3_TILE192 2  /* force the 192 x 256 tile (N >= 512, plain epilogue) whatever its tile count */
 int pn_gemm_s3_f32(const pn_gemm_s3_desc* d, void* stream);
 
 #ifdef __cplusplus

@@ -109,9 +109,58 @@ struct s3_args {
   const uint4* W; const float* bias;
   float* C; int64_t ldc; uint4* CS; uint4* CSP;
   const uint4* RES; const float* gamma; const float* beta; const float* pos; int pos_rows; float eps;
-  int M, N, K, relu;
+  int M, N, K, relu;      // relu: activation 0 none, 1 ReLU, 2 exact (erf) GELU
+  const float* res; int64_t ldres;   // plain epilogue: out = act(acc + bias) + res[m][n] (fp32 rows)
   int nout;      // columns of the S3 outputs' rows (N, or the whole row when N is a column range)
 };
+
+// One 32 x 32 accumulator block's plain epilogue (bias, ReLU, fp32 rows and / or S3 pieces): the
+// accumulator is the TRANSPOSED block (lane l: output row rb * 32 + l % 32; register r: column
+// n0 + (r & 3) + 8 (r >> 2) + 4 (l >> 5)); four v_permlane32_swap per 16 columns give each lane 8
+// consecutive columns, the S3 piece order.
+__device__ __forceinline__ void s3_block_epilogue(const f32x16& acc, const s3_args& p, int rb, int n0,
+                                                  int lane) {
+  const int li = lane & 31, lh = lane >> 5, row = rb * 32 + li;
+  const int KBo = p.nout >> 4;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * j + i]),
+                                                       __float_as_uint(acc[8 * j + 4 + i]), false, false);
+      v[i] = __uint_as_float(sw[0]);
+      v[4 + i] = __uint_as_float(sw[1]);
+    }
+    if (p.bias) {
+      const float4 b0 = ld4(p.bias + n0 + 16 * j + 8 * lh), b1 = ld4(p.bias + n0 + 16 * j + 8 * lh + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (p.relu == 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+    } else if (p.relu == 2) {            // [3P] nn.GELU (erf form), as pn_gemm_f32's
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = 0.5f * v[i] * (1.f + erff(v[i] * 0.70710678118654752f));
+    }
+    if (p.res) {                         // the block's shortcut (`x = x + proj(...)`)
+      const float* rp = p.res + (int64_t)min(row, p.M - 1) * p.ldres + n0 + 16 * j + 8 * lh;
+      const float4 r0 = ld4(rp), r1 = ld4(rp + 4);
+      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    }
+    if (p.C && row < p.M) {
+      float* c = p.C + (int64_t)row * p.ldc + n0 + 16 * j + 8 * lh;
+      st4(c, make_float4(v[0], v[1], v[2], v[3]));
+      st4(c + 4, make_float4(v[4], v[5], v[6], v[7]));
+    }
+    if (p.CS) {
+      s3_frag q0, q1, q2;
+      s3_split8(v, q0, q1, q2);
+      uint4* o = p.CS + ((int64_t)rb * KBo + (n0 >> 4) + j) * 192 + lane;
+      o[0] = q0.u; o[64] = q1.u; o[128] = q2.u;
+    }
+  }
+}
 
 // LN: the row epilogue out = LayerNorm(acc + bias + residual) (N == 256, one column tile)
 #ifndef S3_LATE_B
@@ -277,8 +326,16 @@ __global__ __launch_bounds__(512, 1) void k_gemm_s3(const s3_args p) {
   }
 
   // ---- epilogue, in registers ----
-  const int li = lane & 31, lh = lane >> 5;
   const int n0 = tn * 256 + wave * 32;               // this wave's 32 columns
+  if (!LN) {
+    if (n0 < N) {
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+        if (rb0 + m < RB) s3_block_epilogue(acc[m], p, rb0 + m, n0, lane);
+    }
+    return;
+  }
+  const int li = lane & 31, lh = lane >> 5;
   const bool cols_ok = n0 < N;                       // N % 32 == 0: a wave is all in or all out
   // v[m][j][i]: row (rb0 + m) * 32 + li, column n0 + 16 j + 8 lh + i  (after the swaps)
   float v[MB][2][8];
@@ -416,46 +473,6 @@ __global__ __launch_bounds__(512, 1) void k_gemm_s3(const s3_args p) {
         uint4* o = p.CSP + piece;
         o[0] = q0.u; o[64] = q1.u; o[128] = q2.u;
       }
-    }
-  }
-}
-
-// One 32 x 32 accumulator block's plain epilogue (bias, ReLU, fp32 rows and / or S3 pieces): the
-// accumulator is the TRANSPOSED block (lane l: output row rb * 32 + l % 32; register r: column
-// n0 + (r & 3) + 8 (r >> 2) + 4 (l >> 5)); four v_permlane32_swap per 16 columns give each lane 8
-// consecutive columns, the S3 piece order.
-__device__ __forceinline__ void s3_block_epilogue(const f32x16& acc, const s3_args& p, int rb, int n0,
-                                                  int lane) {
-  const int li = lane & 31, lh = lane >> 5, row = rb * 32 + li;
-  const int KBo = p.nout >> 4;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    float v[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * j + i]),
-                                                       __float_as_uint(acc[8 * j + 4 + i]), false, false);
-      v[i] = __uint_as_float(sw[0]);
-      v[4 + i] = __uint_as_float(sw[1]);
-    }
-    if (p.bias) {
-      const float4 b0 = ld4(p.bias + n0 + 16 * j + 8 * lh), b1 = ld4(p.bias + n0 + 16 * j + 8 * lh + 4);
-      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-    }
-    if (p.relu) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
-    }
-    if (p.C && row < p.M) {
-      float* c = p.C + (int64_t)row * p.ldc + n0 + 16 * j + 8 * lh;
-      st4(c, make_float4(v[0], v[1], v[2], v[3]));
-      st4(c + 4, make_float4(v[4], v[5], v[6], v[7]));
-    }
-    if (p.CS) {
-      s3_frag q0, q1, q2;
-      s3_split8(v, q0, q1, q2);
-      uint4* o = p.CS + ((int64_t)rb * KBo + (n0 >> 4) + j) * 192 + lane;
-      o[0] = q0.u; o[64] = q1.u; o[128] = q2.u;
     }
   }
 }
@@ -671,20 +688,39 @@ extern "C" int pn_gemm_s3_f32(const pn_gemm_s3_desc* d, void* stream) {
   const bool ln = d->gamma != nullptr;
   if (ln && (d->N != 256 || !d->beta || d->relu)) return PN_BAD_ARG;
   if (!ln && d->res_s3) return PN_BAD_ARG;
+  if (d->res && (ln || d->ldres % 4 || d->ldres < d->N)) return PN_BAD_ARG;
+  if (d->act < 0 || d->act > 2 || (ln && d->act)) return PN_BAD_ARG;
   s3_args a;
   a.A = (const uint4*)d->A; a.A2 = (const uint4*)d->A2; a.a2_from_tile = d->A2 ? d->a2_from_col / 256 : 0;
   a.W = (const uint4*)d->W; a.bias = d->bias;
   a.C = d->C; a.ldc = d->ldc; a.CS = (uint4*)d->CS; a.CSP = (uint4*)d->CS_pos;
   a.RES = (const uint4*)d->res_s3; a.gamma = d->gamma; a.beta = d->beta; a.pos = d->pos;
   a.pos_rows = d->pos_rows; a.eps = d->eps;
-  a.M = d->M; a.N = d->N; a.K = d->K; a.relu = d->relu; a.nout = d->N;
+  a.M = d->M; a.N = d->N; a.K = d->K; a.relu = d->act ? d->act : d->relu; a.nout = d->N;
+  a.res = d->res; a.ldres = d->ldres;
   // columns beyond the last whole 256-column tile: at most 64 of them go to the narrow kernel
   // (a whole tile for 32 columns would run 7 of its 8 waves empty)
   const int rem = d->N % 256;
   const bool narrow = !ln && !d->CS_pos && d->N > 256 && rem > 0 && rem <= 64;
   const int RB = (d->M + 31) / 32, mt = (RB + 2) / 3;
-  // two or more column tiles: the 192-row tile whose row groups share W
-  const bool wide = !ln && !d->CS_pos && (d->N - (narrow ? rem : 0)) >= 512 && !(d->flags & PN_GEMM_S3_TILE96);
+  // two or more column tiles: the 192-row tile whose row groups share W -- unless its tile count
+  // quantises worse on the chip's CUs than the 96-row tile's (rounds x phases x measured cycles
+  // per phase: 1 300 with shared W, 1 550 without; labnotes R6.2)
+  bool wide = !ln && !d->CS_pos && (d->N - (narrow ? rem : 0)) >= 512 && !(d->flags & PN_GEMM_S3_TILE96);
+  if (wide && !(d->flags & PN_GEMM_S3_TILE192)) {
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    }
+    const int64_t ntm = (d->N - (narrow ? rem : 0)) / 256, kb = d->K / 16;
+    const int64_t rb = (d->M + 31) / 32;
+    const int64_t t_wide = (((rb + 5) / 6 * ntm + cus - 1) / cus) * (2 * kb + 1) * 1300;
+    const int64_t t_96 = (((rb + 2) / 3 * ntm + cus - 1) / cus) * (kb + 1) * 1550;
+    wide = t_wide <= t_96;
+  }
   if (narrow) {
     a.N = d->N - rem;                       // the main launch sees only the whole tiles ...
     const int nt = a.N / 256;

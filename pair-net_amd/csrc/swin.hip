@@ -8,6 +8,7 @@
 //                    partition and their inverses are index arithmetic, not copies
 // Token maps are channel-last rows [B][H*W][C] throughout.
 #include "common.h"
+#include "s3_common.h"
 
 #define LN_MAXV 12  // float4 per lane: C <= 64 * 4 * 12 = 3072
 
@@ -17,7 +18,10 @@ struct MergeP { int H, W, H2, W2, C; };
 // MERGE: row (b, y2, x2) = [x(2y2, 2x2) | x(2y2, 2x2+1) | x(2y2+1, 2x2) | x(2y2+1, 2x2+1)],
 // zeros beyond an odd map's edge (the reference pads before nn.Unfold); gamma / beta are
 // expected in this neighbour-major order.
-template <bool MERGE>
+// S3OUT: y is an S3 operand [rows x C] (csrc/gemm_s3.hip: the qkv / FFN GEMM's A operand written
+// pre-split): even lanes take their neighbour's four channels and write the three 16-byte plane
+// pieces of 8 consecutive channels of this row.
+template <bool MERGE, bool S3OUT = false>
 __global__ __launch_bounds__(256) void k_ln_rows(const float* __restrict__ x, int64_t ldx,
                                                  const float* __restrict__ g,
                                                  const float* __restrict__ b,
@@ -68,12 +72,39 @@ __global__ __launch_bounds__(256) void k_ln_rows(const float* __restrict__ x, in
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = i * 256 + lane * 4;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < nv && c < C) {
       const float4 gg = ld4(g + c), bb = ld4(b + c);
-      st4(y + row * ldy + c, make_float4(v[i].x * rstd * gg.x + bb.x, v[i].y * rstd * gg.y + bb.y,
-                                         v[i].z * rstd * gg.z + bb.z, v[i].w * rstd * gg.w + bb.w));
+      o = make_float4(v[i].x * rstd * gg.x + bb.x, v[i].y * rstd * gg.y + bb.y,
+                      v[i].z * rstd * gg.z + bb.z, v[i].w * rstd * gg.w + bb.w);
+      if (!S3OUT) st4(y + row * ldy + c, o);
+    }
+    if (S3OUT) {
+      if (i >= nv) continue;                 // (wave-uniform)
+      const float4 nb = make_float4(__shfl_xor(o.x, 1, 64), __shfl_xor(o.y, 1, 64),
+                                    __shfl_xor(o.z, 1, 64), __shfl_xor(o.w, 1, 64));
+      if ((lane & 1) == 0 && c < C) {        // C % 8 == 0: the pair is in or out together
+        const float v8[8] = {o.x, o.y, o.z, o.w, nb.x, nb.y, nb.z, nb.w};
+        s3_frag q0, q1, q2;
+        s3_split8(v8, q0, q1, q2);
+        uint4* dst = reinterpret_cast<uint4*>(y) + ((row >> 5) * (C >> 4) + (c >> 4)) * 192 +
+                     ((c >> 3) & 1) * 32 + (row & 31);
+        dst[0] = q0.u; dst[64] = q1.u; dst[128] = q2.u;
+      }
     }
   }
+}
+
+extern "C" int pn_layernorm_rows_s3_f32(const float* x, int64_t ldx, const float* gamma,
+                                        const float* beta, void* y_s3, int64_t rows, int C,
+                                        float eps, void* stream) {
+  if (!x || !gamma || !beta || !y_s3 || rows <= 0 || C <= 0 || (C & 15) || C > 256 * LN_MAXV ||
+      ldx < C || (ldx & 3))
+    return PN_BAD_ARG;
+  if (((uintptr_t)x | (uintptr_t)y_s3 | (uintptr_t)gamma | (uintptr_t)beta) & 15) return PN_BAD_ARG;
+  hipLaunchKernelGGL((k_ln_rows<false, true>), dim3(pn_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                     x, ldx, gamma, beta, (float*)y_s3, 0, rows, C, eps, MergeP{});
+  return PN_LAUNCH_CHECK();
 }
 
 extern "C" int pn_layernorm_rows_f32(const float* x, int64_t ldx, const float* gamma,

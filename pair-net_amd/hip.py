@@ -47,7 +47,8 @@ class GemmS3Desc(C.Structure):
                 ("C", _vp), ("ldc", _i64),
                 ("CS", _vp),
                 ("CS_pos", _vp), ("pos", _vp), ("pos_rows", _i32),
-                ("res_s3", _vp), ("gamma", _vp), ("beta", _vp), ("eps", _f32), ("flags", _i32)]
+                ("res_s3", _vp), ("gamma", _vp), ("beta", _vp), ("eps", _f32), ("flags", _i32),
+                ("act", _i32), ("res", _vp), ("ldres", _i64)]
 
 
 _SIGS = {
@@ -70,6 +71,7 @@ _SIGS = {
     "pn_winograd_f43_input_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_winograd_f43_output_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pn_layernorm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "pn_layernorm_rows_s3_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "pn_layernorm_rows_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp]),
     "pn_patch_merge_ln_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "pn_patch_im2col4_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
@@ -549,7 +551,7 @@ def s3_join(s3, out):
 
 def gemm_s3(a, w, M, N, K, *, bias=None, relu=False, out=None, out_s3=None, out_s3_pos=None,
             pos=None, a2=None, a2_from_col=0, res_s3=None, gamma=None, beta=None, eps=1e-5,
-            tile96=False):
+            tile96=False, tile192=False, gelu=False, res=None):
     """fp32 GEMM on the bf16 matrix pipe from pre-split operands (csrc/gemm_s3.hip):
     out = act(a @ w.T + bias), or LayerNorm(a @ w.T + bias + res) * gamma + beta (N == 256).
     a, a2, w, res_s3, out_s3, out_s3_pos are S3 buffers; out is 2-D fp32 rows."""
@@ -568,7 +570,12 @@ def gemm_s3(a, w, M, N, K, *, bias=None, relu=False, out=None, out_s3=None, out_
         assert pos.numel() == (pr + 31) // 32 * 32 * N
         d.pos, d.pos_rows = _ptr(pos), pr
     d.res_s3, d.gamma, d.beta, d.eps = _ptr(res_s3), _ptr(gamma), _ptr(beta), eps
-    d.flags = 1 if tile96 else 0     # PN_GEMM_S3_TILE96
+    d.flags = (1 if tile96 else 0) | (2 if tile192 else 0)     # PN_GEMM_S3_TILE96 / _TILE192
+    d.act = 2 if gelu else 0
+    if res is not None:              # fp32 rows added after the activation (a block's shortcut)
+        Mr, ldr = _rowmajor(res)
+        assert Mr == M and res.shape[1] >= N
+        d.res, d.ldres = _ptr(res), ldr
     nbytes = 6.0 * (M * K + N * K) + (4.0 * M * N if out is not None else 0.0) + \
         6.0 * M * N * ((out_s3 is not None) + (out_s3_pos is not None) + (res_s3 is not None))
     name = "k_gemm_s3<ln>" if gamma is not None else "k_gemm_s3"    # (both tile forms)
@@ -585,6 +592,18 @@ def layernorm_rows(x, gamma, beta, out, eps=1e-5):
                    lambda: lib().pn_layernorm_rows_f32(_ptr(x), ldx, _ptr(gamma), _ptr(beta),
                                                        _ptr(out), ldo, rows, x.shape[1], eps,
                                                        _stream())), "pn_layernorm_rows_f32")
+
+
+def layernorm_rows_s3(x, gamma, beta, out_s3, eps=1e-5):
+    """LayerNorm over the last dim of 2-D rows, written as an S3 operand (three bf16 planes:
+    gemm_s3's A) instead of fp32 rows; C % 16 == 0."""
+    rows, ldx = _rowmajor(x)
+    Cc = x.shape[1]
+    assert out_s3.numel() >= s3_floats(rows, Cc)
+    _check(_launch("k_ln_rows<s3>", 0.0, 10.0 * rows * Cc,
+                   lambda: lib().pn_layernorm_rows_s3_f32(_ptr(x), ldx, _ptr(gamma), _ptr(beta),
+                                                          _ptr(out_s3), rows, Cc, eps, _stream())),
+           "pn_layernorm_rows_s3_f32")
 
 
 def patch_merge_ln(x, gamma, beta, out, B, H, W, C, eps=1e-5):

@@ -52,6 +52,11 @@ class SwinTransformerHip:
         self.init_weights(0)
         self.device, self.w, self._plans = None, None, PlanCache()
         self.grid_reserve = 0
+        # the blocks' four GEMMs (qkv, proj, FFN): "bf16x3" = on the bf16 matrix pipe from
+        # operands their producers store as three exact bf16 planes (csrc/gemm_s3.hip; norm1 /
+        # norm2 write S3, the FFN's hidden rows exist only as S3), "fp32" = the exact-fp32 MFMA
+        # kernels.  Patch embedding and patch merging stay fp32 either way.
+        self.gemm_arithmetic = "bf16x3"
 
     # ------------------------------------------------------------------ parameters
     def _param_shapes(self):
@@ -153,6 +158,12 @@ class SwinTransformerHip:
                 c = v.shape[-1] // 4
                 v = v.reshape(*v.shape[:-1], c, 4).transpose(-1, -2).reshape(v.shape)
             w[k] = v.contiguous().to(dev)
+        # the block GEMMs' weights as S3 operands, split once
+        for k in list(w):
+            if k.endswith(("qkv.weight", "proj.weight", "ffn.layers.0.0.weight", "ffn.layers.1.weight")):
+                s3 = torch.empty(hip.s3_floats(*w[k].shape), device=dev, dtype=torch.float32)
+                hip.s3_split(w[k], s3)
+                w[k + ".s3"] = s3
         self.w = w
 
     class _Plan:
@@ -232,6 +243,11 @@ class SwinTransformerHip:
         pl.ao = E(tok_c)
         pl.qkv = E(3 * tok_c)
         pl.hid = E(int(self.mlp_ratio) * tok_c)
+        # S3 operands (gemm_arithmetic == "bf16x3"): normalised tokens / attention output (shared:
+        # never live together), hidden rows; 1.5 x the fp32 size + the padding of the last row block
+        s3max = lambda mul: max(hip.s3_floats(B * hh * ww, mul * c)
+                                for (hh, ww), c in zip(pl.hw, self.num_features))
+        pl.xn_s3, pl.hid_s3 = E(s3max(1)), E(s3max(int(self.mlp_ratio)))
         pl.merged = E(max([B * hh * ww * 2 * c                 # [ceil-halved tokens][4C]
                            for (hh, ww), c in zip(pl.hw[1:], self.num_features[1:])] + [4]))
         pl.out = {i: E(B, pl.hw[i][0], pl.hw[i][1], self.num_features[i]) for i in self.out_indices}
@@ -269,8 +285,26 @@ class SwinTransformerHip:
             xn, ao = pl.xn[:n * C].view(n, C), pl.ao[:n * C].view(n, C)
             qkv = pl.qkv[:3 * n * C].view(n, 3 * C)
             hid = pl.hid[:n * int(self.mlp_ratio * C)].view(n, -1)
+            s3 = self.gemm_arithmetic == "bf16x3"
             for j in range(d):
                 p = "stages.%d.blocks.%d." % (i, j)
+                if s3:
+                    F = int(self.mlp_ratio * C)
+                    hip.layernorm_rows_s3(x, w[p + "norm1.weight"], w[p + "norm1.bias"], pl.xn_s3, EPS)
+                    hip.gemm_s3(pl.xn_s3, w[p + "attn.w_msa.qkv.weight.s3"], n, 3 * C, C,
+                                bias=w[p + "attn.w_msa.qkv.bias"], out=qkv)
+                    hip.window_attention(qkv, w[p + "attn.w_msa.qkv.bias"],
+                                         w[p + "attn.w_msa.relative_position_bias_table"], ao, B, h,
+                                         wd, C, nh, ws, 0 if j % 2 == 0 else ws // 2)
+                    hip.s3_split(ao, pl.xn_s3)
+                    hip.gemm_s3(pl.xn_s3, w[p + "attn.w_msa.proj.weight.s3"], n, C, C,
+                                bias=w[p + "attn.w_msa.proj.bias"], out=x, res=x)
+                    hip.layernorm_rows_s3(x, w[p + "norm2.weight"], w[p + "norm2.bias"], pl.xn_s3, EPS)
+                    hip.gemm_s3(pl.xn_s3, w[p + "ffn.layers.0.0.weight.s3"], n, F, C,
+                                bias=w[p + "ffn.layers.0.0.bias"], gelu=True, out_s3=pl.hid_s3)
+                    hip.gemm_s3(pl.hid_s3, w[p + "ffn.layers.1.weight.s3"], n, C, F,
+                                bias=w[p + "ffn.layers.1.bias"], out=x, res=x)
+                    continue
                 hip.layernorm_rows(x, w[p + "norm1.weight"], w[p + "norm1.bias"], xn, EPS)
                 lin(xn, p + "attn.w_msa.qkv.weight", p + "attn.w_msa.qkv.bias", qkv)
                 hip.window_attention(qkv, w[p + "attn.w_msa.qkv.bias"],

@@ -186,3 +186,39 @@ def test_sampling_kernel_writes_the_same_values_pre_split(hip):
         out = torch.zeros(hip.s3_floats(SN, 256), device=DEV)
         hip.msda(voa, 544, voa.view(-1)[256:], 544, out, 1, shapes, s3_out=True)
         assert torch.equal(joined(hip, out, SN, 256), ref.view(SN, 256))
+
+
+@pytest.mark.parametrize("rows,C", [(4200, 768), (100, 192), (33, 96), (1050, 1536), (70, 3072)])
+def test_layernorm_rows_written_pre_split(hip, rows, C):
+    """pn_layernorm_rows_s3_f32 (the Swin blocks' norm1 / norm2 in front of the bf16x3 GEMMs):
+    bit for bit the split of pn_layernorm_rows_f32's fp32 rows."""
+    x, g, b = G(rows, C, seed=40), G(C, seed=41) * 0.2 + 1.0, G(C, seed=42)
+    ref = torch.empty(rows, C, device=DEV)
+    hip.layernorm_rows(x, g, b, ref)
+    out = torch.zeros(hip.s3_floats(rows, C), device=DEV)
+    hip.layernorm_rows_s3(x, g, b, out)
+    assert torch.equal(joined(hip, out, rows, C), ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(4200, 768, 768), (4200, 3072, 768), (1050, 1536, 6144), (333, 192, 192),
+                                   (4200, 2304, 768)])
+def test_gelu_and_fp32_shortcut_epilogues(hip, M, N, K):
+    """The Swin blocks' forms: out = gelu(x W^T + b) (exact erf GELU, S3 output) and
+    out = x W^T + b + res with the shortcut read from fp32 rows, in place (`out is res`).
+    Against torch in fp64: 2e-5 of the output scale."""
+    x, w, b = G(M, K, seed=50), G(N, K, seed=51, scale=0.5 / math.sqrt(K)), G(N, seed=52)
+    x_s, w_s = s3(hip, x), s3(hip, w)
+    out_s = torch.empty(hip.s3_floats(M, N), device=DEV)
+    hip.gemm_s3(x_s, w_s, M, N, K, bias=b, gelu=True, out_s3=out_s)
+    ref = F.gelu(x.double() @ w.double().T + b.double())
+    got = joined(hip, out_s, M, N)
+    assert (got.double() - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item())
+    res = G(M, N, seed=53)
+    ref = x.double() @ w.double().T + b.double() + res.double()
+    inplace = res.clone()
+    hip.gemm_s3(x_s, w_s, M, N, K, bias=b, out=inplace, res=inplace)
+    assert (inplace.double() - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item())
+    for kw in (dict(tile96=True), dict(tile192=True), dict()):
+        sep = torch.empty(M, N, device=DEV)
+        hip.gemm_s3(x_s, w_s, M, N, K, bias=b, out=sep, res=res, **kw)
+        assert torch.equal(sep, inplace)

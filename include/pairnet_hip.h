@@ -204,6 +204,11 @@ int pn_window_attention_f32(const float* qkv, int64_t ldqkv, const float* qkv_bi
                             const float* bias_table, float* out, int64_t ldo, int B, int H,
                             int W, int C, int heads, int ws, int shift, float scale,
                             void* stream);
+/* The same with the output written as an S3 operand [B H W x C] (three bf16 planes: the proj GEMM's A
+ * operand of pn_gemm_s3_f32, pre-split; bit for bit the split of the fp32 form's output). */
+int pn_window_attention_s3_f32(const float* qkv, int64_t ldqkv, const float* qkv_bias,
+                               const float* bias_table, void* out_s3, int B, int H, int W, int C,
+                               int heads, int ws, int shift, float scale, void* stream);
 
 /* GroupNorm over channel-last x[b][HW][C] with G groups (+ optional ReLU); image b
  * starts at x + b*x_bstride / y + b*y_bstride (floats).  `partials` is caller
@@ -753,7 +758,8 @@ typedef struct pn_gemm_s3_desc {
   const void* res_s3;  const float* gamma;  const float* beta;  float eps;
   int32_t flags;                                 /* PN_GEMM_S3_* (tuning / tests), else 0 */
   /* plain epilogue only (round 6, the Swin blocks): out = act(sum + bias) + res[m][n]; act 0 = `relu`
-   * decides, 1 ReLU, 2 exact (erf) GELU; res fp32 rows [M][ldres] or NULL */
+   * decides, 1 ReLU, 2 exact (erf) GELU, 3 = relu(sum + bias + res) (ReLU after the shortcut: a
+   * ResNet bottleneck's last convolution); res fp32 rows [M][ldres] or NULL */
   int32_t act;  const float* res;  int64_t ldres;
 } pn_gemm_s3_desc;
 #define PN_GEMM_S3_TILE96 1   /* force the 96 x 256 tile where the 192 x 256 one would be taken */

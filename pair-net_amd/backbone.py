@@ -91,6 +91,14 @@ class ResNet50Hip:
         # narrowest 3x3 layer that takes the Winograd form (128: stages 2-4; 64 adds the three
         # K = 64 layers of stage 1 -- measured in round 4, LABNOTES.md 6.0-r4)
         self.wino_min_planes = 128
+        # each bottleneck's last 1x1 convolution (+ BN + shortcut + ReLU; N = 4 planes, K =
+        # planes) on the bf16 matrix pipe from a pre-split operand (csrc/gemm_s3.hip) for
+        # planes >= this; 0 = never (default): measured in round 6 with a split pass in front
+        # (the 3x3 convolution's transforms write fp32), same run: 223.5 images/s without,
+        # 218.4 / 221.2 / 222.2 from 64 / 128 / 256 planes on (labnotes R6.5) -- these GEMMs have
+        # K = 64..512 and 4 200- / 1 050-row maps: two to sixteen k-stages per tile and half-empty
+        # tile rounds
+        self.s3_conv3_min_planes = 0
 
     def _weights_version(self):
         return sum(p._version for p in self._params.values())
@@ -164,6 +172,12 @@ class ResNet50Hip:
                     if conv == "conv2" and co >= 64 and not (b == 0 and i > 0):
                         w[p + "conv2.wino"] = hip.winograd_weights(cw.to(dev))
                         w[p + "conv2.wino4"] = hip.winograd43_weights(cw.to(dev))
+        # conv3 (BN folded) as S3 operands for the bf16-pipe GEMM, split once
+        for k in list(w):
+            if k.endswith("conv3.w"):
+                s3 = torch.empty(hip.s3_floats(*w[k].shape), device=dev, dtype=torch.float32)
+                hip.s3_split(w[k], s3)
+                w[k + ".s3"] = s3
         self.w = w
         self._packed_version = self._weights_version()
 
@@ -217,7 +231,7 @@ class ResNet50Hip:
         return out
 
     def _plan(self, B, H, W, slot=0):
-        key = (B, H, W, slot, self.conv_algo, self.wino_min_planes)   # (a plan's graph bakes both in)
+        key = (B, H, W, slot, self.conv_algo, self.wino_min_planes, self.s3_conv3_min_planes)   # (a plan's graph bakes them in)
         if key in self._plans:
             return self._plans[key]
         if self.w is None:
@@ -262,6 +276,9 @@ class ResNet50Hip:
             else:
                 pl.f43.append(False)
         pl.wV, pl.wM = E(max(nwino, 4)), E(max(nwino, 4))   # Winograd transform planes
+        # the 3x3 convolution's output once more as an S3 operand (conv3's A, s3_conv3_min_planes)
+        pl.t2_s3 = E(max(hip.s3_floats(B * hw[1][0] * hw[1][1], planes)
+                         for hw, (planes, _) in zip(pl.hw, self.stages)))
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -376,9 +393,16 @@ class ResNet50Hip:
                     dst = pl.out[i]
                 else:
                     dst = pl.ping[i] if idt is not pl.ping[i] else pl.idt[i]
-                hip.linear(pl.t2[i].view(-1, planes), w[p + "conv3.w"], w[p + "conv3.b"],
-                           dst.view(-1, planes * 4), res=idt.view(-1, planes * 4),
-                           relu_after=True, scratch=pl.scratch)
+                if self.s3_conv3_min_planes and planes >= self.s3_conv3_min_planes:
+                    t2 = pl.t2[i].view(-1, planes)
+                    hip.s3_split(t2, pl.t2_s3)
+                    hip.gemm_s3(pl.t2_s3, w[p + "conv3.w.s3"], t2.shape[0], planes * 4, planes,
+                                bias=w[p + "conv3.b"], out=dst.view(-1, planes * 4),
+                                res=idt.view(-1, planes * 4), relu_after=True)
+                else:
+                    hip.linear(pl.t2[i].view(-1, planes), w[p + "conv3.w"], w[p + "conv3.b"],
+                               dst.view(-1, planes * 4), res=idt.view(-1, planes * 4),
+                               relu_after=True, scratch=pl.scratch)
                 x, cin = dst, planes * 4
         return tuple(o.permute(0, 3, 1, 2) for o in pl.out)
 

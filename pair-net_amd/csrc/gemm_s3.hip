@@ -109,7 +109,7 @@ struct s3_args {
   const uint4* W; const float* bias;
   float* C; int64_t ldc; uint4* CS; uint4* CSP;
   const uint4* RES; const float* gamma; const float* beta; const float* pos; int pos_rows; float eps;
-  int M, N, K, relu;      // relu: activation 0 none, 1 ReLU, 2 exact (erf) GELU
+  int M, N, K, relu;      // relu: activation 0 none, 1 ReLU, 2 exact (erf) GELU, 3 ReLU after the shortcut
   const float* res; int64_t ldres;   // plain epilogue: out = act(acc + bias) + res[m][n] (fp32 rows)
   int nout;      // columns of the S3 outputs' rows (N, or the whole row when N is a column range)
 };
@@ -147,6 +147,10 @@ __device__ __forceinline__ void s3_block_epilogue(const f32x16& acc, const s3_ar
       const float* rp = p.res + (int64_t)min(row, p.M - 1) * p.ldres + n0 + 16 * j + 8 * lh;
       const float4 r0 = ld4(rp), r1 = ld4(rp + 4);
       v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    }
+    if (p.relu == 3) {                   // ReLU AFTER the shortcut (a ResNet bottleneck's last conv)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
     }
     if (p.C && row < p.M) {
       float* c = p.C + (int64_t)row * p.ldc + n0 + 16 * j + 8 * lh;
@@ -689,7 +693,7 @@ extern "C" int pn_gemm_s3_f32(const pn_gemm_s3_desc* d, void* stream) {
   if (ln && (d->N != 256 || !d->beta || d->relu)) return PN_BAD_ARG;
   if (!ln && d->res_s3) return PN_BAD_ARG;
   if (d->res && (ln || d->ldres % 4 || d->ldres < d->N)) return PN_BAD_ARG;
-  if (d->act < 0 || d->act > 2 || (ln && d->act)) return PN_BAD_ARG;
+  if (d->act < 0 || d->act > 3 || (ln && d->act)) return PN_BAD_ARG;
   s3_args a;
   a.A = (const uint4*)d->A; a.A2 = (const uint4*)d->A2; a.a2_from_tile = d->A2 ? d->a2_from_col / 256 : 0;
   a.W = (const uint4*)d->W; a.bias = d->bias;

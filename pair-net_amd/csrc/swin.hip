@@ -197,6 +197,7 @@ struct WinP {
   int64_t ldqkv, ldo;
   int H, W, Hp, Wp, C, heads, ws, shift, nwx;
   float scale;
+  int s3_out;     // out is an S3 operand [B H W x C] (ldo ignored): the proj GEMM's A, pre-split
 };
 
 __global__ __launch_bounds__(512) void k_window_attn(const WinP p) {
@@ -348,6 +349,33 @@ __global__ __launch_bounds__(512) void k_window_attn(const WinP p) {
     }
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (p.s3_out) {
+    // the accumulator is a transposed 32 x 32 block (lane: one token, 16 of the head's channels):
+    // four v_permlane32_swap per 16 channels give the lane 8 consecutive ones = one S3 piece
+    // element (csrc/gemm_s3.hip); tokens of a window are not consecutive rows: 16-byte stores
+    const float inv = 1.f / l_tot;
+    const bool live = q_ok && qsrc >= 0;
+    const int row = live ? qsrc : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float v8[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[8 * j + i] * inv),
+                                                         __float_as_uint(o[8 * j + 4 + i] * inv), false, false);
+        v8[i] = __uint_as_float(sw[0]);
+        v8[4 + i] = __uint_as_float(sw[1]);
+      }
+      if (live) {
+        s3_frag q0, q1, q2;
+        s3_split8(v8, q0, q1, q2);
+        uint4* dst = reinterpret_cast<uint4*>(p.out) +
+                     ((int64_t)(row >> 5) * (p.C >> 4) + head * 2 + j) * 192 + lh * 32 + (row & 31);
+        dst[0] = q0.u; dst[64] = q1.u; dst[128] = q2.u;
+      }
+    }
+    return;
+  }
   if (!q_ok || qsrc < 0) return;
   const float inv = 1.f / l_tot;
   float* op = p.out + (int64_t)qsrc * p.ldo + head * 32;
@@ -357,10 +385,28 @@ __global__ __launch_bounds__(512) void k_window_attn(const WinP p) {
                                          o[4 * g + 2] * inv, o[4 * g + 3] * inv));
 }
 
+static int window_attention(const float* qkv, int64_t ldqkv, const float* qkv_bias,
+                            const float* bias_table, float* out, int64_t ldo, int B, int H, int W,
+                            int C, int heads, int ws, int shift, float scale, int s3_out,
+                            void* stream);
 extern "C" int pn_window_attention_f32(const float* qkv, int64_t ldqkv, const float* qkv_bias,
                                        const float* bias_table, float* out, int64_t ldo, int B,
                                        int H, int W, int C, int heads, int ws, int shift,
                                        float scale, void* stream) {
+  return window_attention(qkv, ldqkv, qkv_bias, bias_table, out, ldo, B, H, W, C, heads, ws, shift,
+                          scale, 0, stream);
+}
+extern "C" int pn_window_attention_s3_f32(const float* qkv, int64_t ldqkv, const float* qkv_bias,
+                                          const float* bias_table, void* out_s3, int B, int H,
+                                          int W, int C, int heads, int ws, int shift, float scale,
+                                          void* stream) {
+  return window_attention(qkv, ldqkv, qkv_bias, bias_table, (float*)out_s3, C, B, H, W, C, heads, ws,
+                          shift, scale, 1, stream);
+}
+static int window_attention(const float* qkv, int64_t ldqkv, const float* qkv_bias,
+                            const float* bias_table, float* out, int64_t ldo, int B, int H, int W,
+                            int C, int heads, int ws, int shift, float scale, int s3_out,
+                            void* stream) {
   if (!qkv || !qkv_bias || !bias_table || !out || B <= 0 || H <= 0 || W <= 0 || heads <= 0 ||
       C != heads * 32 || ws < 2 || ws * ws > WA_MAXN || shift < 0 || shift >= ws ||
       ldqkv < 3 * C || ldo < C || ((ldqkv | ldo) & 3))
@@ -370,7 +416,7 @@ extern "C" int pn_window_attention_f32(const float* qkv, int64_t ldqkv, const fl
   WinP p{};
   p.qkv = qkv; p.qkv_bias = qkv_bias; p.table = bias_table; p.out = out;
   p.ldqkv = ldqkv; p.ldo = ldo; p.H = H; p.W = W; p.C = C; p.heads = heads; p.ws = ws;
-  p.shift = shift; p.scale = scale;
+  p.shift = shift; p.scale = scale; p.s3_out = s3_out;
   p.Hp = (H + ws - 1) / ws * ws; p.Wp = (W + ws - 1) / ws * ws;
   p.nwx = p.Wp / ws;
   const int nt = (ws * ws + 31) / 32;

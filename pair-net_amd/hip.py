@@ -77,6 +77,7 @@ _SIGS = {
     "pn_patch_im2col4_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_window_attention_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64] + [_i32] * 7 +
                                 [_f32, _vp]),
+    "pn_window_attention_s3_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp] + [_i32] * 7 + [_f32, _vp]),
     "pn_groupnorm_nblk": (C.c_int, [_i64]),
     "pn_groupnorm_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32,
                                         _i32, _f32, _i32, _i64, _i64, _vp]),
@@ -551,7 +552,7 @@ def s3_join(s3, out):
 
 def gemm_s3(a, w, M, N, K, *, bias=None, relu=False, out=None, out_s3=None, out_s3_pos=None,
             pos=None, a2=None, a2_from_col=0, res_s3=None, gamma=None, beta=None, eps=1e-5,
-            tile96=False, tile192=False, gelu=False, res=None):
+            tile96=False, tile192=False, gelu=False, res=None, relu_after=False):
     """fp32 GEMM on the bf16 matrix pipe from pre-split operands (csrc/gemm_s3.hip):
     out = act(a @ w.T + bias), or LayerNorm(a @ w.T + bias + res) * gamma + beta (N == 256).
     a, a2, w, res_s3, out_s3, out_s3_pos are S3 buffers; out is 2-D fp32 rows."""
@@ -571,7 +572,7 @@ def gemm_s3(a, w, M, N, K, *, bias=None, relu=False, out=None, out_s3=None, out_
         d.pos, d.pos_rows = _ptr(pos), pr
     d.res_s3, d.gamma, d.beta, d.eps = _ptr(res_s3), _ptr(gamma), _ptr(beta), eps
     d.flags = (1 if tile96 else 0) | (2 if tile192 else 0)     # PN_GEMM_S3_TILE96 / _TILE192
-    d.act = 2 if gelu else 0
+    d.act = 3 if relu_after else 2 if gelu else 0
     if res is not None:              # fp32 rows added after the activation (a block's shortcut)
         Mr, ldr = _rowmajor(res)
         assert Mr == M and res.shape[1] >= N
@@ -636,6 +637,19 @@ def window_attention(qkv, qkv_bias, table, out, B, H, W, C, heads, ws, shift):
                                                          _ptr(table), _ptr(out), ldo, B, H, W, C,
                                                          heads, ws, shift, 32 ** -0.5, _stream())),
            "pn_window_attention_f32")
+
+
+def window_attention_s3(qkv, qkv_bias, table, out_s3, B, H, W, C, heads, ws, shift):
+    """window_attention() with the output as an S3 operand buffer (gemm_s3's A) instead of rows."""
+    n, ldq = _rowmajor(qkv)
+    assert n == B * H * W and qkv.shape[1] == 3 * C and out_s3.numel() >= s3_floats(n, C)
+    hp, wp = -(-H // ws) * ws, -(-W // ws) * ws
+    flops = 4.0 * B * hp * wp * (ws * ws) * C
+    _check(_launch("k_window_attn", flops, 18.0 * n * C,
+                   lambda: lib().pn_window_attention_s3_f32(_ptr(qkv), ldq, _ptr(qkv_bias), _ptr(table),
+                                                            _ptr(out_s3), B, H, W, C, heads, ws, shift,
+                                                            32 ** -0.5, _stream())),
+           "pn_window_attention_s3_f32")
 
 
 def groupnorm_nblk(hw):

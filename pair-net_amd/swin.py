@@ -57,6 +57,7 @@ class SwinTransformerHip:
         # norm2 write S3, the FFN's hidden rows exist only as S3), "fp32" = the exact-fp32 MFMA
         # kernels.  Patch embedding and patch merging stay fp32 either way.
         self.gemm_arithmetic = "bf16x3"
+        self.attn_s3_out = True      # bf16x3: window attention writes proj's operand pre-split
 
     # ------------------------------------------------------------------ parameters
     def _param_shapes(self):
@@ -293,10 +294,16 @@ class SwinTransformerHip:
                     hip.layernorm_rows_s3(x, w[p + "norm1.weight"], w[p + "norm1.bias"], pl.xn_s3, EPS)
                     hip.gemm_s3(pl.xn_s3, w[p + "attn.w_msa.qkv.weight.s3"], n, 3 * C, C,
                                 bias=w[p + "attn.w_msa.qkv.bias"], out=qkv)
-                    hip.window_attention(qkv, w[p + "attn.w_msa.qkv.bias"],
-                                         w[p + "attn.w_msa.relative_position_bias_table"], ao, B, h,
-                                         wd, C, nh, ws, 0 if j % 2 == 0 else ws // 2)
-                    hip.s3_split(ao, pl.xn_s3)
+                    if self.attn_s3_out:
+                        hip.window_attention_s3(qkv, w[p + "attn.w_msa.qkv.bias"],
+                                                w[p + "attn.w_msa.relative_position_bias_table"],
+                                                pl.xn_s3, B, h, wd, C, nh, ws,
+                                                0 if j % 2 == 0 else ws // 2)
+                    else:
+                        hip.window_attention(qkv, w[p + "attn.w_msa.qkv.bias"],
+                                             w[p + "attn.w_msa.relative_position_bias_table"], ao,
+                                             B, h, wd, C, nh, ws, 0 if j % 2 == 0 else ws // 2)
+                        hip.s3_split(ao, pl.xn_s3)
                     hip.gemm_s3(pl.xn_s3, w[p + "attn.w_msa.proj.weight.s3"], n, C, C,
                                 bias=w[p + "attn.w_msa.proj.bias"], out=x, res=x)
                     hip.layernorm_rows_s3(x, w[p + "norm2.weight"], w[p + "norm2.bias"], pl.xn_s3, EPS)

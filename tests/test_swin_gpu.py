@@ -122,6 +122,16 @@ def test_window_attention_matches_oracle(B, H, W, heads, ws, shift):
                          m.w_msa.relative_position_bias_table.data.t().contiguous().to(DEV), out, B, H, W, C, heads,
                          ws, shift)
     assert rel(out.view(B, H * W, C), want) < 2e-5
+    # the same launch writing the proj GEMM's operand pre-split (pn_window_attention_s3_f32):
+    # bit for bit the split of the fp32 rows
+    n = B * H * W
+    s3 = torch.zeros(hip.s3_floats(n, C), device=DEV)
+    hip.window_attention_s3(qkv.to(DEV), m.w_msa.qkv.bias.data.to(DEV),
+                            m.w_msa.relative_position_bias_table.data.t().contiguous().to(DEV), s3, B, H, W,
+                            C, heads, ws, shift)
+    back = torch.full((n, C), float("nan"), device=DEV)
+    hip.s3_join(s3, back)
+    assert torch.equal(back, out)
 
 
 CONFIGS = {

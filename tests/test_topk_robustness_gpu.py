@@ -9,8 +9,8 @@ implementations round differently.  This test measures the other case: plain see
 seeds at 256 x 320 and 2 at 800 x 1333, through the CPU oracle in fp32 and in fp64 and through
 the HIP path.  Per seed it records the smallest gap between consecutive top-k scores, the
 fp32-vs-fp64 noise of the scores, which of the three lists agree and the first differing rank,
-writes the table to gpurun_out/r05_topk_flip_rate.json (committed as
-profiles/r05_topk_flip_rate.json) and asserts the one property a correct implementation can
+writes the table to gpurun_out/r06_topk_flip_rate.json (committed as
+profiles/r06_topk_flip_rate.json; round 5 under the fp32 arithmetic: r05_...) and asserts the one property a correct implementation can
 promise: wherever the GPU list differs from the oracle's, the scores at that rank are closer
 to a neighbour than 4 x the measured noise.  Seeded weights, not trained ones.
 """
@@ -125,7 +125,7 @@ def test_topk_flip_rate_on_unseparated_seeded_weights():
         if not full:
             raise OSError("subset run: the committed record is written by the full set only")
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "r05_topk_flip_rate.json"), "w") as f:
+        with open(os.path.join(out, "r06_topk_flip_rate.json"), "w") as f:
             json.dump(summary, f, indent=1)
     except OSError:
         pass

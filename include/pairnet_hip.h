@@ -711,6 +711,23 @@ int pn_seesaw_mean_f32(const float* logits, int64_t ld, const int64_t* target,
 int pn_bce_posw_mean_f32(const float* logits, const float* target, float* out /* [2] */, int64_t n,
                          float loss_weight, void* stream);
 
+/* SURVEY 8 f-4, first backward slice: the gradients of the three reductions above with respect to
+ * their logits (`loss_sub_cls` / `loss_obj_cls`, `loss_r_cls`, `loss_match`; pairnet_head.py:518-552):
+ *   CE      g[r][c] = loss_weight / n * class_weight[y] * (softmax(x_r)[c] - [c == y])
+ *   Seesaw  g[r][j] = loss_weight / n * (softmax(x'_r)[j] - [j == y]), the seesaw weights constants of
+ *           the backward pass ([3P] seesaw_ce_loss uses softmax(cls_score.detach()))
+ *   BCE     g[i]    = loss_weight / n * ((1 - t) - (1 + (pos_weight - 1) t) sigmoid(-x))
+ * rows with target < 0 get zeros; n = rows with target >= 0 (CE, Seesaw) / all elements (BCE).
+ * Checked against autograd through the reference-pinned loss oracle (tests/test_losses_gpu.py). */
+int pn_ce_mean_grad_f32(const float* logits, int64_t ld, const int64_t* target,
+                        const float* class_weight /* [C] or NULL */, float* grad, int64_t ldg,
+                        int rows, int C, float loss_weight, void* stream);
+int pn_seesaw_mean_grad_f32(const float* logits, int64_t ld, const int64_t* target,
+                            const float* cum_samples, float* grad, int64_t ldg, int rows, int C,
+                            float p, float q, float eps, float loss_weight, void* stream);
+int pn_bce_posw_mean_grad_f32(const float* logits, const float* target, float* grad, int64_t n,
+                              float loss_weight, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * fp32 GEMMs on the bf16 matrix pipe from PRE-SPLIT operands (csrc/gemm_s3.hip, round 6)
  *

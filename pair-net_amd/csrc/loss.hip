@@ -346,3 +346,136 @@ extern "C" int pn_bce_posw_mean_f32(const float* logits, const float* target, fl
                      out, n, loss_weight);
   return PN_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Gradients of the three loss reductions above with respect to their logits (the
+// first backward slice: d loss / d {sub, obj, rel, importance}; pairnet_head.py:518-552).  Each is
+// the analytic derivative of the forward kernel beside it, in the same row / lane layout; rows
+// the reference masks out (target < 0) get zeros.
+//   CE:      g[r][c] = lw / n * w[y] * (softmax(x_r)[c] - [c == y])
+//   Seesaw:  g[r][j] = lw / n * (softmax(x'_r)[j] - [j == y]);  the seesaw weights are constants of
+//            the backward pass ([3P] seesaw_ce_loss takes softmax(cls_score.detach()))
+//   BCE:     g[i]    = lw / n * ((1 - t) - (1 + (pw - 1) t) sigmoid(-x))
+__global__ __launch_bounds__(256) void k_ce_mean_grad(const float* __restrict__ logits, int64_t ld,
+                                                      const int64_t* __restrict__ target,
+                                                      const float* __restrict__ class_weight,
+                                                      float* __restrict__ grad, int64_t ldg,
+                                                      int rows, int C, float loss_weight) {
+  __shared__ int kept;
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int r = 0; r < rows; ++r) n += target[r] >= 0;
+    kept = n;
+  }
+  __syncthreads();
+  const float scale = kept ? loss_weight / (float)kept : 0.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < rows; r += 4) {
+    const int64_t y = target[r];
+    float* gr = grad + (int64_t)r * ldg;
+    if (y < 0) {                                    // (wave-uniform)
+      for (int c = lane; c < C; c += 64) gr[c] = 0.f;
+      continue;
+    }
+    const float* xr = logits + (int64_t)r * ld;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, xr[c]);
+    m = wave_max(m);
+    float d = 0.f;
+    for (int c = lane; c < C; c += 64) d += expf(xr[c] - m);
+    d = wave_sum(d);
+    const float w = scale * (class_weight ? class_weight[y] : 1.f);
+    for (int c = lane; c < C; c += 64)
+      gr[c] = w * (expf(xr[c] - m) / d - (c == (int)y ? 1.f : 0.f));
+  }
+}
+
+extern "C" int pn_ce_mean_grad_f32(const float* logits, int64_t ld, const int64_t* target,
+                                   const float* class_weight, float* grad, int64_t ldg, int rows,
+                                   int C, float loss_weight, void* stream) {
+  if (!logits || !target || !grad || rows <= 0 || rows > LOSS_MAX_ROWS || C <= 0 || ld < C || ldg < C)
+    return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_ce_mean_grad, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, ld, target,
+                     class_weight, grad, ldg, rows, C, loss_weight);
+  return PN_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void k_seesaw_mean_grad(const float* __restrict__ logits, int64_t ld,
+                                                          const int64_t* __restrict__ target,
+                                                          const float* __restrict__ cum,
+                                                          float* __restrict__ grad, int64_t ldg,
+                                                          int rows, int C, float p, float q,
+                                                          float eps, float loss_weight) {
+  __shared__ int kept;
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int r = 0; r < rows; ++r) n += target[r] >= 0;
+    kept = n;
+  }
+  __syncthreads();
+  const float scale = kept ? loss_weight / (float)kept : 0.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < rows; r += 4) {
+    const int64_t y = target[r];
+    const bool on = lane < C;
+    float g = 0.f;
+    if (y >= 0) {
+      const float xv = on ? logits[(int64_t)r * ld + lane] : -INFINITY;
+      const float m = wave_max(xv);
+      const float e = on ? expf(xv - m) : 0.f;
+      const float s = e / wave_sum(e);
+      const float sy = __shfl(s, (int)y, 64);
+      float w = 1.f;
+      if (p > 0.f) {
+        const float cj = fmaxf(on ? cum[lane] : 1.f, 1.f), cy = fmaxf(cum[y], 1.f);
+        const float ratio = cj / cy;
+        if (ratio < 1.f) w *= powf(ratio, p);
+      }
+      if (q > 0.f) {
+        const float ratio = s / fmaxf(sy, eps);
+        if (ratio > 1.f) w *= powf(ratio, q);
+      }
+      const float xs = on ? (lane == (int)y ? xv : xv + logf(w)) : -INFINITY;
+      const float m2 = wave_max(xs);
+      const float e2 = on ? expf(xs - m2) : 0.f;
+      g = scale * (e2 / wave_sum(e2) - (lane == (int)y ? 1.f : 0.f));
+    }
+    if (on) grad[(int64_t)r * ldg + lane] = g;
+  }
+}
+
+extern "C" int pn_seesaw_mean_grad_f32(const float* logits, int64_t ld, const int64_t* target,
+                                       const float* cum_samples, float* grad, int64_t ldg, int rows,
+                                       int C, float p, float q, float eps, float loss_weight,
+                                       void* stream) {
+  if (!logits || !target || !cum_samples || !grad || rows <= 0 || rows > LOSS_MAX_ROWS || C <= 0 ||
+      C > 64 || ld < C || ldg < C)
+    return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_seesaw_mean_grad, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, ld,
+                     target, cum_samples, grad, ldg, rows, C, p, q, eps, loss_weight);
+  return PN_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(1024) void k_bce_posw_mean_grad(const float* __restrict__ x,
+                                                             const float* __restrict__ t,
+                                                             float* __restrict__ grad, int64_t n,
+                                                             float loss_weight) {
+  __shared__ float red[16];
+  float cnt = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) cnt += t[i] > 0.f ? 1.f : 0.f;
+  cnt = block_sum(cnt, red);
+  const float pw = (float)n / cnt, scale = loss_weight / (float)n;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float xv = x[i], tv = t[i];
+    const float sneg = 1.f / (1.f + expf(xv));                // sigmoid(-x)
+    grad[i] = scale * ((1.f - tv) - (1.f + (pw - 1.f) * tv) * sneg);
+  }
+}
+
+extern "C" int pn_bce_posw_mean_grad_f32(const float* logits, const float* target, float* grad,
+                                         int64_t n, float loss_weight, void* stream) {
+  if (!logits || !target || !grad || n <= 0) return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_bce_posw_mean_grad, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits,
+                     target, grad, n, loss_weight);
+  return PN_LAUNCH_CHECK();
+}

@@ -101,6 +101,10 @@ _SIGS = {
     "pn_seesaw_mean_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32,
                                      _vp]),
     "pn_bce_posw_mean_f32": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp]),
+    "pn_ce_mean_grad_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
+    "pn_seesaw_mean_grad_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32,
+                                          _f32, _f32, _vp]),
+    "pn_bce_posw_mean_grad_f32": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp]),
     "pn_msda_loc_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_msda_bwd_f32": (C.c_int, [_vp, _i64] + [_vp] * 8 + [_i32, _i32, _i32, _i32, _vp]),
     "pn_gather_probe_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
@@ -1110,6 +1114,30 @@ def seesaw_mean(logits, target, cum_samples, out, p, q, eps, loss_weight):
     _check(lib().pn_seesaw_mean_f32(_ptr(logits), ld, _ptr(target, torch.int64), _ptr(cum_samples),
                                     _ptr(out), rows, logits.shape[1], p, q, eps, loss_weight,
                                     _stream()), "pn_seesaw_mean_f32")
+
+
+def ce_mean_grad(logits, target, class_weight, grad, loss_weight):
+    rows, ld = _rowmajor(logits)
+    rg, ldg = _rowmajor(grad)
+    assert rg == rows and grad.shape[1] == logits.shape[1]
+    _check(lib().pn_ce_mean_grad_f32(_ptr(logits), ld, _ptr(target, torch.int64), _ptr(class_weight),
+                                     _ptr(grad), ldg, rows, logits.shape[1], loss_weight, _stream()),
+           "pn_ce_mean_grad_f32")
+
+
+def seesaw_mean_grad(logits, target, cum_samples, grad, p, q, eps, loss_weight):
+    rows, ld = _rowmajor(logits)
+    rg, ldg = _rowmajor(grad)
+    assert rg == rows and grad.shape[1] == logits.shape[1]
+    _check(lib().pn_seesaw_mean_grad_f32(_ptr(logits), ld, _ptr(target, torch.int64),
+                                         _ptr(cum_samples), _ptr(grad), ldg, rows, logits.shape[1],
+                                         p, q, eps, loss_weight, _stream()), "pn_seesaw_mean_grad_f32")
+
+
+def bce_posw_mean_grad(logits, target, grad, loss_weight):
+    assert grad.numel() == logits.numel()
+    _check(lib().pn_bce_posw_mean_grad_f32(_ptr(logits), _ptr(target), _ptr(grad), logits.numel(),
+                                           loss_weight, _stream()), "pn_bce_posw_mean_grad_f32")
 
 
 def bce_posw_mean(logits, target, out, loss_weight):

@@ -4,7 +4,9 @@
 (pairnet/models/relation_heads/pairnet_head.py:419-430) -- the two output dicts of `forward`
 and the per-image ground truth -- and returns the same four terms (`loss_r_cls`,
 `loss_sub_cls`, `loss_obj_cls`, `loss_match`, :470-477) as 0-dim device tensors: the VALUES
-(validation losses).  No backward, no optimizer: training is outside SURVEY.md 8.
+(validation losses) and, with `grads={}`, the gradients of their sum with respect to the four
+logit tensors they are computed from (round 6: the first backward slice; nothing differentiates
+through the head yet, no optimizer: training is outside SURVEY.md 8).
 
 Where the arithmetic runs (csrc/loss.hip, one small kernel each):
   pn_point_sample_f32       [3P] mmcv point_sample of the Q mask logit maps and the ground-truth
@@ -146,7 +148,8 @@ class CrossHead2Loss:
     @torch.no_grad()
     @hip.on_device
     def loss(self, all_cls_scores, all_mask_preds, gt_rels_list, gt_bboxes_list, gt_labels_list,
-             gt_masks_list, img_metas, gt_bboxes_ignore=None, point_coords=None, trace=None):
+             gt_masks_list, img_metas, gt_bboxes_ignore=None, point_coords=None, trace=None,
+             grads=None):
         """`point_coords`: optional list of (1, num_points, 2) tensors, one per image (default:
         `torch.rand` on the device, one draw per image in image order, as the reference)."""
         assert gt_bboxes_ignore is None, "Only supports for gt_bboxes_ignore setting to None."
@@ -178,5 +181,21 @@ class CrossHead2Loss:
                         up(self.cum_samples[:self.num_relations]), out[2:3],
                         self.seesaw["p"], self.seesaw["q"], self.seesaw["eps"],
                         self.seesaw["loss_weight"])
-        hip.bce_posw_mean(imp.contiguous(), up(np.stack(gt_imp, 0)), out[4:6], self.match_w)
+        t_imp = up(np.stack(gt_imp, 0))
+        hip.bce_posw_mean(imp.contiguous(), t_imp, out[4:6], self.match_w)
+        if grads is not None:
+            # SURVEY 8 f-4, first backward slice: d (sum of the four terms) / d their logits, by the
+            # analytic derivative kernels beside each reduction (csrc/loss.hip); every term depends
+            # on its own logits only.  Filled in place: {"obj", "sub", "rel", "importance"}.
+            t_o, t_s, t_r = up(o_ids), up(s_ids), up(r_lab)
+            cum = up(self.cum_samples[:self.num_relations])
+            g = {k: torch.empty_like(v, memory_format=torch.contiguous_format)
+                 for k, v in (("obj", obj), ("sub", sub), ("rel", rel), ("importance", imp))}
+            hip.ce_mean_grad(obj.reshape(-1, nc), t_o, self._cw, g["obj"].view(-1, nc), self.subobj_w)
+            hip.ce_mean_grad(sub.reshape(-1, nc), t_s, self._cw, g["sub"].view(-1, nc), self.subobj_w)
+            hip.seesaw_mean_grad(rel.reshape(-1, self.num_relations), t_r, cum,
+                                 g["rel"].view(-1, self.num_relations), self.seesaw["p"],
+                                 self.seesaw["q"], self.seesaw["eps"], self.seesaw["loss_weight"])
+            hip.bce_posw_mean_grad(imp.contiguous(), t_imp, g["importance"], self.match_w)
+            grads.update(g)
         return dict(loss_r_cls=out[2], loss_sub_cls=out[1], loss_obj_cls=out[0], loss_match=out[4])

@@ -72,6 +72,37 @@ def test_loss_values_and_assignments_match_the_oracle(seed):
     assert float(got2["loss_r_cls"]) != float(got["loss_r_cls"])
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_loss_gradients_match_autograd_through_the_oracle(seed):
+    """SURVEY 8 f-4, first backward slice: d (loss_r_cls + loss_sub_cls + loss_obj_cls + loss_match)
+    / d {rel, sub, obj, importance} from the analytic derivative kernels (csrc/loss.hip) against
+    torch autograd through the reference-pinned loss oracle (the same assignments, the same
+    SeesawLoss counts): 1e-4 relative to the largest gradient entry; masked rows are exactly 0."""
+    head, cls, masks, metas, gt_rels, gt_labels, gt_masks, pts = _outputs(seed)
+    oracle = OracleCrossHead2Loss()
+    leaf = {k: v.detach().cpu().clone().requires_grad_(k in ("rel", "sub", "obj", "importance"))
+            for k, v in cls.items()}
+    want = oracle.loss(leaf, {k: v.detach().cpu().clone() for k, v in masks.items()}, gt_rels,
+                       gt_labels, gt_masks, point_coords=pts)
+    sum(want.values()).backward()
+    grads = {}
+    got = head.loss(cls, masks, gt_rels, None, gt_labels, gt_masks, metas, point_coords=pts,
+                    grads=grads)
+    assert set(grads) == {"rel", "sub", "obj", "importance"}
+    for k in want:
+        assert abs(float(got[k]) - float(want[k])) < 1e-4 * max(1.0, abs(float(want[k]))), k
+    for k, g in grads.items():
+        ref = leaf[k].grad
+        assert tuple(g.shape) == tuple(ref.shape), k
+        err = float((g.cpu() - ref).abs().max())
+        scale = float(ref.abs().max())
+        print(k, "max |grad|", scale, "max err", err)
+        assert scale > 0 and err <= 1e-4 * scale, (k, err, scale)
+        zero = ref.reshape(-1, ref.shape[-1]).abs().sum(-1) == 0
+        if k != "importance":
+            assert torch.all(g.cpu().reshape(-1, g.shape[-1])[zero] == 0), k
+
+
 def test_match_cost_kernels_against_the_restated_costs():
     from pairnet_amd import hip
     g = torch.Generator().manual_seed(4)

@@ -9,7 +9,7 @@
 // first.  Measured against fp64 the result is at or below the error of the fp32 MFMA
 // (v_mfma_f32_32x32x2_f32) on every shape of the path (profiles/r06_gemm_s3_error.txt), at six
 // sixteenths of its instruction time.  Replaces the encoder GEMMs of
-// /root/reference/pairnet/models/relation_heads/pairnet_head.py:262 (mmdet
+// reference pairnet/models/relation_heads/pairnet_head.py:262 (mmdet
 // MSDeformAttnPixelDecoder, cfg configs/mask2former/pairnet.py:33-71).
 //
 // S3 layout of an [R x K] operand (K % 16 == 0; rows padded to 32): blocks of 32 rows x 16 k,

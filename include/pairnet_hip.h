@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 21
+#define PN_ABI_VERSION 22
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -727,6 +727,69 @@ int pn_seesaw_mean_grad_f32(const float* logits, int64_t ld, const int64_t* targ
                             float p, float q, float eps, float loss_weight, void* stream);
 int pn_bce_posw_mean_grad_f32(const float* logits, const float* target, float* grad, int64_t n,
                               float loss_weight, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * SURVEY 8 f-4, second backward slice (csrc/grad.hip): what the backward of Pair-Net's own tail
+ * needs beside the forward kernels above -- the Relation Fusion decoder
+ * (pairnet_head.py:353-378; layers: facebook_detr.py:378-432), the Pair Proposal Network
+ * (pairnet_head.py:322-333) and the Matrix Learner (frameworks/cnn_factory.py:6-53).  In the
+ * reference this is torch.autograd behind `losses.backward()` (mmcv's OptimizerHook, configs/
+ * _base_/schedules/schedule_1x.py); pair-net_amd/grad.py composes these entry points with
+ * pn_gemm_f32 (dX = dY W and dW = dY^T X on transposed operands) and pn_conv2d_nhwc_ex_f32.
+ * Every reduction runs in a fixed order (no atomics).  Checked against autograd through the
+ * reference-pinned oracle (tests/test_grad_gpu.py).
+ * ------------------------------------------------------------------------- */
+/* out[c][r] = in[r][c] for in [rows][ldi >= cols]; out [cols][ldo], columns rows .. out_cols-1 of
+ * every output row are zero-filled (out_cols >= rows: pads a contraction length to 4). */
+int pn_transpose_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int rows, int cols,
+                     int out_cols, void* stream);
+/* out[c] (+)= sum_r x[r][c]  (bias / LayerNorm-weight gradients, second stage of the tap correlations) */
+int pn_colsum_f32(const float* x, int64_t ld, float* out, int rows, int cols, int accumulate,
+                  void* stream);
+/* dx[i] = y[i] > 0 ? dy[i] : 0  (y: the ReLU's output; dx may alias dy) */
+int pn_relu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+/* out[i] = a[i] + b[i % bn]  (x + row-periodic table; bn == n: a plain sum, out may alias a) */
+int pn_add_periodic_f32(const float* a, const float* b, float* out, int64_t n, int64_t bn,
+                        void* stream);
+/* out[i] (+)= sum_b x[b][i], i < n  (gradient of a table broadcast over the batch) */
+int pn_batch_sum_f32(const float* x, float* out, int B, int64_t n, int accumulate, void* stream);
+/* nn.LayerNorm(256) backward from the saved INPUT x [rows][256]: dx, and gxhat = dy * xhat whose
+ * column sum is d weight (d bias = column sum of dy). */
+int pn_layernorm256_bwd_f32(const float* dy, const float* x, const float* gamma, float* dx,
+                            float* gxhat, int rows, float eps, void* stream);
+/* nn.MultiheadAttention core backward, 8 heads x 32 channels, no mask, from the saved projections
+ * q [B*Nq][ldq], k / v [B*Nk][ldk / ldv] and the gradient of the concatenated head outputs dout
+ * [B*Nq][ldo]: dq, dk, dv (same row layouts).  scratch: 2 * B * 8 * Nq * Nk floats. */
+int pn_mha_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                   int64_t ldv, const float* dout, int64_t ldo, float* dq, int64_t lddq, float* dk,
+                   int64_t lddk, float* dv, int64_t lddv, float* scratch, int B, int Nq, int Nk,
+                   float scale, void* stream);
+/* Backward of pn_gather_rows_f32: out[b][row][0:length] (+)= sum_{s: index[b][s] == row}
+ * src[b][s][0:length]; src [B*slots][ld_src], out [B*rows_out][ld_out]. */
+int pn_scatter_rows_add_f32(const float* src, int64_t ld_src, const int64_t* index, float* out,
+                            int64_t ld_out, int B, int rows_out, int slots, int length,
+                            int accumulate, void* stream);
+/* Cosine block backward (pairnet_head.py:325-333): x [B][Q][256] this side's rows BEFORE
+ * F.normalize, other_hat [B][Q][256] the other side's normalised rows, draw [B][Q][Q] the gradient
+ * of importance_raw (transposed != 0: this side indexes draw's columns, i.e. the objects). */
+int pn_cosine_bwd_f32(const float* draw, const float* x, const float* other_hat, float* dx, int B,
+                      int Q, int transposed, float eps, void* stream);
+/* Matrix Learner last layer (64 -> 1): gradient w.r.t. its input c [B][S][S][64] (a ReLU output:
+ * masked where c == 0) from g [B][S][S]; w3 [49][64] as pn_mlearner_last_f32 takes it. */
+int pn_mlearner_last_bwd_data_f32(const float* g, const float* w3, const float* c, float* dc, int B,
+                                  int S, void* stream);
+/* part[b*S + y][tap][c] = sum_x F[b][y][x][c] g[b][y + sgn (kh-3)][x + sgn (kw-3)], F [B][S][S][64],
+ * g [B][S][S]; column-summed over its B*S rows it is d w3 [49][64] (F = the layer's input, g = d
+ * importance, sgn = -1) or (d w1)^T (F = d c1, g = importance_raw, sgn = +1). */
+int pn_tapcorr1_f32(const float* F, const float* g, float* part, int B, int S, int sgn,
+                    void* stream);
+/* The 64 -> 64 layer's weight gradient as MFMA outer products over pixels:
+ * part[chunk][co][tap][ci] = sum over the chunk's pixels of dY[.][co] X[. + tap offset][ci];
+ * chunk = (image, block of rows_per image rows): B * ceil(S / rows_per) chunks of 64*49*64 floats. */
+int pn_tapcorr64_f32(const float* dY, const float* X, float* part, int B, int S, int rows_per,
+                     void* stream);
+/* out[ci][T-1-t][co] = in[co][t][ci]: a "same" convolution's weight as its data gradient reads it */
+int pn_conv_weight_bwd_layout_f32(const float* in, float* out, int Co, int T, int Ci, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * fp32 GEMMs on the bf16 matrix pipe from PRE-SPLIT operands (csrc/gemm_s3.hip, round 6)

@@ -1,0 +1,428 @@
+"""Backward of Pair-Net's own tail on the MI355X (second slice; no optimizer, no
+DDP): given the object decoder's output queries `q` and the gradients of the four loss terms
+with respect to the head's logits (`CrossHead2.loss(..., grads={})`, csrc/loss.hip), the
+gradients of everything between them --
+
+  * the Relation Fusion decoder x6 + `rel_cls_embed` (pairnet_head.py:353-378; post-norm layers
+    in the order cross-attention, norm, self-attention, norm, FFN, norm: facebook_detr.py:378-432),
+  * the pair-feature gather (:342-351) back onto the query rows,
+  * the Pair Proposal Network: `sub_query_update` / `obj_query_update` MLPs, F.normalize, the
+    cosine matrix (:322-333) and the Matrix Learner ConvTiny (frameworks/cnn_factory.py:6-53),
+  * the subject / object class gathers (:380-392) through `cls_embed` and `post_norm` (:236-238)
+
+-- with respect to `q` and to every parameter on the way, named and laid out as the reference's
+state dict.  In the reference this is `torch.autograd` behind `losses.backward()`; here the
+forward is re-run with the product's forward kernels into a tape of per-layer buffers
+(`forward`), and `backward` walks it with csrc/grad.hip's kernels plus `pn_gemm_f32` (a linear
+layer's dX = dY W and dW = dY^T X are GEMMs on transposed operands) and `pn_conv2d_nhwc_ex_f32`
+(the 64 -> 64 convolution's data gradient).  The top-k pair selection is piecewise constant: the
+selected (subject, object) rows are inputs of the backward pass, exactly as autograd treats them.
+
+Not differentiated here (the remaining part of f-4): the mask branch (`mask_embed`, the mask
+logits, point sampling), the nine masked decoder layers, the pixel decoder and the backbone.
+
+Checked against autograd through the reference-pinned oracle (tests/test_grad_gpu.py: 1e-4
+relative on `reldec.npz`, `ppn_sep.npz` and the queries of an 800x1333 image).
+"""
+import math
+
+import torch
+
+from . import hip
+
+__all__ = ["RelationTailGrad"]
+
+
+class RelationTailGrad:
+    """tape = RelationTailGrad(head); out = tape.forward(q); dq, grads = tape.backward(...)
+
+    `q`: [B * Q, 256] fp32 on the head's device, batch-major (a plan's `pl.q`: the last
+    masked-decoder layer's output BEFORE `post_norm`).  `forward` returns dict(rel [B, R, C],
+    importance [B, Q, Q], importance_raw, sub / obj [B, R, nc], cls [B, Q, nc], sub_pos,
+    obj_pos); the pair list is the top-k of `importance` unless `sub_pos` / `obj_pos` [B, R]
+    int64 are given.  `backward(g_rel, g_importance, g_sub, g_obj)` (any subset; shapes of the
+    outputs) returns (dq [B * Q, 256], {reference parameter name: gradient}).
+    """
+
+    def __init__(self, head):
+        if head.device is None or head.device.type != "cuda":
+            raise RuntimeError("RelationTailGrad needs a head on an MI355X (.to('cuda:N')); "
+                               "there is no CPU path")
+        if head.w is None:
+            head._pack()
+        self.head, self.dev = head, head.device
+        self.Q, self.R = head.num_obj_query, head.num_rel_query
+        self.L = head.num_rel_layers
+        self.ffn = head.rel_ffn
+        self.scale = 1.0 / math.sqrt(32.0)
+        self.t = None
+
+    # ------------------------------------------------------------------ small helpers
+    def _E(self, *shape):
+        return torch.empty(*shape, device=self.dev, dtype=torch.float32)
+
+    def _lin_bwd(self, dy, x, W, grads, wname, bname, row0=0, need_dx=True):
+        """y = x W^T + b.  dy [M, N] (row stride free), x [M, K] contiguous, W [N, K] rows of a
+        reference parameter (`row0`: their offset inside it).  Accumulates d W / d b into
+        grads[wname][row0:row0+N] / grads[bname][row0:row0+N]; returns d x [M, K] or None."""
+        M, K = x.shape
+        N = W.shape[0]
+        assert M % 4 == 0 and N % 4 == 0 and K % 4 == 0, (M, N, K)
+        ld_dy = dy.stride(0)
+        xt = self._E(K, M)
+        hip.transpose(x, xt)
+        gw = grads[wname][row0:row0 + N]
+        tmp = self._E(N, K)
+        # dW[n][k] = sum_m dy[m][n] x[m][k]: A = dy read column-major, "W" operand = x^T
+        hip.gemm(dy, xt, tmp, M=N, N=K, K=M, lda=ld_dy, ldw=M, ldc=K, colmajor=True)
+        hip.add_periodic(gw, tmp, gw)
+        if bname is not None:
+            hip.colsum(dy, grads[bname][row0:row0 + N], accumulate=True)
+        if not need_dx:
+            return None
+        Wt = self._E(K, N)
+        hip.transpose(W, Wt)
+        dx = self._E(M, K)
+        hip.gemm(dy, Wt, dx, M=M, N=K, K=N, lda=ld_dy, ldw=N, ldc=K)
+        return dx
+
+    def _ln_bwd(self, dy, x, prefix, grads):
+        """LayerNorm(256) backward from its saved input; accumulates d weight / d bias."""
+        w = self.head.w
+        dx, gx = self._E(*x.shape), self._E(*x.shape)
+        hip.layernorm256_bwd(dy, x, w[prefix + "weight"], dx, gx)
+        hip.colsum(gx, grads[prefix + "weight"], accumulate=True)
+        hip.colsum(dy, grads[prefix + "bias"], accumulate=True)
+        return dx
+
+    def _acc(self, a, b):
+        hip.add_periodic(a, b, a)
+
+    # ------------------------------------------------------------------ forward with a tape
+    @torch.no_grad()
+    @hip.on_device
+    def forward(self, q, sub_pos=None, obj_pos=None):
+        head, w, E = self.head, self.head.w, self._E
+        Q, R = self.Q, self.R
+        if not (q.is_cuda and q.dtype == torch.float32 and q.dim() == 2 and q.shape[1] == 256
+                and q.is_contiguous() and q.shape[0] % Q == 0):
+            raise RuntimeError("q must be a contiguous [B * Q, 256] fp32 device tensor")
+        B = q.shape[0] // Q
+        t = self.t = dict(B=B, q=q)
+        # ---- post_norm + cls_embed (pairnet_head.py:236-238) ----
+        nc = head.num_classes + 1
+        t["qn"] = E(B * Q, 256)
+        hip.layernorm(q, w["transformer_decoder.post_norm.weight"],
+                      w["transformer_decoder.post_norm.bias"], t["qn"])
+        cls = E(B, Q, nc)
+        hip.linear(t["qn"], w["cls_embed.weight"], w["cls_embed.bias"], cls.view(B * Q, nc))
+        # ---- Pair Proposal Network (:322-340) ----
+        for side in ("sub", "obj"):
+            mlp = side + "_query_update"
+            h1, h2, e = E(B * Q, 256), E(B * Q, 256), E(B * Q, 256)
+            hip.linear(q, w[mlp + ".0.weight"], w[mlp + ".0.bias"], h1, relu=True)
+            hip.linear(h1, w[mlp + ".2.weight"], w[mlp + ".2.bias"], h2, relu=True)
+            hip.linear(h2, w[mlp + ".4.weight"], w[mlp + ".4.bias"], e)
+            t[side] = (h1, h2, e)
+        ml = "update_importance.conv_layers."
+        raw, c1, c2, imp = E(B, Q, Q), E(B, Q, Q, 64), E(B, Q, Q, 64), E(B, Q, Q)
+        hip.ppn_front(t["sub"][2], t["obj"][2], w[ml + "0.0.weight"], w[ml + "0.0.bias"], raw, c1,
+                      B, Q)
+        hip.conv2d_ex(c1, w[ml + "1.0.weight"], w[ml + "1.0.bias"], None, c2, B, Q, Q, 64, 64, 7,
+                      7, 1, 3, relu=True)
+        hip.mlearner_last(c2, w[ml + "2.0.weight"], w[ml + "2.0.bias"], imp, B, Q)
+        t.update(raw=raw, c1=c1, c2=c2)
+        i64 = lambda *s: torch.empty(*s, device=self.dev, dtype=torch.int64)
+        pair_idx = i64(B, 2 * R)
+        if sub_pos is None:
+            topk, sub_pos, obj_pos = i64(B, R), i64(B, R), i64(B, R)
+            hip.topk_pairs(imp, topk, sub_pos, obj_pos, B, Q, R, pair=pair_idx)
+        else:
+            sub_pos = sub_pos.to(self.dev, torch.int64).contiguous()
+            obj_pos = obj_pos.to(self.dev, torch.int64).contiguous()
+            pair_idx[:, :R].copy_(sub_pos)
+            pair_idx[:, R:].copy_(obj_pos)
+        t.update(sub_pos=sub_pos, obj_pos=obj_pos, pair_idx=pair_idx)
+        # ---- pair features (:342-351) ----
+        pair = E(B * 2 * R, 256)
+        hip.gather_rows(q, pair_idx, pair, B, Q, 2 * R, 256)
+        rel = self._relation_forward(pair, B)
+        sub, obj = E(B, R, nc), E(B, R, nc)
+        hip.gather_rows(cls, sub_pos, sub, B, Q, R, nc)
+        hip.gather_rows(cls, obj_pos, obj, B, Q, R, nc)
+        return dict(rel=rel, importance=imp, importance_raw=raw, sub=sub, obj=obj, cls=cls,
+                    sub_pos=sub_pos, obj_pos=obj_pos)
+
+    def _relation_forward(self, pair, B):
+        """The six Relation Fusion layers over `pair` [B * 2R, 256] with every intermediate kept."""
+        head, w, E = self.head, self.head.w, self._E
+        R, t = self.R, self.t
+        M, Mk = B * R, B * 2 * R
+        rpos, ppos = w["rel_query_embed.weight"], w["rel_query_embed2.weight"]
+        t["pair"] = pair
+        pairp = E(Mk, 256)                       # pair + key_pos (the keys' operand)
+        hip.add_periodic(pair, ppos, pairp)
+        t["pairp"] = pairp
+        x = head._const(B)["r0"]                 # rel_query_feat repeated over the batch
+        layers = []
+        scr = E(max(hip.attn_scratch_floats(B, R, 2 * R), hip.attn_scratch_floats(B, R, R)))
+        for i in range(self.L):
+            pre = "relation_decoder.layers.%d." % i
+            ac, as_ = pre + "attentions.0.attn.", pre + "attentions.1.attn."
+            Wc, bc = w[ac + "in_proj_weight"], w[ac + "in_proj_bias"]
+            Ws, bs = w[as_ + "in_proj_weight"], w[as_ + "in_proj_bias"]
+            s = dict(x_in=x)
+            # cross-attention over the pair features
+            s["xp"] = E(M, 256)
+            hip.add_periodic(x, rpos, s["xp"])
+            s["Qc"], s["KVc"] = E(M, 256), E(Mk, 512)          # KVc columns: [K | V]
+            hip.linear(s["xp"], Wc[:256], bc[:256], s["Qc"])
+            hip.linear(pairp, Wc[256:512], bc[256:512], s["KVc"][:, :256])
+            hip.linear(pair, Wc[512:], bc[512:], s["KVc"][:, 256:])
+            s["att_c"] = E(M, 256)
+            hip.attention(s["Qc"], 256, s["KVc"], 512, s["KVc"][:, 256:], 512, None, None,
+                          s["att_c"], 256, scr, B, R, 2 * R, self.scale)
+            s["y1"] = E(M, 256)
+            hip.linear(s["att_c"], w[ac + "out_proj.weight"], w[ac + "out_proj.bias"], s["y1"], res=x)
+            s["x1"] = E(M, 256)
+            hip.layernorm(s["y1"], w[pre + "norms.0.weight"], w[pre + "norms.0.bias"], s["x1"])
+            # self-attention
+            s["x1p"] = E(M, 256)
+            hip.add_periodic(s["x1"], rpos, s["x1p"])
+            s["QKVs"] = E(M, 768)                               # columns [Q | K | V]
+            hip.linear(s["x1p"], Ws[:512], bs[:512], s["QKVs"][:, :512])
+            hip.linear(s["x1"], Ws[512:], bs[512:], s["QKVs"][:, 512:])
+            s["att_s"] = E(M, 256)
+            hip.attention(s["QKVs"], 768, s["QKVs"][:, 256:], 768, s["QKVs"][:, 512:], 768, None,
+                          None, s["att_s"], 256, scr, B, R, R, self.scale)
+            s["y2"] = E(M, 256)
+            hip.linear(s["att_s"], w[as_ + "out_proj.weight"], w[as_ + "out_proj.bias"], s["y2"],
+                       res=s["x1"])
+            s["x2"] = E(M, 256)
+            hip.layernorm(s["y2"], w[pre + "norms.1.weight"], w[pre + "norms.1.bias"], s["x2"])
+            # FFN
+            s["h"] = E(M, self.ffn)
+            hip.linear(s["x2"], w[pre + "ffns.0.layers.0.0.weight"],
+                       w[pre + "ffns.0.layers.0.0.bias"], s["h"], relu=True)
+            s["y3"] = E(M, 256)
+            hip.linear(s["h"], w[pre + "ffns.0.layers.1.weight"], w[pre + "ffns.0.layers.1.bias"],
+                       s["y3"], res=s["x2"])
+            x = E(M, 256)
+            hip.layernorm(s["y3"], w[pre + "norms.2.weight"], w[pre + "norms.2.bias"], x)
+            layers.append(s)
+        t["layers"], t["r_out"] = layers, x
+        C = w["rel_cls_embed.weight"].shape[0]
+        rel = E(B, R, C)
+        hip.linear(x, w["rel_cls_embed.weight"], w["rel_cls_embed.bias"], rel.view(M, C))
+        return rel
+
+    # ------------------------------------------------------------------ backward
+    def _zero_grads(self):
+        head = self.head
+        names = ["rel_cls_embed.weight", "rel_cls_embed.bias", "rel_query_feat.weight",
+                 "rel_query_embed.weight", "rel_query_embed2.weight", "cls_embed.weight",
+                 "cls_embed.bias", "transformer_decoder.post_norm.weight",
+                 "transformer_decoder.post_norm.bias"]
+        for i in range(self.L):
+            pre = "relation_decoder.layers.%d." % i
+            for a in ("attentions.0.attn.", "attentions.1.attn."):
+                names += [pre + a + n for n in ("in_proj_weight", "in_proj_bias", "out_proj.weight",
+                                                "out_proj.bias")]
+            names += [pre + "norms.%d.%s" % (j, n) for j in range(3) for n in ("weight", "bias")]
+            names += [pre + "ffns.0.layers.0.0.weight", pre + "ffns.0.layers.0.0.bias",
+                      pre + "ffns.0.layers.1.weight", pre + "ffns.0.layers.1.bias"]
+        for side in ("sub", "obj"):
+            names += ["%s_query_update.%d.%s" % (side, j, n) for j in (0, 2, 4)
+                      for n in ("weight", "bias")]
+        g = {n: torch.zeros(tuple(head._params[n].shape), device=self.dev, dtype=torch.float32)
+             for n in names}
+        return g
+
+    @torch.no_grad()
+    @hip.on_device
+    def backward(self, g_rel=None, g_importance=None, g_sub=None, g_obj=None):
+        if self.t is None:
+            raise RuntimeError("backward() needs a forward() first")
+        t, B, Q, R = self.t, self.t["B"], self.Q, self.R
+        grads = self._zero_grads()
+        dq = torch.zeros(B * Q, 256, device=self.dev, dtype=torch.float32)
+        prep = lambda g: g.to(self.dev, torch.float32).contiguous()
+        if g_rel is not None:
+            # ... and the gather of the pair features back onto the query rows (:342-351)
+            dpair = self._relation_backward(prep(g_rel), grads)
+            hip.scatter_rows_add(dpair, t["pair_idx"], dq, B, Q, 2 * R, 256, accumulate=True)
+        if g_importance is not None:
+            self._ppn_backward(prep(g_importance), grads, dq)
+        if g_sub is not None or g_obj is not None:
+            self._cls_backward(g_sub, g_obj, grads, dq)
+        return dq, grads
+
+    @torch.no_grad()
+    @hip.on_device
+    def relation_forward(self, pair):
+        """The Relation Fusion decoder alone: pair features [B * 2R, 256] (per image the R
+        subject rows, then the R object rows) -> relation logits [B, R, C], taped."""
+        B = pair.shape[0] // (2 * self.R)
+        self.t = dict(B=B, q=None)
+        return self._relation_forward(pair.contiguous(), B)
+
+    @torch.no_grad()
+    @hip.on_device
+    def relation_backward(self, g_rel):
+        """-> (d pair features [B * 2R, 256], {parameter name: gradient}) of the last
+        `relation_forward` / `forward`."""
+        grads = self._zero_grads()
+        return self._relation_backward(g_rel.to(self.dev, torch.float32).contiguous(), grads), grads
+
+    def _relation_backward(self, g_rel, grads):
+        w, E, t = self.head.w, self._E, self.t
+        B, Q, R = t["B"], self.Q, self.R
+        M, Mk = B * R, B * 2 * R
+        C = g_rel.shape[-1]
+        dx = self._lin_bwd(g_rel.view(M, C), t["r_out"], w["rel_cls_embed.weight"], grads,
+                           "rel_cls_embed.weight", "rel_cls_embed.bias")
+        dpair = torch.zeros(Mk, 256, device=self.dev, dtype=torch.float32)
+        dpairp = torch.zeros(Mk, 256, device=self.dev, dtype=torch.float32)   # d (pair + key_pos)
+        drpos_rows = torch.zeros(M, 256, device=self.dev, dtype=torch.float32)  # d (x + query_pos), all uses
+        scr = E(max(hip.mha_bwd_scratch_floats(B, R, 2 * R), hip.mha_bwd_scratch_floats(B, R, R)))
+        for i in reversed(range(self.L)):
+            pre = "relation_decoder.layers.%d." % i
+            ac, as_ = pre + "attentions.0.attn.", pre + "attentions.1.attn."
+            Wc, Ws = w[ac + "in_proj_weight"], w[as_ + "in_proj_weight"]
+            s = t["layers"][i]
+            # norm2 <- FFN
+            dy3 = self._ln_bwd(dx, s["y3"], pre + "norms.2.", grads)
+            dh = self._lin_bwd(dy3, s["h"], w[pre + "ffns.0.layers.1.weight"], grads,
+                               pre + "ffns.0.layers.1.weight", pre + "ffns.0.layers.1.bias")
+            hip.relu_bwd(dh, s["h"], dh)
+            dx2 = self._lin_bwd(dh, s["x2"], w[pre + "ffns.0.layers.0.0.weight"], grads,
+                                pre + "ffns.0.layers.0.0.weight", pre + "ffns.0.layers.0.0.bias")
+            self._acc(dx2, dy3)                                   # the FFN's identity shortcut
+            # norm1 <- self-attention
+            dy2 = self._ln_bwd(dx2, s["y2"], pre + "norms.1.", grads)
+            datt = self._lin_bwd(dy2, s["att_s"], w[as_ + "out_proj.weight"], grads,
+                                 as_ + "out_proj.weight", as_ + "out_proj.bias")
+            dQKV = E(M, 768)
+            hip.mha_bwd(s["QKVs"], s["QKVs"][:, 256:], s["QKVs"][:, 512:], datt, dQKV,
+                        dQKV[:, 256:], dQKV[:, 512:], scr, B, R, R, self.scale)
+            dx1p = self._lin_bwd(dQKV[:, :512], s["x1p"], Ws[:512], grads, as_ + "in_proj_weight",
+                                 as_ + "in_proj_bias", row0=0)
+            dx1 = self._lin_bwd(dQKV[:, 512:], s["x1"], Ws[512:], grads, as_ + "in_proj_weight",
+                                as_ + "in_proj_bias", row0=512)
+            self._acc(dx1, dx1p)
+            self._acc(drpos_rows, dx1p)
+            self._acc(dx1, dy2)                                   # identity shortcut
+            # norm0 <- cross-attention
+            dy1 = self._ln_bwd(dx1, s["y1"], pre + "norms.0.", grads)
+            datt = self._lin_bwd(dy1, s["att_c"], w[ac + "out_proj.weight"], grads,
+                                 ac + "out_proj.weight", ac + "out_proj.bias")
+            dQc, dKVc = E(M, 256), E(Mk, 512)
+            hip.mha_bwd(s["Qc"], s["KVc"], s["KVc"][:, 256:], datt, dQc, dKVc, dKVc[:, 256:], scr,
+                        B, R, 2 * R, self.scale)
+            dxp = self._lin_bwd(dQc, s["xp"], Wc[:256], grads, ac + "in_proj_weight",
+                                ac + "in_proj_bias", row0=0)
+            self._acc(drpos_rows, dxp)
+            dkp = self._lin_bwd(dKVc[:, :256], t["pairp"], Wc[256:512], grads, ac + "in_proj_weight",
+                                ac + "in_proj_bias", row0=256)
+            self._acc(dpairp, dkp)
+            dv = self._lin_bwd(dKVc[:, 256:], t["pair"], Wc[512:], grads, ac + "in_proj_weight",
+                               ac + "in_proj_bias", row0=512)
+            self._acc(dpair, dv)
+            dx = dxp
+            self._acc(dx, dy1)                                    # identity shortcut
+        # layer 0's input is rel_query_feat repeated over the batch
+        hip.batch_sum(dx, grads["rel_query_feat.weight"], B)
+        hip.batch_sum(drpos_rows, grads["rel_query_embed.weight"], B)
+        hip.batch_sum(dpairp, grads["rel_query_embed2.weight"], B)
+        self._acc(dpair, dpairp)
+        return dpair
+
+    def _mlp3_bwd(self, d_out, x, saved, prefix, grads):
+        """Linear-ReLU-Linear-ReLU-Linear backward; saved = (h1, h2, out)."""
+        w = self.head.w
+        h1, h2, _ = saved
+        d2 = self._lin_bwd(d_out, h2, w[prefix + ".4.weight"], grads, prefix + ".4.weight",
+                           prefix + ".4.bias")
+        hip.relu_bwd(d2, h2, d2)
+        d1 = self._lin_bwd(d2, h1, w[prefix + ".2.weight"], grads, prefix + ".2.weight",
+                           prefix + ".2.bias")
+        hip.relu_bwd(d1, h1, d1)
+        return self._lin_bwd(d1, x, w[prefix + ".0.weight"], grads, prefix + ".0.weight",
+                             prefix + ".0.bias")
+
+    def _ppn_backward(self, g_imp, grads, dq):
+        w, E, t = self.head.w, self._E, self.t
+        B, Q = t["B"], self.Q
+        ml = "update_importance.conv_layers."
+        c1, c2, raw = t["c1"], t["c2"], t["raw"]
+        npix = B * Q * Q
+        # ---- last layer (64 -> 1) ----
+        part = E(B * Q, 49 * 64)
+        hip.tapcorr1(c2, g_imp, part, B, Q, -1)
+        dw3 = E(49 * 64)                                          # [tap][ci]
+        hip.colsum(part, dw3)
+        db3 = E(1)
+        hip.colsum(g_imp.view(npix, 1), db3)
+        dc2 = E(B, Q, Q, 64)
+        hip.mlearner_last_bwd_data(g_imp, w[ml + "2.0.weight"], c2, dc2, B, Q)
+        # ---- middle layer (64 -> 64) ----
+        rows_per = 10
+        chunks = B * ((Q + rows_per - 1) // rows_per)
+        part2 = E(chunks, 64 * 49 * 64)
+        hip.tapcorr64(dc2, c1, part2, B, Q, rows_per)
+        dw2 = E(64 * 49 * 64)                                     # [co][tap][ci]
+        hip.colsum(part2, dw2)
+        db2 = E(64)
+        hip.colsum(dc2.view(npix, 64), db2)
+        w2b = E(64 * 49 * 64)
+        hip.conv_weight_bwd_layout(w[ml + "1.0.weight"], w2b, 64, 49, 64)
+        dc1 = E(B, Q, Q, 64)
+        hip.conv2d_ex(dc2, w2b.view(64, 49 * 64), None, None, dc1, B, Q, Q, 64, 64, 7, 7, 1, 3)
+        hip.relu_bwd(dc1, c1, dc1)
+        # ---- first layer (1 -> 64) ----
+        hip.tapcorr1(dc1, raw, part, B, Q, +1)
+        dw1t = E(49 * 64)                                         # [tap][co]
+        hip.colsum(part, dw1t)
+        db1 = E(64)
+        hip.colsum(dc1.view(npix, 64), db1)
+        w1b = E(49 * 64)
+        hip.conv_weight_bwd_layout(w[ml + "0.0.weight"], w1b, 64, 49, 1)    # [1][49 flipped][64]
+        draw = E(B, Q, Q)
+        zero = torch.zeros(1, device=self.dev, dtype=torch.float32)
+        hip.mlearner_last(dc1, w1b.view(49, 64), zero, draw, B, Q)
+        # parameter gradients in the reference's layouts (cnn_factory.py: Conv2d weights [Co][Ci][7][7])
+        grads[ml + "2.0.weight"] = dw3.view(49, 64).t().reshape(1, 64, 7, 7).contiguous()
+        grads[ml + "2.0.bias"] = db3
+        grads[ml + "1.0.weight"] = dw2.view(64, 7, 7, 64).permute(0, 3, 1, 2).contiguous()
+        grads[ml + "1.0.bias"] = db2
+        grads[ml + "0.0.weight"] = dw1t.view(49, 64).t().reshape(64, 1, 7, 7).contiguous()
+        grads[ml + "0.0.bias"] = db1
+        # ---- cosine block + F.normalize ----
+        s_e, o_e = t["sub"][2], t["obj"][2]
+        s_hat, o_hat = E(B * Q, 256), E(B * Q, 256)
+        hip.l2normalize(s_e, s_hat)
+        hip.l2normalize(o_e, o_hat)
+        ds, do = E(B * Q, 256), E(B * Q, 256)
+        hip.cosine_bwd(draw, s_e, o_hat, ds, B, Q, False)
+        hip.cosine_bwd(draw, o_e, s_hat, do, B, Q, True)
+        self._acc(dq, self._mlp3_bwd(ds, t["q"], t["sub"], "sub_query_update", grads))
+        self._acc(dq, self._mlp3_bwd(do, t["q"], t["obj"], "obj_query_update", grads))
+
+    def _cls_backward(self, g_sub, g_obj, grads, dq):
+        w, t = self.head.w, self.t
+        B, Q, R = t["B"], self.Q, self.R
+        nc = self.head.num_classes + 1
+        ncp = (nc + 3) // 4 * 4           # the GEMMs contract over multiples of 4: zero columns
+        zeros = lambda *s: torch.zeros(*s, device=self.dev, dtype=torch.float32)
+        dcls = zeros(B * Q, ncp)
+        for g, pos in ((g_sub, t["sub_pos"]), (g_obj, t["obj_pos"])):
+            if g is not None:
+                g = g.to(self.dev, torch.float32).contiguous().view(B * R, nc)
+                hip.scatter_rows_add(g, pos, dcls, B, Q, R, nc, accumulate=True)
+        Wp = zeros(ncp, 256)
+        Wp[:nc].copy_(w["cls_embed.weight"])
+        gp = {"W": zeros(ncp, 256), "b": zeros(ncp)}
+        dqn = self._lin_bwd(dcls, t["qn"], Wp, gp, "W", "b")
+        self._acc(grads["cls_embed.weight"], gp["W"][:nc])
+        self._acc(grads["cls_embed.bias"], gp["b"][:nc])
+        self._acc(dq, self._ln_bwd(dqn, t["q"], "transformer_decoder.post_norm.", grads))

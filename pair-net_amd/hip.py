@@ -105,6 +105,20 @@ _SIGS = {
     "pn_seesaw_mean_grad_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32,
                                           _f32, _f32, _vp]),
     "pn_bce_posw_mean_grad_f32": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp]),
+    "pn_transpose_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "pn_colsum_f32": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _vp]),
+    "pn_relu_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "pn_add_periodic_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "pn_batch_sum_f32": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp]),
+    "pn_layernorm256_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp]),
+    "pn_mha_bwd_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
+                                 _vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "pn_scatter_rows_add_f32": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "pn_cosine_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "pn_mlearner_last_bwd_data_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "pn_tapcorr1_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "pn_tapcorr64_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "pn_conv_weight_bwd_layout_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_msda_loc_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_msda_bwd_f32": (C.c_int, [_vp, _i64] + [_vp] * 8 + [_i32, _i32, _i32, _i32, _vp]),
     "pn_gather_probe_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
@@ -166,7 +180,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 21   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 22   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -1138,6 +1152,103 @@ def bce_posw_mean_grad(logits, target, grad, loss_weight):
     assert grad.numel() == logits.numel()
     _check(lib().pn_bce_posw_mean_grad_f32(_ptr(logits), _ptr(target), _ptr(grad), logits.numel(),
                                            loss_weight, _stream()), "pn_bce_posw_mean_grad_f32")
+
+
+# ---- backward building blocks of the Pair-Net tail (csrc/grad.hip; composed in grad.py) -----
+def transpose(x, out, out_cols=None):
+    """out[c][r] = x[r][c]; out [cols][ld >= out_cols], zero-filled from column rows on."""
+    rows, ldi = _rowmajor(x)
+    cols, ldo = _rowmajor(out)
+    assert cols == x.shape[1]
+    oc = out.shape[1] if out_cols is None else out_cols
+    _check(lib().pn_transpose_f32(_ptr(x), ldi, _ptr(out), ldo, rows, cols, oc, _stream()),
+           "pn_transpose_f32")
+
+
+def colsum(x, out, accumulate=False):
+    rows, ld = _rowmajor(x)
+    assert out.numel() == x.shape[1] and out.is_contiguous()
+    _check(lib().pn_colsum_f32(_ptr(x), ld, _ptr(out), rows, x.shape[1], int(accumulate), _stream()),
+           "pn_colsum_f32")
+
+
+def relu_bwd(dy, y, dx):
+    assert dy.is_contiguous() and y.is_contiguous() and dx.is_contiguous() and \
+        dy.numel() == y.numel() == dx.numel()
+    _check(lib().pn_relu_bwd_f32(_ptr(dy), _ptr(y), _ptr(dx), dy.numel(), _stream()),
+           "pn_relu_bwd_f32")
+
+
+def add_periodic(a, b, out):
+    """out = a + b tiled over a's leading rows (b.numel() divides a.numel()); out may be a."""
+    assert a.is_contiguous() and b.is_contiguous() and out.is_contiguous() and \
+        a.numel() == out.numel() and a.numel() % b.numel() == 0
+    _check(lib().pn_add_periodic_f32(_ptr(a), _ptr(b), _ptr(out), a.numel(), b.numel(), _stream()),
+           "pn_add_periodic_f32")
+
+
+def batch_sum(x, out, B, accumulate=False):
+    assert x.is_contiguous() and out.is_contiguous() and x.numel() == B * out.numel()
+    _check(lib().pn_batch_sum_f32(_ptr(x), _ptr(out), B, out.numel(), int(accumulate), _stream()),
+           "pn_batch_sum_f32")
+
+
+def layernorm256_bwd(dy, x, gamma, dx, gxhat, eps=1e-5):
+    rows = x.shape[0]
+    for t in (dy, x, dx, gxhat):
+        assert t.is_contiguous() and tuple(t.shape) == (rows, 256)
+    _check(lib().pn_layernorm256_bwd_f32(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(dx), _ptr(gxhat),
+                                         rows, eps, _stream()), "pn_layernorm256_bwd_f32")
+
+
+def mha_bwd_scratch_floats(B, Nq, Nk):
+    return 2 * B * 8 * Nq * Nk
+
+
+def mha_bwd(q, k, v, dout, dq, dk, dv, scratch, B, Nq, Nk, scale):
+    """q / dout / dq: 2-D views [B*Nq, 256] (any row stride), k / v / dk / dv [B*Nk, 256]."""
+    ld = lambda t: _rowmajor(t)[1]
+    assert scratch.numel() >= mha_bwd_scratch_floats(B, Nq, Nk)
+    _check(lib().pn_mha_bwd_f32(_ptr(q), ld(q), _ptr(k), ld(k), _ptr(v), ld(v), _ptr(dout), ld(dout),
+                                _ptr(dq), ld(dq), _ptr(dk), ld(dk), _ptr(dv), ld(dv), _ptr(scratch),
+                                B, Nq, Nk, scale, _stream()), "pn_mha_bwd_f32")
+
+
+def scatter_rows_add(src, index, out, B, rows_out, slots, length, accumulate=False):
+    """src [B * slots, >= length], out [B * rows_out, >= length] (2-D views, free row strides)."""
+    (rs, lds), (ro, ldo) = _rowmajor(src), _rowmajor(out)
+    assert rs == B * slots and ro == B * rows_out and index.numel() == B * slots
+    _check(lib().pn_scatter_rows_add_f32(_ptr(src), lds, _ptr(index, torch.int64), _ptr(out), ldo,
+                                         B, rows_out, slots, length, int(accumulate), _stream()),
+           "pn_scatter_rows_add_f32")
+
+
+def cosine_bwd(draw, x, other_hat, dx, B, Q, transposed, eps=1e-12):
+    _check(lib().pn_cosine_bwd_f32(_ptr(draw), _ptr(x), _ptr(other_hat), _ptr(dx), B, Q,
+                                   int(transposed), eps, _stream()), "pn_cosine_bwd_f32")
+
+
+def mlearner_last_bwd_data(g, w3, c, dc, B, S):
+    _check(lib().pn_mlearner_last_bwd_data_f32(_ptr(g), _ptr(w3), _ptr(c), _ptr(dc), B, S, _stream()),
+           "pn_mlearner_last_bwd_data_f32")
+
+
+def tapcorr1(F, g, part, B, S, sgn):
+    assert part.numel() == B * S * 49 * 64
+    _check(lib().pn_tapcorr1_f32(_ptr(F), _ptr(g), _ptr(part), B, S, sgn, _stream()),
+           "pn_tapcorr1_f32")
+
+
+def tapcorr64(dY, X, part, B, S, rows_per):
+    assert part.numel() == B * ((S + rows_per - 1) // rows_per) * 64 * 49 * 64
+    _check(lib().pn_tapcorr64_f32(_ptr(dY), _ptr(X), _ptr(part), B, S, rows_per, _stream()),
+           "pn_tapcorr64_f32")
+
+
+def conv_weight_bwd_layout(w, out, Co, T, Ci):
+    assert w.numel() == out.numel() == Co * T * Ci
+    _check(lib().pn_conv_weight_bwd_layout_f32(_ptr(w), _ptr(out), Co, T, Ci, _stream()),
+           "pn_conv_weight_bwd_layout_f32")
 
 
 def bce_posw_mean(logits, target, out, loss_weight):

@@ -365,6 +365,55 @@ def test_ring_entry_waits_for_the_collective_that_read_it():
 
 
 @pytest.mark.gpu
+def test_a_late_collective_does_not_hold_the_producing_stream():
+    """a slow peer shows up on a rank as a collective that COMPLETES late.
+    Injected here as a ~50 ms spin on the collector's side stream in front of one step's
+    collective: the stream that produces and packs the records must run on undisturbed -- this
+    step and the next three finish on it while the side stream is still held (its only tie to
+    the side stream is a ring entry's `sent` event: step j re-packs the entry whose collective
+    was issued at step j - ring + depth, ring = depth + 4) -- and every record still arrives,
+    in order."""
+    from pairnet_amd.dist import TripletBatch, TripletCollector
+
+    class Head(_HostHead):
+        device = torch.device("cuda:0")
+    dev, depth, steps = Head.device, 2, 12
+    col = TripletCollector(Head(), depth=depth, n_local=1, keep_steps=steps)
+    producer = torch.cuda.Stream(dev)
+    recs = []
+    for i in range(steps):
+        res, sub, obj = _HostDetector.detect(torch.full((1,), float(i)))
+        recs.append((tuple(t.to(dev) if t is not None else None for t in res),
+                     sub.to(dev), obj.to(dev)))
+    torch.cuda.synchronize()
+    held_at = 3
+    hold = torch.cuda.Event()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    torch.cuda._sleep(1000000)                # (the spin kernel's clock rate is measured)
+    t1.record()
+    t1.synchronize()
+    spin_cycles = int(1000000 * 50.0 / max(t0.elapsed_time(t1), 1e-3))     # ~50 ms
+    still_held = None
+    for i, (res, sub, obj) in enumerate(recs):
+        if i == held_at:
+            with torch.cuda.stream(col.side):
+                torch.cuda._sleep(spin_cycles)
+                hold.record(col.side)
+        col.add(TripletBatch([res], [sub], [obj], stream=producer))
+        if i == held_at + 3:
+            # everything queued on the producing stream so far is done ...
+            producer.synchronize()
+            # ... while the side stream is still inside the injected delay
+            still_held = not hold.query()
+    rec = col.finish()
+    assert still_held is True, "the producing stream waited for the held side stream"
+    assert col.stored == steps
+    for i in range(steps):
+        assert torch.equal(rec[i].cpu(), _record(i)), i
+
+
+@pytest.mark.gpu
 def test_pack_triplets_kernel_equals_the_torch_packing():
     from pairnet_amd import hip
     g = torch.Generator().manual_seed(3)

@@ -8,7 +8,8 @@ gradients of everything between them --
   * the pair-feature gather (:342-351) back onto the query rows,
   * the Pair Proposal Network: `sub_query_update` / `obj_query_update` MLPs, F.normalize, the
     cosine matrix (:322-333) and the Matrix Learner ConvTiny (frameworks/cnn_factory.py:6-53),
-  * the subject / object class gathers (:380-392) through `cls_embed` and `post_norm` (:236-238)
+  * optionally the subject / object class gathers (:380-390) through `cls_embed` and `post_norm`
+    (:236-238) -- the reference DETACHES `cls_pred` there, so by default they carry no gradient
 
 -- with respect to `q` and to every parameter on the way, named and laid out as the reference's
 state dict.  In the reference this is `torch.autograd` behind `losses.backward()`; here the
@@ -40,8 +41,8 @@ class RelationTailGrad:
     masked-decoder layer's output BEFORE `post_norm`).  `forward` returns dict(rel [B, R, C],
     importance [B, Q, Q], importance_raw, sub / obj [B, R, nc], cls [B, Q, nc], sub_pos,
     obj_pos); the pair list is the top-k of `importance` unless `sub_pos` / `obj_pos` [B, R]
-    int64 are given.  `backward(g_rel, g_importance, g_sub, g_obj)` (any subset; shapes of the
-    outputs) returns (dq [B * Q, 256], {reference parameter name: gradient}).
+    int64 are given.  `backward(g_rel, g_importance, g_sub, g_obj, cls_detached=True)` (any subset;
+    shapes of the outputs) returns (dq [B * Q, 256], {reference parameter name: gradient}).
     """
 
     def __init__(self, head):
@@ -240,7 +241,12 @@ class RelationTailGrad:
 
     @torch.no_grad()
     @hip.on_device
-    def backward(self, g_rel=None, g_importance=None, g_sub=None, g_obj=None):
+    def backward(self, g_rel=None, g_importance=None, g_sub=None, g_obj=None, cls_detached=True):
+        """`cls_detached` (default: the reference's graph): pairnet_head.py:380-390 gathers the
+        subject / object class logits from `cls_pred.clone().detach()`, so `loss_sub_cls` and
+        `loss_obj_cls` reach no parameter -- `g_sub` / `g_obj` are accepted and, like autograd
+        does there, contribute nothing.  With `cls_detached=False` they are propagated through
+        the gathers, `cls_embed` and `post_norm` (the derivative of the un-detached expression)."""
         if self.t is None:
             raise RuntimeError("backward() needs a forward() first")
         t, B, Q, R = self.t, self.t["B"], self.Q, self.R
@@ -253,7 +259,7 @@ class RelationTailGrad:
             hip.scatter_rows_add(dpair, t["pair_idx"], dq, B, Q, 2 * R, 256, accumulate=True)
         if g_importance is not None:
             self._ppn_backward(prep(g_importance), grads, dq)
-        if g_sub is not None or g_obj is not None:
+        if not cls_detached and (g_sub is not None or g_obj is not None):
             self._cls_backward(g_sub, g_obj, grads, dq)
         return dq, grads
 

@@ -31,10 +31,13 @@ def _oracle64(sd):
     return head.double()
 
 
-def _tail(head_o, q, sub_pos, obj_pos):
-    """oracle/head.py forward's tail (pairnet_head.py:322-392) with autograd ON: q [Q, B, 256]."""
+def _tail(head_o, q, sub_pos, obj_pos, cls_detached=False):
+    """oracle/head.py forward's tail (pairnet_head.py:322-392) with autograd ON: q [Q, B, 256].
+    `cls_detached`: gather sub / obj from `cls_pred.clone().detach()` as the reference does."""
     x = head_o.transformer_decoder.post_norm(q).transpose(0, 1)
     cls = head_o.cls_embed(x)
+    if cls_detached:
+        cls = cls.clone().detach()
     s = F.normalize(head_o.sub_query_update(q).transpose(0, 1), p=2, dim=-1, eps=1e-12)
     o = F.normalize(head_o.obj_query_update(q).transpose(0, 1), p=2, dim=-1, eps=1e-12)
     raw = torch.matmul(s, o.transpose(1, 2))
@@ -221,15 +224,19 @@ def test_pair_proposal_backward_on_golden_queries():
     _print(report)
 
 
-def test_tail_backward_from_the_losses_at_800x1333():
-    """The whole slice at the bench's size: head forward at 800x1333, `CrossHead2.loss(grads=)`
-    gives d loss / d {rel, importance, sub, obj}; the taped tail re-runs from the plan's decoder
-    queries (same outputs as the inference kernels to 1e-4), and its backward -- d queries and
-    every parameter from `post_norm` / `cls_embed` to `rel_cls_embed` -- equals autograd through
-    the oracle's tail evaluated on the same queries and the same selected pairs."""
+@pytest.mark.parametrize("cls_detached", [True, False])
+def test_tail_backward_from_the_losses_at_800x1333(cls_detached):
+    """The whole slice at the bench's size (an 800x1333 image padded to 800x1344): head forward,
+    `CrossHead2.loss(grads=)` gives d loss / d {rel, importance, sub, obj}; the taped tail re-runs
+    from the plan's decoder queries (same outputs as the inference kernels to 1e-4), and its
+    backward -- d queries and every parameter between `post_norm` and `rel_cls_embed` -- equals
+    autograd through the oracle's tail on the same queries and the same selected pairs.
+    `cls_detached=True` is the reference's graph (pairnet_head.py:380-390: the class logits are
+    detached before the subject / object gathers, so two of the four loss terms train nothing);
+    False checks the un-detached derivative through the gathers, `cls_embed` and `post_norm`."""
     from pairnet_amd import RelationTailGrad
     from test_losses_gpu import _outputs
-    head, cls, masks, metas, gt_rels, gt_labels, gt_masks, pts = _outputs(1, H=800, W=1333, bs=1)
+    head, cls, masks, metas, gt_rels, gt_labels, gt_masks, pts = _outputs(1, H=800, W=1344, bs=1)
     up = {}
     head.loss(cls, masks, gt_rels, None, gt_labels, gt_masks, metas, point_coords=pts, grads=up)
     pl = head._last_plan
@@ -242,17 +249,22 @@ def test_tail_backward_from_the_losses_at_800x1333():
     for k in ("rel", "importance", "sub", "obj", "cls"):
         assert float((out[k] - cls[k]).abs().max()) < 1e-4, k
     dq, grads = tape.backward(g_rel=up["rel"], g_importance=up["importance"], g_sub=up["sub"],
-                              g_obj=up["obj"])
+                              g_obj=up["obj"], cls_detached=cls_detached)
     torch.cuda.synchronize()
 
     head_o = _oracle64(head.state_dict())
     q_o = q.cpu().double().view(B, Q, 256).transpose(0, 1).contiguous().requires_grad_()
-    o = _tail(head_o, q_o, pl.sub_pos.cpu(), pl.obj_pos.cpu())
+    o = _tail(head_o, q_o, pl.sub_pos.cpu(), pl.obj_pos.cpu(), cls_detached)
     sum((o[k] * up[k].cpu().double()).sum() for k in ("rel", "importance", "sub", "obj")).backward()
     report = []
     _compare("query", dq.view(B, Q, 256).transpose(0, 1), q_o.grad, report)
-    names = _rel_names() + _ppn_names() + ["cls_embed.weight", "cls_embed.bias",
-                                           "transformer_decoder.post_norm.weight",
-                                           "transformer_decoder.post_norm.bias"]
+    names = _rel_names() + _ppn_names()
+    cls_names = ["cls_embed.weight", "cls_embed.bias", "transformer_decoder.post_norm.weight",
+                 "transformer_decoder.post_norm.bias"]
+    if cls_detached:
+        for k in cls_names:
+            assert float(grads[k].abs().max()) == 0.0, k
+    else:
+        names += cls_names
     _compare_params(grads, head_o, report, names)
     _print(report)

@@ -5,6 +5,9 @@ pipeline is in flight still give a wrong image?
     python tools/capture_in_flight_probe.py unsafe 60      # capture wherever a graph is missing
     python tools/capture_in_flight_probe.py quiet 20       # the product's policy (control)
     python tools/capture_in_flight_probe.py unsafe+sync 60 # in flight, device wait kept in _capture
+    PAIRNET_LIB=tools/gpubin/libpairnet_packed.so python tools/capture_in_flight_probe.py unsafe 60 fp32
+        # round 5's conditions: a library WITH packed fp32 (python tools/build_variant.py packed
+        # "-Xclang -target-feature -Xclang +packed-fp32-ops") and exact-fp32 GEMMs everywhere
 
 A trial = 36 images (two distinct ones, ResNet-50 -> head -> get_bboxes) through
 PipelinedHead(depth=4, a_streams=2) with backbone, stage and get_bboxes graphs on; after the 8th
@@ -31,6 +34,7 @@ import pairnet_amd.plans as plans  # noqa: E402
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "unsafe"
 trials = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+arith = sys.argv[3] if len(sys.argv) > 3 else None     # "fp32": rounds 1-5's GEMMs everywhere
 DEV = torch.device("cuda:0")
 torch.cuda.set_device(DEV)
 
@@ -39,6 +43,8 @@ cfg.pop("type")
 head = CrossHead2(**cfg)
 head.init_weights(seed=0)
 head.to(DEV)
+if arith:
+    head.gemm_arithmetic = arith
 net = ResNet50Hip().to(DEV)
 H, W = 800, 1333
 g = torch.Generator().manual_seed(7)
@@ -173,7 +179,8 @@ for t in range(trials):
         if len(details) < 12:
             details.append(dict(trial=t, wrong_images=wrong,
                                 captures_per_submission=had_capture))
-out = dict(mode=mode, trials=trials, images_per_trial=len(order), trials_with_a_wrong_image=bad_trials,
+out = dict(mode=mode, gemm_arithmetic=head.gemm_arithmetic, library=os.environ.get("PAIRNET_LIB", "product"),
+           trials=trials, images_per_trial=len(order), trials_with_a_wrong_image=bad_trials,
            wrong_images=bad_images, wrong_images_within_3_submissions_of_a_capture=bad_with_capture,
            submissions_with_a_capture=capture_subs, graphs_captured=CrossHead2.captures,
            calls_while_capturing_first_trial=dict(LOG), details=details,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 22
+#define PN_ABI_VERSION 23
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -790,6 +790,25 @@ int pn_tapcorr64_f32(const float* dY, const float* X, float* part, int B, int S,
                      void* stream);
 /* out[ci][T-1-t][co] = in[co][t][ci]: a "same" convolution's weight as its data gradient reads it */
 int pn_conv_weight_bwd_layout_f32(const float* in, float* out, int Co, int T, int Ci, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * The optimizer step (csrc/optim.hip) over one flat fp32 parameter buffer: what mmcv's
+ * OptimizerHook(grad_clip=dict(max_norm=0.1, norm_type=2)) + torch.optim.AdamW do per iteration
+ * (configs/mask2former/pairnet.py:353-368; paramwise lr_mult / norm_decay_mult as per-segment
+ * multipliers).  pair-net_amd/train.py drives it.
+ * ------------------------------------------------------------------------- */
+/* out[0] = || pre * g ||_2, out[1] = min(1, max_norm / (out[0] + 1e-6)) (1 if max_norm <= 0);
+ * scratch: 256 doubles.  Deterministic (two-stage sum in double, fixed order). */
+int pn_grad_norm_clip_f32(const float* g, int64_t n, float pre, float max_norm, float* out,
+                          double* scratch, void* stream);
+/* AdamW (torch.optim.AdamW's arithmetic) on p / g / m / v [n] with the effective gradient
+ * pre * clip[1] * g (clip: the device pair written by pn_grad_norm_clip_f32, or NULL); segment s
+ * covers [seg_off[s], seg_off[s+1]) and uses lr * seg_lr[s], weight_decay * seg_wd[s]; `step`
+ * counts from 1 (bias corrections). */
+int pn_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_off,
+                 const float* seg_lr, const float* seg_wd, int nseg, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int step, const float* clip, float pre,
+                 void* stream);
 
 /* ------------------------------------------------------------------------- *
  * fp32 GEMMs on the bf16 matrix pipe from PRE-SPLIT operands (csrc/gemm_s3.hip, round 6)

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpairnet_hip.so")
-SOURCES = ["gemm", "gemm_ln", "gemm_s3", "stem", "winograd", "ffn", "norm", "msda", "resize", "attn", "ppn", "postproc", "swin", "preprocess", "detr", "loss", "grad"]
+SOURCES = ["gemm", "gemm_ln", "gemm_s3", "stem", "winograd", "ffn", "norm", "msda", "resize", "attn", "ppn", "postproc", "swin", "preprocess", "detr", "loss", "grad", "optim"]
 # No packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in the
 # library: while waves of the bf16-MFMA GEMM (csrc/gemm_s3.hip: dense MFMAs + LDS-DMA) are
 # resident on a CU, such instructions in OTHER kernels' waves were measured to return wrong

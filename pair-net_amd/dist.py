@@ -467,3 +467,72 @@ def multi_gpu_test(detector, dataset, annotations=None, evaluator=None, metrics=
                 metrics.add(ev, gt_rels, iou=iou)
             out["metrics"] = metrics.summary()
     return out
+
+
+class GradReducer:
+    """Data-parallel gradient reduction for the training step (what mmcv's MMDistributedDataParallel
+    does behind tools/train.py:115-241): the gradients live in ONE flat buffer laid out in the
+    order the backward pass completes them (`RelationTailGrad.flat_grad`), cut into buckets of
+    `bucket_bytes`; `ready(end)` -- the backward pass's hook -- starts the all-reduce (SUM; RCCL
+    over xGMI for backend "nccl") of every bucket that lies wholly inside flat[:end] on a side
+    stream, behind an event on the computing stream, so the collectives of the early buckets run
+    under the rest of the backward pass; `finish()` orders the computing stream behind all of them.
+    The average is not a pass over the buffer: `scale` (= 1 / world) is what the consumer
+    multiplies by where it reads the gradient (`pn_grad_norm_clip_f32` / `pn_adamw_f32`'s `pre`).
+
+    Bucket size: xGMI is point to point, a ring all-reduce is bound per link, and a collective's
+    fixed cost is tens of microseconds -- so few, large buckets (default 32 MiB: the 41 MB of the
+    Pair-Net tail are two collectives), not the 25 MB / many-bucket habit of NVSwitch nodes.
+    With one rank (or no process group) every call is a no-op and `scale` is 1."""
+
+    def __init__(self, flat, group=None, bucket_bytes=32 << 20, force_collective=False):
+        ini = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if ini else 1
+        self.active = ini and (self.world > 1 or force_collective)
+        self.flat, self.group = flat, group
+        self.scale = 1.0 / self.world
+        per = max(64, int(bucket_bytes) // 4 // 64 * 64)
+        n = flat.numel()
+        self.bounds = [(b, min(b + per, n)) for b in range(0, n, per)]
+        self.on_gpu = flat.is_cuda
+        self.side = torch.cuda.Stream(flat.device) if (self.on_gpu and self.active) else None
+        self.next, self.works = 0, []
+        self.collectives = 0
+
+    def start(self):
+        """Begin a new backward pass (the buffer is about to be zeroed and refilled)."""
+        if self.works:
+            raise RuntimeError("GradReducer.start(): the previous pass was not finish()ed")
+        self.next = 0      # (finish() ordered the computing stream behind the last pass's reads)
+
+    def ready(self, end):
+        if not self.active:
+            return
+        ev = None
+        while self.next < len(self.bounds) and self.bounds[self.next][1] <= end:
+            b, e = self.bounds[self.next]
+            view = self.flat[b:e]
+            if self.side is not None:
+                if ev is None:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(self.flat.device))
+                    self.side.wait_event(ev)
+                with torch.cuda.stream(self.side):
+                    self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group,
+                                                      async_op=True))
+            else:
+                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group,
+                                                  async_op=True))
+            self.collectives += 1
+            self.next += 1
+
+    def finish(self):
+        """Every bucket reduced; the caller's current stream is ordered behind the collectives."""
+        if not self.active:
+            return
+        self.ready(self.flat.numel())
+        for w in self.works:
+            w.wait()
+        if self.side is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.side)
+        self.works = []

@@ -26,6 +26,7 @@ Checked against autograd through the reference-pinned oracle (tests/test_grad_gp
 relative on `reldec.npz`, `ppn_sep.npz` and the queries of an 800x1333 image).
 """
 import math
+from collections import OrderedDict
 
 import torch
 
@@ -57,6 +58,52 @@ class RelationTailGrad:
         self.ffn = head.rel_ffn
         self.scale = 1.0 / math.sqrt(32.0)
         self.t = None
+        # every gradient is a view of ONE flat buffer, parameters in the order their gradients are
+        # COMPLETED by backward() (rel_cls_embed, relation layers last to first, the relation
+        # embeddings, the Matrix Learner, the two PPN MLPs, then the optional class path): the
+        # optimizer runs over it in one launch and a data-parallel reducer can all-reduce a
+        # finished prefix while the rest of the backward pass is still running (train.py, dist.py)
+        self.layout, off = OrderedDict(), 0
+        self.group_end = OrderedDict()           # group name -> end offset of its last segment
+        for group, names in self.param_groups(head):
+            for n in names:
+                shape = tuple(head._params[n].shape)
+                numel = int(torch.Size(shape).numel())
+                self.layout[n] = (off, shape, numel)
+                off += (numel + 63) // 64 * 64
+            self.group_end[group] = off
+        self.flat_numel = off
+        self.flat_grad = torch.zeros(off, device=self.dev, dtype=torch.float32)
+        self.grads = {n: self.flat_grad[o:o + k].view(shape)
+                      for n, (o, shape, k) in self.layout.items()}
+
+    @staticmethod
+    def param_groups(head):
+        """[(group, [reference parameter names])] in the order backward() completes them."""
+        L = head.num_rel_layers
+        groups = [("rel_cls_embed", ["rel_cls_embed.weight", "rel_cls_embed.bias"])]
+        for i in reversed(range(L)):
+            pre = "relation_decoder.layers.%d." % i
+            names = []
+            for a in ("attentions.0.attn.", "attentions.1.attn."):
+                names += [pre + a + n for n in ("in_proj_weight", "in_proj_bias", "out_proj.weight",
+                                                "out_proj.bias")]
+            names += [pre + "norms.%d.%s" % (j, n) for j in range(3) for n in ("weight", "bias")]
+            names += [pre + "ffns.0.layers.0.0.weight", pre + "ffns.0.layers.0.0.bias",
+                      pre + "ffns.0.layers.1.weight", pre + "ffns.0.layers.1.bias"]
+            groups.append(("relation_decoder.layers.%d" % i, names))
+        groups.append(("rel_query", ["rel_query_feat.weight", "rel_query_embed.weight",
+                                     "rel_query_embed2.weight"]))
+        ml = "update_importance.conv_layers."
+        groups.append(("update_importance", [ml + "%d.0.%s" % (j, n) for j in (2, 1, 0)
+                                             for n in ("weight", "bias")]))
+        for side in ("sub", "obj"):
+            groups.append((side + "_query_update", ["%s_query_update.%d.%s" % (side, j, n)
+                                                    for j in (4, 2, 0) for n in ("weight", "bias")]))
+        groups.append(("cls", ["cls_embed.weight", "cls_embed.bias",
+                               "transformer_decoder.post_norm.weight",
+                               "transformer_decoder.post_norm.bias"]))
+        return groups
 
     # ------------------------------------------------------------------ small helpers
     def _E(self, *shape):
@@ -219,34 +266,20 @@ class RelationTailGrad:
 
     # ------------------------------------------------------------------ backward
     def _zero_grads(self):
-        head = self.head
-        names = ["rel_cls_embed.weight", "rel_cls_embed.bias", "rel_query_feat.weight",
-                 "rel_query_embed.weight", "rel_query_embed2.weight", "cls_embed.weight",
-                 "cls_embed.bias", "transformer_decoder.post_norm.weight",
-                 "transformer_decoder.post_norm.bias"]
-        for i in range(self.L):
-            pre = "relation_decoder.layers.%d." % i
-            for a in ("attentions.0.attn.", "attentions.1.attn."):
-                names += [pre + a + n for n in ("in_proj_weight", "in_proj_bias", "out_proj.weight",
-                                                "out_proj.bias")]
-            names += [pre + "norms.%d.%s" % (j, n) for j in range(3) for n in ("weight", "bias")]
-            names += [pre + "ffns.0.layers.0.0.weight", pre + "ffns.0.layers.0.0.bias",
-                      pre + "ffns.0.layers.1.weight", pre + "ffns.0.layers.1.bias"]
-        for side in ("sub", "obj"):
-            names += ["%s_query_update.%d.%s" % (side, j, n) for j in (0, 2, 4)
-                      for n in ("weight", "bias")]
-        g = {n: torch.zeros(tuple(head._params[n].shape), device=self.dev, dtype=torch.float32)
-             for n in names}
-        return g
+        self.flat_grad.zero_()
+        return self.grads
 
     @torch.no_grad()
     @hip.on_device
-    def backward(self, g_rel=None, g_importance=None, g_sub=None, g_obj=None, cls_detached=True):
+    def backward(self, g_rel=None, g_importance=None, g_sub=None, g_obj=None, cls_detached=True,
+                 on_ready=None):
         """`cls_detached` (default: the reference's graph): pairnet_head.py:380-390 gathers the
         subject / object class logits from `cls_pred.clone().detach()`, so `loss_sub_cls` and
         `loss_obj_cls` reach no parameter -- `g_sub` / `g_obj` are accepted and, like autograd
         does there, contribute nothing.  With `cls_detached=False` they are propagated through
-        the gathers, `cls_embed` and `post_norm` (the derivative of the un-detached expression)."""
+        the gathers, `cls_embed` and `post_norm` (the derivative of the un-detached expression).
+        The gradients are views of `self.flat_grad` (valid until the next backward);
+        `on_ready(end)`: called whenever flat_grad[:end] has become final (a reducer's hook)."""
         if self.t is None:
             raise RuntimeError("backward() needs a forward() first")
         t, B, Q, R = self.t, self.t["B"], self.Q, self.R
@@ -255,12 +288,16 @@ class RelationTailGrad:
         prep = lambda g: g.to(self.dev, torch.float32).contiguous()
         if g_rel is not None:
             # ... and the gather of the pair features back onto the query rows (:342-351)
-            dpair = self._relation_backward(prep(g_rel), grads)
+            dpair = self._relation_backward(prep(g_rel), grads, on_ready)
             hip.scatter_rows_add(dpair, t["pair_idx"], dq, B, Q, 2 * R, 256, accumulate=True)
+        ready = on_ready if on_ready is not None else (lambda end: None)
+        ready(self.group_end["rel_query"])
         if g_importance is not None:
             self._ppn_backward(prep(g_importance), grads, dq)
+        ready(self.group_end["obj_query_update"])
         if not cls_detached and (g_sub is not None or g_obj is not None):
             self._cls_backward(g_sub, g_obj, grads, dq)
+        ready(self.flat_numel)
         return dq, grads
 
     @torch.no_grad()
@@ -280,13 +317,15 @@ class RelationTailGrad:
         grads = self._zero_grads()
         return self._relation_backward(g_rel.to(self.dev, torch.float32).contiguous(), grads), grads
 
-    def _relation_backward(self, g_rel, grads):
+    def _relation_backward(self, g_rel, grads, on_ready=None):
         w, E, t = self.head.w, self._E, self.t
         B, Q, R = t["B"], self.Q, self.R
         M, Mk = B * R, B * 2 * R
         C = g_rel.shape[-1]
+        ready = on_ready if on_ready is not None else (lambda end: None)
         dx = self._lin_bwd(g_rel.view(M, C), t["r_out"], w["rel_cls_embed.weight"], grads,
                            "rel_cls_embed.weight", "rel_cls_embed.bias")
+        ready(self.group_end["rel_cls_embed"])
         dpair = torch.zeros(Mk, 256, device=self.dev, dtype=torch.float32)
         dpairp = torch.zeros(Mk, 256, device=self.dev, dtype=torch.float32)   # d (pair + key_pos)
         drpos_rows = torch.zeros(M, 256, device=self.dev, dtype=torch.float32)  # d (x + query_pos), all uses
@@ -336,6 +375,7 @@ class RelationTailGrad:
             self._acc(dpair, dv)
             dx = dxp
             self._acc(dx, dy1)                                    # identity shortcut
+            ready(self.group_end["relation_decoder.layers.%d" % i])
         # layer 0's input is rel_query_feat repeated over the batch
         hip.batch_sum(dx, grads["rel_query_feat.weight"], B)
         hip.batch_sum(drpos_rows, grads["rel_query_embed.weight"], B)
@@ -397,12 +437,13 @@ class RelationTailGrad:
         zero = torch.zeros(1, device=self.dev, dtype=torch.float32)
         hip.mlearner_last(dc1, w1b.view(49, 64), zero, draw, B, Q)
         # parameter gradients in the reference's layouts (cnn_factory.py: Conv2d weights [Co][Ci][7][7])
-        grads[ml + "2.0.weight"] = dw3.view(49, 64).t().reshape(1, 64, 7, 7).contiguous()
-        grads[ml + "2.0.bias"] = db3
-        grads[ml + "1.0.weight"] = dw2.view(64, 7, 7, 64).permute(0, 3, 1, 2).contiguous()
-        grads[ml + "1.0.bias"] = db2
-        grads[ml + "0.0.weight"] = dw1t.view(49, 64).t().reshape(64, 1, 7, 7).contiguous()
-        grads[ml + "0.0.bias"] = db1
+        # (copies that only re-order: [tap][ci] -> [1][ci][7][7], [co][tap][ci] -> [co][ci][7][7], ...)
+        grads[ml + "2.0.weight"].copy_(dw3.view(49, 64).t().reshape(1, 64, 7, 7))
+        grads[ml + "2.0.bias"].copy_(db3)
+        grads[ml + "1.0.weight"].copy_(dw2.view(64, 7, 7, 64).permute(0, 3, 1, 2))
+        grads[ml + "1.0.bias"].copy_(db2)
+        grads[ml + "0.0.weight"].copy_(dw1t.view(49, 64).t().reshape(64, 1, 7, 7))
+        grads[ml + "0.0.bias"].copy_(db1)
         # ---- cosine block + F.normalize ----
         s_e, o_e = t["sub"][2], t["obj"][2]
         s_hat, o_hat = E(B * Q, 256), E(B * Q, 256)

@@ -119,6 +119,9 @@ _SIGS = {
     "pn_tapcorr1_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_tapcorr64_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_conv_weight_bwd_layout_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "pn_grad_norm_clip_f32": (C.c_int, [_vp, _i64, _f32, _f32, _vp, _vp, _vp]),
+    "pn_adamw_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32,
+                               _f32, _i32, _vp, _f32, _vp]),
     "pn_msda_loc_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pn_msda_bwd_f32": (C.c_int, [_vp, _i64] + [_vp] * 8 + [_i32, _i32, _i32, _i32, _vp]),
     "pn_gather_probe_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
@@ -180,7 +183,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 22   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 23   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -1249,6 +1252,25 @@ def conv_weight_bwd_layout(w, out, Co, T, Ci):
     assert w.numel() == out.numel() == Co * T * Ci
     _check(lib().pn_conv_weight_bwd_layout_f32(_ptr(w), _ptr(out), Co, T, Ci, _stream()),
            "pn_conv_weight_bwd_layout_f32")
+
+
+def grad_norm_clip(g, out, scratch, pre=1.0, max_norm=0.0):
+    """out[0] = ||pre * g||, out[1] = clip coefficient; g flat fp32, scratch >= 256 float64."""
+    assert g.is_contiguous() and out.numel() >= 2 and scratch.numel() >= 256
+    _check(lib().pn_grad_norm_clip_f32(_ptr(g), g.numel(), pre, max_norm, _ptr(out),
+                                       _ptr(scratch, torch.float64), _stream()),
+           "pn_grad_norm_clip_f32")
+
+
+def adamw(p, g, m, v, seg_off, seg_lr, seg_wd, lr, beta1, beta2, eps, weight_decay, step,
+          clip=None, pre=1.0):
+    n = p.numel()
+    assert all(t.is_contiguous() and t.numel() == n for t in (p, g, m, v))
+    nseg = seg_lr.numel()
+    assert seg_off.numel() == nseg + 1 and seg_wd.numel() == nseg
+    _check(lib().pn_adamw_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, _ptr(seg_off, torch.int64),
+                              _ptr(seg_lr), _ptr(seg_wd), nseg, lr, beta1, beta2, eps, weight_decay,
+                              step, _ptr(clip), pre, _stream()), "pn_adamw_f32")
 
 
 def bce_posw_mean(logits, target, out, loss_weight):

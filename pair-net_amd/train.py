@@ -1,0 +1,157 @@
+"""One training iteration of Pair-Net's own parameters on the MI355X: the
+reference's `forward_train` -> `loss` -> `backward` -> clip -> AdamW step (frameworks/psgtr.py:112-146,
+pairnet_head.py:419-757, tools/train.py:115-241, configs/mask2former/pairnet.py:353-368) for the
+parameters the backward slices built so far reach -- the Relation Fusion decoder, `rel_cls_embed`,
+the relation query / position embeddings, the Pair Proposal Network's MLPs and the Matrix Learner
+(10.3 M of the head's parameters) -- with the detector in front of them (backbone, pixel decoder,
+the nine masked decoder layers) FROZEN: in the reference those train at `lr_mult=0.1`; their
+backward pass is the part of f-4 that is not built, and this module says so rather than pretend.
+Everything the reference's loss can reach enters through two logits: `loss_r_cls` through
+`rel`, `loss_match` through `importance` (`loss_sub_cls` / `loss_obj_cls` read DETACHED class
+logits, pairnet_head.py:380-390, and train nothing).
+
+    trainer = TailTrainer(head)                       # AdamW(lr=1e-4, wd=1e-4), clip 0.1
+    losses = trainer.step(feats, img_metas, gt_rels, gt_labels, gt_masks)
+
+Per step: `head.forward` (the inference kernels; hipGraphs if on) -> `head.loss(grads=)` (csrc/
+loss.hip; the two Hungarian assignments on the host as the reference) -> `RelationTailGrad`
+forward-with-tape + backward into one flat gradient buffer -> (world > 1) bucketed all-reduce
+overlapped with the backward pass (`dist.GradReducer`) -> global-norm clip coefficient on the
+device -> ONE AdamW launch over the flat parameter buffer that the head's weight dict aliases ->
+refresh of the derived weight packs the inference kernels read.  No host synchronisation inside a
+step apart from the reference's own (the Hungarian cost matrices).
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import hip
+from .dist import GradReducer
+from .grad import RelationTailGrad
+
+__all__ = ["TailTrainer"]
+
+
+class TailTrainer:
+    FROZEN_GROUPS = ("cls",)      # cls_embed / post_norm: no gradient in the reference's graph
+
+    def __init__(self, head, lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8,
+                 max_norm=0.1, norm_decay_mult=0.0, lr_mult=None, group=None,
+                 bucket_bytes=32 << 20):
+        self.head = head
+        if head.w is None:
+            head._pack()
+        # plans captured so far bake the addresses of the weight tensors that are re-homed below
+        # into their hipGraphs: start from fresh plans (the arenas, shape-dependent only, stay)
+        from .plans import PlanCache
+        head._plans = PlanCache(head._plans.max_plans)
+        self.tape = tape = RelationTailGrad(head)
+        dev = self.dev = head.device
+        self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        # the trainable prefix of the flat layout (the frozen class path sits at its end)
+        self.n = min([tape.layout[n][0] for g, names in tape.param_groups(head)
+                      if g in self.FROZEN_GROUPS for n in names] or [tape.flat_numel])
+        self.names = [n for n, (o, _, _) in tape.layout.items() if o < self.n]
+        # ---- flat parameters; the head's device weights become views of them ----
+        self.flat_p = torch.zeros(self.n, device=dev, dtype=torch.float32)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        w = head.w
+        self.params = OrderedDict()
+        ml = "update_importance.conv_layers."
+        self._repacked = {ml + "1.0.weight", ml + "2.0.weight"}   # w[...] holds another layout
+        for n in self.names:
+            o, shape, k = tape.layout[n]
+            view = self.flat_p[o:o + k].view(shape)
+            view.copy_(head._params[n].to(dev))
+            self.params[n] = view
+            if n not in self._repacked:
+                # same bytes as the reference layout (ConvTiny's first layer: [64,1,7,7] == [64,49])
+                w[n] = view.view(w[n].shape)
+        # ---- per-segment multipliers (mmcv paramwise_cfg) ----
+        lr_mult = dict(lr_mult or {})
+        offs, lrs, wds = [], [], []
+        for n in self.names:
+            o, shape, k = tape.layout[n]
+            offs.append(o)
+            lrs.append(next((m for key, m in lr_mult.items() if key in n), 1.0))
+            is_norm = ".norms." in n or "post_norm" in n
+            wds.append(norm_decay_mult if is_norm else 1.0)
+        offs.append(self.n)
+        self.seg_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self.seg_lr = torch.tensor(lrs, dtype=torch.float32, device=dev)
+        self.seg_wd = torch.tensor(wds, dtype=torch.float32, device=dev)
+        self.clip = torch.zeros(2, device=dev, dtype=torch.float32)     # [grad norm, coefficient]
+        self._scratch = torch.zeros(256, device=dev, dtype=torch.float64)
+        self.reducer = GradReducer(tape.flat_grad[:self.n], group=group, bucket_bytes=bucket_bytes)
+        self.steps = 0
+        self._refresh_derived()
+
+    # ------------------------------------------------------------------
+    def _refresh_derived(self):
+        """The weight packs the INFERENCE kernels read that are functions of trained parameters,
+        rewritten in place (captured hipGraphs keep their pointers)."""
+        head, w, p = self.head, self.head.w, self.params
+        for i in range(head.num_rel_layers):
+            a = "relation_decoder.layers.%d.attentions.1.attn." % i
+            W, b = p[a + "in_proj_weight"], p[a + "in_proj_bias"]
+            w[a + "vqk.weight"][:256].copy_(W[512:])
+            w[a + "vqk.weight"][256:].copy_(W[:512])
+            w[a + "vqk.bias"][:256].copy_(b[512:])
+            w[a + "vqk.bias"][256:].copy_(b[:512])
+            a = "relation_decoder.layers.%d.attentions.0.attn." % i
+            W, b = p[a + "in_proj_weight"], p[a + "in_proj_bias"]
+            w[a + "vk.weight"][:256].copy_(W[512:])
+            w[a + "vk.weight"][256:].copy_(W[256:512])
+            w[a + "vk.bias"][:256].copy_(b[512:])
+            w[a + "vk.bias"][256:].copy_(b[256:512])
+        ml = "update_importance.conv_layers."
+        w[ml + "1.0.weight"].copy_(p[ml + "1.0.weight"].permute(0, 2, 3, 1).reshape(64, -1))
+        w[ml + "2.0.weight"].copy_(p[ml + "2.0.weight"].reshape(64, 49).t())
+        for c in head._consts.values():           # rel_query_feat repeated over the batch
+            if "r0" in c:
+                B = c["r0"].shape[0] // p["rel_query_feat.weight"].shape[0]
+                c["r0"].view(B, -1, 256).copy_(p["rel_query_feat.weight"].unsqueeze(0).expand(B, -1, -1))
+
+    def write_back(self):
+        """Copy the trained values into the head's state dict (checkpoints, `state_dict()`)."""
+        head = self.head
+        for n, v in self.params.items():
+            head._params[n].copy_(v.to(head._params[n].device))
+        head._packed_version = head._weights_version()     # the packed device weights ARE these values
+
+    # ------------------------------------------------------------------
+    @torch.no_grad()
+    @hip.on_device
+    def step(self, feats, img_metas, gt_rels, gt_labels, gt_masks, point_coords=None):
+        """One iteration on one batch; returns the four loss terms (device scalars, as
+        `CrossHead2.loss`) plus `grad_norm` (device scalar, before clipping)."""
+        head, tape = self.head, self.tape
+        outs = head.forward(feats, img_metas)
+        up = {}
+        losses = head.loss(*outs, gt_rels, None, gt_labels, gt_masks, img_metas,
+                           point_coords=point_coords, grads=up)
+        pl = head._last_plan
+        tape.forward(pl.q, pl.sub_pos, pl.obj_pos)
+        self.reducer.start()
+        end = self.n
+        tape.backward(g_rel=up["rel"], g_importance=up["importance"],
+                      on_ready=lambda e: self.reducer.ready(min(e, end)))
+        self.reducer.finish()
+        self.apply_gradients()
+        out = dict(losses)
+        out["grad_norm"] = self.clip[0]
+        return out
+
+    @torch.no_grad()
+    @hip.on_device
+    def apply_gradients(self):
+        """Clip (global L2 norm over the trainable gradients) + AdamW on `tape.flat_grad`."""
+        g = self.tape.flat_grad[:self.n]
+        pre = self.reducer.scale
+        hip.grad_norm_clip(g, self.clip, self._scratch, pre=pre, max_norm=self.max_norm)
+        self.steps += 1
+        hip.adamw(self.flat_p, g, self.flat_m, self.flat_v, self.seg_off, self.seg_lr, self.seg_wd,
+                  self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.steps,
+                  clip=self.clip, pre=pre)
+        self._refresh_derived()

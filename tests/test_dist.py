@@ -792,6 +792,61 @@ def test_multi_gpu_test_with_the_sibling_heads(model):
     assert d["rel_dists"].shape == (head.num_rel_query, head.num_relations + 1)
 
 
+def _reducer_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pairnet_amd.dist import GradReducer
+    n = 5000
+    flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    red = GradReducer(flat, bucket_bytes=4096)            # 1024 floats per bucket: 5 buckets
+    log = []
+    for _ in range(2):                                    # two "backward passes"
+        flat.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+        red.start()
+        for end in (100, 1024, 3000, 3072):               # the backward pass's ready() calls
+            red.ready(end)
+            log.append(red.next)
+        red.finish()
+        log.append(red.next)
+    q.put((rank, flat.clone(), red.scale, red.collectives, log, [b for b in red.bounds]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_buckets_world2_gloo():
+    """`GradReducer` (the training step's DDP half) over gloo: buckets are all-reduced as soon as
+    the backward pass reports a prefix complete, never before; after finish() every rank holds
+    the SUM, and `scale` = 1 / world is what the optimizer kernels multiply by."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = torch.arange(5000, dtype=torch.float32) * 3.0          # rank 0: x1, rank 1: x2
+    for rank, flat, scale, ncoll, log, bounds in got:
+        assert torch.equal(flat, want), rank
+        assert scale == 0.5 and ncoll == 10
+        assert bounds == [(0, 1024), (1024, 2048), (2048, 3072), (3072, 4096), (4096, 5000)]
+        # buckets issued after ready(100), ready(1024), ready(3000), ready(3072), finish()
+        assert log == [0, 1, 2, 3, 5] * 2
+
+
+def test_grad_reducer_is_a_no_op_without_a_process_group():
+    from pairnet_amd.dist import GradReducer
+    flat = torch.ones(300)
+    red = GradReducer(flat)
+    red.start()
+    red.ready(300)
+    red.finish()
+    assert red.scale == 1.0 and red.collectives == 0 and torch.equal(flat, torch.ones(300))
+
+
 def test_numa_binding_reads_sysfs_and_is_best_effort(tmp_path):
     """`dist.bind_to_gpu_numa` (bench.py --gpus N binds every rank to its GPU's NUMA node):
     the node and cpu list come from sysfs; unknown topology (node -1, no files, no GPU) means

@@ -162,7 +162,7 @@ def test_building_blocks_against_torch():
 def test_relation_decoder_backward_on_golden_pair_features():
     """`reldec.npz`'s pair features through the taped Relation Fusion decoder: the forward
     reproduces the reference's recorded rel_preds, the backward equals autograd through the
-    oracle's six layers for a random upstream gradient (d pair features and all 131 parameter
+    oracle's six layers for a random upstream gradient (d pair features and all 113 parameter
     tensors of relation_decoder.* / rel_cls_embed / rel_query_*)."""
     from pairnet_amd import RelationTailGrad
     fx = golden("reldec")

@@ -1,0 +1,117 @@
+"""GPU: the optimizer kernels (csrc/optim.hip) against torch.optim.AdamW + clip_grad_norm_ -- the
+reference's optimizer and OptimizerHook (configs/mask2former/pairnet.py:353-368) -- and the
+training step of Pair-Net's own parameters (pair-net_amd/train.py) end to end."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_adamw_and_clip_kernels_equal_torch():
+    """Three steps over a flat buffer of three segments (different lr / decay multipliers, one
+    a zero-decay "norm" segment) with global-norm clipping and a data-parallel pre-scale: every
+    parameter, both moments, the norm and the clip coefficient against torch on the host."""
+    from pairnet_amd import hip
+    g = torch.Generator().manual_seed(5)
+    sizes, pads = [1000, 37, 4096], [1024, 64, 4096]
+    lr_mult, wd_mult = [1.0, 0.1, 1.0], [1.0, 1.0, 0.0]
+    offs = np.concatenate([[0], np.cumsum(pads)]).astype(np.int64)
+    n = int(offs[-1])
+    ref_p = [torch.randn(s, generator=g).double().requires_grad_() for s in sizes]
+    lr, wd, b1, b2, eps, max_norm, pre = 1e-3, 1e-2, 0.9, 0.999, 1e-8, 0.1, 0.5
+    opt = torch.optim.AdamW([dict(params=[p], lr=lr * lm, weight_decay=wd * wm)
+                             for p, lm, wm in zip(ref_p, lr_mult, wd_mult)], betas=(b1, b2), eps=eps)
+    flat_p = torch.zeros(n)
+    for p, o in zip(ref_p, offs):
+        flat_p[o:o + p.numel()] = p.detach().float()
+    flat_p = flat_p.to(DEV)
+    flat_m, flat_v = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
+    seg_off = torch.from_numpy(offs).to(DEV)
+    seg_lr = torch.tensor(lr_mult, device=DEV)
+    seg_wd = torch.tensor(wd_mult, device=DEV)
+    clip = torch.zeros(2, device=DEV)
+    scratch = torch.zeros(256, device=DEV, dtype=torch.float64)
+    for step in range(1, 4):
+        grads = [torch.randn(s, generator=g) * (10.0 if step == 2 else 0.001) for s in sizes]
+        flat_g = torch.zeros(n)
+        for gr, o in zip(grads, offs):
+            flat_g[o:o + gr.numel()] = gr
+        flat_g = flat_g.to(DEV)
+        hip.grad_norm_clip(flat_g, clip, scratch, pre=pre, max_norm=max_norm)
+        hip.adamw(flat_p, flat_g, flat_m, flat_v, seg_off, seg_lr, seg_wd, lr, b1, b2, eps, wd, step,
+                  clip=clip, pre=pre)
+        for p, gr in zip(ref_p, grads):
+            p.grad = (gr.float() * pre).double()
+        norm = torch.nn.utils.clip_grad_norm_(ref_p, max_norm)
+        opt.step()
+        assert abs(float(clip[0]) - float(norm)) < 1e-5 * float(norm)
+        assert abs(float(clip[1]) - min(1.0, max_norm / (float(norm) + 1e-6))) < 1e-6
+        got = flat_p.cpu()
+        for p, o in zip(ref_p, offs):
+            err = float((got[o:o + p.numel()].double() - p.detach()).abs().max())
+            assert err < 2e-6, (step, err)
+    # the padding between segments never moves
+    assert float(flat_p[1000:1024].abs().max()) == 0.0
+
+
+def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent():
+    """`TailTrainer.step` on a fixed batch: (1) the first update of every trained tensor equals
+    torch's AdamW + clip on the gradients the step produced; (2) the loss the step optimises goes
+    down over a few steps; (3) after training, the INFERENCE kernels (packed [V|Q|K] / [V|K]
+    projections, the Matrix Learner's packed weights, the repeated initial queries) and the taped
+    forward give the same outputs -- the derived weight packs were refreshed; (4) `write_back()`
+    puts the trained values into `state_dict()`; the frozen detector did not move."""
+    from pairnet_amd import RelationTailGrad, TailTrainer
+    from test_losses_gpu import _outputs
+    head, cls, masks, metas, gt_rels, gt_labels, gt_masks, pts = _outputs(2, H=96, W=128, bs=2)
+    g = torch.Generator().manual_seed(2)
+    feats = [torch.randn(2, c, 96 // s, 128 // s, generator=g).to(DEV)
+             for c, s in zip((256, 512, 1024, 2048), (4, 8, 16, 32))]
+    before = {k: v.clone() for k, v in head.state_dict().items()}
+    lr = 1e-3
+    tr = TailTrainer(head, lr=lr)
+    p0 = tr.flat_p.clone()
+    out = tr.step(feats, metas, gt_rels, gt_labels, gt_masks, point_coords=pts)
+    torch.cuda.synchronize()
+    # (1) the update, recomputed with torch from the step's own gradients
+    gflat = tr.tape.flat_grad[:tr.n].cpu().double()
+    norm = float(gflat.norm())
+    assert abs(float(out["grad_norm"]) - norm) < 1e-4 * norm and norm > 0
+    coef = min(1.0, tr.max_norm / (norm + 1e-6))
+    worst = 0.0
+    for n, v in tr.params.items():
+        o, shape, k = tr.tape.layout[n]
+        p = p0[o:o + k].cpu().double().requires_grad_()
+        is_norm = ".norms." in n
+        opt = torch.optim.AdamW([p], lr=lr, weight_decay=0.0 if is_norm else tr.wd, betas=tr.betas,
+                                eps=tr.eps)
+        p.grad = gflat[o:o + k] * coef
+        opt.step()
+        worst = max(worst, float((v.reshape(-1).cpu().double() - p.detach()).abs().max()))
+    print("first AdamW update: worst |difference| vs torch %.2e (lr %.0e)" % (worst, lr))
+    assert worst < 2e-2 * lr
+    # (2) a few more steps on the same batch
+    hist = [float(out["loss_match"])]
+    for _ in range(7):
+        hist.append(float(tr.step(feats, metas, gt_rels, gt_labels, gt_masks,
+                                  point_coords=pts)["loss_match"]))
+    print("loss_match over 8 steps:", ["%.4f" % h for h in hist])
+    assert hist[1] < hist[0] and min(hist) < 0.95 * hist[0]       # (lr 1e-3 on one batch: bouncy)
+    # (3) inference kernels vs the taped forward on the trained weights
+    outs, _ = head.forward(feats, metas)
+    pl = head._last_plan
+    taped = RelationTailGrad(head).forward(pl.q.clone(), pl.sub_pos, pl.obj_pos)
+    torch.cuda.synchronize()
+    for k in ("rel", "importance"):
+        assert float((taped[k] - outs[k]).abs().max()) < 1e-4, k
+    # (4) state dict
+    tr.write_back()
+    sd = head.state_dict()
+    moved = [k for k in sd if not torch.equal(sd[k].cpu(), before[k].cpu())]
+    assert set(moved) == set(tr.names), (set(moved) ^ set(tr.names))
+    for n, v in tr.params.items():
+        assert torch.equal(sd[n].cpu(), v.cpu()), n
+    outs2, _ = head.forward(feats, metas)          # (write_back must not trigger a stale re-pack)
+    assert torch.equal(outs2["rel"], outs["rel"])

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 23
+#define PN_ABI_VERSION 24
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -757,13 +757,15 @@ int pn_batch_sum_f32(const float* x, float* out, int B, int64_t n, int accumulat
  * column sum is d weight (d bias = column sum of dy). */
 int pn_layernorm256_bwd_f32(const float* dy, const float* x, const float* gamma, float* dx,
                             float* gxhat, int rows, float eps, void* stream);
-/* nn.MultiheadAttention core backward, 8 heads x 32 channels, no mask, from the saved projections
+/* nn.MultiheadAttention core backward, 8 heads x 32 channels, from the saved projections
  * q [B*Nq][ldq], k / v [B*Nk][ldk / ldv] and the gradient of the concatenated head outputs dout
- * [B*Nq][ldo]: dq, dk, dv (same row layouts).  scratch: 2 * B * 8 * Nq * Nk floats. */
+ * [B*Nq][ldo]: dq, dk, dv (same row layouts).  bits / rowall: the forward's boolean mask as
+ * pn_mask_pack wrote it (both NULL: no mask).  scratch: 2 * B * 8 * Nq * Nk floats. */
 int pn_mha_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
                    int64_t ldv, const float* dout, int64_t ldo, float* dq, int64_t lddq, float* dk,
-                   int64_t lddk, float* dv, int64_t lddv, float* scratch, int B, int Nq, int Nk,
-                   float scale, void* stream);
+                   int64_t lddk, float* dv, int64_t lddv, const uint32_t* bits,
+                   const int32_t* rowall, float* scratch, int B, int Nq, int Nk, float scale,
+                   void* stream);
 /* Backward of pn_gather_rows_f32: out[b][row][0:length] (+)= sum_{s: index[b][s] == row}
  * src[b][s][0:length]; src [B*slots][ld_src], out [B*rows_out][ld_out]. */
 int pn_scatter_rows_add_f32(const float* src, int64_t ld_src, const int64_t* index, float* out,

@@ -163,16 +163,22 @@ extern "C" int pn_layernorm256_bwd_f32(const float* dy, const float* x, const fl
   return PN_LAUNCH_CHECK();
 }
 
-// ---- multi-head attention backward (8 heads x 32 channels, no mask: the Relation Fusion
-// decoder's attentions, Nq, Nk <= a few hundred).  Four passes over a [B][8][Nq][Nk] scratch
+// ---- multi-head attention backward (8 heads x 32 channels; optional bit-packed boolean mask:
+// the Relation Fusion decoder's attentions, Nk <= a few hundred, and the masked decoder's cross-
+// attentions over a level's 1 050 - 16 700 keys).  Four passes over a [B][8][Nq][Nk] scratch
 // pair: P = softmax(scale q k^T) recomputed from the saved projections, dS = P (dP - sum P dP)
 // with dP = dO v^T, then dq = scale dS k, dk = scale dS^T q, dv = P^T dO.  One wave per
 // (query | key, head); latency-sized (3 MFLOP per head), so plain FMA rows, not MFMA tiles.
 __global__ __launch_bounds__(64) void k_mha_probs(const float* __restrict__ q, int64_t ldq,
                                                   const float* __restrict__ k, int64_t ldk,
                                                   float* __restrict__ P, int Nq, int Nk,
-                                                  float scale) {
+                                                  float scale, const uint32_t* __restrict__ bits,
+                                                  const int32_t* __restrict__ rowall) {
   const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+  // the boolean attention mask of pn_mask_pack (bit set = key not attendable), shared by the
+  // heads; a row whose keys are ALL masked attends to everything (pairnet_head.py:300)
+  const int64_t mrow = (int64_t)b * Nq + i;
+  const uint32_t* mb = (bits && !rowall[mrow]) ? bits + mrow * ((Nk + 31) >> 5) : nullptr;
   const float* qr = q + ((int64_t)b * Nq + i) * ldq + h * 32;
   float4 qv[8];
 #pragma unroll
@@ -188,6 +194,7 @@ __global__ __launch_bounds__(64) void k_mha_probs(const float* __restrict__ q, i
       s += qv[d].x * kv.x + qv[d].y * kv.y + qv[d].z * kv.z + qv[d].w * kv.w;
     }
     s *= scale;
+    if (mb && ((mb[j >> 5] >> (j & 31)) & 1u)) s = -INFINITY;
     Pr[j] = s;
     mx = fmaxf(mx, s);
   }
@@ -269,10 +276,10 @@ __global__ __launch_bounds__(64) void k_mha_bwd_dkv(const float* __restrict__ dS
 extern "C" int pn_mha_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
                               const float* v, int64_t ldv, const float* dout, int64_t ldo,
                               float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv,
-                              int64_t lddv, float* scratch, int B, int Nq, int Nk, float scale,
-                              void* stream) {
+                              int64_t lddv, const uint32_t* bits, const int32_t* rowall,
+                              float* scratch, int B, int Nq, int Nk, float scale, void* stream) {
   if (!q || !k || !v || !dout || !dq || !dk || !dv || !scratch || B <= 0 || Nq <= 0 || Nk <= 0 ||
-      B > 65535)
+      B > 65535 || (bits && !rowall))
     return PN_BAD_ARG;
   if ((ldq | ldk | ldv | ldo) % 4 || ldq < 256 || ldk < 256 || ldv < 256 || ldo < 256 ||
       lddq < 256 || lddk < 256 || lddv < 256)
@@ -281,7 +288,8 @@ extern "C" int pn_mha_bwd_f32(const float* q, int64_t ldq, const float* k, int64
   hipStream_t s = (hipStream_t)stream;
   float* P = scratch;
   float* dS = scratch + (int64_t)B * 8 * Nq * Nk;
-  hipLaunchKernelGGL(k_mha_probs, dim3(Nq, 8, B), dim3(64), 0, s, q, ldq, k, ldk, P, Nq, Nk, scale);
+  hipLaunchKernelGGL(k_mha_probs, dim3(Nq, 8, B), dim3(64), 0, s, q, ldq, k, ldk, P, Nq, Nk, scale,
+                     bits, rowall);
   hipLaunchKernelGGL(k_mha_bwd_ds, dim3(Nq, 8, B), dim3(64), 0, s, dout, ldo, v, ldv, P, dS, Nq, Nk);
   hipLaunchKernelGGL(k_mha_bwd_dq, dim3(Nq, 8, B), dim3(64), 0, s, dS, k, ldk, dq, lddq, Nq, Nk,
                      scale);

@@ -32,7 +32,7 @@ import torch
 
 from . import hip
 
-__all__ = ["RelationTailGrad"]
+__all__ = ["RelationTailGrad", "HeadGrad"]
 
 
 class RelationTailGrad:
@@ -100,10 +100,22 @@ class RelationTailGrad:
         for side in ("sub", "obj"):
             groups.append((side + "_query_update", ["%s_query_update.%d.%s" % (side, j, n)
                                                     for j in (4, 2, 0) for n in ("weight", "bias")]))
-        groups.append(("cls", ["cls_embed.weight", "cls_embed.bias",
-                               "transformer_decoder.post_norm.weight",
-                               "transformer_decoder.post_norm.bias"]))
+        groups.append(RelationTailGrad.CLS_GROUP)
         return groups
+
+    CLS_GROUP = ("cls", ["cls_embed.weight", "cls_embed.bias", "transformer_decoder.post_norm.weight",
+                         "transformer_decoder.post_norm.bias"])
+
+    @staticmethod
+    def _layer_names(pre):
+        names = []
+        for a in ("attentions.0.attn.", "attentions.1.attn."):
+            names += [pre + a + n for n in ("in_proj_weight", "in_proj_bias", "out_proj.weight",
+                                            "out_proj.bias")]
+        names += [pre + "norms.%d.%s" % (j, n) for j in range(3) for n in ("weight", "bias")]
+        names += [pre + "ffns.0.layers.0.0.weight", pre + "ffns.0.layers.0.0.bias",
+                  pre + "ffns.0.layers.1.weight", pre + "ffns.0.layers.1.bias"]
+        return names
 
     # ------------------------------------------------------------------ small helpers
     def _E(self, *shape):
@@ -115,14 +127,21 @@ class RelationTailGrad:
         grads[wname][row0:row0+N] / grads[bname][row0:row0+N]; returns d x [M, K] or None."""
         M, K = x.shape
         N = W.shape[0]
-        assert M % 4 == 0 and N % 4 == 0 and K % 4 == 0, (M, N, K)
-        ld_dy = dy.stride(0)
-        xt = self._E(K, M)
-        hip.transpose(x, xt)
+        assert N % 4 == 0 and K % 4 == 0, (M, N, K)
+        Mp = (M + 3) // 4 * 4                  # the dW contraction runs over M: multiples of 4
+        dyw = dy
+        if Mp != M:                            # (zero rows: a level of 1 050 keys)
+            dyw = torch.zeros(Mp, N, device=self.dev, dtype=torch.float32)
+            dyw[:M].copy_(dy)
+        xt = self._E(K, Mp)
+        hip.transpose(x, xt)                   # (columns M .. Mp-1 zero-filled)
         gw = grads[wname][row0:row0 + N]
         tmp = self._E(N, K)
-        # dW[n][k] = sum_m dy[m][n] x[m][k]: A = dy read column-major, "W" operand = x^T
-        hip.gemm(dy, xt, tmp, M=N, N=K, K=M, lda=ld_dy, ldw=M, ldc=K, colmajor=True)
+        # dW[n][k] = sum_m dy[m][n] x[m][k]: A = dy read column-major, "W" operand = x^T;
+        # a long contraction over few output tiles is split (deterministic split-K + reduce)
+        scratch = self._E(8 * N * K) if Mp >= 2048 else None
+        hip.gemm(dyw, xt, tmp, M=N, N=K, K=Mp, lda=dyw.stride(0), ldw=Mp, ldc=K, colmajor=True,
+                 scratch=scratch)
         hip.add_periodic(gw, tmp, gw)
         if bname is not None:
             hip.colsum(dy, grads[bname][row0:row0 + N], accumulate=True)
@@ -131,7 +150,7 @@ class RelationTailGrad:
         Wt = self._E(K, N)
         hip.transpose(W, Wt)
         dx = self._E(M, K)
-        hip.gemm(dy, Wt, dx, M=M, N=K, K=N, lda=ld_dy, ldw=N, ldc=K)
+        hip.gemm(dy, Wt, dx, M=M, N=K, K=N, lda=dy.stride(0), ldw=N, ldc=K)
         return dx
 
     def _ln_bwd(self, dy, x, prefix, grads):
@@ -201,6 +220,95 @@ class RelationTailGrad:
         return dict(rel=rel, importance=imp, importance_raw=raw, sub=sub, obj=obj, cls=cls,
                     sub_pos=sub_pos, obj_pos=obj_pos)
 
+    def _layer_fwd(self, pre, x, qpos, K, V, B, nq, nk, ffn, scr, bits=None, rowall=None):
+        """One post-norm decoder layer (facebook_detr.py:378-432; order cross-attention, norm,
+        self-attention, norm, FFN, norm) over given key / value projections K, V (2-D views
+        [B * nk, 256], free row strides) with every intermediate kept; returns (tape, output)."""
+        w, E = self.head.w, self._E
+        M = B * nq
+        ac, as_ = pre + "attentions.0.attn.", pre + "attentions.1.attn."
+        Wc, bc = w[ac + "in_proj_weight"], w[ac + "in_proj_bias"]
+        Ws, bs = w[as_ + "in_proj_weight"], w[as_ + "in_proj_bias"]
+        s = dict(x_in=x, K=K, V=V, bits=bits, rowall=rowall)
+        # cross-attention
+        s["xp"] = E(M, 256)
+        hip.add_periodic(x, qpos, s["xp"])
+        s["Qc"] = E(M, 256)
+        hip.linear(s["xp"], Wc[:256], bc[:256], s["Qc"])
+        s["att_c"] = E(M, 256)
+        hip.attention(s["Qc"], 256, K, K.stride(0), V, V.stride(0), bits, rowall, s["att_c"], 256,
+                      scr, B, nq, nk, self.scale)
+        s["y1"] = E(M, 256)
+        hip.linear(s["att_c"], w[ac + "out_proj.weight"], w[ac + "out_proj.bias"], s["y1"], res=x)
+        s["x1"] = E(M, 256)
+        hip.layernorm(s["y1"], w[pre + "norms.0.weight"], w[pre + "norms.0.bias"], s["x1"])
+        # self-attention
+        s["x1p"] = E(M, 256)
+        hip.add_periodic(s["x1"], qpos, s["x1p"])
+        s["QKVs"] = E(M, 768)                               # columns [Q | K | V]
+        hip.linear(s["x1p"], Ws[:512], bs[:512], s["QKVs"][:, :512])
+        hip.linear(s["x1"], Ws[512:], bs[512:], s["QKVs"][:, 512:])
+        s["att_s"] = E(M, 256)
+        hip.attention(s["QKVs"], 768, s["QKVs"][:, 256:], 768, s["QKVs"][:, 512:], 768, None,
+                      None, s["att_s"], 256, scr, B, nq, nq, self.scale)
+        s["y2"] = E(M, 256)
+        hip.linear(s["att_s"], w[as_ + "out_proj.weight"], w[as_ + "out_proj.bias"], s["y2"],
+                   res=s["x1"])
+        s["x2"] = E(M, 256)
+        hip.layernorm(s["y2"], w[pre + "norms.1.weight"], w[pre + "norms.1.bias"], s["x2"])
+        # FFN
+        s["h"] = E(M, ffn)
+        hip.linear(s["x2"], w[pre + "ffns.0.layers.0.0.weight"],
+                   w[pre + "ffns.0.layers.0.0.bias"], s["h"], relu=True)
+        s["y3"] = E(M, 256)
+        hip.linear(s["h"], w[pre + "ffns.0.layers.1.weight"], w[pre + "ffns.0.layers.1.bias"],
+                   s["y3"], res=s["x2"])
+        out = E(M, 256)
+        hip.layernorm(s["y3"], w[pre + "norms.2.weight"], w[pre + "norms.2.bias"], out)
+        return s, out
+
+    def _layer_bwd(self, pre, s, dx, grads, B, nq, nk, scr, dqpos_rows):
+        """Backward of `_layer_fwd`: accumulates the layer's parameter gradients and d (x +
+        query_pos) (all three uses) into `dqpos_rows`; returns (d input, d K, d V)."""
+        w, E = self.head.w, self._E
+        M = B * nq
+        ac, as_ = pre + "attentions.0.attn.", pre + "attentions.1.attn."
+        Wc, Ws = w[ac + "in_proj_weight"], w[as_ + "in_proj_weight"]
+        # norm2 <- FFN
+        dy3 = self._ln_bwd(dx, s["y3"], pre + "norms.2.", grads)
+        dh = self._lin_bwd(dy3, s["h"], w[pre + "ffns.0.layers.1.weight"], grads,
+                           pre + "ffns.0.layers.1.weight", pre + "ffns.0.layers.1.bias")
+        hip.relu_bwd(dh, s["h"], dh)
+        dx2 = self._lin_bwd(dh, s["x2"], w[pre + "ffns.0.layers.0.0.weight"], grads,
+                            pre + "ffns.0.layers.0.0.weight", pre + "ffns.0.layers.0.0.bias")
+        self._acc(dx2, dy3)                                   # the FFN's identity shortcut
+        # norm1 <- self-attention
+        dy2 = self._ln_bwd(dx2, s["y2"], pre + "norms.1.", grads)
+        datt = self._lin_bwd(dy2, s["att_s"], w[as_ + "out_proj.weight"], grads,
+                             as_ + "out_proj.weight", as_ + "out_proj.bias")
+        dQKV = E(M, 768)
+        hip.mha_bwd(s["QKVs"], s["QKVs"][:, 256:], s["QKVs"][:, 512:], datt, dQKV,
+                    dQKV[:, 256:], dQKV[:, 512:], scr, B, nq, nq, self.scale)
+        dx1p = self._lin_bwd(dQKV[:, :512], s["x1p"], Ws[:512], grads, as_ + "in_proj_weight",
+                             as_ + "in_proj_bias", row0=0)
+        dx1 = self._lin_bwd(dQKV[:, 512:], s["x1"], Ws[512:], grads, as_ + "in_proj_weight",
+                            as_ + "in_proj_bias", row0=512)
+        self._acc(dx1, dx1p)
+        self._acc(dqpos_rows, dx1p)
+        self._acc(dx1, dy2)                                   # identity shortcut
+        # norm0 <- cross-attention
+        dy1 = self._ln_bwd(dx1, s["y1"], pre + "norms.0.", grads)
+        datt = self._lin_bwd(dy1, s["att_c"], w[ac + "out_proj.weight"], grads,
+                             ac + "out_proj.weight", ac + "out_proj.bias")
+        dQc, dK, dV = E(M, 256), E(B * nk, 256), E(B * nk, 256)
+        hip.mha_bwd(s["Qc"], s["K"], s["V"], datt, dQc, dK, dV, scr, B, nq, nk, self.scale,
+                    bits=s["bits"], rowall=s["rowall"])
+        dxp = self._lin_bwd(dQc, s["xp"], Wc[:256], grads, ac + "in_proj_weight",
+                            ac + "in_proj_bias", row0=0)
+        self._acc(dqpos_rows, dxp)
+        self._acc(dxp, dy1)                                   # identity shortcut
+        return dxp, dK, dV
+
     def _relation_forward(self, pair, B):
         """The six Relation Fusion layers over `pair` [B * 2R, 256] with every intermediate kept."""
         head, w, E = self.head, self.head.w, self._E
@@ -216,47 +324,13 @@ class RelationTailGrad:
         scr = E(max(hip.attn_scratch_floats(B, R, 2 * R), hip.attn_scratch_floats(B, R, R)))
         for i in range(self.L):
             pre = "relation_decoder.layers.%d." % i
-            ac, as_ = pre + "attentions.0.attn.", pre + "attentions.1.attn."
+            ac = pre + "attentions.0.attn."
             Wc, bc = w[ac + "in_proj_weight"], w[ac + "in_proj_bias"]
-            Ws, bs = w[as_ + "in_proj_weight"], w[as_ + "in_proj_bias"]
-            s = dict(x_in=x)
-            # cross-attention over the pair features
-            s["xp"] = E(M, 256)
-            hip.add_periodic(x, rpos, s["xp"])
-            s["Qc"], s["KVc"] = E(M, 256), E(Mk, 512)          # KVc columns: [K | V]
-            hip.linear(s["xp"], Wc[:256], bc[:256], s["Qc"])
-            hip.linear(pairp, Wc[256:512], bc[256:512], s["KVc"][:, :256])
-            hip.linear(pair, Wc[512:], bc[512:], s["KVc"][:, 256:])
-            s["att_c"] = E(M, 256)
-            hip.attention(s["Qc"], 256, s["KVc"], 512, s["KVc"][:, 256:], 512, None, None,
-                          s["att_c"], 256, scr, B, R, 2 * R, self.scale)
-            s["y1"] = E(M, 256)
-            hip.linear(s["att_c"], w[ac + "out_proj.weight"], w[ac + "out_proj.bias"], s["y1"], res=x)
-            s["x1"] = E(M, 256)
-            hip.layernorm(s["y1"], w[pre + "norms.0.weight"], w[pre + "norms.0.bias"], s["x1"])
-            # self-attention
-            s["x1p"] = E(M, 256)
-            hip.add_periodic(s["x1"], rpos, s["x1p"])
-            s["QKVs"] = E(M, 768)                               # columns [Q | K | V]
-            hip.linear(s["x1p"], Ws[:512], bs[:512], s["QKVs"][:, :512])
-            hip.linear(s["x1"], Ws[512:], bs[512:], s["QKVs"][:, 512:])
-            s["att_s"] = E(M, 256)
-            hip.attention(s["QKVs"], 768, s["QKVs"][:, 256:], 768, s["QKVs"][:, 512:], 768, None,
-                          None, s["att_s"], 256, scr, B, R, R, self.scale)
-            s["y2"] = E(M, 256)
-            hip.linear(s["att_s"], w[as_ + "out_proj.weight"], w[as_ + "out_proj.bias"], s["y2"],
-                       res=s["x1"])
-            s["x2"] = E(M, 256)
-            hip.layernorm(s["y2"], w[pre + "norms.1.weight"], w[pre + "norms.1.bias"], s["x2"])
-            # FFN
-            s["h"] = E(M, self.ffn)
-            hip.linear(s["x2"], w[pre + "ffns.0.layers.0.0.weight"],
-                       w[pre + "ffns.0.layers.0.0.bias"], s["h"], relu=True)
-            s["y3"] = E(M, 256)
-            hip.linear(s["h"], w[pre + "ffns.0.layers.1.weight"], w[pre + "ffns.0.layers.1.bias"],
-                       s["y3"], res=s["x2"])
-            x = E(M, 256)
-            hip.layernorm(s["y3"], w[pre + "norms.2.weight"], w[pre + "norms.2.bias"], x)
+            KV = E(Mk, 512)                                     # columns [K | V]
+            hip.linear(pairp, Wc[256:512], bc[256:512], KV[:, :256])
+            hip.linear(pair, Wc[512:], bc[512:], KV[:, 256:])
+            s, x = self._layer_fwd(pre, x, rpos, KV[:, :256], KV[:, 256:], B, R, 2 * R, self.ffn,
+                                   scr)
             layers.append(s)
         t["layers"], t["r_out"] = layers, x
         C = w["rel_cls_embed.weight"].shape[0]
@@ -280,24 +354,29 @@ class RelationTailGrad:
         the gathers, `cls_embed` and `post_norm` (the derivative of the un-detached expression).
         The gradients are views of `self.flat_grad` (valid until the next backward);
         `on_ready(end)`: called whenever flat_grad[:end] has become final (a reducer's hook)."""
+        dq, grads = self._backward_tail(g_rel, g_importance, g_sub, g_obj, cls_detached, on_ready)
+        if on_ready is not None:
+            on_ready(self.flat_numel)
+        return dq, grads
+
+    def _backward_tail(self, g_rel, g_importance, g_sub, g_obj, cls_detached, on_ready):
         if self.t is None:
             raise RuntimeError("backward() needs a forward() first")
         t, B, Q, R = self.t, self.t["B"], self.Q, self.R
         grads = self._zero_grads()
         dq = torch.zeros(B * Q, 256, device=self.dev, dtype=torch.float32)
         prep = lambda g: g.to(self.dev, torch.float32).contiguous()
+        ready = on_ready if on_ready is not None else (lambda end: None)
         if g_rel is not None:
             # ... and the gather of the pair features back onto the query rows (:342-351)
             dpair = self._relation_backward(prep(g_rel), grads, on_ready)
             hip.scatter_rows_add(dpair, t["pair_idx"], dq, B, Q, 2 * R, 256, accumulate=True)
-        ready = on_ready if on_ready is not None else (lambda end: None)
         ready(self.group_end["rel_query"])
         if g_importance is not None:
             self._ppn_backward(prep(g_importance), grads, dq)
         ready(self.group_end["obj_query_update"])
         if not cls_detached and (g_sub is not None or g_obj is not None):
             self._cls_backward(g_sub, g_obj, grads, dq)
-        ready(self.flat_numel)
         return dq, grads
 
     @torch.no_grad()
@@ -326,55 +405,22 @@ class RelationTailGrad:
         dx = self._lin_bwd(g_rel.view(M, C), t["r_out"], w["rel_cls_embed.weight"], grads,
                            "rel_cls_embed.weight", "rel_cls_embed.bias")
         ready(self.group_end["rel_cls_embed"])
-        dpair = torch.zeros(Mk, 256, device=self.dev, dtype=torch.float32)
-        dpairp = torch.zeros(Mk, 256, device=self.dev, dtype=torch.float32)   # d (pair + key_pos)
-        drpos_rows = torch.zeros(M, 256, device=self.dev, dtype=torch.float32)  # d (x + query_pos), all uses
+        zeros = lambda *s_: torch.zeros(*s_, device=self.dev, dtype=torch.float32)
+        dpair, dpairp = zeros(Mk, 256), zeros(Mk, 256)       # d pair, d (pair + key_pos)
+        drpos_rows = zeros(M, 256)                            # d (x + query_pos), all uses
         scr = E(max(hip.mha_bwd_scratch_floats(B, R, 2 * R), hip.mha_bwd_scratch_floats(B, R, R)))
         for i in reversed(range(self.L)):
             pre = "relation_decoder.layers.%d." % i
-            ac, as_ = pre + "attentions.0.attn.", pre + "attentions.1.attn."
-            Wc, Ws = w[ac + "in_proj_weight"], w[as_ + "in_proj_weight"]
-            s = t["layers"][i]
-            # norm2 <- FFN
-            dy3 = self._ln_bwd(dx, s["y3"], pre + "norms.2.", grads)
-            dh = self._lin_bwd(dy3, s["h"], w[pre + "ffns.0.layers.1.weight"], grads,
-                               pre + "ffns.0.layers.1.weight", pre + "ffns.0.layers.1.bias")
-            hip.relu_bwd(dh, s["h"], dh)
-            dx2 = self._lin_bwd(dh, s["x2"], w[pre + "ffns.0.layers.0.0.weight"], grads,
-                                pre + "ffns.0.layers.0.0.weight", pre + "ffns.0.layers.0.0.bias")
-            self._acc(dx2, dy3)                                   # the FFN's identity shortcut
-            # norm1 <- self-attention
-            dy2 = self._ln_bwd(dx2, s["y2"], pre + "norms.1.", grads)
-            datt = self._lin_bwd(dy2, s["att_s"], w[as_ + "out_proj.weight"], grads,
-                                 as_ + "out_proj.weight", as_ + "out_proj.bias")
-            dQKV = E(M, 768)
-            hip.mha_bwd(s["QKVs"], s["QKVs"][:, 256:], s["QKVs"][:, 512:], datt, dQKV,
-                        dQKV[:, 256:], dQKV[:, 512:], scr, B, R, R, self.scale)
-            dx1p = self._lin_bwd(dQKV[:, :512], s["x1p"], Ws[:512], grads, as_ + "in_proj_weight",
-                                 as_ + "in_proj_bias", row0=0)
-            dx1 = self._lin_bwd(dQKV[:, 512:], s["x1"], Ws[512:], grads, as_ + "in_proj_weight",
-                                as_ + "in_proj_bias", row0=512)
-            self._acc(dx1, dx1p)
-            self._acc(drpos_rows, dx1p)
-            self._acc(dx1, dy2)                                   # identity shortcut
-            # norm0 <- cross-attention
-            dy1 = self._ln_bwd(dx1, s["y1"], pre + "norms.0.", grads)
-            datt = self._lin_bwd(dy1, s["att_c"], w[ac + "out_proj.weight"], grads,
-                                 ac + "out_proj.weight", ac + "out_proj.bias")
-            dQc, dKVc = E(M, 256), E(Mk, 512)
-            hip.mha_bwd(s["Qc"], s["KVc"], s["KVc"][:, 256:], datt, dQc, dKVc, dKVc[:, 256:], scr,
-                        B, R, 2 * R, self.scale)
-            dxp = self._lin_bwd(dQc, s["xp"], Wc[:256], grads, ac + "in_proj_weight",
-                                ac + "in_proj_bias", row0=0)
-            self._acc(drpos_rows, dxp)
-            dkp = self._lin_bwd(dKVc[:, :256], t["pairp"], Wc[256:512], grads, ac + "in_proj_weight",
+            ac = pre + "attentions.0.attn."
+            Wc = w[ac + "in_proj_weight"]
+            dx, dK, dV = self._layer_bwd(pre, t["layers"][i], dx, grads, B, R, 2 * R, scr,
+                                         drpos_rows)
+            dkp = self._lin_bwd(dK, t["pairp"], Wc[256:512], grads, ac + "in_proj_weight",
                                 ac + "in_proj_bias", row0=256)
             self._acc(dpairp, dkp)
-            dv = self._lin_bwd(dKVc[:, 256:], t["pair"], Wc[512:], grads, ac + "in_proj_weight",
+            dv = self._lin_bwd(dV, t["pair"], Wc[512:], grads, ac + "in_proj_weight",
                                ac + "in_proj_bias", row0=512)
             self._acc(dpair, dv)
-            dx = dxp
-            self._acc(dx, dy1)                                    # identity shortcut
             ready(self.group_end["relation_decoder.layers.%d" % i])
         # layer 0's input is rel_query_feat repeated over the batch
         hip.batch_sum(dx, grads["rel_query_feat.weight"], B)
@@ -473,3 +519,108 @@ class RelationTailGrad:
         self._acc(grads["cls_embed.weight"], gp["W"][:nc])
         self._acc(grads["cls_embed.bias"], gp["b"][:nc])
         self._acc(dq, self._ln_bwd(dqn, t["q"], "transformer_decoder.post_norm.", grads))
+
+
+class HeadGrad(RelationTailGrad):
+    """RelationTailGrad + the nine masked-attention decoder layers in front of it
+    (pairnet_head.py:289-320; the reference's `transformer_decoder`, trained at lr_mult 0.1):
+    everything of CrossHead2 that the reference's loss reaches behind the pixel decoder.
+
+        tape = HeadGrad(head); head.forward(feats, metas); pl = head._last_plan
+        out = tape.forward_from_plan(pl)               # re-runs the query chain with a tape
+        dmem, grads = tape.backward(g_rel, g_importance)
+
+    `forward_from_plan` needs a plan whose stage A has run (`head.forward`): the memory tokens
+    `pl.X`, the K / V projections of the nine layers, the stencil rows of the mask feature.  The
+    boolean attention masks (:244-256, `detach()`ed in the reference) are recomputed per layer by
+    the product's own fused kernel and kept as packed bits.  `backward` returns the gradient with
+    respect to the pixel decoder's memory tokens [B, sum_l N_l, 256] (what the pixel decoder's
+    backward -- not built -- would take) and the parameter gradients incl. `query_feat`,
+    `query_embed`, `level_embed` and the cross-attentions' K / V projection rows."""
+
+    @staticmethod
+    def param_groups(head):
+        groups = [g for g in RelationTailGrad.param_groups(head) if g[0] != "cls"]
+        for i in reversed(range(head.num_dec_layers)):
+            groups.append(("transformer_decoder.layers.%d" % i,
+                           RelationTailGrad._layer_names("transformer_decoder.layers.%d." % i)))
+        groups.append(("query", ["query_feat.weight", "query_embed.weight", "level_embed.weight"]))
+        groups.append(RelationTailGrad.CLS_GROUP)
+        return groups
+
+    @torch.no_grad()
+    @hip.on_device
+    def forward_from_plan(self, pl, sub_pos=None, obj_pos=None):
+        head, w, E = self.head, self.head.w, self._E
+        B, Q = pl.B, self.Q
+        full = head.exact_mask_order == "full"
+        qpos = w["query_embed.weight"]
+        x = pl.q0
+        if full:
+            head._head_embed(pl.q0, pl, False, True)
+        scr = E(max([hip.attn_scratch_floats(B, Q, n) for n in pl.N] +
+                    [hip.attn_scratch_floats(B, Q, Q)]))
+        layers = []
+        for i in range(head.num_dec_layers):
+            l = i % 3
+            head._attn_mask(pl, l, None, me=pl.me0 if (i == 0 and not full) else None)
+            nw = (pl.N[l] + 31) // 32
+            bits, rowall = pl.bits[:B * Q * nw].clone(), pl.rowall.clone()
+            s, x = self._layer_fwd("transformer_decoder.layers.%d." % i, x, qpos,
+                                   pl.Kp[i].view(B * pl.N[l], 256), pl.Vp[i].view(B * pl.N[l], 256),
+                                   B, Q, pl.N[l], head.dec_ffn, scr, bits, rowall)
+            s["level"] = l
+            layers.append(s)
+            if i + 1 < head.num_dec_layers:      # post_norm + mask_embed -> the next layer's mask
+                head._head_embed(x, pl, False, full)
+        self.dt = dict(layers=layers, pl=pl, q_out=x)
+        return self.forward(x, sub_pos, obj_pos)
+
+    @torch.no_grad()
+    @hip.on_device
+    def backward(self, g_rel=None, g_importance=None, g_sub=None, g_obj=None, cls_detached=True,
+                 on_ready=None):
+        """-> (d memory tokens [B, SN, 256], {parameter name: gradient}); `self.dq_out` keeps the
+        gradient w.r.t. the decoder's output queries."""
+        dq, grads = self._backward_tail(g_rel, g_importance, g_sub, g_obj, cls_detached, on_ready)
+        self.dq_out = dq
+        head, w, E = self.head, self.head.w, self._E
+        ready = on_ready if on_ready is not None else (lambda end: None)
+        pl, layers = self.dt["pl"], self.dt["layers"]
+        B, Q = pl.B, self.Q
+        zeros = lambda *s_: torch.zeros(*s_, device=self.dev, dtype=torch.float32)
+        dmem = zeros(B, pl.SN, 256)
+        dqpos_rows = zeros(B * Q, 256)
+        scr = E(max([hip.mha_bwd_scratch_floats(B, Q, n) for n in pl.N] +
+                    [hip.mha_bwd_scratch_floats(B, Q, Q)]))
+        le, dle = w["level_embed.weight"], grads["level_embed.weight"]
+        dx = dq.clone()
+        for i in reversed(range(head.num_dec_layers)):
+            pre = "transformer_decoder.layers.%d." % i
+            ac = pre + "attentions.0.attn."
+            Wc = w[ac + "in_proj_weight"]
+            s = layers[i]
+            l, N = s["level"], pl.N[s["level"]]
+            dx, dK, dV = self._layer_bwd(pre, s, dx, grads, B, Q, N, scr, dqpos_rows)
+            # K = (mem_l + level_embed_l + pe_l) Wk^T + bk, V = (mem_l + level_embed_l) Wv^T + bv
+            # (pairnet_head.py:278-287, :302-312), image by image: a level's tokens of one image
+            # are contiguous rows of pl.X
+            for b in range(B):
+                mem = pl.X[b, pl.start[l]:pl.start[l] + N]
+                memk, memv = E(N, 256), E(N, 256)
+                hip.add_periodic(mem, pl.dec_kpos[l], memk)
+                hip.add_periodic(mem, le[l:l + 1], memv)
+                dmk = self._lin_bwd(dK[b * N:(b + 1) * N], memk, Wc[256:512], grads,
+                                    ac + "in_proj_weight", ac + "in_proj_bias", row0=256)
+                dmv = self._lin_bwd(dV[b * N:(b + 1) * N], memv, Wc[512:], grads,
+                                    ac + "in_proj_weight", ac + "in_proj_bias", row0=512)
+                self._acc(dmk, dmv)
+                dm = dmem[b, pl.start[l]:pl.start[l] + N]
+                self._acc(dm, dmk)
+                hip.colsum(dmk, dle[l], accumulate=True)      # level_embed_l feeds K and V
+            ready(self.group_end["transformer_decoder.layers.%d" % i])
+        hip.batch_sum(dx, grads["query_feat.weight"], B)
+        hip.batch_sum(dqpos_rows, grads["query_embed.weight"], B)
+        ready(self.group_end["query"])
+        ready(self.flat_numel)
+        return dmem, grads

@@ -112,7 +112,7 @@ _SIGS = {
     "pn_batch_sum_f32": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp]),
     "pn_layernorm256_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp]),
     "pn_mha_bwd_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
-                                 _vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp]),
+                                 _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "pn_scatter_rows_add_f32": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pn_cosine_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "pn_mlearner_last_bwd_data_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
@@ -183,7 +183,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 23   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 24   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -1208,12 +1208,14 @@ def mha_bwd_scratch_floats(B, Nq, Nk):
     return 2 * B * 8 * Nq * Nk
 
 
-def mha_bwd(q, k, v, dout, dq, dk, dv, scratch, B, Nq, Nk, scale):
-    """q / dout / dq: 2-D views [B*Nq, 256] (any row stride), k / v / dk / dv [B*Nk, 256]."""
+def mha_bwd(q, k, v, dout, dq, dk, dv, scratch, B, Nq, Nk, scale, bits=None, rowall=None):
+    """q / dout / dq: 2-D views [B*Nq, 256] (any row stride), k / v / dk / dv [B*Nk, 256];
+    bits / rowall: the forward's packed boolean mask (pn_mask_pack's outputs) or None."""
     ld = lambda t: _rowmajor(t)[1]
     assert scratch.numel() >= mha_bwd_scratch_floats(B, Nq, Nk)
     _check(lib().pn_mha_bwd_f32(_ptr(q), ld(q), _ptr(k), ld(k), _ptr(v), ld(v), _ptr(dout), ld(dout),
-                                _ptr(dq), ld(dq), _ptr(dk), ld(dk), _ptr(dv), ld(dv), _ptr(scratch),
+                                _ptr(dq), ld(dq), _ptr(dk), ld(dk), _ptr(dv), ld(dv),
+                                _ptr(bits, torch.int32), _ptr(rowall, torch.int32), _ptr(scratch),
                                 B, Nq, Nk, scale, _stream()), "pn_mha_bwd_f32")
 
 

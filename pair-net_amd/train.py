@@ -27,7 +27,7 @@ import torch
 
 from . import hip
 from .dist import GradReducer
-from .grad import RelationTailGrad
+from .grad import HeadGrad, RelationTailGrad
 
 __all__ = ["TailTrainer"]
 
@@ -37,15 +37,23 @@ class TailTrainer:
 
     def __init__(self, head, lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8,
                  max_norm=0.1, norm_decay_mult=0.0, lr_mult=None, group=None,
-                 bucket_bytes=32 << 20):
+                 bucket_bytes=32 << 20, train_decoder=False):
+        """`train_decoder`: also train the nine masked decoder layers, `query_feat`, `query_embed`
+        and `level_embed` (`HeadGrad`; the reference's `transformer_decoder` group, lr_mult 0.1 by
+        default here as in configs/mask2former/pairnet.py:358-363) -- everything of the head behind
+        the pixel decoder.  `lr_mult`: {substring of a parameter name: multiplier} (mmcv's
+        `paramwise_cfg.custom_keys`)."""
         self.head = head
+        self.train_decoder = bool(train_decoder)
+        if lr_mult is None:
+            lr_mult = {"transformer_decoder": 0.1}
         if head.w is None:
             head._pack()
         # plans captured so far bake the addresses of the weight tensors that are re-homed below
         # into their hipGraphs: start from fresh plans (the arenas, shape-dependent only, stay)
         from .plans import PlanCache
         head._plans = PlanCache(head._plans.max_plans)
-        self.tape = tape = RelationTailGrad(head)
+        self.tape = tape = (HeadGrad if train_decoder else RelationTailGrad)(head)
         dev = self.dev = head.device
         self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
         # the trainable prefix of the flat layout (the frozen class path sits at its end)
@@ -92,13 +100,18 @@ class TailTrainer:
         """The weight packs the INFERENCE kernels read that are functions of trained parameters,
         rewritten in place (captured hipGraphs keep their pointers)."""
         head, w, p = self.head, self.head.w, self.params
-        for i in range(head.num_rel_layers):
-            a = "relation_decoder.layers.%d.attentions.1.attn." % i
-            W, b = p[a + "in_proj_weight"], p[a + "in_proj_bias"]
-            w[a + "vqk.weight"][:256].copy_(W[512:])
-            w[a + "vqk.weight"][256:].copy_(W[:512])
-            w[a + "vqk.bias"][:256].copy_(b[512:])
-            w[a + "vqk.bias"][256:].copy_(b[:512])
+        decs = [("relation_decoder", head.num_rel_layers)]
+        if self.train_decoder:
+            decs.append(("transformer_decoder", head.num_dec_layers))
+        for dec, nl in decs:                       # self-attention as one [V | Q | K] projection
+            for i in range(nl):
+                a = "%s.layers.%d.attentions.1.attn." % (dec, i)
+                W, b = p[a + "in_proj_weight"], p[a + "in_proj_bias"]
+                w[a + "vqk.weight"][:256].copy_(W[512:])
+                w[a + "vqk.weight"][256:].copy_(W[:512])
+                w[a + "vqk.bias"][:256].copy_(b[512:])
+                w[a + "vqk.bias"][256:].copy_(b[:512])
+        for i in range(head.num_rel_layers):       # relation cross-attention keys / values: [V | K]
             a = "relation_decoder.layers.%d.attentions.0.attn." % i
             W, b = p[a + "in_proj_weight"], p[a + "in_proj_bias"]
             w[a + "vk.weight"][:256].copy_(W[512:])
@@ -112,6 +125,23 @@ class TailTrainer:
             if "r0" in c:
                 B = c["r0"].shape[0] // p["rel_query_feat.weight"].shape[0]
                 c["r0"].view(B, -1, 256).copy_(p["rel_query_feat.weight"].unsqueeze(0).expand(B, -1, -1))
+        if self.train_decoder:
+            from types import SimpleNamespace
+            for c in head._consts.values():       # the initial queries and their mask embedding
+                if "q0" not in c:
+                    continue
+                BQ = c["q0"].shape[0]
+                B = BQ // p["query_feat.weight"].shape[0]
+                c["q0"].view(B, -1, 256).copy_(p["query_feat.weight"].unsqueeze(0).expand(B, -1, -1))
+                if c.get("me0") is not None:
+                    tmp = SimpleNamespace(B=B, cls=None, MP=None,
+                                          **{n: torch.empty(BQ, 256, device=self.dev)
+                                             for n in ("qn", "m1", "m2", "me")})
+                    head._head_embed(c["q0"], tmp, False, False)
+                    c["me0"].copy_(tmp.me)
+            for shapes, ent in head._pe.items():  # key position tables carry level_embed
+                for l, (h, wd) in enumerate(shapes):
+                    hip.sine_pe(ent[1][l], p["level_embed.weight"][l], h, wd)
 
     def write_back(self):
         """Copy the trained values into the head's state dict (checkpoints, `state_dict()`)."""
@@ -132,7 +162,10 @@ class TailTrainer:
         losses = head.loss(*outs, gt_rels, None, gt_labels, gt_masks, img_metas,
                            point_coords=point_coords, grads=up)
         pl = head._last_plan
-        tape.forward(pl.q, pl.sub_pos, pl.obj_pos)
+        if self.train_decoder:
+            tape.forward_from_plan(pl, pl.sub_pos, pl.obj_pos)
+        else:
+            tape.forward(pl.q, pl.sub_pos, pl.obj_pos)
         self.reducer.start()
         end = self.n
         tape.backward(g_rel=up["rel"], g_importance=up["importance"],

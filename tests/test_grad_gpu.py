@@ -268,3 +268,75 @@ def test_tail_backward_from_the_losses_at_800x1333(cls_detached):
         names += cls_names
     _compare_params(grads, head_o, report, names)
     _print(report)
+
+
+def _unpack_mask(bits, rowall, B, Q, N):
+    """The boolean attention mask (True = not attendable) of one layer from pn_mask_pack's bits,
+    with the reference's all-masked fix (pairnet_head.py:300) applied."""
+    nw = (N + 31) // 32
+    words = bits.view(B * Q, nw).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    j = np.arange(N)
+    m = ((words[:, j >> 5] >> (j & 31)) & 1).astype(bool)
+    m[rowall.cpu().numpy().astype(bool)] = False
+    return torch.from_numpy(m).view(B, Q, N)
+
+
+def test_masked_decoder_backward_against_the_oracle():
+    """`HeadGrad`: the nine masked-attention decoder layers + the tail.  The taped query chain
+    reproduces the inference kernels' outputs; its backward -- d memory tokens (what the pixel
+    decoder's backward would receive), `query_feat`, `query_embed`, `level_embed`, the 9 x 18
+    decoder tensors and the tail -- equals autograd through the oracle's layers fed with the SAME
+    memory tokens and the SAME boolean masks (the masks are `detach()`ed thresholds,
+    pairnet_head.py:256: a logit within rounding of 0 may flip between two fp32 implementations,
+    which is a different function, not a gradient error).  A level of 6 keys (2 x 3) exercises
+    the padded contraction of the K / V projection gradients."""
+    from oracle import seeded
+    from pairnet_amd import HeadGrad
+    _, sd, _ = oracle_head(1234)
+    head = _hip_head(sd)
+    H, W = 64, 96
+    feats = seeded.seeded_feats(99, 2, H, W)
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[1.5] * 4)] * 2
+    cls, _ = head.forward([f.to(DEV) for f in feats], metas)
+    pl = head._last_plan
+    B, Q = pl.B, head.num_obj_query
+    ref_out = {k: cls[k].clone() for k in ("rel", "importance")}
+    tape = HeadGrad(head)
+    out = tape.forward_from_plan(pl, pl.sub_pos, pl.obj_pos)
+    torch.cuda.synchronize()
+    for k in ("rel", "importance"):
+        assert float((out[k] - ref_out[k]).abs().max()) < 1e-4, k
+    gen = torch.Generator().manual_seed(13)
+    g1, g2 = torch.randn(out["rel"].shape, generator=gen), torch.randn(B, Q, Q, generator=gen)
+    dmem, grads = tape.backward(g_rel=g1, g_importance=g2)
+    torch.cuda.synchronize()
+
+    head_o = _oracle64(sd)
+    mem = pl.X.cpu().double().requires_grad_()                     # [B, SN, 256]
+    keys, key_pos = [], []
+    for l in range(3):
+        h, w = pl.shapes[l]
+        m = mem[:, pl.start[l]:pl.start[l] + pl.N[l]].transpose(0, 1)
+        keys.append(m + head_o.level_embed.weight[l].view(1, 1, -1))
+        pad = torch.zeros((B, h, w), dtype=torch.bool)
+        key_pos.append(head_o.decoder_positional_encoding(pad).flatten(2).permute(2, 0, 1).double())
+    q = head_o.query_feat.weight.unsqueeze(1).repeat((1, B, 1))
+    q_pos = head_o.query_embed.weight.unsqueeze(1).repeat((1, B, 1))
+    for i, layer in enumerate(head_o.transformer_decoder.layers):
+        s = tape.dt["layers"][i]
+        l = i % 3
+        mask = _unpack_mask(s["bits"], s["rowall"], B, Q, pl.N[l])
+        mask = mask.unsqueeze(1).repeat((1, head_o.n_heads, 1, 1)).flatten(0, 1)
+        q = layer(query=q, key=keys[l], value=keys[l], query_pos=q_pos, key_pos=key_pos[l],
+                  attn_masks=[mask, None], query_key_padding_mask=None, key_padding_mask=None)
+    o = _tail(head_o, q, pl.sub_pos.cpu(), pl.obj_pos.cpu())
+    ((o["rel"] * g1.double()).sum() + (o["importance"] * g2.double()).sum()).backward()
+    report = []
+    _compare("memory tokens", dmem, mem.grad, report)
+    names = _rel_names() + _ppn_names() + ["query_feat.weight", "query_embed.weight",
+                                           "level_embed.weight"]
+    from pairnet_amd.grad import RelationTailGrad
+    for i in range(9):
+        names += RelationTailGrad._layer_names("transformer_decoder.layers.%d." % i)
+    _compare_params(grads, head_o, report, names)
+    _print(report)

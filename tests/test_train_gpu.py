@@ -56,13 +56,18 @@ def test_adamw_and_clip_kernels_equal_torch():
     assert float(flat_p[1000:1024].abs().max()) == 0.0
 
 
-def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent():
+@pytest.mark.parametrize("train_decoder", [False, True])
+def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent(train_decoder):
     """`TailTrainer.step` on a fixed batch: (1) the first update of every trained tensor equals
     torch's AdamW + clip on the gradients the step produced; (2) the loss the step optimises goes
     down over a few steps; (3) after training, the INFERENCE kernels (packed [V|Q|K] / [V|K]
     projections, the Matrix Learner's packed weights, the repeated initial queries) and the taped
     forward give the same outputs -- the derived weight packs were refreshed; (4) `write_back()`
-    puts the trained values into `state_dict()`; the frozen detector did not move."""
+    puts the trained values into `state_dict()`; the frozen detector did not move; a FRESH head
+    loaded from that state dict gives bit for bit the trained head's outputs (every derived pack
+    -- [V|Q|K], [V|K], ConvTiny layouts, repeated initial queries and their mask embedding, the
+    key position tables that carry `level_embed` -- was refreshed).  `train_decoder`: also the nine
+    masked decoder layers (lr_mult 0.1 as the reference's `transformer_decoder` group)."""
     from pairnet_amd import RelationTailGrad, TailTrainer
     from test_losses_gpu import _outputs
     head, cls, masks, metas, gt_rels, gt_labels, gt_masks, pts = _outputs(2, H=96, W=128, bs=2)
@@ -71,7 +76,7 @@ def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent():
              for c, s in zip((256, 512, 1024, 2048), (4, 8, 16, 32))]
     before = {k: v.clone() for k, v in head.state_dict().items()}
     lr = 1e-3
-    tr = TailTrainer(head, lr=lr)
+    tr = TailTrainer(head, lr=lr, train_decoder=train_decoder)
     p0 = tr.flat_p.clone()
     out = tr.step(feats, metas, gt_rels, gt_labels, gt_masks, point_coords=pts)
     torch.cuda.synchronize()
@@ -85,8 +90,9 @@ def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent():
         o, shape, k = tr.tape.layout[n]
         p = p0[o:o + k].cpu().double().requires_grad_()
         is_norm = ".norms." in n
-        opt = torch.optim.AdamW([p], lr=lr, weight_decay=0.0 if is_norm else tr.wd, betas=tr.betas,
-                                eps=tr.eps)
+        lr_n = lr * (0.1 if "transformer_decoder" in n else 1.0)
+        opt = torch.optim.AdamW([p], lr=lr_n, weight_decay=0.0 if is_norm else tr.wd,
+                                betas=tr.betas, eps=tr.eps)
         p.grad = gflat[o:o + k] * coef
         opt.step()
         worst = max(worst, float((v.reshape(-1).cpu().double() - p.detach()).abs().max()))
@@ -98,7 +104,10 @@ def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent():
         hist.append(float(tr.step(feats, metas, gt_rels, gt_labels, gt_masks,
                                   point_coords=pts)["loss_match"]))
     print("loss_match over 8 steps:", ["%.4f" % h for h in hist])
-    assert hist[1] < hist[0] and min(hist) < 0.95 * hist[0]       # (lr 1e-3 on one batch: bouncy)
+    assert all(np.isfinite(h) for h in hist)
+    if not train_decoder:     # (lr 1e-3 on one batch: bouncy; with the decoder's 14 M weights each
+        # moving 1e-4 per Adam step without warm-up the first steps need not go down at all)
+        assert hist[1] < hist[0] and min(hist) < 0.95 * hist[0]
     # (3) inference kernels vs the taped forward on the trained weights
     outs, _ = head.forward(feats, metas)
     pl = head._last_plan
@@ -115,3 +124,12 @@ def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent():
         assert torch.equal(sd[n].cpu(), v.cpu()), n
     outs2, _ = head.forward(feats, metas)          # (write_back must not trigger a stale re-pack)
     assert torch.equal(outs2["rel"], outs["rel"])
+    from pairnet_amd import CrossHead2
+    from helpers import head_cfg
+    fresh = CrossHead2(**head_cfg())
+    fresh.load_state_dict(sd)
+    fresh.to(DEV)
+    outs3, _ = fresh.forward(feats, metas)
+    for k in ("rel", "importance", "cls"):
+        assert torch.equal(outs3[k], outs2[k]), k
+    assert any("transformer_decoder.layers" in n for n in tr.names) == train_decoder

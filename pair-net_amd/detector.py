@@ -792,8 +792,10 @@ class PSGTr:
     def forward(self, img=None, img_metas=None, return_loss=False, rescale=False, **kw):
         """mmdet's `model(return_loss=False, rescale=True, img=[..], img_metas=[..])`."""
         if return_loss:
-            raise NotImplementedError("no training step (backward, optimizer) here: "
-                                      "`val_losses` gives forward_train's loss VALUES")
+            raise NotImplementedError("model(return_loss=True) + autograd is not how this detector "
+                                      "trains: `val_losses` gives forward_train's loss VALUES, "
+                                      "`pairnet_amd.TailTrainer(det.bbox_head).step(det.extract_feat(img), ...)` "
+                                      "runs one iteration for the head behind the pixel decoder")
         if isinstance(img, (list, tuple)):
             img, img_metas = img[0], img_metas[0]
         return self.simple_test(img, img_metas, rescale=rescale)

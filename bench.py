@@ -1430,6 +1430,19 @@ def main():
         torch.cuda.synchronize()
         out["swin_l_200q"] = leg(["--in-channels", "192,384,768,1536", "--queries", "200"])
         out["box_trunk"] = leg(["--head", "bbox"])
+        # what one training iteration of the head behind the pixel decoder costs
+        # (tools/train_step_probe.py in a child process: it re-homes the head's weights)
+        try:
+            t0 = time.perf_counter()
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_step_probe.py"), "10"],
+                                capture_output=True, text=True, timeout=600)
+            line = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+            out["training_step"] = json.loads(line[-1]) if line else \
+                "no result (rc %d): %s" % (cp.returncode, cp.stderr[-400:])
+            if isinstance(out["training_step"], dict):
+                out["training_step"]["child_process_s"] = time.perf_counter() - t0
+        except Exception as e:          # noqa: BLE001 -- a secondary leg, never the headline
+            out["training_step"] = repr(e)
 
     gc.enable()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

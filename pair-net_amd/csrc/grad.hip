@@ -235,18 +235,39 @@ __global__ __launch_bounds__(64) void k_mha_bwd_ds(const float* __restrict__ dou
   for (int j = lane; j < Nk; j += 64) dS[ro + j] = P[ro + j] * (dS[ro + j] - delta);
 }
 
-__global__ __launch_bounds__(64) void k_mha_bwd_dq(const float* __restrict__ dS,
-                                                   const float* __restrict__ k, int64_t ldk,
-                                                   float* __restrict__ dq, int64_t lddq, int Nq,
-                                                   int Nk, float scale) {
-  const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int d = threadIdx.x & 31, half = threadIdx.x >> 5;
-  const float* dsr = dS + (((int64_t)b * 8 + h) * Nq + i) * Nk;
-  float acc = 0.f;
-  for (int j = half; j < Nk; j += 2)
-    acc += dsr[j] * k[((int64_t)b * Nk + j) * ldk + h * 32 + d];
-  acc += __shfl_xor(acc, 32, 64);
-  if (half == 0) dq[((int64_t)b * Nq + i) * lddq + h * 32 + d] = scale * acc;
+// dq[i][d] = scale sum_j dS[i][j] k[j][d].  A workgroup owns one head and a tile of 8 queries:
+// 8 key groups x 32 channels, a key row is loaded once for the 8 queries (the 16 700-key level
+// otherwise re-reads its 2 MB of keys per query), group partials summed in group order.
+__global__ __launch_bounds__(256) void k_mha_bwd_dq(const float* __restrict__ dS,
+                                                    const float* __restrict__ k, int64_t ldk,
+                                                    float* __restrict__ dq, int64_t lddq, int Nq,
+                                                    int Nk, float scale) {
+  __shared__ float red[8][8][32];
+  const int i0 = blockIdx.x * 8, h = blockIdx.y, b = blockIdx.z;
+  const int d = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const float* dsr[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    dsr[q] = dS + (((int64_t)b * 8 + h) * Nq + min(i0 + q, Nq - 1)) * Nk;
+  float acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+  const float* kb = k + (int64_t)b * Nk * ldk + h * 32 + d;
+  for (int j = g; j < Nk; j += 8) {
+    const float kv = kb[(int64_t)j * ldk];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] += dsr[q][j] * kv;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) red[g][q][d] = acc[q];
+  __syncthreads();
+  const int q = g;
+  if (i0 + q < Nq) {
+    float t = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) t += red[gg][q][d];
+    dq[((int64_t)b * Nq + i0 + q) * lddq + h * 32 + d] = scale * t;
+  }
 }
 
 __global__ __launch_bounds__(64) void k_mha_bwd_dkv(const float* __restrict__ dS,
@@ -291,8 +312,8 @@ extern "C" int pn_mha_bwd_f32(const float* q, int64_t ldq, const float* k, int64
   hipLaunchKernelGGL(k_mha_probs, dim3(Nq, 8, B), dim3(64), 0, s, q, ldq, k, ldk, P, Nq, Nk, scale,
                      bits, rowall);
   hipLaunchKernelGGL(k_mha_bwd_ds, dim3(Nq, 8, B), dim3(64), 0, s, dout, ldo, v, ldv, P, dS, Nq, Nk);
-  hipLaunchKernelGGL(k_mha_bwd_dq, dim3(Nq, 8, B), dim3(64), 0, s, dS, k, ldk, dq, lddq, Nq, Nk,
-                     scale);
+  hipLaunchKernelGGL(k_mha_bwd_dq, dim3(pn_cdiv(Nq, 8), 8, B), dim3(256), 0, s, dS, k, ldk, dq, lddq,
+                     Nq, Nk, scale);
   hipLaunchKernelGGL(k_mha_bwd_dkv, dim3(Nk, 8, B), dim3(64), 0, s, dS, P, q, ldq, dout, ldo, dk,
                      lddk, dv, lddv, Nq, Nk, scale);
   return PN_LAUNCH_CHECK();

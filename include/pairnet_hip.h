@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 24
+#define PN_ABI_VERSION 25
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -790,6 +790,20 @@ int pn_tapcorr1_f32(const float* F, const float* g, float* part, int B, int S, i
  * chunk = (image, block of rows_per image rows): B * ceil(S / rows_per) chunks of 64*49*64 floats. */
 int pn_tapcorr64_f32(const float* dY, const float* X, float* part, int B, int S, int rows_per,
                      void* stream);
+/* Pixel decoder (pairnet_head.py:262; mmcv MultiScaleDeformableAttention.forward): from pn_msda_bwd_f32's
+ * grad_sampling_loc / grad_attn_weight back to the gradient of the [offsets 8*L*4*2 | logits 8*L*4]
+ * projection rows (stride ld) that pn_token_sampling_f32 turned into those operands on an unpadded
+ * batch: d offset = d loc / (W_l, H_l), d logit = aw (d aw - sum aw d aw) per head. */
+int pn_msda_offaw_bwd_f32(const float* grad_loc, const float* grad_aw, const float* aw,
+                          float* d_offaw, int64_t ld, int64_t rows, int L,
+                          const int32_t* level_h /* host */, const int32_t* level_w /* host */,
+                          void* stream);
+/* Backward of pn_groupnorm_nhwc_f32 (no ReLU) from its INPUT x: dx [B][HW][256] (dense), gxhat = dy *
+ * xhat (column sum over B*HW rows: d weight; d bias: column sum of dy); stats: B * G * 4 floats of
+ * scratch; x / dy images start at multiples of x_bstride / dy_bstride floats. */
+int pn_groupnorm_nhwc_bwd_f32(const float* x, const float* dy, const float* gamma, float* dx,
+                              float* gxhat, float* stats, int B, int64_t HW, int G, float eps,
+                              int64_t x_bstride, int64_t dy_bstride, void* stream);
 /* out[ci][T-1-t][co] = in[co][t][ci]: a "same" convolution's weight as its data gradient reads it */
 int pn_conv_weight_bwd_layout_f32(const float* in, float* out, int Co, int T, int Ci, void* stream);
 

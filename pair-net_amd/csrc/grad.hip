@@ -540,3 +540,137 @@ extern "C" int pn_conv_weight_bwd_layout_f32(const float* in, float* out, int Co
                      (hipStream_t)stream, in, out, Co, T, Ci);
   return PN_LAUNCH_CHECK();
 }
+
+// ---- pixel decoder: from the sampling operator's gradients back to the projection that made
+// its operands (mmcv MultiScaleDeformableAttention.forward: sampling_locations = reference_points
+// + sampling_offsets / (W_l, H_l), attention_weights = softmax over each head's L * 4 logits):
+//   d offset[h][l][p][xy] = d loc[h][l][p][xy] / (W_l | H_l)
+//   d logit[h][l][p]      = aw (d aw - sum_{l', p'} aw d aw)
+// offaw rows [offsets 8*L*4*2 | logits 8*L*4] at stride ld, as pn_token_sampling_f32 reads them.
+struct LevelDims { int h[4], w[4]; };
+__global__ __launch_bounds__(256) void k_msda_offaw_bwd(const float* __restrict__ grad_loc,
+                                                        const float* __restrict__ grad_aw,
+                                                        const float* __restrict__ aw,
+                                                        float* __restrict__ d_offaw, int64_t ld,
+                                                        int64_t rows, int L, LevelDims dims) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one thread per (row, head)
+  if (t >= rows * 8) return;
+  const int64_t r = t >> 3;
+  const int h = (int)(t & 7), LP = L * 4;
+  const float* gl = grad_loc + (r * 8 + h) * LP * 2;
+  const float* ga = grad_aw + (r * 8 + h) * LP;
+  const float* a = aw + (r * 8 + h) * LP;
+  float* doff = d_offaw + r * ld + h * LP * 2;
+  float* dlg = d_offaw + r * ld + 8 * LP * 2 + h * LP;
+  float dot = 0.f;
+  for (int i = 0; i < LP; ++i) dot += a[i] * ga[i];
+  for (int i = 0; i < LP; ++i) {
+    const int l = i >> 2;
+    doff[2 * i] = gl[2 * i] / (float)dims.w[l];
+    doff[2 * i + 1] = gl[2 * i + 1] / (float)dims.h[l];
+    dlg[i] = a[i] * (ga[i] - dot);
+  }
+}
+
+extern "C" int pn_msda_offaw_bwd_f32(const float* grad_loc, const float* grad_aw, const float* aw,
+                                     float* d_offaw, int64_t ld, int64_t rows, int L,
+                                     const int32_t* level_h, const int32_t* level_w, void* stream) {
+  if (!grad_loc || !grad_aw || !aw || !d_offaw || rows <= 0 || L <= 0 || L > 4 || !level_h ||
+      !level_w || ld < 8 * L * 12)
+    return PN_BAD_ARG;
+  LevelDims d;
+  for (int l = 0; l < 4; ++l) {
+    d.h[l] = l < L ? level_h[l] : 1;
+    d.w[l] = l < L ? level_w[l] : 1;
+    if (d.h[l] <= 0 || d.w[l] <= 0) return PN_BAD_ARG;
+  }
+  hipLaunchKernelGGL(k_msda_offaw_bwd, dim3(pn_cdiv(rows * 8, 256)), dim3(256), 0,
+                     (hipStream_t)stream, grad_loc, grad_aw, aw, d_offaw, ld, rows, L, d);
+  return PN_LAUNCH_CHECK();
+}
+
+// ---- GroupNorm backward over channel-last x[b][HW][256], G groups (the pixel decoder's
+// ConvModule norm).  Pass 1, one workgroup per (image, group): the group's moments and the two
+// means of the backward formula, in double, fixed order -> stats[b][g] = (mean, rstd, m1, m2)
+// with g_c = gamma_c dy, m1 = mean(g), m2 = mean(g xhat).  Pass 2, elementwise:
+//   dx = rstd (g - m1 - xhat m2);  gxhat = dy xhat  (column sums: d gamma; d beta = colsum dy)
+__global__ __launch_bounds__(1024) void k_gn_bwd_stats(const float* __restrict__ x,
+                                                       const float* __restrict__ dy,
+                                                       const float* __restrict__ gamma,
+                                                       float* __restrict__ stats, int64_t HW,
+                                                       int G, int64_t x_bstride,
+                                                       int64_t dy_bstride, float eps) {
+  __shared__ double red[16][2];
+  const int g = blockIdx.x, b = blockIdx.y, cpg = 256 / G;
+  const float* xb = x + (int64_t)b * x_bstride + g * cpg;
+  const float* db = dy + (int64_t)b * dy_bstride + g * cpg;
+  const int64_t n = HW * cpg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto reduce2 = [&](double a, double c, double* oa, double* oc) {
+    a = wave_sum_d(a); c = wave_sum_d(c);
+    __syncthreads();
+    if (lane == 0) { red[wave][0] = a; red[wave][1] = c; }
+    __syncthreads();
+    double ta = 0.0, tc = 0.0;
+    for (int w = 0; w < 16; ++w) { ta += red[w][0]; tc += red[w][1]; }
+    *oa = ta; *oc = tc;
+  };
+  double s = 0.0, ss = 0.0;
+  for (int64_t e = threadIdx.x; e < n; e += 1024) {
+    const double v = (double)xb[(e / cpg) * 256 + (e % cpg)];
+    s += v; ss += v * v;
+  }
+  double S, SS;
+  reduce2(s, ss, &S, &SS);
+  const double mean = S / (double)n;
+  const double var = fmax(SS / (double)n - mean * mean, 0.0);
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  double a1 = 0.0, a2 = 0.0;
+  for (int64_t e = threadIdx.x; e < n; e += 1024) {
+    const int c = (int)(e % cpg);
+    const int64_t o = (e / cpg) * 256 + c;
+    const double gd = (double)gamma[g * cpg + c] * (double)db[o];
+    a1 += gd;
+    a2 += gd * ((double)xb[o] - mean) * rstd;
+  }
+  double A1, A2;
+  reduce2(a1, a2, &A1, &A2);
+  if (threadIdx.x == 0) {
+    float* st = stats + ((int64_t)b * G + g) * 4;
+    st[0] = (float)mean; st[1] = (float)rstd;
+    st[2] = (float)(A1 / (double)n); st[3] = (float)(A2 / (double)n);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gn_bwd_apply(const float* __restrict__ x,
+                                                      const float* __restrict__ dy,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ stats,
+                                                      float* __restrict__ dx,
+                                                      float* __restrict__ gxhat, int64_t HW, int G,
+                                                      int64_t x_bstride, int64_t dy_bstride) {
+  const int64_t p = blockIdx.x;           // pixel
+  const int b = blockIdx.y, c = threadIdx.x, cpg = 256 / G;
+  const float* st = stats + ((int64_t)b * G + c / cpg) * 4;
+  const float xv = x[(int64_t)b * x_bstride + p * 256 + c];
+  const float d = dy[(int64_t)b * dy_bstride + p * 256 + c];
+  const float xh = (xv - st[0]) * st[1];
+  const int64_t o = ((int64_t)b * HW + p) * 256 + c;
+  dx[o] = st[1] * (gamma[c] * d - st[2] - xh * st[3]);
+  gxhat[o] = d * xh;
+}
+
+extern "C" int pn_groupnorm_nhwc_bwd_f32(const float* x, const float* dy, const float* gamma,
+                                         float* dx, float* gxhat, float* stats, int B, int64_t HW,
+                                         int G, float eps, int64_t x_bstride, int64_t dy_bstride,
+                                         void* stream) {
+  if (!x || !dy || !gamma || !dx || !gxhat || !stats || B <= 0 || B > 65535 || HW <= 0 ||
+      HW > 2147483647 || G <= 0 || 256 % G)
+    return PN_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_gn_bwd_stats, dim3(G, B), dim3(1024), 0, s, x, dy, gamma, stats, HW, G,
+                     x_bstride, dy_bstride, eps);
+  hipLaunchKernelGGL(k_gn_bwd_apply, dim3((unsigned)HW, B), dim3(256), 0, s, x, dy, gamma, stats,
+                     dx, gxhat, HW, G, x_bstride, dy_bstride);
+  return PN_LAUNCH_CHECK();
+}

@@ -32,7 +32,7 @@ import torch
 
 from . import hip
 
-__all__ = ["RelationTailGrad", "HeadGrad"]
+__all__ = ["RelationTailGrad", "HeadGrad", "PixelDecoderGrad"]
 
 
 class RelationTailGrad:
@@ -624,3 +624,202 @@ class HeadGrad(RelationTailGrad):
         ready(self.group_end["query"])
         ready(self.flat_numel)
         return dmem, grads
+
+
+class PixelDecoderGrad(RelationTailGrad):
+    """The pixel decoder's path from the backbone features to the memory tokens the masked decoder
+    attends to (MSDeformAttnPixelDecoder behind pairnet_head.py:262: three 1x1 input convolutions +
+    GroupNorm, six deformable-attention encoder layers), taped and differentiated:
+
+        tape = PixelDecoderGrad(head)
+        mem = tape.forward(feats)                     # [B, sum_l N_l, 256], levels coarsest first
+        dfeats, grads = tape.backward(dmem)           # dmem e.g. from HeadGrad.backward
+
+    `dfeats[l]` is the gradient w.r.t. the level-l feature map (`feats[3 - l]`: C5, C4, C3) as a
+    contiguous [B, C_l, h, w] tensor -- where a backbone's backward would continue.  The mask-feature
+    branch (lateral / output convolutions, `mask_feature`) is not here: the reference's loss does not
+    reach it (the masks are detached, pairnet_head.py:256, :391-398).  The sampling operator is
+    differentiated in mmcv's own operand set (`pn_msda_loc_f32` forward, `pn_msda_bwd_f32`: atomics
+    on grad_value, like mmcv's), its operands come from `pn_token_sampling_f32` and go back through
+    `pn_msda_offaw_bwd_f32`; the forward runs on the exact-fp32 MFMA kernels whatever
+    `head.gemm_arithmetic` says."""
+
+    PD = "pixel_decoder."
+
+    @staticmethod
+    def param_groups(head):
+        pd = PixelDecoderGrad.PD
+        groups = []
+        for i in reversed(range(head.num_enc_layers)):
+            p = pd + "encoder.layers.%d." % i
+            a = p + "attentions.0."
+            names = [a + n + s for n in ("value_proj", "sampling_offsets", "attention_weights",
+                                         "output_proj") for s in (".weight", ".bias")]
+            names += [p + "norms.%d.%s" % (j, n) for j in range(2) for n in ("weight", "bias")]
+            names += [p + "ffns.0.layers.0.0.weight", p + "ffns.0.layers.0.0.bias",
+                      p + "ffns.0.layers.1.weight", p + "ffns.0.layers.1.bias"]
+            groups.append(("encoder.layers.%d" % i, names))
+        groups.append(("level_encoding", [pd + "level_encoding.weight"]))
+        for l in range(3):
+            groups.append(("input_convs.%d" % l,
+                           [pd + "input_convs.%d.%s" % (l, n)
+                            for n in ("conv.weight", "conv.bias", "gn.weight", "gn.bias")]))
+        return groups
+
+    @staticmethod
+    def _rows(fb):
+        """One image's feature map [C, h, w] as pixel rows [h*w, C] (a view for channels-last
+        memory, a transpose pass for NCHW)."""
+        C, h, w = fb.shape
+        if fb.stride(0) == 1:
+            return fb.permute(1, 2, 0).reshape(h * w, C)
+        out = torch.empty(h * w, C, device=fb.device, dtype=torch.float32)
+        hip.transpose(fb.reshape(C, h * w), out)
+        return out
+
+    @torch.no_grad()
+    @hip.on_device
+    def forward(self, feats):
+        head, w, E, pd = self.head, self.head.w, self._E, self.PD
+        B = feats[0].shape[0]
+        shapes = [tuple(feats[3 - l].shape[-2:]) for l in range(3)]
+        N = [h * wd for h, wd in shapes]
+        start = [0, N[0], N[0] + N[1]]
+        SN, M = sum(N), B * sum(N)
+        enc_pos = head._position_tables(shapes)[0]                  # sine pe + level_encoding
+        t = self.t = dict(B=B, shapes=shapes, N=N, start=start, SN=SN, convs=[], rows=[])
+        X = E(B, SN, 256)
+        G = head.gn_groups
+        part = torch.empty(B * hip.groupnorm_nblk(max(N)) * G * 2, device=self.dev,
+                           dtype=torch.float64)
+        for l in range(3):
+            f = feats[3 - l]
+            conv = E(B, N[l], 256)
+            rows = [self._rows(f[b]) for b in range(B)]
+            for b in range(B):
+                hip.linear(rows[b], w[pd + "input_convs.%d.conv.weight" % l],
+                           w[pd + "input_convs.%d.conv.bias" % l], conv[b])
+            hip.groupnorm_nhwc(conv, w[pd + "input_convs.%d.gn.weight" % l],
+                               w[pd + "input_convs.%d.gn.bias" % l], X[:, start[l]:], part, B, N[l],
+                               G, False, N[l] * 256, SN * 256)
+            t["convs"].append(conv)
+            t["rows"].append(rows)
+        t["shapes_dev"] = torch.tensor(shapes, dtype=torch.int64, device=self.dev)
+        t["lsi_dev"] = torch.tensor(start, dtype=torch.int64, device=self.dev)
+        ones = torch.ones(B, 3, 2, device=self.dev, dtype=torch.float32)     # unpadded batch
+        x = X.view(M, 256)
+        layers = []
+        F = head.enc_ffn
+        for i in range(head.num_enc_layers):
+            p = pd + "encoder.layers.%d." % i
+            a = p + "attentions.0."
+            s = dict(x_in=x)
+            s["xq"] = E(M, 256)
+            hip.add_periodic(x, enc_pos, s["xq"])
+            s["value"] = E(M, 256)
+            hip.linear(x, w[a + "value_proj.weight"], w[a + "value_proj.bias"], s["value"])
+            offaw = E(M, 288)
+            hip.linear(s["xq"], w[a + "sampling_offsets.weight"], w[a + "sampling_offsets.bias"],
+                       offaw[:, :192])
+            hip.linear(s["xq"], w[a + "attention_weights.weight"], w[a + "attention_weights.bias"],
+                       offaw[:, 192:])
+            s["loc"], s["aw"] = E(M * 8 * 3 * 4 * 2), E(M * 8 * 3 * 4)
+            hip.token_sampling(offaw, 288, ones, s["loc"], s["aw"], B, shapes)
+            s["S"] = E(M, 256)
+            hip.msda_loc(s["value"], 256, t["shapes_dev"], t["lsi_dev"], s["loc"], s["aw"], s["S"],
+                         B, SN, SN, 3)
+            s["y1"] = E(M, 256)
+            hip.linear(s["S"], w[a + "output_proj.weight"], w[a + "output_proj.bias"], s["y1"],
+                       res=x)
+            s["x1"] = E(M, 256)
+            hip.layernorm(s["y1"], w[p + "norms.0.weight"], w[p + "norms.0.bias"], s["x1"])
+            s["h"] = E(M, F)
+            hip.linear(s["x1"], w[p + "ffns.0.layers.0.0.weight"], w[p + "ffns.0.layers.0.0.bias"],
+                       s["h"], relu=True)
+            s["y2"] = E(M, 256)
+            hip.linear(s["h"], w[p + "ffns.0.layers.1.weight"], w[p + "ffns.0.layers.1.bias"],
+                       s["y2"], res=s["x1"])
+            x = E(M, 256)
+            hip.layernorm(s["y2"], w[p + "norms.1.weight"], w[p + "norms.1.bias"], x)
+            layers.append(s)
+        t["layers"] = layers
+        return x.view(B, SN, 256)
+
+    @torch.no_grad()
+    @hip.on_device
+    def backward(self, dmem, on_ready=None):
+        if self.t is None or "layers" not in self.t:
+            raise RuntimeError("backward() needs a forward() first")
+        head, w, E, pd, t = self.head, self.head.w, self._E, self.PD, self.t
+        B, shapes, N, start, SN = t["B"], t["shapes"], t["N"], t["start"], t["SN"]
+        M = B * SN
+        ready = on_ready if on_ready is not None else (lambda end: None)
+        grads = self._zero_grads()
+        zeros = lambda *s_: torch.zeros(*s_, device=self.dev, dtype=torch.float32)
+        dx = dmem.to(self.dev, torch.float32).contiguous().view(M, 256).clone()
+        dpos_rows = zeros(M, 256)
+        for i in reversed(range(head.num_enc_layers)):
+            p = pd + "encoder.layers.%d." % i
+            a = p + "attentions.0."
+            s = t["layers"][i]
+            dy2 = self._ln_bwd(dx, s["y2"], p + "norms.1.", grads)
+            dh = self._lin_bwd(dy2, s["h"], w[p + "ffns.0.layers.1.weight"], grads,
+                               p + "ffns.0.layers.1.weight", p + "ffns.0.layers.1.bias")
+            hip.relu_bwd(dh, s["h"], dh)
+            dx1 = self._lin_bwd(dh, s["x1"], w[p + "ffns.0.layers.0.0.weight"], grads,
+                                p + "ffns.0.layers.0.0.weight", p + "ffns.0.layers.0.0.bias")
+            del dh
+            self._acc(dx1, dy2)
+            dxn = self._ln_bwd(dx1, s["y1"], p + "norms.0.", grads)        # = dy1: the shortcut's share
+            dS = self._lin_bwd(dxn, s["S"], w[a + "output_proj.weight"], grads,
+                               a + "output_proj.weight", a + "output_proj.bias")
+            gval, gloc, gaw = zeros(M, 256), E(M * 8 * 3 * 4 * 2), E(M * 8 * 3 * 4)
+            hip.msda_bwd(s["value"], 256, t["shapes_dev"], t["lsi_dev"], s["loc"], s["aw"], dS, gval,
+                         gloc, gaw, B, SN, SN, 3)
+            self._acc(dxn, self._lin_bwd(gval, s["x_in"], w[a + "value_proj.weight"], grads,
+                                         a + "value_proj.weight", a + "value_proj.bias"))
+            d_offaw = E(M, 288)
+            hip.msda_offaw_bwd(gloc, gaw, s["aw"], d_offaw, shapes)
+            dxq = self._lin_bwd(d_offaw[:, :192], s["xq"], w[a + "sampling_offsets.weight"], grads,
+                                a + "sampling_offsets.weight", a + "sampling_offsets.bias")
+            self._acc(dxq, self._lin_bwd(d_offaw[:, 192:], s["xq"], w[a + "attention_weights.weight"],
+                                         grads, a + "attention_weights.weight",
+                                         a + "attention_weights.bias"))
+            self._acc(dxn, dxq)
+            self._acc(dpos_rows, dxq)
+            dx = dxn
+            ready(self.group_end["encoder.layers.%d" % i])
+        # query_pos = sine table + level_encoding[l] on the tokens of level l
+        dle = grads[pd + "level_encoding.weight"]
+        for b in range(B):
+            for l in range(3):
+                r0 = b * SN + start[l]
+                hip.colsum(dpos_rows[r0:r0 + N[l]], dle[l], accumulate=True)
+        ready(self.group_end["level_encoding"])
+        # input convolutions: GroupNorm, then the 1x1 convolution as a linear layer over pixels
+        G = head.gn_groups
+        stats = E(B * G * 4)
+        dX = dx.view(B, SN, 256)
+        dfeats = []
+        for l in range(3):
+            n = N[l]
+            conv = t["convs"][l]
+            dconv, gx = E(B * n, 256), E(B * n, 256)
+            hip.groupnorm_nhwc_bwd(conv, dX[:, start[l]:], w[pd + "input_convs.%d.gn.weight" % l],
+                                   dconv, gx, stats, B, n, G, n * 256, SN * 256)
+            hip.colsum(gx, grads[pd + "input_convs.%d.gn.weight" % l], accumulate=True)
+            C = t["rows"][l][0].shape[1]
+            h, wd = shapes[l]
+            df = E(B, C, h, wd)
+            for b in range(B):
+                hip.colsum(dX[b, start[l]:start[l] + n], grads[pd + "input_convs.%d.gn.bias" % l],
+                           accumulate=True)
+                drows = self._lin_bwd(dconv[b * n:(b + 1) * n], t["rows"][l][b],
+                                      w[pd + "input_convs.%d.conv.weight" % l].view(256, C), grads,
+                                      pd + "input_convs.%d.conv.weight" % l,
+                                      pd + "input_convs.%d.conv.bias" % l)
+                hip.transpose(drows, df[b].view(C, n))
+            dfeats.append(df)
+            ready(self.group_end["input_convs.%d" % l])
+        ready(self.flat_numel)
+        return dfeats, grads

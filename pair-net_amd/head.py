@@ -1118,6 +1118,15 @@ class CrossHead2:
                         if e["graph"] is None:
                             del pl.graphs_a[k]
                             break
+                    else:
+                        # every entry owns a graph: the least recently used one goes (at a quiet
+                        # point: its graph may still be replaying otherwise).  Its `feats` are what
+                        # kept a producer's OLD buffers alive -- e.g. the backbone's arena of
+                        # before a growth, hundreds of MB that nothing would ever read again
+                        # 
+                        if plans.quiet(cur):
+                            torch.cuda.current_stream(self.device).synchronize()
+                            pl.graphs_a.popitem(last=False)
                 if len(pl.graphs_a) < self.STAGE_A_GRAPHS:
                     ent = pl.graphs_a[ptrs] = dict(calls=0, graph=None, feats=None)
             else:

@@ -119,6 +119,10 @@ _SIGS = {
     "pn_tapcorr1_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_tapcorr64_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_conv_weight_bwd_layout_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "pn_msda_offaw_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, C.POINTER(_i32),
+                                        C.POINTER(_i32), _vp]),
+    "pn_groupnorm_nhwc_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i64,
+                                            _i64, _vp]),
     "pn_grad_norm_clip_f32": (C.c_int, [_vp, _i64, _f32, _f32, _vp, _vp, _vp]),
     "pn_adamw_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32,
                                _f32, _i32, _vp, _f32, _vp]),
@@ -183,7 +187,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 24   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 25   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -1254,6 +1258,22 @@ def conv_weight_bwd_layout(w, out, Co, T, Ci):
     assert w.numel() == out.numel() == Co * T * Ci
     _check(lib().pn_conv_weight_bwd_layout_f32(_ptr(w), _ptr(out), Co, T, Ci, _stream()),
            "pn_conv_weight_bwd_layout_f32")
+
+
+def msda_offaw_bwd(grad_loc, grad_aw, aw, d_offaw, shapes):
+    """d [offsets | logits] rows (2-D view, free row stride) from pn_msda_bwd_f32's outputs."""
+    rows, ld = _rowmajor(d_offaw)
+    L = len(shapes)
+    hs = (C.c_int32 * L)(*[h for h, _ in shapes])
+    ws = (C.c_int32 * L)(*[w for _, w in shapes])
+    _check(lib().pn_msda_offaw_bwd_f32(_ptr(grad_loc), _ptr(grad_aw), _ptr(aw), _ptr(d_offaw), ld,
+                                       rows, L, hs, ws, _stream()), "pn_msda_offaw_bwd_f32")
+
+
+def groupnorm_nhwc_bwd(x, dy, gamma, dx, gxhat, stats, B, HW, G, x_bstride, dy_bstride, eps=1e-5):
+    _check(lib().pn_groupnorm_nhwc_bwd_f32(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(dx), _ptr(gxhat),
+                                           _ptr(stats), B, HW, G, eps, x_bstride, dy_bstride,
+                                           _stream()), "pn_groupnorm_nhwc_bwd_f32")
 
 
 def grad_norm_clip(g, out, scratch, pre=1.0, max_norm=0.0):

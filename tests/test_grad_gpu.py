@@ -340,3 +340,36 @@ def test_masked_decoder_backward_against_the_oracle():
         names += RelationTailGrad._layer_names("transformer_decoder.layers.%d." % i)
     _compare_params(grads, head_o, report, names)
     _print(report)
+
+
+def test_pixel_decoder_backward_against_the_oracle():
+    """`PixelDecoderGrad`: backbone features -> 1x1 input convolutions + GroupNorm -> six
+    deformable-attention encoder layers -> memory tokens, taped on the exact-fp32 kernels; the
+    backward (sampling operator in mmcv's operand set, its operands' projections, LayerNorm / FFN,
+    GroupNorm, the convolutions) against autograd through the HF-pinned oracle pixel decoder in
+    float64: d features (C3, C4, C5) and all 109 parameter tensors."""
+    from oracle import seeded
+    from pairnet_amd import PixelDecoderGrad
+    _, sd, _ = oracle_head(1234)
+    head = _hip_head(sd)
+    H, W = 64, 96
+    feats = seeded.seeded_feats(99, 2, H, W)
+    tape = PixelDecoderGrad(head)
+    mem = tape.forward([f.to(DEV) for f in feats])
+    torch.cuda.synchronize()
+    head_o = _oracle64(sd)
+    f64 = [f.double().requires_grad_() for f in feats]
+    _, memories = head_o.pixel_decoder(f64)
+    mem_ref = torch.cat([m.flatten(2).transpose(1, 2) for m in memories], 1)      # [B, SN, 256]
+    assert float((mem.cpu().double() - mem_ref.detach()).abs().max()) < 1e-4
+    G = torch.randn(mem_ref.shape, generator=torch.Generator().manual_seed(14))
+    dfeats, grads = tape.backward(G)
+    torch.cuda.synchronize()
+    (mem_ref * G.double()).sum().backward()
+    report = []
+    for l in range(3):
+        _compare("features of level %d" % l, dfeats[l], f64[3 - l].grad, report)
+    names = [n for _, ns in PixelDecoderGrad.param_groups(head) for n in ns]
+    _compare_params(grads, head_o, report, names)
+    assert f64[0].grad is None or float(f64[0].grad.abs().max()) == 0.0     # C2 feeds the mask branch only
+    _print(report)

@@ -675,3 +675,35 @@ def test_get_bboxes_with_different_image_shapes_in_one_batch():
             assert float((r[4].cpu() != o[4]).float().mean()) < 5e-3             # pan_img
             assert np.array_equal(r[2].numpy() if not r[2].is_cuda else r[2].cpu().numpy(),
                                   np.asarray(o[2]))
+
+
+def test_stage_a_graph_table_evicts_the_least_recently_used_entry():
+    """a plan keeps at most STAGE_A_GRAPHS stage-A graphs, one per set of caller feature
+    buffers.  When all of them own a graph and the caller arrives with yet another buffer set (a
+    backbone whose arena grew), the least recently used entry goes -- with it the reference that
+    kept the old buffers alive -- instead of the newcomer being served eagerly for ever; results
+    stay the eager ones throughout."""
+    from pairnet_amd import CrossHead2
+    head = CrossHead2(**head_cfg())
+    head.init_weights(seed=2)
+    head.to(DEV)
+    H, W = 64, 96
+    g = torch.Generator().manual_seed(8)
+    feats = [torch.randn(1, c, H // s, W // s, generator=g).to(DEV)
+             for c, s in zip((256, 512, 1024, 2048), (4, 8, 16, 32))]
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[1.0] * 4)]
+    head.use_graphs = False
+    ref = head.forward(feats, metas)[0]["rel"].clone()
+    head.use_graphs = True
+    sets = [[f.clone() for f in feats] for _ in range(head.STAGE_A_GRAPHS + 2)]
+    key = lambda s: tuple(f.data_ptr() for f in s)
+    for s in sets[:head.STAGE_A_GRAPHS] * 2 + [sets[-2]] * 2 + [sets[0]] * 2 + [sets[-1]] * 2:
+        out = head.forward(s, metas)[0]["rel"]
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+    pl = head._last_plan
+    assert len(pl.graphs_a) == head.STAGE_A_GRAPHS
+    assert all(e["graph"] is not None for e in pl.graphs_a.values())
+    # the two newcomers and the re-admitted first set are in, the least recently used ones are out
+    assert key(sets[-1]) in pl.graphs_a and key(sets[-2]) in pl.graphs_a and key(sets[0]) in pl.graphs_a
+    assert key(sets[1]) not in pl.graphs_a and key(sets[2]) not in pl.graphs_a

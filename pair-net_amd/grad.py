@@ -46,7 +46,9 @@ class RelationTailGrad:
     shapes of the outputs) returns (dq [B * Q, 256], {reference parameter name: gradient}).
     """
 
-    def __init__(self, head):
+    def __init__(self, head, flat=None, base=0):
+        """`flat`, `base`: keep the gradients in flat[base : base + flat_numel] of a caller-owned
+        buffer (several tapes sharing one buffer: one optimizer launch, one reducer)."""
         if head.device is None or head.device.type != "cuda":
             raise RuntimeError("RelationTailGrad needs a head on an MI355X (.to('cuda:N')); "
                                "there is no CPU path")
@@ -65,6 +67,7 @@ class RelationTailGrad:
         # finished prefix while the rest of the backward pass is still running (train.py, dist.py)
         self.layout, off = OrderedDict(), 0
         self.group_end = OrderedDict()           # group name -> end offset of its last segment
+        self.size_of(head)                       # (same walk, kept in one place below)
         for group, names in self.param_groups(head):
             for n in names:
                 shape = tuple(head._params[n].shape)
@@ -73,9 +76,19 @@ class RelationTailGrad:
                 off += (numel + 63) // 64 * 64
             self.group_end[group] = off
         self.flat_numel = off
-        self.flat_grad = torch.zeros(off, device=self.dev, dtype=torch.float32)
+        if flat is None:
+            self.flat_grad = torch.zeros(off, device=self.dev, dtype=torch.float32)
+        else:
+            self.flat_grad = flat[base:base + off]
+            assert self.flat_grad.numel() == off and base % 64 == 0
         self.grads = {n: self.flat_grad[o:o + k].view(shape)
                       for n, (o, shape, k) in self.layout.items()}
+
+    @classmethod
+    def size_of(cls, head):
+        """Floats of the flat gradient buffer of this tape for `head` (segments padded to 64)."""
+        return sum((int(torch.Size(tuple(head._params[n].shape)).numel()) + 63) // 64 * 64
+                   for _, names in cls.param_groups(head) for n in names)
 
     @staticmethod
     def param_groups(head):

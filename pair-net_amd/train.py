@@ -27,7 +27,7 @@ import torch
 
 from . import hip
 from .dist import GradReducer
-from .grad import HeadGrad, RelationTailGrad
+from .grad import HeadGrad, PixelDecoderGrad, RelationTailGrad
 
 __all__ = ["TailTrainer"]
 
@@ -37,29 +37,44 @@ class TailTrainer:
 
     def __init__(self, head, lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8,
                  max_norm=0.1, norm_decay_mult=0.0, lr_mult=None, group=None,
-                 bucket_bytes=32 << 20, train_decoder=False):
+                 bucket_bytes=32 << 20, train_decoder=False, train_pixel_decoder=False):
         """`train_decoder`: also train the nine masked decoder layers, `query_feat`, `query_embed`
         and `level_embed` (`HeadGrad`; the reference's `transformer_decoder` group, lr_mult 0.1 by
         default here as in configs/mask2former/pairnet.py:358-363) -- everything of the head behind
         the pixel decoder.  `lr_mult`: {substring of a parameter name: multiplier} (mmcv's
         `paramwise_cfg.custom_keys`)."""
         self.head = head
-        self.train_decoder = bool(train_decoder)
+        self.train_pixel_decoder = bool(train_pixel_decoder)
+        self.train_decoder = bool(train_decoder) or self.train_pixel_decoder
+        train_decoder = self.train_decoder
         if lr_mult is None:
-            lr_mult = {"transformer_decoder": 0.1}
+            lr_mult = {"transformer_decoder": 0.1, "pixel_decoder": 0.1}
         if head.w is None:
             head._pack()
         # plans captured so far bake the addresses of the weight tensors that are re-homed below
         # into their hipGraphs: start from fresh plans (the arenas, shape-dependent only, stay)
         from .plans import PlanCache
         head._plans = PlanCache(head._plans.max_plans)
-        self.tape = tape = (HeadGrad if train_decoder else RelationTailGrad)(head)
         dev = self.dev = head.device
+        tape_cls = HeadGrad if train_decoder else RelationTailGrad
+        # ONE flat gradient buffer for every tape: [head tape | pixel decoder tape]
+        n_head = tape_cls.size_of(head)
+        n_pd = PixelDecoderGrad.size_of(head) if self.train_pixel_decoder else 0
+        self.flat_grad = torch.zeros(n_head + n_pd, device=dev, dtype=torch.float32)
+        self.tape = tape = tape_cls(head, flat=self.flat_grad, base=0)
+        self.pd_tape = PixelDecoderGrad(head, flat=self.flat_grad, base=n_head) \
+            if self.train_pixel_decoder else None
         self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
-        # the trainable prefix of the flat layout (the frozen class path sits at its end)
-        self.n = min([tape.layout[n][0] for g, names in tape.param_groups(head)
-                      if g in self.FROZEN_GROUPS for n in names] or [tape.flat_numel])
-        self.names = [n for n, (o, _, _) in tape.layout.items() if o < self.n]
+        # name -> (offset in the shared buffer, shape, numel); the class path (cls_embed /
+        # post_norm: no gradient in the reference's graph) stays in the layout with lr 0
+        self.layout = OrderedDict(tape.layout)
+        if self.pd_tape is not None:
+            for n, (o, shape, k) in self.pd_tape.layout.items():
+                self.layout[n] = (o + n_head, shape, k)
+        frozen = {n for g, names in tape.param_groups(head) if g in self.FROZEN_GROUPS for n in names}
+        self.n = n_head + n_pd
+        self.names = [n for n in self.layout if n not in frozen]
+        self._frozen = frozen
         # ---- flat parameters; the head's device weights become views of them ----
         self.flat_p = torch.zeros(self.n, device=dev, dtype=torch.float32)
         self.flat_m = torch.zeros_like(self.flat_p)
@@ -68,30 +83,34 @@ class TailTrainer:
         self.params = OrderedDict()
         ml = "update_importance.conv_layers."
         self._repacked = {ml + "1.0.weight", ml + "2.0.weight"}   # w[...] holds another layout
-        for n in self.names:
-            o, shape, k = tape.layout[n]
+        for n in self.layout:
+            o, shape, k = self.layout[n]
             view = self.flat_p[o:o + k].view(shape)
             view.copy_(head._params[n].to(dev))
+            if n in frozen:
+                continue
             self.params[n] = view
             if n not in self._repacked:
-                # same bytes as the reference layout (ConvTiny's first layer: [64,1,7,7] == [64,49])
+                # same bytes as the reference layout (ConvTiny's first layer: [64,1,7,7] == [64,49],
+                # the 1x1 input convolutions: [256,C,1,1] == [256,C])
                 w[n] = view.view(w[n].shape)
         # ---- per-segment multipliers (mmcv paramwise_cfg) ----
         lr_mult = dict(lr_mult or {})
         offs, lrs, wds = [], [], []
-        for n in self.names:
-            o, shape, k = tape.layout[n]
+        for n in self.layout:
+            o, shape, k = self.layout[n]
             offs.append(o)
-            lrs.append(next((m for key, m in lr_mult.items() if key in n), 1.0))
-            is_norm = ".norms." in n or "post_norm" in n
-            wds.append(norm_decay_mult if is_norm else 1.0)
+            lrs.append(0.0 if n in frozen else
+                       next((m for key, m in lr_mult.items() if key in n), 1.0))
+            is_norm = ".norms." in n or "post_norm" in n or ".gn." in n
+            wds.append(0.0 if n in frozen else (norm_decay_mult if is_norm else 1.0))
         offs.append(self.n)
         self.seg_off = torch.tensor(offs, dtype=torch.int64, device=dev)
         self.seg_lr = torch.tensor(lrs, dtype=torch.float32, device=dev)
         self.seg_wd = torch.tensor(wds, dtype=torch.float32, device=dev)
         self.clip = torch.zeros(2, device=dev, dtype=torch.float32)     # [grad norm, coefficient]
         self._scratch = torch.zeros(256, device=dev, dtype=torch.float64)
-        self.reducer = GradReducer(tape.flat_grad[:self.n], group=group, bucket_bytes=bucket_bytes)
+        self.reducer = GradReducer(self.flat_grad, group=group, bucket_bytes=bucket_bytes)
         self.steps = 0
         self._refresh_derived()
 
@@ -142,6 +161,26 @@ class TailTrainer:
             for shapes, ent in head._pe.items():  # key position tables carry level_embed
                 for l, (h, wd) in enumerate(shapes):
                     hip.sine_pe(ent[1][l], p["level_embed.weight"][l], h, wd)
+        if self.train_pixel_decoder:
+            pd = "pixel_decoder."
+            for i in range(head.num_enc_layers):
+                q, a = pd + "encoder.layers.%d." % i, pd + "encoder.layers.%d.attentions.0." % i
+                # one [value_proj | sampling_offsets | attention_weights] projection per layer
+                o = 0
+                for n in ("value_proj", "sampling_offsets", "attention_weights"):
+                    r = p[a + n + ".weight"].shape[0]
+                    w[a + "voa.weight"][o:o + r].copy_(p[a + n + ".weight"])
+                    w[a + "voa.bias"][o:o + r].copy_(p[a + n + ".bias"])
+                    o += r
+                for k in (a + "voa.weight", a + "output_proj.weight", q + "ffns.0.layers.0.0.weight",
+                          q + "ffns.0.layers.1.weight"):
+                    hip.s3_split(w[k], w[k + ".s3"])          # the bf16-pipe GEMMs' operands
+            for shapes, ent in head._pe.items():  # query position tables carry level_encoding
+                o = 0
+                for l, (h, wd) in enumerate(shapes):
+                    hip.sine_pe(ent[0][o:o + h * wd], p[pd + "level_encoding.weight"][l], h, wd)
+                    o += h * wd
+                ent[3].copy_(hip.pos8(ent[0]))
 
     def write_back(self):
         """Copy the trained values into the head's state dict (checkpoints, `state_dict()`)."""
@@ -166,10 +205,14 @@ class TailTrainer:
             tape.forward_from_plan(pl, pl.sub_pos, pl.obj_pos)
         else:
             tape.forward(pl.q, pl.sub_pos, pl.obj_pos)
+        if self.pd_tape is not None:
+            self.pd_tape.forward(feats)
         self.reducer.start()
-        end = self.n
-        tape.backward(g_rel=up["rel"], g_importance=up["importance"],
-                      on_ready=lambda e: self.reducer.ready(min(e, end)))
+        nh = tape.flat_numel
+        back = tape.backward(g_rel=up["rel"], g_importance=up["importance"],
+                             on_ready=lambda e: self.reducer.ready(min(e, nh)))
+        if self.pd_tape is not None:           # back[0]: d memory tokens (HeadGrad)
+            self.pd_tape.backward(back[0], on_ready=lambda e: self.reducer.ready(nh + e))
         self.reducer.finish()
         self.apply_gradients()
         out = dict(losses)
@@ -180,7 +223,7 @@ class TailTrainer:
     @hip.on_device
     def apply_gradients(self):
         """Clip (global L2 norm over the trainable gradients) + AdamW on `tape.flat_grad`."""
-        g = self.tape.flat_grad[:self.n]
+        g = self.flat_grad
         pre = self.reducer.scale
         hip.grad_norm_clip(g, self.clip, self._scratch, pre=pre, max_norm=self.max_norm)
         self.steps += 1

@@ -56,8 +56,8 @@ def test_adamw_and_clip_kernels_equal_torch():
     assert float(flat_p[1000:1024].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("train_decoder", [False, True])
-def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent(train_decoder):
+@pytest.mark.parametrize("scope", ["tail", "head", "head+pixel_decoder"])
+def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent(scope):
     """`TailTrainer.step` on a fixed batch: (1) the first update of every trained tensor equals
     torch's AdamW + clip on the gradients the step produced; (2) the loss the step optimises goes
     down over a few steps; (3) after training, the INFERENCE kernels (packed [V|Q|K] / [V|K]
@@ -66,8 +66,12 @@ def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent(tr
     puts the trained values into `state_dict()`; the frozen detector did not move; a FRESH head
     loaded from that state dict gives bit for bit the trained head's outputs (every derived pack
     -- [V|Q|K], [V|K], ConvTiny layouts, repeated initial queries and their mask embedding, the
-    key position tables that carry `level_embed` -- was refreshed).  `train_decoder`: also the nine
-    masked decoder layers (lr_mult 0.1 as the reference's `transformer_decoder` group)."""
+    key position tables that carry `level_embed`, the encoder's [value | offsets | weights]
+    projection, its bf16-plane weight splits and the query position tables that carry
+    `level_encoding` -- was refreshed).  `scope`: the tail alone; + the nine masked decoder layers;
+    + the pixel decoder's encoder path (both at lr_mult 0.1 as the reference's `transformer_decoder`
+    / `pixel_decoder` groups), i.e. everything the loss reaches behind the backbone."""
+    train_decoder = scope != "tail"
     from pairnet_amd import RelationTailGrad, TailTrainer
     from test_losses_gpu import _outputs
     head, cls, masks, metas, gt_rels, gt_labels, gt_masks, pts = _outputs(2, H=96, W=128, bs=2)
@@ -76,21 +80,22 @@ def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent(tr
              for c, s in zip((256, 512, 1024, 2048), (4, 8, 16, 32))]
     before = {k: v.clone() for k, v in head.state_dict().items()}
     lr = 1e-3
-    tr = TailTrainer(head, lr=lr, train_decoder=train_decoder)
+    tr = TailTrainer(head, lr=lr, train_decoder=train_decoder,
+                     train_pixel_decoder=scope == "head+pixel_decoder")
     p0 = tr.flat_p.clone()
     out = tr.step(feats, metas, gt_rels, gt_labels, gt_masks, point_coords=pts)
     torch.cuda.synchronize()
     # (1) the update, recomputed with torch from the step's own gradients
-    gflat = tr.tape.flat_grad[:tr.n].cpu().double()
+    gflat = tr.flat_grad.cpu().double()
     norm = float(gflat.norm())
     assert abs(float(out["grad_norm"]) - norm) < 1e-4 * norm and norm > 0
     coef = min(1.0, tr.max_norm / (norm + 1e-6))
     worst = 0.0
     for n, v in tr.params.items():
-        o, shape, k = tr.tape.layout[n]
+        o, shape, k = tr.layout[n]
         p = p0[o:o + k].cpu().double().requires_grad_()
-        is_norm = ".norms." in n
-        lr_n = lr * (0.1 if "transformer_decoder" in n else 1.0)
+        is_norm = ".norms." in n or ".gn." in n
+        lr_n = lr * (0.1 if ("transformer_decoder" in n or "pixel_decoder" in n) else 1.0)
         opt = torch.optim.AdamW([p], lr=lr_n, weight_decay=0.0 if is_norm else tr.wd,
                                 betas=tr.betas, eps=tr.eps)
         p.grad = gflat[o:o + k] * coef
@@ -133,3 +138,6 @@ def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent(tr
     for k in ("rel", "importance", "cls"):
         assert torch.equal(outs3[k], outs2[k]), k
     assert any("transformer_decoder.layers" in n for n in tr.names) == train_decoder
+    assert any("pixel_decoder.encoder" in n for n in tr.names) == (scope == "head+pixel_decoder")
+    # the class path is in the layout but frozen (no gradient in the reference's graph)
+    assert "cls_embed.weight" in tr.layout and "cls_embed.weight" not in tr.names

@@ -1,6 +1,7 @@
 """What one training iteration of the head behind the pixel decoder costs on one MI355X
 (pair-net_amd/train.py): ms per `TailTrainer.step` at 800x1333, one image, for the
-tail alone and with the nine masked decoder layers, and where the time goes (HIP events around the
+tail alone, with the nine masked decoder layers, and with the pixel decoder's encoder path as
+well (everything behind the frozen backbone), and where the time goes (HIP events around the
 phases of a step; the Hungarian assignments inside `loss` are host work as in the reference).
 Prints one JSON line.  `rocprofv3 --kernel-trace --stats -- python tools/train_step_probe.py`
 gives the per-kernel view (profiles/r06_train_step_kernel_stats.csv)."""
@@ -42,8 +43,9 @@ pts = [torch.rand(1, 12544, 2, generator=g) for _ in range(B)]
 out = {"what": "TailTrainer.step, 800x1333, one image, frozen ResNet-50 features resident in HBM; "
                "ms per step over %d steps (device wait at both ends) and the phases of one step "
                "(HIP events; `loss` includes the two Hungarian assignments on the host)" % steps}
-for mode in (False, True):
-    tr = TailTrainer(head, train_decoder=mode)
+for scope in ("tail", "head", "head+pixel_decoder"):
+    mode = scope != "tail"
+    tr = TailTrainer(head, train_decoder=mode, train_pixel_decoder=scope == "head+pixel_decoder")
     for _ in range(3):
         vals = tr.step(feats, metas, gt_rels, gt_labels, gt_masks, point_coords=pts)
     torch.cuda.synchronize()
@@ -54,6 +56,7 @@ for mode in (False, True):
     ms = 1e3 * (time.perf_counter() - t0) / steps
     # phases of one step
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    nh = tr.tape.flat_numel
     with torch.no_grad():
         ev[0].record()
         outs = head.forward(feats, metas)
@@ -66,14 +69,18 @@ for mode in (False, True):
             tr.tape.forward_from_plan(pl, pl.sub_pos, pl.obj_pos)
         else:
             tr.tape.forward(pl.q, pl.sub_pos, pl.obj_pos)
+        if tr.pd_tape is not None:
+            tr.pd_tape.forward(feats)
         ev[3].record()
-        tr.tape.backward(g_rel=up["rel"], g_importance=up["importance"])
+        back = tr.tape.backward(g_rel=up["rel"], g_importance=up["importance"])
+        if tr.pd_tape is not None:
+            tr.pd_tape.backward(back[0])
         ev[4].record()
         tr.apply_gradients()
         ev[5].record()
     torch.cuda.synchronize()
     ph = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
-    out["head" if mode else "tail"] = {
+    out[scope] = {
         "ms_per_step": ms, "trained_parameters": int(sum(v.numel() for v in tr.params.values())),
         "phases_ms": dict(zip(("inference_forward", "loss_and_logit_gradients", "taped_forward",
                                "backward", "clip_adamw_refresh"), ph)),

@@ -743,9 +743,11 @@ int pn_bce_posw_mean_grad_f32(const float* logits, const float* target, float* g
  * every output row are zero-filled (out_cols >= rows: pads a contraction length to 4). */
 int pn_transpose_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int rows, int cols,
                      int out_cols, void* stream);
-/* out[c] (+)= sum_r x[r][c]  (bias / LayerNorm-weight gradients, second stage of the tap correlations) */
+/* out[c] (+)= sum_r x[r][c]  (bias / LayerNorm-weight gradients, second stage of the tap correlations);
+ * scratch (nullable): up to 64 * cols floats, lets a tall matrix be summed in row chunks by many
+ * workgroups + one combining launch (fixed order either way). */
 int pn_colsum_f32(const float* x, int64_t ld, float* out, int rows, int cols, int accumulate,
-                  void* stream);
+                  float* scratch, int64_t scratch_floats, void* stream);
 /* dx[i] = y[i] > 0 ? dy[i] : 0  (y: the ReLU's output; dx may alias dy) */
 int pn_relu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 /* out[i] = a[i] + b[i % bn]  (x + row-periodic table; bn == n: a plain sum, out may alias a) */

@@ -41,24 +41,27 @@ extern "C" int pn_transpose_f32(const float* in, int64_t ldi, float* out, int64_
 
 // ---- out[c] (+)= sum_r x[r][c]: a bias gradient, a LayerNorm weight gradient, the second
 // stage of the tap correlations.  64 columns per workgroup; 16 waves stride the rows, their
-// partials are added in wave order.
+// partials are added in wave order.  Tall matrices (the pixel decoder's 21 950 token rows) are cut
+// into row chunks (blockIdx.y) whose sums go to a caller scratch [chunks][cols] and are summed
+// by a second launch of the same kernel: fixed order either way.
 __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ x, int64_t ld,
                                                  float* __restrict__ out, int rows, int cols,
-                                                 int accumulate) {
+                                                 int accumulate, int rows_per_chunk) {
   __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(r0 + rows_per_chunk, rows);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < cols) {
     const float* p = x + c;
-    int r = wave;
-    for (; r + 48 < rows; r += 64) {
+    int r = r0 + wave;
+    for (; r + 48 < r1; r += 64) {
       s0 += p[(int64_t)r * ld];
       s1 += p[(int64_t)(r + 16) * ld];
       s2 += p[(int64_t)(r + 32) * ld];
       s3 += p[(int64_t)(r + 48) * ld];
     }
-    for (; r < rows; r += 16) s0 += p[(int64_t)r * ld];
+    for (; r < r1; r += 16) s0 += p[(int64_t)r * ld];
   }
   red[wave][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
@@ -66,15 +69,29 @@ __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ x, in
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) t += red[w][lane];
-    out[c] = accumulate ? out[c] + t : t;
+    float* o = out + (int64_t)blockIdx.y * cols + c;         // (blockIdx.y > 0 only into scratch)
+    *o = accumulate ? *o + t : t;
   }
 }
 
 extern "C" int pn_colsum_f32(const float* x, int64_t ld, float* out, int rows, int cols,
-                             int accumulate, void* stream) {
+                             int accumulate, float* scratch, int64_t scratch_floats,
+                             void* stream) {
   if (!x || !out || rows <= 0 || cols <= 0 || ld < cols) return PN_BAD_ARG;
-  hipLaunchKernelGGL(k_colsum, dim3(pn_cdiv(cols, 64)), dim3(1024), 0, (hipStream_t)stream, x, ld,
-                     out, rows, cols, accumulate);
+  hipStream_t s = (hipStream_t)stream;
+  int chunks = scratch ? min(64, rows / 512) : 1;
+  if (chunks > 1 && (int64_t)chunks * cols > scratch_floats) chunks = (int)(scratch_floats / cols);
+  if (chunks < 2) {
+    hipLaunchKernelGGL(k_colsum, dim3(pn_cdiv(cols, 64), 1), dim3(1024), 0, s, x, ld, out, rows,
+                       cols, accumulate, rows);
+    return PN_LAUNCH_CHECK();
+  }
+  const int per = pn_cdiv(rows, chunks);
+  chunks = pn_cdiv(rows, per);
+  hipLaunchKernelGGL(k_colsum, dim3(pn_cdiv(cols, 64), chunks), dim3(1024), 0, s, x, ld, scratch,
+                     rows, cols, 0, per);
+  hipLaunchKernelGGL(k_colsum, dim3(pn_cdiv(cols, 64), 1), dim3(1024), 0, s, scratch, (int64_t)cols,
+                     out, chunks, cols, accumulate, chunks);
   return PN_LAUNCH_CHECK();
 }
 

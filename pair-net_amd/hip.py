@@ -106,7 +106,7 @@ _SIGS = {
                                           _f32, _f32, _vp]),
     "pn_bce_posw_mean_grad_f32": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp]),
     "pn_transpose_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
-    "pn_colsum_f32": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _vp]),
+    "pn_colsum_f32": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp]),
     "pn_relu_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "pn_add_periodic_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "pn_batch_sum_f32": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp]),
@@ -1174,8 +1174,12 @@ def transpose(x, out, out_cols=None):
 
 def colsum(x, out, accumulate=False):
     rows, ld = _rowmajor(x)
-    assert out.numel() == x.shape[1] and out.is_contiguous()
-    _check(lib().pn_colsum_f32(_ptr(x), ld, _ptr(out), rows, x.shape[1], int(accumulate), _stream()),
+    cols = x.shape[1]
+    assert out.numel() == cols and out.is_contiguous()
+    scratch = torch.empty(min(64, rows // 512) * cols, device=x.device, dtype=torch.float32) \
+        if rows >= 1024 else None               # tall matrices: row chunks on many workgroups
+    _check(lib().pn_colsum_f32(_ptr(x), ld, _ptr(out), rows, cols, int(accumulate), _ptr(scratch),
+                               scratch.numel() if scratch is not None else 0, _stream()),
            "pn_colsum_f32")
 
 

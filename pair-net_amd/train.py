@@ -1,11 +1,12 @@
 """One training iteration of Pair-Net's own parameters on the MI355X: the
 reference's `forward_train` -> `loss` -> `backward` -> clip -> AdamW step (frameworks/psgtr.py:112-146,
 pairnet_head.py:419-757, tools/train.py:115-241, configs/mask2former/pairnet.py:353-368) for the
-parameters the backward slices built so far reach -- the Relation Fusion decoder, `rel_cls_embed`,
-the relation query / position embeddings, the Pair Proposal Network's MLPs and the Matrix Learner
-(10.3 M of the head's parameters) -- with the detector in front of them (backbone, pixel decoder,
-the nine masked decoder layers) FROZEN: in the reference those train at `lr_mult=0.1`; their
-backward pass is the part of f-4 that is not built, and this module says so rather than pretend.
+parameters of `CrossHead2` the loss reaches: by default the Relation Fusion decoder,
+`rel_cls_embed`, the relation query / position embeddings, the Pair Proposal Network's MLPs and the
+Matrix Learner (10.2 M), with `train_decoder` the nine masked decoder layers as well (+14.3 M) and
+with `train_pixel_decoder` the pixel decoder's encoder path (+5.3 M).  The BACKBONE is frozen: in
+the reference it trains at `lr_mult=0.1`; its backward pass is the part of f-4 that is not built,
+and this module says so rather than pretend.
 Everything the reference's loss can reach enters through two logits: `loss_r_cls` through
 `rel`, `loss_match` through `importance` (`loss_sub_cls` / `loss_obj_cls` read DETACHED class
 logits, pairnet_head.py:380-390, and train nothing).

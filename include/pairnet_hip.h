@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 25
+#define PN_ABI_VERSION 26
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -806,6 +806,21 @@ int pn_msda_offaw_bwd_f32(const float* grad_loc, const float* grad_aw, const flo
 int pn_groupnorm_nhwc_bwd_f32(const float* x, const float* dy, const float* gamma, float* dx,
                               float* gxhat, float* stats, int B, int64_t HW, int G, float eps,
                               int64_t x_bstride, int64_t dy_bstride, void* stream);
+/* Backbone backward (mmdet ResNet behind configs/mask2former/pairnet.py:9-19, frozen BatchNorm folded
+ * into the convolutions; pair-net_amd/grad.py BackboneGrad).  Weight gradient of a K x K convolution
+ * (stride, pad) between channel-last maps dY [B][Ho][Wo][Co] and X [B][Hi][Wi][Ci] (Ci, Co % 64 == 0):
+ * part[chunk][co][tap][ci] over chunks of rows_per output rows per image, B * ceil(Ho / rows_per)
+ * chunks of Co*K*K*Ci floats; their column sum is dW [Co][K*K][Ci]. */
+int pn_conv_wgrad_f32(const float* dY, const float* X, float* part, int B, int Hi, int Wi, int Ho,
+                      int Wo, int Ci, int Co, int K, int stride, int pad, int rows_per, void* stream);
+/* out[b][y][x][:] (+)= in[b][y/2][x/2][:] at even (y, x), 0 elsewhere: [B][Ho][Wo][C] -> [B][Hi][Wi][C] */
+int pn_dilate2_f32(const float* in, float* out, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                   int accumulate, void* stream);
+/* out[b][i][j][:] = in[b][2i][2j][:]: [B][Hi][Wi][C] -> [B][Ho][Wo][C] */
+int pn_subsample2_f32(const float* in, float* out, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                      void* stream);
+/* x[r][0:cols] *= s[r] */
+int pn_scale_rows_f32(float* x, const float* s, int64_t rows, int64_t cols, void* stream);
 /* out[ci][T-1-t][co] = in[co][t][ci]: a "same" convolution's weight as its data gradient reads it */
 int pn_conv_weight_bwd_layout_f32(const float* in, float* out, int Co, int T, int Ci, void* stream);
 

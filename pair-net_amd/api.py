@@ -11,7 +11,7 @@ from .bbox_head import CrossHeadBBox  # noqa: F401
 from .neck import ChannelMapper  # noqa: F401
 from .head import CrossHead2  # noqa: F401
 from .pipeline import PipelinedHead  # noqa: F401
-from .grad import HeadGrad, PixelDecoderGrad, RelationTailGrad  # noqa: F401
+from .grad import BackboneGrad, HeadGrad, PixelDecoderGrad, RelationTailGrad  # noqa: F401
 from .train import TailTrainer  # noqa: F401
 from .preprocess import TestPipeline  # noqa: F401
 from .detector import (PSGTr, Result, ResultStreamer, build_detector, load_checkpoint,  # noqa: F401
@@ -26,4 +26,4 @@ __all__ = ["ConfigDict", "load_config", "pairnet_head_cfg", "pairnet_r50", "Cros
            "baseline_r50", "PSGTrHead2", "psgtr2_head_cfg", "psgtr2_r50", "ResNet50Hip",
            "SwinTransformerHip", "pairnet_swin", "swin_backbone_cfg", "TestPipeline", "test_pipeline_cfg",
            "CrossHeadBBox", "ChannelMapper", "bbox_head_cfg", "channel_mapper_cfg", "cross_r101_vg",
-           "TripletEvaluator", "SceneGraphMetrics", "dataset", "RelationTailGrad", "HeadGrad", "PixelDecoderGrad", "TailTrainer"]
+           "TripletEvaluator", "SceneGraphMetrics", "dataset", "RelationTailGrad", "HeadGrad", "PixelDecoderGrad", "BackboneGrad", "TailTrainer"]

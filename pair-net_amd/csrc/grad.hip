@@ -691,3 +691,135 @@ extern "C" int pn_groupnorm_nhwc_bwd_f32(const float* x, const float* dy, const 
                      dx, gxhat, HW, G, x_bstride, dy_bstride);
   return PN_LAUNCH_CHECK();
 }
+
+// ---- backbone (mmdet ResNet, frozen BatchNorm folded into the convolutions): the pieces its
+// backward needs beside the GEMMs.
+// Weight gradient of a K x K convolution (stride s, padding p) between channel-last maps, as
+// MFMA outer products over output pixels -- the general form of k_tapcorr64:
+//   dW[co][tap][ci] = sum_{b,y,x} dY[b][y][x][co] X[b][y s + kh - p][x s + kw - p][ci]
+// A workgroup owns one tap, one 64 x 64 (co, ci) block and one chunk of `rows_per` output rows;
+// part[chunk][co][tap][ci], column-summed over the chunks by the caller (fixed order).
+__global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ dY,
+                                                    const float* __restrict__ X,
+                                                    float* __restrict__ part, int Hi, int Wi,
+                                                    int Ho, int Wo, int Ci, int Co, int K,
+                                                    int stride, int pad, int rows_per,
+                                                    int chunks_per_image) {
+  const int T = K * K, nci = Ci >> 6;
+  int id = blockIdx.x;
+  const int cib = id % nci; id /= nci;
+  const int tap = id % T;
+  const int cob = id / T;
+  const int chunk = blockIdx.y;
+  const int b = chunk / chunks_per_image, y0 = (chunk % chunks_per_image) * rows_per;
+  const int kh = tap / K, kw = tap % K;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int co0 = cob * 64 + (wave & 1) * 32, ci0 = cib * 64 + (wave >> 1) * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int y1 = min(y0 + rows_per, Ho);
+  for (int y = y0; y < y1; ++y) {
+    const int yy = y * stride + kh - pad;
+    if (yy < 0 || yy >= Hi) continue;                      // (workgroup-uniform)
+    const float* dr = dY + (((int64_t)b * Ho + y) * Wo) * Co + co0 + li;
+    const float* xr = X + (((int64_t)b * Hi + yy) * Wi) * Ci + ci0 + li;
+    for (int x = 0; x < Wo; x += 2) {
+      const int xp = x + lh, xx = xp * stride + kw - pad;
+      const float a = xp < Wo ? dr[(int64_t)xp * Co] : 0.f;
+      const float w = (xp < Wo && xx >= 0 && xx < Wi) ? xr[(int64_t)xx * Ci] : 0.f;
+      acc = mfma32(a, w, acc);
+    }
+  }
+  float* out = part + (int64_t)chunk * Co * T * Ci;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + mfma32_row(r, lh), ci = ci0 + li;
+    out[((int64_t)co * T + tap) * Ci + ci] = acc[r];
+  }
+}
+
+extern "C" int pn_conv_wgrad_f32(const float* dY, const float* X, float* part, int B, int Hi,
+                                 int Wi, int Ho, int Wo, int Ci, int Co, int K, int stride, int pad,
+                                 int rows_per, void* stream) {
+  if (!dY || !X || !part || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || Ci <= 0 ||
+      Co <= 0 || (Ci & 63) || (Co & 63) || K <= 0 || K > 7 || stride <= 0 || pad < 0 || rows_per <= 0)
+    return PN_BAD_ARG;
+  const int cpi = pn_cdiv(Ho, rows_per);
+  const int64_t gx = (int64_t)K * K * (Co >> 6) * (Ci >> 6);
+  if ((int64_t)B * cpi > 65535 || gx > 2147483647) return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)gx, B * cpi), dim3(256), 0, (hipStream_t)stream,
+                     dY, X, part, Hi, Wi, Ho, Wo, Ci, Co, K, stride, pad, rows_per, cpi);
+  return PN_LAUNCH_CHECK();
+}
+
+// out[b][y][x][:] (+)= (y, x both even and inside) ? in[b][y/2][x/2][:] : 0 -- the zero-dilated
+// gradient map of a stride-2 layer ([B][Ho][Wo][C] -> [B][Hi][Wi][C]): its data gradient is then
+// the stride-1 convolution with the reversed taps; with `accumulate` the backward of the
+// stride-2 subsampling in front of a 1x1 projection shortcut.
+__global__ __launch_bounds__(256) void k_dilate2(const float* __restrict__ in, float* out, int Hi,
+                                                 int Wi, int Ho, int Wo, int C, int64_t n,
+                                                 int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const int64_t p = i / C;
+  const int x = (int)(p % Wi), y = (int)((p / Wi) % Hi);
+  const int64_t b = p / ((int64_t)Wi * Hi);
+  float v = 0.f;
+  if (!(y & 1) && !(x & 1) && (y >> 1) < Ho && (x >> 1) < Wo)
+    v = in[((b * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c];
+  out[i] = accumulate ? out[i] + v : v;
+}
+
+extern "C" int pn_dilate2_f32(const float* in, float* out, int B, int Hi, int Wi, int Ho, int Wo,
+                              int C, int accumulate, void* stream) {
+  if (!in || !out || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 ||
+      2 * (Ho - 1) > Hi - 1 || 2 * (Wo - 1) > Wi - 1)
+    return PN_BAD_ARG;
+  const int64_t n = (int64_t)B * Hi * Wi * C;
+  hipLaunchKernelGGL(k_dilate2, dim3(pn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     Hi, Wi, Ho, Wo, C, n, accumulate);
+  return PN_LAUNCH_CHECK();
+}
+
+// out[b][i][j][:] = in[b][2 i][2 j][:]  (what a stride-2 1x1 convolution reads)
+__global__ __launch_bounds__(256) void k_subsample2(const float* __restrict__ in,
+                                                    float* __restrict__ out, int Hi, int Wi,
+                                                    int Ho, int Wo, int C, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const int64_t p = i / C;
+  const int x = (int)(p % Wo), y = (int)((p / Wo) % Ho);
+  const int64_t b = p / ((int64_t)Wo * Ho);
+  out[i] = in[((b * Hi + 2 * y) * Wi + 2 * x) * C + c];
+}
+
+extern "C" int pn_subsample2_f32(const float* in, float* out, int B, int Hi, int Wi, int Ho, int Wo,
+                                 int C, void* stream) {
+  if (!in || !out || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 ||
+      2 * (Ho - 1) > Hi - 1 || 2 * (Wo - 1) > Wi - 1)
+    return PN_BAD_ARG;
+  const int64_t n = (int64_t)B * Ho * Wo * C;
+  hipLaunchKernelGGL(k_subsample2, dim3(pn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     Hi, Wi, Ho, Wo, C, n);
+  return PN_LAUNCH_CHECK();
+}
+
+// x[r][:] *= s[r]  (a folded convolution's weight gradient back to the un-folded weight:
+// W' = W * gamma / sqrt(var + eps) per output channel)
+__global__ __launch_bounds__(256) void k_scale_rows(float* x, const float* __restrict__ s,
+                                                    int64_t cols, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] *= s[i / cols];
+}
+
+extern "C" int pn_scale_rows_f32(float* x, const float* s, int64_t rows, int64_t cols,
+                                 void* stream) {
+  if (!x || !s || rows <= 0 || cols <= 0) return PN_BAD_ARG;
+  hipLaunchKernelGGL(k_scale_rows, dim3(pn_cdiv(rows * cols, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, s, cols, rows * cols);
+  return PN_LAUNCH_CHECK();
+}

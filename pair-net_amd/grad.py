@@ -32,7 +32,7 @@ import torch
 
 from . import hip
 
-__all__ = ["RelationTailGrad", "HeadGrad", "PixelDecoderGrad"]
+__all__ = ["RelationTailGrad", "HeadGrad", "PixelDecoderGrad", "BackboneGrad"]
 
 
 class RelationTailGrad:
@@ -60,14 +60,16 @@ class RelationTailGrad:
         self.ffn = head.rel_ffn
         self.scale = 1.0 / math.sqrt(32.0)
         self.t = None
-        # every gradient is a view of ONE flat buffer, parameters in the order their gradients are
-        # COMPLETED by backward() (rel_cls_embed, relation layers last to first, the relation
-        # embeddings, the Matrix Learner, the two PPN MLPs, then the optional class path): the
-        # optimizer runs over it in one launch and a data-parallel reducer can all-reduce a
-        # finished prefix while the rest of the backward pass is still running (train.py, dist.py)
+        self._build_layout(head, flat, base)
+
+    def _build_layout(self, head, flat, base):
+        """Every gradient is a view of ONE flat buffer, parameters in the order their gradients are
+        COMPLETED by backward() (rel_cls_embed, relation layers last to first, the relation
+        embeddings, the Matrix Learner, the two PPN MLPs, then the optional class path): the
+        optimizer runs over it in one launch and a data-parallel reducer can all-reduce a
+        finished prefix while the rest of the backward pass is still running (train.py, dist.py)."""
         self.layout, off = OrderedDict(), 0
         self.group_end = OrderedDict()           # group name -> end offset of its last segment
-        self.size_of(head)                       # (same walk, kept in one place below)
         for group, names in self.param_groups(head):
             for n in names:
                 shape = tuple(head._params[n].shape)
@@ -836,3 +838,171 @@ class PixelDecoderGrad(RelationTailGrad):
             ready(self.group_end["input_convs.%d" % l])
         ready(self.flat_numel)
         return dfeats, grads
+
+
+class BackboneGrad(RelationTailGrad):
+    """The backbone's trainable part -- mmdet ResNet-50 / -101 stages 2-4 (`frozen_stages=1`: stem
+    and layer1 fixed; BatchNorm frozen, `norm_eval`: configs/mask2former/pairnet.py:9-19) -- taped
+    and differentiated from C2 (layer1's output) to C3 / C4 / C5:
+
+        tape = BackboneGrad(det.backbone)
+        c3, c4, c5 = tape.forward(c2)                  # channel-last [B, h, w, C] maps
+        grads = tape.backward(d_c3, d_c4, d_c5)        # [B, C, h, w], e.g. PixelDecoderGrad's dfeats
+
+    Frozen BatchNorm is folded into the convolutions (W' = W gamma / sqrt(var + eps), as the
+    inference path does); the gradient of the un-folded weight is the folded one's times the same
+    per-channel factor.  1x1 convolutions are linear layers over pixels (`pn_gemm_f32` on
+    transposed operands), the 3x3 convolutions' data gradient is the forward implicit-GEMM kernel on
+    the tap-reversed, channel-swapped weight (over the zero-dilated gradient map for the stride-2
+    layers), their weight gradient `pn_conv_wgrad_f32` (MFMA outer products over pixels).  The taped
+    forward uses the direct implicit-GEMM convolution where inference uses Winograd (same values to
+    ~1e-5).  Gradients are named like the backbone's state dict (`layer3.4.conv2.weight`)."""
+
+    def __init__(self, backbone, flat=None, base=0):
+        if backbone.device is None or backbone.device.type != "cuda":
+            raise RuntimeError("BackboneGrad needs a backbone on an MI355X (.to('cuda:N'))")
+        if backbone.w is None:
+            backbone._pack()
+        self.head, self.dev, self.t = backbone, backbone.device, None
+        self._build_layout(backbone, flat, base)
+        P = backbone._params
+        self.bn_scale, self.bn_scale64 = {}, {}
+        for n in self.layout:                      # conv name -> gamma / sqrt(var + eps)
+            conv = n[:-len(".weight")]
+            bn = conv.replace("conv", "bn") if "downsample" not in conv else conv[:-1] + "1"
+            sc = P[bn + ".weight"].double() / torch.sqrt(P[bn + ".running_var"].double() + 1e-5)
+            self.bn_scale[n] = sc.float().to(self.dev)
+            self.bn_scale64[n] = sc.to(self.dev)
+
+    @staticmethod
+    def param_groups(backbone):
+        groups = []
+        stages = list(enumerate(backbone.stages))
+        for i, (planes, blocks) in reversed(stages[1:]):
+            for b in reversed(range(blocks)):
+                p = "layer%d.%d." % (i + 1, b)
+                names = [p + "conv3.weight", p + "conv2.weight", p + "conv1.weight"]
+                if b == 0:
+                    names.append(p + "downsample.0.weight")
+                groups.append((p[:-1], names))
+        return groups
+
+    @torch.no_grad()
+    @hip.on_device
+    def forward(self, c2):
+        bb, w, E = self.head, self.head.w, self._E
+        B, cin, h, wd = c2.shape
+        x = c2.permute(0, 2, 3, 1).contiguous()             # channel-last rows
+        blocks_t, outs = [], []
+        for i, (planes, blocks) in list(enumerate(bb.stages))[1:]:
+            for b in range(blocks):
+                p = "layer%d.%d." % (i + 1, b)
+                stride = 2 if b == 0 else 1
+                hi, wi = h, wd
+                if stride == 2:
+                    h, wd = (h - 1) // 2 + 1, (wd - 1) // 2 + 1
+                s = dict(p=p, x=x, cin=cin, planes=planes, stride=stride, hi=hi, wi=wi, h=h, w=wd)
+                s["t1"] = E(B, hi, wi, planes)
+                hip.linear(x.view(-1, cin), w[p + "conv1.w"], w[p + "conv1.b"],
+                           s["t1"].view(-1, planes), relu=True)
+                s["t2"] = E(B, h, wd, planes)
+                hip.conv2d_ex(s["t1"], w[p + "conv2.w"], w[p + "conv2.b"], None, s["t2"], B, hi, wi,
+                              planes, planes, 3, 3, stride, 1, relu=True)
+                if b == 0:
+                    idt = E(B, h, wd, planes * 4)
+                    hip.conv2d_ex(x, w[p + "downsample.0.w"], w[p + "downsample.0.b"], None, idt, B,
+                                  hi, wi, cin, planes * 4, 1, 1, stride, 0)
+                else:
+                    idt = x
+                s["out"] = E(B, h, wd, planes * 4)
+                hip.linear(s["t2"].view(-1, planes), w[p + "conv3.w"], w[p + "conv3.b"],
+                           s["out"].view(-1, planes * 4), res=idt.view(-1, planes * 4),
+                           relu_after=True)
+                x, cin = s["out"], planes * 4
+                blocks_t.append(s)
+            outs.append(x)
+        self.t = dict(B=B, blocks=blocks_t)
+        return tuple(outs)
+
+    def _conv3x3_bwd(self, s, d_t2, grads, B):
+        """d_t2 [B, h, w, planes] (pre-ReLU) -> d t1 (post-ReLU input of the 3x3), + its weight."""
+        w, E = self.head.w, self._E
+        p, planes, stride = s["p"], s["planes"], s["stride"]
+        hi, wi, h, wd = s["hi"], s["wi"], s["h"], s["w"]
+        rows_per = max(1, min(h, 8))
+        chunks = B * ((h + rows_per - 1) // rows_per)
+        part = E(chunks, planes * 9 * planes)
+        hip.conv_wgrad(d_t2, s["t1"], part, B, hi, wi, h, wd, planes, planes, 3, stride, 1, rows_per)
+        dwp = E(planes * 9 * planes)                          # [co][tap][ci]: the packed layout
+        hip.colsum(part, dwp)
+        g = grads[p + "conv2.weight"]
+        g.copy_(dwp.view(planes, 3, 3, planes).permute(0, 3, 1, 2))      # -> [co][ci][3][3]
+        hip.scale_rows(g, self.bn_scale[p + "conv2.weight"])
+        wb = E(planes * 9 * planes)
+        hip.conv_weight_bwd_layout(w[p + "conv2.w"], wb, planes, 9, planes)
+        d_t1 = E(B, hi, wi, planes)
+        if stride == 1:
+            src = d_t2
+        else:
+            src = E(B, hi, wi, planes)
+            hip.dilate2(d_t2, src, B, hi, wi, h, wd, planes)
+        hip.conv2d_ex(src, wb.view(planes, 9 * planes), None, None, d_t1, B, hi, wi, planes, planes,
+                      3, 3, 1, 1)
+        return d_t1
+
+    @torch.no_grad()
+    @hip.on_device
+    def backward(self, d_c3, d_c4, d_c5, on_ready=None):
+        if self.t is None:
+            raise RuntimeError("backward() needs a forward() first")
+        w, E, t = self.head.w, self._E, self.t
+        B = t["B"]
+        ready = on_ready if on_ready is not None else (lambda end: None)
+        grads = self._zero_grads()
+        nhwc = lambda g: g.to(self.dev, torch.float32).permute(0, 2, 3, 1).contiguous()
+        stage_grads = {2: nhwc(d_c3), 3: nhwc(d_c4), 4: nhwc(d_c5)}     # by layer number
+        dx = None
+        for s in reversed(t["blocks"]):
+            p, planes, cin, stride = s["p"], s["planes"], s["cin"], s["stride"]
+            hi, wi, h, wd = s["hi"], s["wi"], s["h"], s["w"]
+            layer, blk = int(p[5]), int(p[7:-1])
+            last_of_stage = blk == self.head.stages[layer - 1][1] - 1
+            if last_of_stage:                      # a stage's output also feeds the pixel decoder
+                g = stage_grads[layer]
+                if dx is not None:
+                    self._acc(g, dx)
+                dx = g
+            dy = E(B, h, wd, planes * 4)
+            hip.relu_bwd(dx, s["out"], dy)         # ReLU after the shortcut
+            # conv3 (1x1) + BN
+            d_t2 = self._lin_bwd(dy.view(-1, planes * 4), s["t2"].view(-1, planes), w[p + "conv3.w"],
+                                 grads, p + "conv3.weight", None)
+            hip.scale_rows(grads[p + "conv3.weight"], self.bn_scale[p + "conv3.weight"])
+            hip.relu_bwd(d_t2, s["t2"].view(-1, planes), d_t2)
+            d_t1 = self._conv3x3_bwd(s, d_t2.view(B, h, wd, planes), grads, B)
+            hip.relu_bwd(d_t1, s["t1"], d_t1)
+            first = layer == 2 and blk == 0        # its input is the frozen layer1's output
+            dxin = self._lin_bwd(d_t1.view(-1, planes), s["x"].view(-1, cin), w[p + "conv1.w"], grads,
+                                 p + "conv1.weight", None, need_dx=not first)
+            hip.scale_rows(grads[p + "conv1.weight"], self.bn_scale[p + "conv1.weight"])
+            if blk == 0:                           # projection shortcut (1x1, stride s)
+                xs = s["x"]
+                if stride == 2:
+                    xs = E(B, h, wd, cin)
+                    hip.subsample2(s["x"], xs, B, hi, wi, h, wd, cin)
+                dxs = self._lin_bwd(dy.view(-1, planes * 4), xs.view(-1, cin),
+                                    w[p + "downsample.0.w"], grads, p + "downsample.0.weight", None,
+                                    need_dx=not first)
+                hip.scale_rows(grads[p + "downsample.0.weight"],
+                               self.bn_scale[p + "downsample.0.weight"])
+                if not first:
+                    if stride == 2:
+                        hip.dilate2(dxs, dxin, B, hi, wi, h, wd, cin, accumulate=True)
+                    else:
+                        self._acc(dxin, dxs)
+            else:                                  # identity shortcut
+                self._acc(dxin, dy.view(-1, planes * 4))
+            dx = None if first else dxin.view(B, hi, wi, cin)
+            ready(self.group_end[p[:-1]])
+        ready(self.flat_numel)
+        return grads

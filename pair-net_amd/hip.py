@@ -123,6 +123,10 @@ _SIGS = {
                                         C.POINTER(_i32), _vp]),
     "pn_groupnorm_nhwc_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i64,
                                             _i64, _vp]),
+    "pn_conv_wgrad_f32": (C.c_int, [_vp, _vp, _vp] + [_i32] * 11 + [_vp]),
+    "pn_dilate2_f32": (C.c_int, [_vp, _vp] + [_i32] * 7 + [_vp]),
+    "pn_subsample2_f32": (C.c_int, [_vp, _vp] + [_i32] * 6 + [_vp]),
+    "pn_scale_rows_f32": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "pn_grad_norm_clip_f32": (C.c_int, [_vp, _i64, _f32, _f32, _vp, _vp, _vp]),
     "pn_adamw_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32,
                                _f32, _i32, _vp, _f32, _vp]),
@@ -187,7 +191,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 25   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 26   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -1278,6 +1282,29 @@ def groupnorm_nhwc_bwd(x, dy, gamma, dx, gxhat, stats, B, HW, G, x_bstride, dy_b
     _check(lib().pn_groupnorm_nhwc_bwd_f32(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(dx), _ptr(gxhat),
                                            _ptr(stats), B, HW, G, eps, x_bstride, dy_bstride,
                                            _stream()), "pn_groupnorm_nhwc_bwd_f32")
+
+
+def conv_wgrad(dY, X, part, B, Hi, Wi, Ho, Wo, Ci, Co, K, stride, pad, rows_per):
+    assert part.numel() == B * ((Ho + rows_per - 1) // rows_per) * Co * K * K * Ci
+    _check(lib().pn_conv_wgrad_f32(_ptr(dY), _ptr(X), _ptr(part), B, Hi, Wi, Ho, Wo, Ci, Co, K,
+                                   stride, pad, rows_per, _stream()), "pn_conv_wgrad_f32")
+
+
+def dilate2(x, out, B, Hi, Wi, Ho, Wo, Cc, accumulate=False):
+    _check(lib().pn_dilate2_f32(_ptr(x), _ptr(out), B, Hi, Wi, Ho, Wo, Cc, int(accumulate),
+                                _stream()), "pn_dilate2_f32")
+
+
+def subsample2(x, out, B, Hi, Wi, Ho, Wo, Cc):
+    _check(lib().pn_subsample2_f32(_ptr(x), _ptr(out), B, Hi, Wi, Ho, Wo, Cc, _stream()),
+           "pn_subsample2_f32")
+
+
+def scale_rows(x, s):
+    rows = s.numel()
+    assert x.is_contiguous() and x.numel() % rows == 0
+    _check(lib().pn_scale_rows_f32(_ptr(x), _ptr(s), rows, x.numel() // rows, _stream()),
+           "pn_scale_rows_f32")
 
 
 def grad_norm_clip(g, out, scratch, pre=1.0, max_norm=0.0):

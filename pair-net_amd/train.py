@@ -28,7 +28,7 @@ import torch
 
 from . import hip
 from .dist import GradReducer
-from .grad import HeadGrad, PixelDecoderGrad, RelationTailGrad
+from .grad import BackboneGrad, HeadGrad, PixelDecoderGrad, RelationTailGrad
 
 __all__ = ["TailTrainer"]
 
@@ -38,18 +38,24 @@ class TailTrainer:
 
     def __init__(self, head, lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8,
                  max_norm=0.1, norm_decay_mult=0.0, lr_mult=None, group=None,
-                 bucket_bytes=32 << 20, train_decoder=False, train_pixel_decoder=False):
+                 bucket_bytes=32 << 20, train_decoder=False, train_pixel_decoder=False,
+                 backbone=None):
         """`train_decoder`: also train the nine masked decoder layers, `query_feat`, `query_embed`
         and `level_embed` (`HeadGrad`; the reference's `transformer_decoder` group, lr_mult 0.1 by
         default here as in configs/mask2former/pairnet.py:358-363) -- everything of the head behind
         the pixel decoder.  `lr_mult`: {substring of a parameter name: multiplier} (mmcv's
         `paramwise_cfg.custom_keys`)."""
         self.head = head
+        # `backbone` (a ResNet50Hip): also train its stages 2-4 (`BackboneGrad`; the reference's
+        # `backbone` group at lr_mult 0.1, stem / layer1 / BatchNorm frozen as in its config):
+        # `step()` then takes the IMAGE tensor.  Its parameters appear as "backbone.<name>".
+        self.backbone = backbone
+        train_pixel_decoder = bool(train_pixel_decoder) or backbone is not None
         self.train_pixel_decoder = bool(train_pixel_decoder)
         self.train_decoder = bool(train_decoder) or self.train_pixel_decoder
         train_decoder = self.train_decoder
         if lr_mult is None:
-            lr_mult = {"transformer_decoder": 0.1, "pixel_decoder": 0.1}
+            lr_mult = {"transformer_decoder": 0.1, "pixel_decoder": 0.1, "backbone.": 0.1}
         if head.w is None:
             head._pack()
         # plans captured so far bake the addresses of the weight tensors that are re-homed below
@@ -61,10 +67,18 @@ class TailTrainer:
         # ONE flat gradient buffer for every tape: [head tape | pixel decoder tape]
         n_head = tape_cls.size_of(head)
         n_pd = PixelDecoderGrad.size_of(head) if self.train_pixel_decoder else 0
-        self.flat_grad = torch.zeros(n_head + n_pd, device=dev, dtype=torch.float32)
+        if backbone is not None:
+            if backbone.device is None:
+                backbone.to(dev)
+            if backbone.w is None:
+                backbone._pack()
+        n_bb = BackboneGrad.size_of(backbone) if backbone is not None else 0
+        self.flat_grad = torch.zeros(n_head + n_pd + n_bb, device=dev, dtype=torch.float32)
         self.tape = tape = tape_cls(head, flat=self.flat_grad, base=0)
         self.pd_tape = PixelDecoderGrad(head, flat=self.flat_grad, base=n_head) \
             if self.train_pixel_decoder else None
+        self.bb_tape = BackboneGrad(backbone, flat=self.flat_grad, base=n_head + n_pd) \
+            if backbone is not None else None
         self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
         # name -> (offset in the shared buffer, shape, numel); the class path (cls_embed /
         # post_norm: no gradient in the reference's graph) stays in the layout with lr 0
@@ -72,8 +86,13 @@ class TailTrainer:
         if self.pd_tape is not None:
             for n, (o, shape, k) in self.pd_tape.layout.items():
                 self.layout[n] = (o + n_head, shape, k)
+        src = {n: head._params[n] for n in self.layout}          # where a parameter's value lives
+        if self.bb_tape is not None:
+            for n, (o, shape, k) in self.bb_tape.layout.items():
+                self.layout["backbone." + n] = (o + n_head + n_pd, shape, k)
+                src["backbone." + n] = backbone._params[n]
         frozen = {n for g, names in tape.param_groups(head) if g in self.FROZEN_GROUPS for n in names}
-        self.n = n_head + n_pd
+        self.n = n_head + n_pd + n_bb
         self.names = [n for n in self.layout if n not in frozen]
         self._frozen = frozen
         # ---- flat parameters; the head's device weights become views of them ----
@@ -87,10 +106,12 @@ class TailTrainer:
         for n in self.layout:
             o, shape, k = self.layout[n]
             view = self.flat_p[o:o + k].view(shape)
-            view.copy_(head._params[n].to(dev))
+            view.copy_(src[n].to(dev))
             if n in frozen:
                 continue
             self.params[n] = view
+            if n.startswith("backbone."):
+                continue          # the backbone's packed weights are all derived (BatchNorm folded)
             if n not in self._repacked:
                 # same bytes as the reference layout (ConvTiny's first layer: [64,1,7,7] == [64,49],
                 # the 1x1 input convolutions: [256,C,1,1] == [256,C])
@@ -182,21 +203,48 @@ class TailTrainer:
                     hip.sine_pe(ent[0][o:o + h * wd], p[pd + "level_encoding.weight"][l], h, wd)
                     o += h * wd
                 ent[3].copy_(hip.pos8(ent[0]))
+        if self.bb_tape is not None:
+            self._refresh_backbone()
+
+    def _refresh_backbone(self):
+        """Re-fold BatchNorm into the trained convolutions and rewrite the backbone's packed
+        weights (channel-last rows, Winograd transforms, bf16-plane splits) in place."""
+        bb, p = self.backbone, self.params
+        w = bb.w
+        for n, sc in self.bb_tape.bn_scale64.items():
+            conv = n[:-len(".weight")]
+            # W' = W gamma / sqrt(var + eps), formed in double and rounded once like `_fold`
+            cw = (p["backbone." + n].double() * sc.view(-1, 1, 1, 1)).float()
+            co = cw.shape[0]
+            w[conv + ".w"].copy_(cw.permute(0, 2, 3, 1).reshape(co, -1))
+            if conv + ".wino" in w:
+                w[conv + ".wino"].copy_(hip.winograd_weights(cw.contiguous()))
+                w[conv + ".wino4"].copy_(hip.winograd43_weights(cw.contiguous()))
+            if conv + ".w.s3" in w:
+                hip.s3_split(w[conv + ".w"], w[conv + ".w.s3"])
 
     def write_back(self):
-        """Copy the trained values into the head's state dict (checkpoints, `state_dict()`)."""
+        """Copy the trained values into the head's (and the backbone's) state dict (checkpoints,
+        `state_dict()`)."""
         head = self.head
         for n, v in self.params.items():
-            head._params[n].copy_(v.to(head._params[n].device))
+            dst = self.backbone._params[n[len("backbone."):]] if n.startswith("backbone.") \
+                else head._params[n]
+            dst.copy_(v.to(dst.device))
         head._packed_version = head._weights_version()     # the packed device weights ARE these values
+        if self.backbone is not None:
+            self.backbone._packed_version = self.backbone._weights_version()
 
     # ------------------------------------------------------------------
     @torch.no_grad()
     @hip.on_device
     def step(self, feats, img_metas, gt_rels, gt_labels, gt_masks, point_coords=None):
         """One iteration on one batch; returns the four loss terms (device scalars, as
-        `CrossHead2.loss`) plus `grad_norm` (device scalar, before clipping)."""
+        `CrossHead2.loss`) plus `grad_norm` (device scalar, before clipping).  `feats`: the four
+        backbone feature maps -- or, for a trainer built with `backbone=`, the image tensor."""
         head, tape = self.head, self.tape
+        if self.backbone is not None:
+            feats = [f.clone(memory_format=torch.preserve_format) for f in self.backbone(feats)]
         outs = head.forward(feats, img_metas)
         up = {}
         losses = head.loss(*outs, gt_rels, None, gt_labels, gt_masks, img_metas,
@@ -213,7 +261,12 @@ class TailTrainer:
         back = tape.backward(g_rel=up["rel"], g_importance=up["importance"],
                              on_ready=lambda e: self.reducer.ready(min(e, nh)))
         if self.pd_tape is not None:           # back[0]: d memory tokens (HeadGrad)
-            self.pd_tape.backward(back[0], on_ready=lambda e: self.reducer.ready(nh + e))
+            npd = self.pd_tape.flat_numel
+            dfeats, _ = self.pd_tape.backward(back[0], on_ready=lambda e: self.reducer.ready(nh + e))
+            if self.bb_tape is not None:       # dfeats: d C5, d C4, d C3
+                self.bb_tape.forward(feats[0])
+                self.bb_tape.backward(dfeats[2], dfeats[1], dfeats[0],
+                                      on_ready=lambda e: self.reducer.ready(nh + npd + e))
         self.reducer.finish()
         self.apply_gradients()
         out = dict(losses)

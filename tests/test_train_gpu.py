@@ -56,7 +56,7 @@ def test_adamw_and_clip_kernels_equal_torch():
     assert float(flat_p[1000:1024].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("scope", ["tail", "head", "head+pixel_decoder"])
+@pytest.mark.parametrize("scope", ["tail", "head", "head+pixel_decoder", "all"])
 def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent(scope):
     """`TailTrainer.step` on a fixed batch: (1) the first update of every trained tensor equals
     torch's AdamW + clip on the gradients the step produced; (2) the loss the step optimises goes
@@ -70,7 +70,9 @@ def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent(sc
     projection, its bf16-plane weight splits and the query position tables that carry
     `level_encoding` -- was refreshed).  `scope`: the tail alone; + the nine masked decoder layers;
     + the pixel decoder's encoder path (both at lr_mult 0.1 as the reference's `transformer_decoder`
-    / `pixel_decoder` groups), i.e. everything the loss reaches behind the backbone."""
+    / `pixel_decoder` groups), i.e. everything the loss reaches behind the backbone; "all": + the
+    ResNet-50's stages 2-4 from the IMAGE (BatchNorm, stem and layer1 frozen as in the reference's
+    config) -- the whole of the reference's trainable graph."""
     train_decoder = scope != "tail"
     from pairnet_amd import RelationTailGrad, TailTrainer
     from test_losses_gpu import _outputs
@@ -80,8 +82,14 @@ def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent(sc
              for c, s in zip((256, 512, 1024, 2048), (4, 8, 16, 32))]
     before = {k: v.clone() for k, v in head.state_dict().items()}
     lr = 1e-3
+    bb = None
+    if scope == "all":
+        from pairnet_amd import ResNet50Hip
+        bb = ResNet50Hip().to(DEV)
+        bb_before = {k: v.clone() for k, v in bb.state_dict().items()}
+        feats = torch.randn(2, 3, 96, 128, generator=g).to(DEV)       # the IMAGE
     tr = TailTrainer(head, lr=lr, train_decoder=train_decoder,
-                     train_pixel_decoder=scope == "head+pixel_decoder")
+                     train_pixel_decoder=scope == "head+pixel_decoder", backbone=bb)
     p0 = tr.flat_p.clone()
     out = tr.step(feats, metas, gt_rels, gt_labels, gt_masks, point_coords=pts)
     torch.cuda.synchronize()
@@ -95,7 +103,8 @@ def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent(sc
         o, shape, k = tr.layout[n]
         p = p0[o:o + k].cpu().double().requires_grad_()
         is_norm = ".norms." in n or ".gn." in n
-        lr_n = lr * (0.1 if ("transformer_decoder" in n or "pixel_decoder" in n) else 1.0)
+        lr_n = lr * (0.1 if ("transformer_decoder" in n or "pixel_decoder" in n
+                             or n.startswith("backbone.")) else 1.0)
         opt = torch.optim.AdamW([p], lr=lr_n, weight_decay=0.0 if is_norm else tr.wd,
                                 betas=tr.betas, eps=tr.eps)
         p.grad = gflat[o:o + k] * coef
@@ -114,6 +123,9 @@ def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent(sc
         # moving 1e-4 per Adam step without warm-up the first steps need not go down at all)
         assert hist[1] < hist[0] and min(hist) < 0.95 * hist[0]
     # (3) inference kernels vs the taped forward on the trained weights
+    image = feats
+    if bb is not None:
+        feats = [f.clone(memory_format=torch.preserve_format) for f in bb(image)]
     outs, _ = head.forward(feats, metas)
     pl = head._last_plan
     taped = RelationTailGrad(head).forward(pl.q.clone(), pl.sub_pos, pl.obj_pos)
@@ -124,9 +136,10 @@ def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent(sc
     tr.write_back()
     sd = head.state_dict()
     moved = [k for k in sd if not torch.equal(sd[k].cpu(), before[k].cpu())]
-    assert set(moved) == set(tr.names), (set(moved) ^ set(tr.names))
-    for n, v in tr.params.items():
-        assert torch.equal(sd[n].cpu(), v.cpu()), n
+    head_names = [n for n in tr.names if not n.startswith("backbone.")]
+    assert set(moved) == set(head_names), (set(moved) ^ set(head_names))
+    for n in head_names:
+        assert torch.equal(sd[n].cpu(), tr.params[n].cpu()), n
     outs2, _ = head.forward(feats, metas)          # (write_back must not trigger a stale re-pack)
     assert torch.equal(outs2["rel"], outs["rel"])
     from pairnet_amd import CrossHead2
@@ -134,10 +147,23 @@ def test_tail_training_step_updates_like_adamw_and_keeps_inference_consistent(sc
     fresh = CrossHead2(**head_cfg())
     fresh.load_state_dict(sd)
     fresh.to(DEV)
+    if bb is not None:         # ... and a fresh backbone from ITS written-back state dict
+        from pairnet_amd import ResNet50Hip
+        bsd = bb.state_dict()
+        bmoved = {k for k in bsd if not torch.equal(bsd[k].cpu(), bb_before[k].cpu())}
+        assert bmoved == {n[len("backbone."):] for n in tr.names if n.startswith("backbone.")}
+        assert len(bmoved) == 42 and not any(k.startswith(("conv1", "bn1", "layer1")) for k in bmoved)
+        assert torch.equal(bb(image)[3], feats[3])             # (no stale re-pack after write_back)
+        fresh_bb = ResNet50Hip()
+        fresh_bb.load_state_dict(bsd)
+        fresh_bb.to(DEV)
+        f2 = fresh_bb(image)
+        for a, b_ in zip(f2, feats):
+            assert torch.equal(a, b_)
     outs3, _ = fresh.forward(feats, metas)
     for k in ("rel", "importance", "cls"):
         assert torch.equal(outs3[k], outs2[k]), k
     assert any("transformer_decoder.layers" in n for n in tr.names) == train_decoder
-    assert any("pixel_decoder.encoder" in n for n in tr.names) == (scope == "head+pixel_decoder")
+    assert any("pixel_decoder.encoder" in n for n in tr.names) == (scope in ("head+pixel_decoder", "all"))
     # the class path is in the layout but frozen (no gradient in the reference's graph)
     assert "cls_embed.weight" in tr.layout and "cls_embed.weight" not in tr.names

@@ -1,7 +1,8 @@
 """What one training iteration of the head behind the pixel decoder costs on one MI355X
 (pair-net_amd/train.py): ms per `TailTrainer.step` at 800x1333, one image, for the
 tail alone, with the nine masked decoder layers, and with the pixel decoder's encoder path as
-well (everything behind the frozen backbone), and where the time goes (HIP events around the
+well (everything behind the frozen backbone), and from the image with the ResNet-50's stages 2-4
+("all": the reference's whole trainable graph), and where the time goes (HIP events around the
 phases of a step; the Hungarian assignments inside `loss` are host work as in the reference).
 Prints one JSON line.  `rocprofv3 --kernel-trace --stats -- python tools/train_step_probe.py`
 gives the per-kernel view (profiles/r06_train_step_kernel_stats.csv)."""
@@ -40,18 +41,22 @@ gt_rels = [torch.stack([torch.randint(0, G, (T,), generator=g), torch.randint(0,
            for _ in range(B)]
 pts = [torch.rand(1, 12544, 2, generator=g) for _ in range(B)]
 
-out = {"what": "TailTrainer.step, 800x1333, one image, frozen ResNet-50 features resident in HBM; "
+out = {"what": "TailTrainer.step, 800x1333, one image, frozen ResNet-50 features resident in HBM "
+               "(scope `all`: from the image, backbone stages 2-4 trained; its taped forward is "
+               "counted under `backward`); "
                "ms per step over %d steps (device wait at both ends) and the phases of one step "
                "(HIP events; `loss` includes the two Hungarian assignments on the host)" % steps}
-for scope in ("tail", "head", "head+pixel_decoder"):
+for scope in ("tail", "head", "head+pixel_decoder", "all"):
     mode = scope != "tail"
-    tr = TailTrainer(head, train_decoder=mode, train_pixel_decoder=scope == "head+pixel_decoder")
+    tr = TailTrainer(head, train_decoder=mode, train_pixel_decoder=scope == "head+pixel_decoder",
+                     backbone=net if scope == "all" else None)
+    inp = img if scope == "all" else feats
     for _ in range(3):
-        vals = tr.step(feats, metas, gt_rels, gt_labels, gt_masks, point_coords=pts)
+        vals = tr.step(inp, metas, gt_rels, gt_labels, gt_masks, point_coords=pts)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        vals = tr.step(feats, metas, gt_rels, gt_labels, gt_masks, point_coords=pts)
+        vals = tr.step(inp, metas, gt_rels, gt_labels, gt_masks, point_coords=pts)
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
     # phases of one step
@@ -59,6 +64,8 @@ for scope in ("tail", "head", "head+pixel_decoder"):
     nh = tr.tape.flat_numel
     with torch.no_grad():
         ev[0].record()
+        if scope == "all":
+            feats = [f.clone(memory_format=torch.preserve_format) for f in net(img)]
         outs = head.forward(feats, metas)
         ev[1].record()
         up = {}
@@ -74,7 +81,10 @@ for scope in ("tail", "head", "head+pixel_decoder"):
         ev[3].record()
         back = tr.tape.backward(g_rel=up["rel"], g_importance=up["importance"])
         if tr.pd_tape is not None:
-            tr.pd_tape.backward(back[0])
+            dfeats, _ = tr.pd_tape.backward(back[0])
+            if tr.bb_tape is not None:
+                tr.bb_tape.forward(feats[0])
+                tr.bb_tape.backward(dfeats[2], dfeats[1], dfeats[0])
         ev[4].record()
         tr.apply_gradients()
         ev[5].record()

@@ -795,7 +795,7 @@ class PSGTr:
             raise NotImplementedError("model(return_loss=True) + autograd is not how this detector "
                                       "trains: `val_losses` gives forward_train's loss VALUES, "
                                       "`pairnet_amd.TailTrainer(det.bbox_head).step(det.extract_feat(img), ...)` "
-                                      "runs one iteration for the head behind the pixel decoder")
+                                      "(backbone=det.backbone to train it too) runs one iteration")
         if isinstance(img, (list, tuple)):
             img, img_metas = img[0], img_metas[0]
         return self.simple_test(img, img_metas, rescale=rescale)

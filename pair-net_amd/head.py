@@ -1474,8 +1474,7 @@ class CrossHead2:
             "forward_train + autograd is not how this head trains: `val_losses()` / `loss()` give the "
             "reference's loss values, `loss(..., grads={})` their gradients w.r.t. the logits, and "
             "`pairnet_amd.TailTrainer(head).step(...)` runs one iteration (loss -> backward through "
-            "the head behind the pixel decoder -> clip -> AdamW); the pixel decoder's and the "
-            "backbone's backward are not built")
+            "the head, optionally the backbone -> clip -> AdamW)")
 
     def val_losses(self, x, img_metas, gt_rels, gt_bboxes, gt_labels=None, gt_masks=None,
                    gt_bboxes_ignore=None, **kw):

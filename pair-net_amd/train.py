@@ -4,9 +4,10 @@ pairnet_head.py:419-757, tools/train.py:115-241, configs/mask2former/pairnet.py:
 parameters of `CrossHead2` the loss reaches: by default the Relation Fusion decoder,
 `rel_cls_embed`, the relation query / position embeddings, the Pair Proposal Network's MLPs and the
 Matrix Learner (10.2 M), with `train_decoder` the nine masked decoder layers as well (+14.3 M) and
-with `train_pixel_decoder` the pixel decoder's encoder path (+5.3 M).  The BACKBONE is frozen: in
-the reference it trains at `lr_mult=0.1`; its backward pass is the part of f-4 that is not built,
-and this module says so rather than pretend.
+with `train_pixel_decoder` the pixel decoder's encoder path (+5.3 M), with `backbone=` the ResNet's
+stages 2-4 (+23.2 M; stem, layer1 and BatchNorm frozen as in the reference's config) -- 53.0 M, the
+reference's whole trainable graph.  Without `backbone=` the backbone is frozen (a fine-tuning
+regime); a Swin backbone has no backward here.
 Everything the reference's loss can reach enters through two logits: `loss_r_cls` through
 `rel`, `loss_match` through `importance` (`loss_sub_cls` / `loss_obj_cls` read DETACHED class
 logits, pairnet_head.py:380-390, and train nothing).
@@ -16,7 +17,8 @@ logits, pairnet_head.py:380-390, and train nothing).
 
 Per step: `head.forward` (the inference kernels; hipGraphs if on) -> `head.loss(grads=)` (csrc/
 loss.hip; the two Hungarian assignments on the host as the reference) -> `RelationTailGrad`
-forward-with-tape + backward into one flat gradient buffer -> (world > 1) bucketed all-reduce
+(/ `HeadGrad` / `PixelDecoderGrad` / `BackboneGrad`) forward-with-tape + backward into one flat
+gradient buffer -> (world > 1) bucketed all-reduce
 overlapped with the backward pass (`dist.GradReducer`) -> global-norm clip coefficient on the
 device -> ONE AdamW launch over the flat parameter buffer that the head's weight dict aliases ->
 refresh of the derived weight packs the inference kernels read.  No host synchronisation inside a

@@ -5,7 +5,7 @@
 #                                                `bench.py --no-extras --no-cpu-baseline`
 #   gpurun_out/<tag>_kernel_stats_head_only.csv  same with `--path head`
 #   (Swin-L / 200 queries and the box trunk are child legs of the default bench line since round 6)
-#   gpurun_out/<tag>_train_step.json, <tag>_train_step_kernel_stats.csv   tools/train_step_probe.py, plain and under rocprofv3
+#   gpurun_out/<tag>_train_step_kernel_stats.csv tools/train_step_probe.py under rocprofv3 (plain: bench line's `training_step`)
 #   gpurun_out/pmc_traffic.json                  tools/pmc_traffic.sh (separate --pmc passes)
 # usage: tools/profile_round.sh r04_v1
 set -u
@@ -22,7 +22,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$
 f=$(find "$OUT/prof_${TAG}" -name "full_kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_kernel_stats.csv"
 f=$(find "$OUT/prof_${TAG}" -name "head_kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_kernel_stats_head_only.csv"
 # the training step: phases + per-kernel view of tools/train_step_probe.py
-timeout 600 python "$ROOT/tools/train_step_probe.py" 10 2> "$OUT/${TAG}_train_step.err" | tail -1 > "$OUT/${TAG}_train_step.json"
+# (its plain timings are the bench line's `training_step`)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}" -o train -- \
   python "$ROOT/tools/train_step_probe.py" 10 > "$OUT/prof_${TAG}_train.log" 2>&1
 f=$(find "$OUT/prof_${TAG}" -name "train_kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_train_step_kernel_stats.csv"

@@ -499,36 +499,71 @@ class PSGTr:
         validation loss: extract_feat -> ground-truth masks zero-padded to the batch tensor's
         (H, W) and nearest-resized to (H // 2, W // 2) (:126-141, one kernel per image:
         `pn_gt_mask_prepare_u8`) -> `bbox_head.val_losses` (head forward + `loss`).  Forward
-        only: no autograd graph, no optimizer (training is outside SURVEY.md 8).
+        only; the training iteration is `train_step`.
 
         `gt_masks[i]`: image i's instance masks [G, h, w], 0/1 -- a BitmapMasks-like object
         (`.to_ndarray()`), a numpy array or a tensor (host or device)."""
-        from . import hip
         if type(self.bbox_head) is not CrossHead2:     # (the siblings INHERIT val_losses)
             raise NotImplementedError("loss values are built for CrossHead2 only (%s has no "
                                       "loss forward here)" % type(self.bbox_head).__name__)
         x = self.extract_feat(img)
-        if getattr(self.bbox_head, "use_mask", True):
-            assert gt_masks is not None
-            H, W = int(img.shape[2]), int(img.shape[3])
-            dev = self.bbox_head.device
-            prepared = []
-            with torch.cuda.device(dev):
-                for each in gt_masks:
-                    m = each.to_ndarray() if hasattr(each, "to_ndarray") else each
-                    m = torch.as_tensor(m).to(dev)
-                    if m.dtype not in (torch.bool, torch.uint8):
-                        m = (m != 0)
-                    if m.dim() != 3 or m.shape[1] > H or m.shape[2] > W:
-                        raise ValueError("gt_masks: [G, h, w] with h <= %d, w <= %d, got %s"
-                                         % (H, W, tuple(m.shape)))
-                    out = torch.empty((m.shape[0], H // 2, W // 2), dtype=torch.uint8, device=dev)
-                    if m.shape[0]:
-                        hip.gt_mask_prepare(m.contiguous(), out, H, W)
-                    prepared.append(out)
-            gt_masks = prepared
+        gt_masks = self._prepare_gt_masks(img, gt_masks)
         return self.bbox_head.val_losses(x, img_metas, gt_rels, gt_bboxes, gt_labels, gt_masks,
                                          gt_bboxes_ignore, **kw)
+
+    def _prepare_gt_masks(self, img, gt_masks):
+        """PSGTr.forward_train's ground-truth mask preparation (psgtr.py:126-141): zero-pad to the
+        batch tensor's (H, W), nearest-resize to (H // 2, W // 2); one kernel per image."""
+        from . import hip
+        if not getattr(self.bbox_head, "use_mask", True):
+            return gt_masks
+        assert gt_masks is not None
+        H, W = int(img.shape[2]), int(img.shape[3])
+        dev = self.bbox_head.device
+        prepared = []
+        with torch.cuda.device(dev):
+            for each in gt_masks:
+                m = each.to_ndarray() if hasattr(each, "to_ndarray") else each
+                m = torch.as_tensor(m).to(dev)
+                if m.dtype not in (torch.bool, torch.uint8):
+                    m = (m != 0)
+                if m.dim() != 3 or m.shape[1] > H or m.shape[2] > W:
+                    raise ValueError("gt_masks: [G, h, w] with h <= %d, w <= %d, got %s"
+                                     % (H, W, tuple(m.shape)))
+                out = torch.empty((m.shape[0], H // 2, W // 2), dtype=torch.uint8, device=dev)
+                if m.shape[0]:
+                    hip.gt_mask_prepare(m.contiguous(), out, H, W)
+                prepared.append(out)
+        return prepared
+
+    def trainer(self, train_backbone=True, **kw):
+        """The per-iteration part of the reference's training (tools/train.py:115-241 with mmcv's
+        runner: `forward_train` -> `losses.backward()` -> OptimizerHook(grad_clip) -> AdamW, under
+        DDP) for this detector: a `pairnet_amd.TailTrainer` over every parameter the reference's R50
+        config trains.  `train_backbone=False` (or a Swin backbone, which has no
+        backward here) freezes the backbone; other keywords go to TailTrainer (lr, lr_mult, group,
+        train_decoder=False / train_pixel_decoder=False for the frozen-detector regimes)."""
+        from .backbone import ResNet50Hip
+        from .train import TailTrainer
+        if type(self.bbox_head) is not CrossHead2:
+            raise NotImplementedError("training is built for CrossHead2 only")
+        bb = self.backbone if (train_backbone and isinstance(self.backbone, ResNet50Hip)) else None
+        kw.setdefault("train_decoder", True)
+        kw.setdefault("train_pixel_decoder", True)
+        if not (kw["train_decoder"] and kw["train_pixel_decoder"]):
+            bb = None
+        self._trainer = TailTrainer(self.bbox_head, backbone=bb, **kw)
+        return self._trainer
+
+    def train_step(self, img, img_metas, gt_rels, gt_bboxes=None, gt_labels=None, gt_masks=None,
+                   point_coords=None):
+        """One training iteration on one batch, in `forward_train`'s argument order
+        (psgtr.py:113-146): ground-truth masks prepared like the reference's, then
+        `trainer().step`.  Returns the loss terms + `grad_norm` (device scalars)."""
+        tr = getattr(self, "_trainer", None) or self.trainer()
+        gt_masks = self._prepare_gt_masks(img, gt_masks)
+        x = img if tr.backbone is not None else self.extract_feat(img)
+        return tr.step(x, img_metas, gt_rels, gt_labels, gt_masks, point_coords=point_coords)
 
     @torch.no_grad()
     def detect(self, image, rescale=False):

@@ -225,3 +225,38 @@ def test_data_parallel_training_through_rccl_with_one_rank(tmp_path):
     ref = _run_workers(tmp_path, "none", 1, {"DDP_BATCH_SEED": "20"}, noapply=True, tag="_ref")[0]
     assert got["collectives"] == got["buckets"] >= 3
     assert torch.equal(got["grad1"], ref["grad1"])
+
+
+def test_detector_train_step_from_the_image():
+    """`PSGTr.train_step` in `forward_train`'s argument order: ground-truth masks at image size are
+    prepared like the reference's (pad + nearest half-size), the detector's own trainer runs the
+    iteration over backbone stages 2-4 + head; stem / layer1 / BatchNorm and the mask branch stay."""
+    from pairnet_amd import build_detector, pairnet_r50
+    det = build_detector(pairnet_r50())
+    det.bbox_head.init_weights(seed=4)
+    det.to(DEV)
+    g = torch.Generator().manual_seed(9)
+    H, W = 96, 128
+    img = torch.randn(1, 3, H, W, generator=g).to(DEV)
+    metas = [dict(img_shape=(H, W, 3), scale_factor=[1.0] * 4, batch_input_shape=(H, W))]
+    gt_labels = [torch.tensor([3, 17, 90, 120])]
+    gt_masks = [(torch.rand(4, H, W, generator=g) > 0.6).numpy()]
+    gt_rels = [torch.tensor([[0, 1, 5], [2, 3, 17], [1, 0, 56]])]
+    bb0 = {k: v.clone() for k, v in det.backbone.state_dict().items()}
+    hd0 = {k: v.clone() for k, v in det.bbox_head.state_dict().items()}
+    for _ in range(2):
+        out = det.train_step(img, metas, gt_rels, None, gt_labels, gt_masks)
+    assert set(out) == {"loss_r_cls", "loss_sub_cls", "loss_obj_cls", "loss_match", "grad_norm"}
+    assert all(np.isfinite(float(v)) for v in out.values()) and float(out["grad_norm"]) > 0
+    det._trainer.write_back()
+    bb1, hd1 = det.backbone.state_dict(), det.bbox_head.state_dict()
+    moved = {k for k in bb1 if not torch.equal(bb1[k].cpu(), bb0[k].cpu())}
+    assert len(moved) == 42 and all(k.startswith(("layer2", "layer3", "layer4")) for k in moved)
+    hmoved = {k for k in hd1 if not torch.equal(hd1[k].cpu(), hd0[k].cpu())}
+    assert "relation_decoder.layers.0.ffns.0.layers.1.weight" in hmoved
+    assert "pixel_decoder.encoder.layers.0.attentions.0.sampling_offsets.weight" in hmoved
+    assert not any(k.startswith(("mask_embed", "cls_embed", "pixel_decoder.mask_feature",
+                                 "pixel_decoder.lateral_convs", "pixel_decoder.output_convs"))
+                   for k in hmoved)
+    res = det.simple_test(img, metas)              # inference still runs on the trained weights
+    assert len(res) == 1

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 26
+#define PN_ABI_VERSION 27
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -125,6 +125,11 @@ int pn_winograd_f23_input_f32(const float* in, float* V, int B, int H, int W, in
                               void* stream);
 int pn_winograd_f23_output_f32(const float* M, const float* bias, float* out, int B, int H,
                                int W, int C, int relu, void* stream);
+/* Weight transform U = G g G^T of a 3x3 convolution weight w [Co][Ci][3][3] on the device (double
+ * arithmetic, rounded once): form 2 -> F(2x2,3x3), U [16][Co][Ci]; form 4 -> F(4x4,3x3), U [36][Co][Ci]
+ * (what pn_conv3x3_winograd* take).  Used at pack time and after every optimizer step of a trained
+ * backbone. */
+int pn_winograd_weights_f32(const float* w, float* U, int Co, int Ci, int form, void* stream);
 /* F(4x4, 3x3): 36 positions (V, M: [36][B*ceil(H/4)*ceil(W/4)][C], U [36][Cout][Cin]), 4x fewer
  * multiplications than the direct form; any H, W (edge tiles are padded / clipped).  Its
  * transform constants (up to 8 and 1/24) cost about one more decimal digit than F(2x2). */

@@ -912,6 +912,11 @@ static bool gemm_use_skinny(const pn_gemm_desc* d) {
   if (d->flags & (PN_GEMM_FORCE_TILE | PN_GEMM_FORCE_TILE64 | PN_GEMM_FORCE_TILE128x64))
     skinny = false;
   if (d->flags & PN_GEMM_FORCE_SKINNY) skinny = true;
+  // K < 32: the tile kernels' ragged-tail path loads "chunk 0" unconditionally, i.e. 32 columns
+  // of every row -- with fewer than 32 it would read past the last row of W (found through the
+  // backward pass's dW GEMMs, whose contraction runs over a few dozen pixels at small sizes);
+  // the skinny kernel clamps every load into its row
+  if (d->K < 32) skinny = true;
   return skinny;
 }
 

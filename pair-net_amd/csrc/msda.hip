@@ -696,6 +696,85 @@ __global__ __launch_bounds__(256) void k_msda_bwd(const float* __restrict__ valu
   }
 }
 
+// The same backward with lane = channel (round 6): a wave owns one head and two points at a
+// time, its 32-lane halves each cover ONE 128-byte value row per tap, so every atomic instruction
+// touches two whole lines instead of eight 16-byte-strided partial ones (4x fewer line visits at
+// the L2's atomic units, which is where this kernel's time goes: 270 M fp32 atomics per launch at
+// 21 950 queries).  The channel sums are 5-step shuffles inside a half.  -DPN_MSDA_BWD_LANES=0
+// builds the first form instead (A/B with a variant library).
+template <int L>
+__global__ __launch_bounds__(512) void k_msda_bwd_lanes(const float* __restrict__ value,
+                                                        const int64_t* __restrict__ shapes,
+                                                        const int64_t* __restrict__ starts,
+                                                        const float* __restrict__ loc,
+                                                        const float* __restrict__ aw,
+                                                        const float* __restrict__ gout,
+                                                        float* __restrict__ gvalue,
+                                                        float* __restrict__ gloc,
+                                                        float* __restrict__ gaw, const int N,
+                                                        const int Nq, const int64_t ldv) {
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, q = blockIdx.x;
+  constexpr int LP = L * 4;
+  const int c = tid & 31, half = (tid >> 5) & 1, head = tid >> 6;
+  const float g = gout[((int64_t)b * Nq + q) * 256 + head * 32 + c];
+  const float* vb = value + (int64_t)b * N * ldv + head * 32 + c;
+  float* gvb = gvalue + (int64_t)b * N * ldv + head * 32 + c;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+    const int64_t base = starts[l];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const int pt = pp * 2 + half;
+      const int64_t slot = (((int64_t)b * Nq + q) * 8 + head) * LP + l * 4 + pt;
+      const float2 lc = *reinterpret_cast<const float2*>(loc + 2 * slot);
+      const float a = aw[slot];
+      const float h_im = lc.y * (float)Hl - 0.5f, w_im = lc.x * (float)Wl - 0.5f;
+      float ga = 0.f, gx = 0.f, gy = 0.f;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {   // (uniform in the half)
+        const float fy = floorf(h_im), fx = floorf(w_im);
+        const int y0 = (int)fy, x0 = (int)fx;
+        const float lh = h_im - fy, lw = w_im - fx, hh = 1.f - lh, hw = 1.f - lw;
+        const bool yin0 = y0 >= 0, yin1 = y0 + 1 <= Hl - 1, xin0 = x0 >= 0, xin1 = x0 + 1 <= Wl - 1;
+        const int ya = max(y0, 0), yb = min(y0 + 1, Hl - 1), xa = max(x0, 0), xb = min(x0 + 1, Wl - 1);
+        const int64_t r1 = (base + (int64_t)ya * Wl + xa) * ldv, r2 = (base + (int64_t)ya * Wl + xb) * ldv;
+        const int64_t r3 = (base + (int64_t)yb * Wl + xa) * ldv, r4 = (base + (int64_t)yb * Wl + xb) * ldv;
+        const bool in1 = yin0 && xin0, in2 = yin0 && xin1, in3 = yin1 && xin0, in4 = yin1 && xin1;
+        float v1 = vb[r1], v2 = vb[r2], v3 = vb[r3], v4 = vb[r4];
+        v1 = in1 ? v1 : 0.f; v2 = in2 ? v2 : 0.f; v3 = in3 ? v3 : 0.f; v4 = in4 ? v4 : 0.f;
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        const float tg = g * a;                               // top_grad * attn_weight
+        const float gh = -hw * v1 - lw * v2 + hw * v3 + lw * v4;
+        const float gw = -hh * v1 - lh * v3 + hh * v2 + lh * v4;
+        ga = g * (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+        gx = (float)Wl * gw * tg;
+        gy = (float)Hl * gh * tg;
+        if (in1) unsafeAtomicAdd(gvb + r1, w1 * tg);
+        if (in2) unsafeAtomicAdd(gvb + r2, w2 * tg);
+        if (in3) unsafeAtomicAdd(gvb + r3, w3 * tg);
+        if (in4) unsafeAtomicAdd(gvb + r4, w4 * tg);
+      }
+      // sum over the point's 32 channels: the half's lanes (fixed order: deterministic)
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        ga += __shfl_xor(ga, o, 64);
+        gx += __shfl_xor(gx, o, 64);
+        gy += __shfl_xor(gy, o, 64);
+      }
+      if (c == 0) {
+        gaw[slot] = ga;
+        *reinterpret_cast<float2*>(gloc + 2 * slot) = make_float2(gx, gy);
+      }
+    }
+  }
+}
+
+#ifndef PN_MSDA_BWD_LANES        // build-time A/B knob (tools/build_variant.py): 0 = the first form
+#define PN_MSDA_BWD_LANES 1
+#endif
+static constexpr int msda_bwd_lanes() { return PN_MSDA_BWD_LANES; }
+
 extern "C" int pn_msda_bwd_f32(const float* value, int64_t ld_value,
                                const int64_t* spatial_shapes, const int64_t* level_start_index,
                                const float* sampling_locations, const float* attention_weights,
@@ -713,9 +792,14 @@ extern "C" int pn_msda_bwd_f32(const float* value, int64_t ld_value,
   const dim3 grid(Nq, B);
   hipStream_t s = (hipStream_t)stream;
 #define PN_MSDA_BWD(LL)                                                                        \
-  hipLaunchKernelGGL(k_msda_bwd<LL>, grid, dim3(256), 0, s, value, spatial_shapes,             \
-                     level_start_index, sampling_locations, attention_weights, grad_output,    \
-                     grad_value, grad_sampling_loc, grad_attn_weight, N, Nq, ld_value)
+  if (msda_bwd_lanes())                                                                        \
+    hipLaunchKernelGGL(k_msda_bwd_lanes<LL>, grid, dim3(512), 0, s, value, spatial_shapes,     \
+                       level_start_index, sampling_locations, attention_weights, grad_output,  \
+                       grad_value, grad_sampling_loc, grad_attn_weight, N, Nq, ld_value);      \
+  else                                                                                         \
+    hipLaunchKernelGGL(k_msda_bwd<LL>, grid, dim3(256), 0, s, value, spatial_shapes,           \
+                       level_start_index, sampling_locations, attention_weights, grad_output,  \
+                       grad_value, grad_sampling_loc, grad_attn_weight, N, Nq, ld_value)
   switch (L) {
     case 1: PN_MSDA_BWD(1); break;
     case 2: PN_MSDA_BWD(2); break;

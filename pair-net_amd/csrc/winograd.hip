@@ -266,3 +266,45 @@ extern "C" int pn_winograd_f43_output_f32(const float* Mx, const float* bias, fl
                      (hipStream_t)stream, Mx, bias, out, H, W, C / 4, th, tw, tiles, relu);
   return PN_LAUNCH_CHECK();
 }
+
+// ---- weight transforms U = G g G^T on the device (load time, and after every optimizer step of
+// a trained backbone: pair-net_amd/train.py): one thread per (co, ci) filter, double arithmetic in
+// a fixed order, rounded to fp32 once.  form 2: F(2x2,3x3), U [16][Co][Ci]; form 4: F(4x4,3x3),
+// U [36][Co][Ci].  (Rounds 1-5 did this with a float64 torch.einsum, i.e. a rocBLAS call, at
+// pack time; inside a long-lived training process that call was seen to abort the process.)
+template <int R>
+__global__ __launch_bounds__(256) void k_winograd_weights(const float* __restrict__ w,
+                                                          float* __restrict__ U, int Co, int Ci) {
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= (int64_t)Co * Ci) return;
+  double G[R][3];
+  if (R == 4) {
+    const double g4[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    for (int i = 0; i < 4; ++i) for (int k = 0; k < 3; ++k) G[i][k] = g4[i][k];
+  } else {
+    const double g6[6][3] = {{1.0 / 4, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6},
+                             {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 24, 1.0 / 12, 1.0 / 6},
+                             {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    for (int i = 0; i < 6; ++i) for (int k = 0; k < 3; ++k) G[i % R][k] = g6[i][k];
+  }
+  double g[3][3];
+  for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = (double)w[f * 9 + k];
+  double t[R][3];
+  for (int i = 0; i < R; ++i)
+    for (int l = 0; l < 3; ++l) t[i][l] = G[i][0] * g[0][l] + G[i][1] * g[1][l] + G[i][2] * g[2][l];
+  for (int i = 0; i < R; ++i)
+    for (int j = 0; j < R; ++j)
+      U[((int64_t)(i * R + j)) * Co * Ci + f] =
+          (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+}
+
+extern "C" int pn_winograd_weights_f32(const float* w, float* U, int Co, int Ci, int form,
+                                       void* stream) {
+  if (!w || !U || Co <= 0 || Ci <= 0 || (form != 2 && form != 4)) return PN_BAD_ARG;
+  const dim3 grid(pn_cdiv((int64_t)Co * Ci, 256));
+  if (form == 2)
+    hipLaunchKernelGGL(k_winograd_weights<4>, grid, dim3(256), 0, (hipStream_t)stream, w, U, Co, Ci);
+  else
+    hipLaunchKernelGGL(k_winograd_weights<6>, grid, dim3(256), 0, (hipStream_t)stream, w, U, Co, Ci);
+  return PN_LAUNCH_CHECK();
+}

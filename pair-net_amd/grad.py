@@ -143,9 +143,11 @@ class RelationTailGrad:
         M, K = x.shape
         N = W.shape[0]
         assert N % 4 == 0 and K % 4 == 0, (M, N, K)
-        Mp = (M + 3) // 4 * 4                  # the dW contraction runs over M: multiples of 4
+        # the dW contraction runs over M: padded with zero rows to whole 32-deep k-chunks of the
+        # GEMM kernels (no ragged-tail slow path; M % 4 == 0 is required anyway)
+        Mp = (M + 31) // 32 * 32
         dyw = dy
-        if Mp != M:                            # (zero rows: a level of 1 050 keys)
+        if Mp != M:
             dyw = torch.zeros(Mp, N, device=self.dev, dtype=torch.float32)
             dyw[:M].copy_(dy)
         xt = self._E(K, Mp)

@@ -123,6 +123,7 @@ _SIGS = {
                                         C.POINTER(_i32), _vp]),
     "pn_groupnorm_nhwc_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i64,
                                             _i64, _vp]),
+    "pn_winograd_weights_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_conv_wgrad_f32": (C.c_int, [_vp, _vp, _vp] + [_i32] * 11 + [_vp]),
     "pn_dilate2_f32": (C.c_int, [_vp, _vp] + [_i32] * 7 + [_vp]),
     "pn_subsample2_f32": (C.c_int, [_vp, _vp] + [_i32] * 6 + [_vp]),
@@ -191,7 +192,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 26   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 27   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -476,8 +477,21 @@ def maxpool3x3s2(x, out, B, H, W, Cc):
            "pn_maxpool3x3s2_nhwc_f32")
 
 
+def _winograd_weights_dev(w, form):
+    """The device form of the two transforms below (one HIP kernel, no BLAS call)."""
+    w = w.contiguous()
+    co, ci = w.shape[0], w.shape[1]
+    U = torch.empty((16 if form == 2 else 36), co, ci, device=w.device, dtype=torch.float32)
+    _check(lib().pn_winograd_weights_f32(_ptr(w), _ptr(U), co, ci, form, _stream()),
+           "pn_winograd_weights_f32")
+    return U
+
+
 def winograd_weights(w):
-    """conv weight [Cout][Cin][3][3] (any device, fp32) -> U [16][Cout][Cin] = G g G^T."""
+    """conv weight [Cout][Cin][3][3] (fp32) -> U [16][Cout][Cin] = G g G^T.  Device tensors go
+    through `pn_winograd_weights_f32`; host tensors (tests, tools) through the einsum below."""
+    if w.is_cuda:
+        return _winograd_weights_dev(w, 2)
     G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
                      dtype=torch.float64, device=w.device)
     U = torch.einsum("ik,ockl,jl->ijoc", G, w.double(), G)
@@ -486,6 +500,8 @@ def winograd_weights(w):
 
 def winograd43_weights(w):
     """conv weight [Cout][Cin][3][3] -> U [36][Cout][Cin] = G g G^T for F(4x4, 3x3)."""
+    if w.is_cuda:
+        return _winograd_weights_dev(w, 4)
     G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
                       [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
                      dtype=torch.float64, device=w.device)

@@ -856,3 +856,17 @@ def test_stencil_rows_and_stencil_mask_pack(hip, hi, wi, ho, wo):
     l4[3].fill_(-1.0)
     hip.mask_pack_stencil(l4, bits_s, all_s, B * Q, hi, wi, ho, wo)
     assert int(all_s[3]) == 1
+
+
+def test_winograd_weight_transform_kernel_equals_the_einsum():
+    """`pn_winograd_weights_f32` (device, what the heads / backbones pack with since round 6)
+    against the float64 einsum it replaced (still the host-tensor path): both round G g G^T,
+    formed in double, to fp32 once."""
+    from pairnet_amd import hip
+    w = torch.randn(96, 40, 3, 3, generator=torch.Generator().manual_seed(21))
+    for fn, n in ((hip.winograd_weights, 16), (hip.winograd43_weights, 36)):
+        dev, host = fn(w.to(DEV)), fn(w)
+        assert tuple(dev.shape) == tuple(host.shape) == (n, 96, 40)
+        diff = (dev.cpu() - host).abs()
+        assert float(diff.max()) <= 2e-7 * float(host.abs().max())       # (last-bit differences:
+        assert float((diff > 0).float().mean()) < 2e-2                   #  another summation order)

@@ -870,3 +870,22 @@ def test_winograd_weight_transform_kernel_equals_the_einsum():
         diff = (dev.cpu() - host).abs()
         assert float(diff.max()) <= 2e-7 * float(host.abs().max())       # (last-bit differences:
         assert float((diff > 0).float().mean()) < 2e-2                   #  another summation order)
+
+
+def test_gemm_with_fewer_than_32_contraction_columns():
+    """K < 32 at sizes that used to take the 64x64 tile kernel, whose ragged-tail path loads 32
+    columns of every W row (past the last row for K < 32: a GPU fault when the buffer ends a
+    mapped segment -- found through the backward pass's dW GEMMs): dispatched to the skinny kernel
+    since round 6; row-major and column-major A."""
+    from pairnet_amd import hip
+    g = torch.Generator().manual_seed(23)
+    M, N, K = 2048, 1024, 24
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    want = A.double() @ W.double().t()
+    out = torch.empty(M, N, device=DEV)
+    hip.gemm(A.to(DEV), W.to(DEV), out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N)
+    assert float((out.cpu().double() - want).abs().max()) < 1e-4
+    At = A.t().contiguous().to(DEV)                      # [K][M]: A read column-major
+    out2 = torch.empty(M, N, device=DEV)
+    hip.gemm(At, W.to(DEV), out2, M=M, N=N, K=K, lda=M, ldw=K, ldc=N, colmajor=True)
+    assert float((out2.cpu().double() - want).abs().max()) < 1e-4

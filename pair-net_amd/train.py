@@ -32,7 +32,13 @@ from . import hip
 from .dist import GradReducer
 from .grad import BackboneGrad, HeadGrad, PixelDecoderGrad, RelationTailGrad
 
-__all__ = ["TailTrainer"]
+__all__ = ["TailTrainer", "step_lr"]
+
+
+def step_lr(base_lr, epoch, steps=(5, 10), gamma=0.5):
+    """mmcv's StepLrUpdaterHook by epoch (`lr_config = dict(policy="step", gamma=0.5, step=[5, 10])`,
+    configs/mask2former/pairnet.py:370): the learning rate of 0-based `epoch`."""
+    return base_lr * gamma ** sum(1 for s in steps if epoch >= s)
 
 
 class TailTrainer:
@@ -224,6 +230,13 @@ class TailTrainer:
                 w[conv + ".wino4"].copy_(hip.winograd43_weights(cw.contiguous()))
             if conv + ".w.s3" in w:
                 hip.s3_split(w[conv + ".w"], w[conv + ".w.s3"])
+
+    def set_epoch(self, epoch, steps=(5, 10), gamma=0.5):
+        """The reference's learning-rate schedule (step policy by epoch): sets `self.lr`."""
+        if not hasattr(self, "base_lr"):
+            self.base_lr = self.lr
+        self.lr = step_lr(self.base_lr, epoch, steps, gamma)
+        return self.lr
 
     def write_back(self):
         """Copy the trained values into the head's (and the backbone's) state dict (checkpoints,

@@ -64,3 +64,9 @@ def test_backbone_layout_is_stages_2_to_4_convolutions():
     assert sorted(names) == sorted(want) and len(names) == 42
     # completion order: the deepest block first
     assert names[0].startswith("layer4.2.") and names[-1].startswith("layer2.0.")
+
+
+def test_step_lr_is_the_reference_schedule():
+    from pairnet_amd.train import step_lr
+    lrs = [step_lr(1e-4, e) for e in range(15)]          # max_epochs = 15, step = [5, 10], gamma 0.5
+    assert lrs[:5] == [1e-4] * 5 and lrs[5:10] == [5e-5] * 5 and lrs[10:] == [2.5e-5] * 5

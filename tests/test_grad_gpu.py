@@ -281,7 +281,8 @@ def _unpack_mask(bits, rowall, B, Q, N):
     return torch.from_numpy(m).view(B, Q, N)
 
 
-def test_masked_decoder_backward_against_the_oracle():
+@pytest.mark.parametrize("exact_mask_order", [True, False, "full"])
+def test_masked_decoder_backward_against_the_oracle(exact_mask_order):
     """`HeadGrad`: the nine masked-attention decoder layers + the tail.  The taped query chain
     reproduces the inference kernels' outputs; its backward -- d memory tokens (what the pixel
     decoder's backward would receive), `query_feat`, `query_embed`, `level_embed`, the 9 x 18
@@ -294,6 +295,7 @@ def test_masked_decoder_backward_against_the_oracle():
     from pairnet_amd import HeadGrad
     _, sd, _ = oracle_head(1234)
     head = _hip_head(sd)
+    head.exact_mask_order = exact_mask_order       # (the three forms of the attention-mask step)
     H, W = 64, 96
     feats = seeded.seeded_feats(99, 2, H, W)
     metas = [dict(img_shape=(H, W, 3), scale_factor=[1.5] * 4)] * 2

@@ -1188,19 +1188,33 @@ class CrossHead2:
         if cs is None:
             cs = CrossHead2._capture_streams[dev] = torch.cuda.Stream(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(cs):
-            g.capture_begin(capture_error_mode="thread_local")
-            try:
-                fn()
-            except BaseException as first:
-                # end the capture so that the stream leaves capture mode, but report what went
-                # wrong inside it (a refused launch, a shape error), not the invalidated capture
+        # No cyclic garbage collection while the stream is capturing: a collection that happens to
+        # run now would destroy whatever unreachable hipGraphs / events / device tensors the
+        # PROCESS has lying around (another, dropped detector's plans are such a cycle) from inside
+        # the capture, and a runtime call that is not allowed there ends in abort() -- seen in the
+        # test suite once it had grown enough garbage in front of a capture (round 6).
+        # torch.cuda.graph() collects up front for the same reason; deferring costs nothing.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.stream(cs):
+                g.capture_begin(capture_error_mode="thread_local")
                 try:
-                    g.capture_end()
-                except Exception:
-                    pass
-                raise first
-            g.capture_end()
+                    fn()
+                except BaseException as first:
+                    # end the capture so that the stream leaves capture mode, but report what
+                    # went wrong inside it (a refused launch, a shape error), not the invalidated
+                    # capture
+                    try:
+                        g.capture_end()
+                    except Exception:
+                        pass
+                    raise first
+                g.capture_end()
+        finally:
+            if gc_was_on:
+                gc.enable()
         CrossHead2.captures += 1          # (counted once it exists)
         return g
 

@@ -32,6 +32,7 @@ def _hip_head(sd):
 
 
 def _err(a, b):
+    b = b.detach() if isinstance(b, torch.Tensor) else b
     return float((a.detach().cpu().double() - torch.as_tensor(b).double()).abs().max())
 
 

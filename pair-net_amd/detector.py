@@ -555,15 +555,43 @@ class PSGTr:
         self._trainer = TailTrainer(self.bbox_head, backbone=bb, **kw)
         return self._trainer
 
-    def train_step(self, img, img_metas, gt_rels, gt_bboxes=None, gt_labels=None, gt_masks=None,
-                   point_coords=None):
-        """One training iteration on one batch, in `forward_train`'s argument order
-        (psgtr.py:113-146): ground-truth masks prepared like the reference's, then
-        `trainer().step`.  Returns the loss terms + `grad_norm` (device scalars)."""
+    def train_step(self, img, img_metas=None, gt_rels=None, gt_bboxes=None, gt_labels=None,
+                   gt_masks=None, point_coords=None):
+        """One training iteration on one batch.  Two call forms:
+
+        * `train_step(img, img_metas, gt_rels, gt_bboxes, gt_labels, gt_masks)` -- `forward_train`'s
+          argument order (psgtr.py:113-146); returns the loss terms + `grad_norm` (device scalars);
+        * `train_step(data_batch, optimizer)` -- mmdet's `BaseDetector.train_step`, what mmcv's
+          `EpochBasedRunner.train` calls per iteration (`data_batch`: the collated dict with keys
+          img / img_metas / gt_rels / gt_bboxes / gt_labels / gt_masks; `optimizer` is ignored:
+          the step's own clip + AdamW have already run, so the runner needs NO OptimizerHook);
+          returns mmdet's dict(loss, log_vars, num_samples) with `loss` = the sum of the terms whose
+          name contains "loss" (`_parse_losses`).
+
+        Ground-truth masks at image size are prepared like the reference's (pad to the batch
+        tensor, nearest half-size), then `trainer().step` runs."""
+        mmdet_form = isinstance(img, dict)
+        if mmdet_form:
+            data = img
+            unwrap = lambda v: getattr(v, "data", v)        # (mmcv DataContainer)
+            first = lambda v: v[0] if isinstance(v, (list, tuple)) and len(v) == 1 and \
+                isinstance(v[0], (list, tuple)) else v
+            img = unwrap(data["img"])
+            if isinstance(img, (list, tuple)):
+                img = img[0]
+            img_metas = first(unwrap(data["img_metas"]))
+            gt_rels, gt_labels = first(unwrap(data["gt_rels"])), first(unwrap(data["gt_labels"]))
+            gt_masks = first(unwrap(data["gt_masks"]))
+            gt_bboxes = first(unwrap(data.get("gt_bboxes")))
         tr = getattr(self, "_trainer", None) or self.trainer()
         gt_masks = self._prepare_gt_masks(img, gt_masks)
         x = img if tr.backbone is not None else self.extract_feat(img)
-        return tr.step(x, img_metas, gt_rels, gt_labels, gt_masks, point_coords=point_coords)
+        out = tr.step(x, img_metas, gt_rels, gt_labels, gt_masks, point_coords=point_coords)
+        if not mmdet_form:
+            return out
+        loss = sum(v for k, v in out.items() if "loss" in k)
+        return dict(loss=loss, log_vars={k: float(v) for k, v in list(out.items()) + [("loss", loss)]},
+                    num_samples=len(img_metas))
 
     @torch.no_grad()
     def detect(self, image, rescale=False):

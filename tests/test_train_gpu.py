@@ -260,6 +260,12 @@ def test_detector_train_step_from_the_image():
                    for k in hmoved)
     res = det.simple_test(img, metas)              # inference still runs on the trained weights
     assert len(res) == 1
+    # mmdet's own form: what EpochBasedRunner.train calls per iteration
+    rec = det.train_step(dict(img=img, img_metas=metas, gt_rels=gt_rels, gt_bboxes=None,
+                              gt_labels=gt_labels, gt_masks=gt_masks), None)
+    assert set(rec) == {"loss", "log_vars", "num_samples"} and rec["num_samples"] == 1
+    terms = [v for k, v in rec["log_vars"].items() if "loss_" in k]
+    assert len(terms) == 4 and abs(float(rec["loss"]) - sum(terms)) < 1e-3 * sum(terms)
 
 
 def test_the_tail_overfits_a_fixed_batch_at_the_reference_learning_rate():

@@ -142,6 +142,7 @@ class TailTrainer:
         self._scratch = torch.zeros(256, device=dev, dtype=torch.float64)
         self.reducer = GradReducer(self.flat_grad, group=group, bucket_bytes=bucket_bytes)
         self.steps = 0
+        self._w_dicts = (head.w, backbone.w if backbone is not None else None)
         self._refresh_derived()
 
     # ------------------------------------------------------------------
@@ -258,6 +259,12 @@ class TailTrainer:
         `CrossHead2.loss`) plus `grad_norm` (device scalar, before clipping).  `feats`: the four
         backbone feature maps -- or, for a trainer built with `backbone=`, the image tensor."""
         head, tape = self.head, self.tape
+        if head.w is not self._w_dicts[0] or (self.backbone is not None
+                                              and self.backbone.w is not self._w_dicts[1]):
+            # load_state_dict / an in-place parameter update made the module re-pack its device
+            # weights: the flat buffers of this trainer no longer back them
+            raise RuntimeError("the head (or backbone) re-packed its weights since this TailTrainer "
+                               "was built (load_state_dict, parameter update, .to()): build a new one")
         if self.backbone is not None:
             feats = [f.clone(memory_format=torch.preserve_format) for f in self.backbone(feats)]
         outs = head.forward(feats, img_metas)

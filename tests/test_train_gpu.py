@@ -260,6 +260,13 @@ def test_detector_train_step_from_the_image():
                    for k in hmoved)
     res = det.simple_test(img, metas)              # inference still runs on the trained weights
     assert len(res) == 1
+    # a state dict loaded behind the trainer's back re-packs the weights: the trainer must refuse
+    stale = det._trainer
+    det.bbox_head.load_state_dict(det.bbox_head.state_dict())
+    det.simple_test(img, metas)
+    with pytest.raises(RuntimeError, match="re-packed"):
+        stale.step(img, metas, gt_rels, gt_labels, det._prepare_gt_masks(img, gt_masks))
+    det._trainer = None                            # (train_step builds a fresh one)
     # mmdet's own form: what EpochBasedRunner.train calls per iteration
     rec = det.train_step(dict(img=img, img_metas=metas, gt_rels=gt_rels, gt_bboxes=None,
                               gt_labels=gt_labels, gt_masks=gt_masks), None)

@@ -552,8 +552,8 @@ class HeadGrad(RelationTailGrad):
     `pl.X`, the K / V projections of the nine layers, the stencil rows of the mask feature.  The
     boolean attention masks (:244-256, `detach()`ed in the reference) are recomputed per layer by
     the product's own fused kernel and kept as packed bits.  `backward` returns the gradient with
-    respect to the pixel decoder's memory tokens [B, sum_l N_l, 256] (what the pixel decoder's
-    backward -- not built -- would take) and the parameter gradients incl. `query_feat`,
+    respect to the pixel decoder's memory tokens [B, sum_l N_l, 256] (what
+    `PixelDecoderGrad.backward` takes) and the parameter gradients incl. `query_feat`,
     `query_embed`, `level_embed` and the cross-attentions' K / V projection rows."""
 
     @staticmethod

@@ -69,7 +69,8 @@ class CrossHead2:
         if mapper != "conv_tiny":
             raise NotImplementedError("only mapper='conv_tiny' (configs/mask2former/pairnet.py:26)")
         # train_cfg (mmdet passes the model-level one to the head): kept for `loss()` -- the
-        # forward VALUES of the reference's loss (losses.py); there is no backward here
+        # VALUES of the reference's loss and their gradients w.r.t. the logits (losses.py); the
+        # backward through the network and the optimizer step live in grad.py / train.py
         self._loss_cfg = dict(train_cfg=train_cfg, rel_cls_loss=rel_cls_loss,
                               subobj_cls_loss=subobj_cls_loss,
                               importance_match_loss=importance_match_loss)

@@ -5,8 +5,8 @@
 and the per-image ground truth -- and returns the same four terms (`loss_r_cls`,
 `loss_sub_cls`, `loss_obj_cls`, `loss_match`, :470-477) as 0-dim device tensors: the VALUES
 (validation losses) and, with `grads={}`, the gradients of their sum with respect to the four
-logit tensors they are computed from (round 6: the first backward slice; nothing differentiates
-through the head yet, no optimizer: training is outside SURVEY.md 8).
+logit tensors they are computed from (round 6: where the backward pass of grad.py starts;
+train.py runs the whole iteration).
 
 Where the arithmetic runs (csrc/loss.hip, one small kernel each):
   pn_point_sample_f32       [3P] mmcv point_sample of the Q mask logit maps and the ground-truth

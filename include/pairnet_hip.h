@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 27
+#define PN_ABI_VERSION 28
 int pn_abi_version(void);
 
 /* ------------------------------------------------------------------------- *
@@ -792,11 +792,6 @@ int pn_mlearner_last_bwd_data_f32(const float* g, const float* w3, const float* 
  * importance, sgn = -1) or (d w1)^T (F = d c1, g = importance_raw, sgn = +1). */
 int pn_tapcorr1_f32(const float* F, const float* g, float* part, int B, int S, int sgn,
                     void* stream);
-/* The 64 -> 64 layer's weight gradient as MFMA outer products over pixels:
- * part[chunk][co][tap][ci] = sum over the chunk's pixels of dY[.][co] X[. + tap offset][ci];
- * chunk = (image, block of rows_per image rows): B * ceil(S / rows_per) chunks of 64*49*64 floats. */
-int pn_tapcorr64_f32(const float* dY, const float* X, float* part, int B, int S, int rows_per,
-                     void* stream);
 /* Pixel decoder (pairnet_head.py:262; mmcv MultiScaleDeformableAttention.forward): from pn_msda_bwd_f32's
  * grad_sampling_loc / grad_attn_weight back to the gradient of the [offsets 8*L*4*2 | logits 8*L*4]
  * projection rows (stride ld) that pn_token_sampling_f32 turned into those operands on an unpadded
@@ -812,7 +807,8 @@ int pn_groupnorm_nhwc_bwd_f32(const float* x, const float* dy, const float* gamm
                               float* gxhat, float* stats, int B, int64_t HW, int G, float eps,
                               int64_t x_bstride, int64_t dy_bstride, void* stream);
 /* Backbone backward (mmdet ResNet behind configs/mask2former/pairnet.py:9-19, frozen BatchNorm folded
- * into the convolutions; pair-net_amd/grad.py BackboneGrad).  Weight gradient of a K x K convolution
+ * into the convolutions; pair-net_amd/grad.py BackboneGrad) and the Matrix Learner's 64 -> 64 7x7 layer
+ * (cnn_factory.py:30-41).  Weight gradient of a K x K convolution
  * (stride, pad) between channel-last maps dY [B][Ho][Wo][Co] and X [B][Hi][Wi][Ci] (Ci, Co % 64 == 0):
  * part[chunk][co][tap][ci] over chunks of rows_per output rows per image, B * ceil(Ho / rows_per)
  * chunks of Co*K*K*Ci floats; their column sum is dW [Co][K*K][Ci]. */

@@ -7,7 +7,7 @@
 // there), the 64 -> 64 convolution's data gradient is pn_conv2d_nhwc_ex_f32 on a re-laid-out
 // weight (pn_conv_weight_bwd_layout_f32).  What is new here is everything else: reductions over
 // rows / batch, LayerNorm / softmax-attention / ReLU / L2-normalise derivatives, the scatter that
-// undoes a row gather, and the Matrix Learner's weight gradients (an MFMA tap correlation).
+// undoes a row gather, and the convolutions' weight gradients (MFMA outer products over pixels).
 // All sums run in a fixed order (no atomics): a gradient is bitwise reproducible.
 #include "common.h"
 
@@ -486,58 +486,6 @@ extern "C" int pn_tapcorr1_f32(const float* F, const float* g, float* part, int 
   return PN_LAUNCH_CHECK();
 }
 
-// ---- the 64 -> 64 layer's weight gradient: 49 correlations of two 64-channel maps,
-//   dW[co][tap][ci] = sum_{b,y,x} dY[b][y][x][co] X[b][y + kh - 3][x + kw - 3][ci],
-// as MFMA outer products over pixels.  A workgroup owns one tap and one chunk of `rows_per`
-// image rows; its four waves own the four 32 x 32 quadrants of the 64 x 64 (co, ci) block; a
-// k-step is two neighbouring pixels, and both operands are read straight from the channel-last
-// maps (a lane's operand element is [pixel = lane / 32][channel = lane % 32]: two 128-byte
-// lines per wave per map, no LDS, no transposes).  part[chunk][co][tap][ci]; the caller
-// column-sums the chunks (fixed order).
-__global__ __launch_bounds__(256) void k_tapcorr64(const float* __restrict__ dY,
-                                                   const float* __restrict__ X,
-                                                   float* __restrict__ part, int S, int rows_per,
-                                                   int chunks_per_image) {
-  const int tap = blockIdx.x, chunk = blockIdx.y;
-  const int b = chunk / chunks_per_image, y0 = (chunk % chunks_per_image) * rows_per;
-  const int kh = tap / 7, kw = tap % 7;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 31, lh = lane >> 5;
-  const int co0 = (wave & 1) * 32, ci0 = (wave >> 1) * 32;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int y1 = min(y0 + rows_per, S);
-  for (int y = y0; y < y1; ++y) {
-    const int yy = y + kh - 3;
-    if (yy < 0 || yy >= S) continue;                      // (workgroup-uniform)
-    const float* dr = dY + (((int64_t)b * S + y) * S) * 64 + co0 + li;
-    const float* xr = X + (((int64_t)b * S + yy) * S) * 64 + ci0 + li;
-    for (int x = 0; x < S; x += 2) {
-      const int xp = x + lh, xx = xp + kw - 3;
-      const float a = xp < S ? dr[(int64_t)xp * 64] : 0.f;
-      const float w = (xp < S && xx >= 0 && xx < S) ? xr[(int64_t)xx * 64] : 0.f;
-      acc = mfma32(a, w, acc);
-    }
-  }
-  float* out = part + (int64_t)chunk * 64 * 49 * 64;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = co0 + mfma32_row(r, lh), ci = ci0 + li;
-    out[((int64_t)co * 49 + tap) * 64 + ci] = acc[r];
-  }
-}
-
-extern "C" int pn_tapcorr64_f32(const float* dY, const float* X, float* part, int B, int S,
-                                int rows_per, void* stream) {
-  if (!dY || !X || !part || B <= 0 || S <= 0 || rows_per <= 0) return PN_BAD_ARG;
-  const int cpi = pn_cdiv(S, rows_per);
-  if ((int64_t)B * cpi > 65535) return PN_BAD_ARG;
-  hipLaunchKernelGGL(k_tapcorr64, dim3(49, B * cpi), dim3(256), 0, (hipStream_t)stream, dY, X, part,
-                     S, rows_per, cpi);
-  return PN_LAUNCH_CHECK();
-}
-
 // ---- a convolution weight in the layout its DATA gradient needs (a "same" convolution's data
 // gradient is a convolution with the taps reversed and the channel roles swapped):
 //   out[ci][T - 1 - t][co] = in[co][t][ci]      (in [Co][T][Ci] -> out [Ci][T][Co])
@@ -693,12 +641,15 @@ extern "C" int pn_groupnorm_nhwc_bwd_f32(const float* x, const float* dy, const 
 }
 
 // ---- backbone (mmdet ResNet, frozen BatchNorm folded into the convolutions): the pieces its
-// backward needs beside the GEMMs.
+// backward needs beside the GEMMs -- and the Matrix Learner's 64 -> 64 7x7 layer.
 // Weight gradient of a K x K convolution (stride s, padding p) between channel-last maps, as
-// MFMA outer products over output pixels -- the general form of k_tapcorr64:
+// MFMA outer products over output pixels:
 //   dW[co][tap][ci] = sum_{b,y,x} dY[b][y][x][co] X[b][y s + kh - p][x s + kw - p][ci]
 // A workgroup owns one tap, one 64 x 64 (co, ci) block and one chunk of `rows_per` output rows;
-// part[chunk][co][tap][ci], column-summed over the chunks by the caller (fixed order).
+// its four waves own the four 32 x 32 quadrants; a k-step is two neighbouring output pixels, and
+// both operands are read straight from the channel-last maps (a lane's operand element is
+// [pixel = lane / 32][channel = lane % 32]: two 128-byte lines per wave per map, no LDS, no
+// transposes).  part[chunk][co][tap][ci], column-summed over the chunks by the caller (fixed order).
 __global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ dY,
                                                     const float* __restrict__ X,
                                                     float* __restrict__ part, int Hi, int Wi,

@@ -479,7 +479,7 @@ class RelationTailGrad:
         rows_per = 10
         chunks = B * ((Q + rows_per - 1) // rows_per)
         part2 = E(chunks, 64 * 49 * 64)
-        hip.tapcorr64(dc2, c1, part2, B, Q, rows_per)
+        hip.conv_wgrad(dc2, c1, part2, B, Q, Q, Q, Q, 64, 64, 7, 1, 3, rows_per)
         dw2 = E(64 * 49 * 64)                                     # [co][tap][ci]
         hip.colsum(part2, dw2)
         db2 = E(64)

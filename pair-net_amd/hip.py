@@ -117,7 +117,6 @@ _SIGS = {
     "pn_cosine_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "pn_mlearner_last_bwd_data_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "pn_tapcorr1_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "pn_tapcorr64_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_conv_weight_bwd_layout_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "pn_msda_offaw_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, C.POINTER(_i32),
                                         C.POINTER(_i32), _vp]),
@@ -192,7 +191,7 @@ _SIGS = {
                                                 _i32, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 27   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
+ABI_VERSION = 28   # PN_ABI_VERSION of include/pairnet_hip.h these bindings were written for
 
 _lib = None
 
@@ -1270,12 +1269,6 @@ def tapcorr1(F, g, part, B, S, sgn):
     assert part.numel() == B * S * 49 * 64
     _check(lib().pn_tapcorr1_f32(_ptr(F), _ptr(g), _ptr(part), B, S, sgn, _stream()),
            "pn_tapcorr1_f32")
-
-
-def tapcorr64(dY, X, part, B, S, rows_per):
-    assert part.numel() == B * ((S + rows_per - 1) // rows_per) * 64 * 49 * 64
-    _check(lib().pn_tapcorr64_f32(_ptr(dY), _ptr(X), _ptr(part), B, S, rows_per, _stream()),
-           "pn_tapcorr64_f32")
 
 
 def conv_weight_bwd_layout(w, out, Co, T, Ci):
